@@ -1,0 +1,47 @@
+"""Generate tests/golden/*.npz from the reference's shipped DATA files (run in the build
+container only; /root/reference does not exist on the GPU box).
+
+Fixtures are data, not code: input clouds (float32 xyz from the binary PCDs), the FGR pose the
+reference's stage 2 reads as its initial transform, and the multiscale-GICP pose its author
+shipped for the same pair (SURVEY.md §8c "strong" pin).
+
+    python tests/golden/make_golden.py [/root/reference]
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+pio = importlib.import_module("point-cloud-registration-with-global-refinement_amd.io")
+
+GOLDEN_PAIRS = [10, 25, 145, 465, 500, 865, 899]   # stable members of the pinned list + 899 (small, noisy)
+
+
+def main(ref):
+    nclt = os.path.join(ref, "nuvens/nuvens_pre_processadas/NCLT")
+    for i in GOLDEN_PAIRS:
+        src = pio.read_pcd_xyz(os.path.join(nclt, f"s{i + 1}.pcd"))
+        tgt = pio.read_pcd_xyz(os.path.join(nclt, f"s{i}.pcd"))
+        T_fgr = pio.read_pose(os.path.join(ref, f"relative_poses_FGR/NCLT/pose_{i + 1}_{i}.txt"))
+        T_gicp = pio.read_pose(os.path.join(ref, f"relative_poses_FGR_GICP/NCLT/pose_{i + 1}_{i}.txt"))
+        np.savez_compressed(os.path.join(HERE, f"nclt_pair_{i:03d}.npz"), source=src, target=tgt, T_fgr=T_fgr,
+                            T_gicp=T_gicp, pair=np.int64(i))
+        print(f"pair {i}: source {src.shape[0]} pts, target {tgt.shape[0]} pts")
+    # pose chains for the host-side pose-algebra tests (tiny)
+    for name, n in (("Facade", 7), ("Courtyard", 8)):
+        rel = [pio.read_pose(os.path.join(ref, f"relative_poses_FGR_GICP/{name}/{f}"))
+               for f in sorted(os.listdir(os.path.join(ref, f"relative_poses_FGR_GICP/{name}")))]
+        names = sorted(os.listdir(os.path.join(ref, f"relative_poses_FGR_GICP/{name}")))
+        ab_dir = os.path.join(ref, f"absolute_poses_FGR_GICP/{name}")
+        ab_names = sorted(os.listdir(ab_dir))
+        ab = [pio.read_pose(os.path.join(ab_dir, f)) for f in ab_names]
+        np.savez_compressed(os.path.join(HERE, f"poses_{name.lower()}.npz"), relative=np.stack(rel),
+                            relative_names=np.array(names), absolute=np.stack(ab), absolute_names=np.array(ab_names))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "/root/reference")
