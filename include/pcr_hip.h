@@ -1,0 +1,166 @@
+/*
+ * pcr_hip.h -- C ABI of libpcr_hip.so, the MI355X (gfx950) pairwise-registration hot path.
+ *
+ * The reference has no FFI of its own: its hot path is reached through Open3D's pybind
+ * module from ALL_FUNCTIONS.py / scripts 1-2.  Each entry point below
+ * therefore names the Open3D binding call it replaces and the reference line that makes
+ * that call.  INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every cloud/normal/feature pointer is a DEVICE pointer (HIP, current device of the
+ *     context); `T`, option structs and result structs are HOST pointers;
+ *   - clouds are packed float32 xyz rows (N x 3), normals likewise, FPFH is N x 33 float32;
+ *   - poses are row-major 4x4 float64, source -> target;
+ *   - caller owns every buffer; the library owns a per-context scratch arena;
+ *   - return 0 on success, negative pcr_status otherwise; degenerate-but-valid results
+ *     (no correspondences: fitness 0, rmse 0, T = init) are NOT errors (Open3D behaviour);
+ *   - calls are ordered on the context's stream and return after their scalar outputs are
+ *     on the host.
+ */
+#ifndef PCR_HIP_H
+#define PCR_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PCR_OK = 0,
+    PCR_EINVAL = -1,      /* Open3D would raise (voxel_size<=0, max_dist<=0, nb_neighbors<1, std_ratio<=0 ...) */
+    PCR_ENOMEM = -2,
+    PCR_EHIP = -3,        /* a HIP runtime call failed; see pcr_last_error() */
+    PCR_ENUMERIC = -4,    /* non-finite pose */
+    PCR_ECAPACITY = -5    /* caller buffer too small */
+} pcr_status;
+
+/* == o3d.geometry.KDTreeSearchParam{KNN,Radius,Hybrid}  (ALL_FUNCTIONS.py:181,185,213,301) */
+typedef enum { PCR_SEARCH_KNN = 0, PCR_SEARCH_RADIUS = 1, PCR_SEARCH_HYBRID = 2 } pcr_search_kind;
+/* == o3d.pipelines.registration.{L2Loss,L1Loss,GMLoss} (ALL_FUNCTIONS.py:219,284) */
+typedef enum { PCR_LOSS_L2 = 0, PCR_LOSS_L1 = 1, PCR_LOSS_GM = 2 } pcr_loss_kind;
+
+typedef struct pcr_context pcr_context;
+
+/* == o3d.pipelines.registration.RegistrationResult (fields read at ALL_FUNCTIONS.py:312,323,369) */
+typedef struct {
+    double transformation[16];
+    double fitness;
+    double inlier_rmse;
+    int64_t n_correspondences;
+    int32_t iterations;       /* pose updates applied */
+    int32_t converged;
+} pcr_result;
+
+/* == TransformationEstimationForGeneralizedICP(loss) + ICPConvergenceCriteria(...)
+ *    (ALL_FUNCTIONS.py:308-311, 2_MGICP...py:159-162)                                   */
+typedef struct {
+    int32_t loss;             /* pcr_loss_kind */
+    double loss_k;            /* GMLoss k */
+    double epsilon;           /* GICP covariance regulariser, Open3D default 1e-3 */
+    double relative_fitness;
+    double relative_rmse;
+    int32_t max_iteration;
+} pcr_gicp_params;
+
+/* per-scale record of pcr_multiscale_gicp (what the roofline byte model needs) */
+typedef struct {
+    int64_t n_voxel[2];       /* D_k: source, target after voxel_down_sample           */
+    int64_t n_clean[2];       /* C_k: after remove_statistical_outlier                 */
+    pcr_result icp;
+} pcr_scale_record;
+
+/* == FastGlobalRegistrationOption (ALL_FUNCTIONS.py:189-196) */
+typedef struct {
+    double division_factor;
+    int32_t use_absolute_scale;
+    int32_t decrease_mu;
+    double maximum_correspondence_distance;
+    int32_t iteration_number;
+    double tuple_scale;
+    int32_t maximum_tuple_count;
+    int32_t tuple_test;
+    uint64_t seed;            /* Open3D seeds from std::random_device; here explicit */
+} pcr_fgr_option;
+
+/* ---- context ---------------------------------------------------------------------- */
+int pcr_create(int device, pcr_context **out);
+int pcr_destroy(pcr_context *ctx);
+int pcr_set_stream(pcr_context *ctx, void *hip_stream);       /* NULL = context-owned stream */
+const char *pcr_last_error(const pcr_context *ctx);
+int pcr_version(void);
+
+/* ---- geometry: PointCloud methods ------------------------------------------------- */
+/* == PointCloud.get_min_bound/get_max_bound (ALL_FUNCTIONS.py:1093-1097); bounds6 host = min xyz, max xyz */
+int pcr_bounds(pcr_context *ctx, const float *xyz, int64_t n, double *bounds6);
+
+/* == PointCloud.voxel_down_sample (ALL_FUNCTIONS.py:293-294; 2_MGICP...py:146-147).
+ * out capacity n rows. normals_in/out optional (mean, not re-normalised). Output is in Morton
+ * order of the voxel index (Open3D's order is unspecified hash order).                      */
+int pcr_voxel_down_sample(pcr_context *ctx, const float *xyz, const float *normals_in, int64_t n, double voxel_size,
+                          float *out_xyz, float *out_normals, int64_t *out_n);
+
+/* == PointCloud.remove_statistical_outlier (ALL_FUNCTIONS.py:297-298). keep_mask: n bytes (device),
+ * out_xyz optional compacted cloud (capacity n), out_index optional int64 indices (device).      */
+int pcr_remove_statistical_outlier(pcr_context *ctx, const float *xyz, int64_t n, int nb_neighbors, double std_ratio,
+                                   uint8_t *keep_mask, float *out_xyz, int64_t *out_index, int64_t *out_n);
+
+/* == PointCloud.estimate_normals(search_param) (ALL_FUNCTIONS.py:182-183, 214-215, 301-302).
+ * prior_normals optional: new normal flipped to agree with it (Open3D when has_normals).         */
+int pcr_estimate_normals(pcr_context *ctx, const float *xyz, int64_t n, int search_kind, int knn, double radius,
+                         const float *prior_normals, float *normals);
+
+/* == PointCloud.estimate_covariances(search_param) (ALL_FUNCTIONS.py:216-217); cov6 = xx,xy,xz,yy,yz,zz */
+int pcr_estimate_covariances(pcr_context *ctx, const float *xyz, int64_t n, int search_kind, int knn, double radius,
+                             float *cov6);
+
+/* ---- registration ------------------------------------------------------------------ */
+/* == registration_generalized_icp (ALL_FUNCTIONS.py:304-311; 2_MGICP...py:155-162).
+ * correspondences optional device int32 [n_src x 2]; filled with n_correspondences rows.       */
+int pcr_registration_generalized_icp(pcr_context *ctx, const float *src_xyz, const float *src_normals, int64_t n_src,
+                                     const float *tgt_xyz, const float *tgt_normals, int64_t n_tgt,
+                                     double max_correspondence_distance, const double *init_T,
+                                     const pcr_gicp_params *params, pcr_result *result, int32_t *correspondences);
+
+/* == the whole body of Multiscale_GICP (ALL_FUNCTIONS.py:286-312 / 2_MGICP...py:140-163), device resident:
+ * per scale voxel_down_sample -> remove_statistical_outlier(sor_k, sor_std) -> estimate_normals(KNN normal_k)
+ * -> registration_generalized_icp, chained.  src/tgt_normals optional (AF flow orientation prior).
+ * records: n_scales entries (host). correspondences: optional device int32 [n_src x 2] of the last scale. */
+int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const float *src_normals, int64_t n_src,
+                        const float *tgt_xyz, const float *tgt_normals, int64_t n_tgt, const double *voxel_sizes,
+                        const double *max_distances, int n_scales, int sor_k, double sor_std, int normal_k,
+                        const double *init_T, const pcr_gicp_params *params, pcr_scale_record *records,
+                        int32_t *correspondences);
+
+/* == evaluate_registration (ALL_FUNCTIONS.py:809-820) */
+int pcr_evaluate_registration(pcr_context *ctx, const float *src_xyz, int64_t n_src, const float *tgt_xyz,
+                              int64_t n_tgt, double max_correspondence_distance, const double *T, pcr_result *result,
+                              int32_t *correspondences);
+
+/* == get_information_matrix_from_point_clouds (ALL_FUNCTIONS.py:327-331); info36 host */
+int pcr_information_matrix(pcr_context *ctx, const float *src_xyz, int64_t n_src, const float *tgt_xyz, int64_t n_tgt,
+                           double max_correspondence_distance, const double *T, double *info36);
+
+/* == compute_fpfh_feature (ALL_FUNCTIONS.py:186-187); feat33: n x 33 float32 (device) */
+int pcr_compute_fpfh_feature(pcr_context *ctx, const float *xyz, const float *normals, int64_t n, int search_kind,
+                             int knn, double radius, float *feat33);
+
+/* == registration_fgr_based_on_feature_matching (ALL_FUNCTIONS.py:198-202) */
+int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, const float *src_feat33, int64_t n_src,
+                         const float *tgt_xyz, const float *tgt_feat33, int64_t n_tgt, const pcr_fgr_option *option,
+                         pcr_result *result, int32_t *correspondences);
+
+/* ---- test hooks (exercised by tests/ only) ----------------------------------------- */
+/* exact k nearest neighbours of every point of a cloud (self included), through the same index the
+ * pipeline uses. idx: n x k int32, d2: n x k float32 (device), rows sorted ascending.              */
+int pcr_debug_knn(pcr_context *ctx, const float *xyz, int64_t n, int k, double radius, int32_t *idx, float *d2,
+                  int32_t *counts);
+/* one GICP linearisation at pose T: search + A.6 sums. JTJ36, JTr6, stats3 = {count, sum d^2, sum r^2} (host) */
+int pcr_debug_gicp_linearize(pcr_context *ctx, const float *src_xyz, const float *src_normals, int64_t n_src,
+                             const float *tgt_xyz, const float *tgt_normals, int64_t n_tgt, double max_dist,
+                             const double *T, const pcr_gicp_params *params, double *JTJ36, double *JTr6,
+                             double *stats3, int32_t *match /* device n_src, optional */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,123 @@
+"""ctypes loader of ``libpcr_hip.so`` (C ABI: ``include/pcr_hip.h``).
+
+There is NO CPU fallback: if the shared library is missing, or no HIP device is visible, every
+compute entry point raises ``RuntimeError`` (the CPU oracle under ``oracle/`` is test
+infrastructure and is never imported from here).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libpcr_hip.so")
+
+PCR_OK, PCR_EINVAL, PCR_ENOMEM, PCR_EHIP, PCR_ENUMERIC, PCR_ECAPACITY = 0, -1, -2, -3, -4, -5
+SEARCH_KNN, SEARCH_RADIUS, SEARCH_HYBRID = 0, 1, 2
+LOSS_L2, LOSS_L1, LOSS_GM = 0, 1, 2
+
+
+class PcrResult(C.Structure):
+    _fields_ = [("transformation", C.c_double * 16), ("fitness", C.c_double), ("inlier_rmse", C.c_double),
+                ("n_correspondences", C.c_int64), ("iterations", C.c_int32), ("converged", C.c_int32)]
+
+
+class PcrGicpParams(C.Structure):
+    _fields_ = [("loss", C.c_int32), ("loss_k", C.c_double), ("epsilon", C.c_double), ("relative_fitness", C.c_double),
+                ("relative_rmse", C.c_double), ("max_iteration", C.c_int32)]
+
+
+class PcrScaleRecord(C.Structure):
+    _fields_ = [("n_voxel", C.c_int64 * 2), ("n_clean", C.c_int64 * 2), ("icp", PcrResult)]
+
+
+class PcrFgrOption(C.Structure):
+    _fields_ = [("division_factor", C.c_double), ("use_absolute_scale", C.c_int32), ("decrease_mu", C.c_int32),
+                ("maximum_correspondence_distance", C.c_double), ("iteration_number", C.c_int32),
+                ("tuple_scale", C.c_double), ("maximum_tuple_count", C.c_int32), ("tuple_test", C.c_int32),
+                ("seed", C.c_uint64)]
+
+
+# every symbol include/pcr_hip.h declares (tests check the export table against this list)
+EXPORTS = [
+    "pcr_create", "pcr_destroy", "pcr_set_stream", "pcr_last_error", "pcr_version", "pcr_bounds",
+    "pcr_voxel_down_sample", "pcr_remove_statistical_outlier", "pcr_estimate_normals", "pcr_estimate_covariances",
+    "pcr_registration_generalized_icp", "pcr_multiscale_gicp", "pcr_evaluate_registration", "pcr_information_matrix",
+    "pcr_compute_fpfh_feature", "pcr_registration_fgr", "pcr_debug_knn", "pcr_debug_gicp_linearize",
+]
+
+_lib = None
+_lock = threading.Lock()
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    script = os.path.join(_HERE, "csrc", "build.sh")
+    env = dict(os.environ)
+    if force:
+        for f in os.listdir(os.path.join(_HERE, "csrc")):
+            if f.endswith(".o"):
+                os.remove(os.path.join(_HERE, "csrc", f))
+    subprocess.check_call(["bash", script], env=env)
+    return SO_PATH
+
+
+def load():
+    """Return the ctypes handle of libpcr_hip.so; raise RuntimeError if it is not built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(SO_PATH):
+                raise RuntimeError(
+                    f"libpcr_hip.so not found at {SO_PATH}: the HIP extension is not built "
+                    "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+            lib = C.CDLL(SO_PATH)
+            lib.pcr_last_error.restype = C.c_char_p
+            lib.pcr_last_error.argtypes = [C.c_void_p]
+            lib.pcr_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+            lib.pcr_destroy.argtypes = [C.c_void_p]
+            lib.pcr_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+            _lib = lib
+    return _lib
+
+
+class Context:
+    """One libpcr_hip context (scratch arena + stream) per (device, torch stream)."""
+
+    _cache: dict = {}
+
+    def __init__(self, device: int, stream_ptr: int):
+        lib = load()
+        h = C.c_void_p()
+        rc = lib.pcr_create(int(device), C.byref(h))
+        if rc != PCR_OK:
+            raise RuntimeError(f"pcr_create(device={device}) failed with code {rc}: no usable HIP device "
+                               "(the MI355X path has no CPU fallback)")
+        self.handle = h
+        self.device = device
+        self.lib = lib
+        lib.pcr_set_stream(h, C.c_void_p(stream_ptr))
+
+    @classmethod
+    def current(cls) -> "Context":
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible to torch: the MI355X registration path cannot run (no CPU fallback)")
+        dev = torch.cuda.current_device()
+        sp = int(torch.cuda.current_stream(dev).cuda_stream)
+        key = (dev, sp, threading.get_ident())
+        ctx = cls._cache.get(key)
+        if ctx is None:
+            ctx = cls(dev, sp)
+            cls._cache[key] = ctx
+        return ctx
+
+    def check(self, rc: int, what: str):
+        if rc == PCR_OK:
+            return
+        msg = self.lib.pcr_last_error(self.handle)
+        msg = msg.decode() if msg else ""
+        # Open3D raises RuntimeError for invalid arguments; mirror that (SURVEY.md §8b error convention)
+        raise RuntimeError(f"{what}: {msg} (pcr status {rc})")

@@ -1,0 +1,388 @@
+// pcr_api.hip -- the extern "C" boundary of libpcr_hip.so (declared in include/pcr_hip.h) plus the context /
+// scratch-arena plumbing.  Each entry point replaces one Open3D binding call of the reference; see the header.
+#include <cmath>
+#include <cstring>
+#include "pcr_device.h"
+
+// ------------------------------------------------------------------------------------------- context
+extern "C" int pcr_version(void) { return 100; }
+
+extern "C" int pcr_create(int device, pcr_context **out) {
+    if (!out) return PCR_EINVAL;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return PCR_EHIP;     // no GPU: fail loudly, no CPU fallback
+    if (device < 0 || device >= count) return PCR_EINVAL;
+    if (hipSetDevice(device) != hipSuccess) return PCR_EHIP;
+    pcr_context *ctx = new pcr_context();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PCR_EHIP; }
+    ctx->stream = ctx->own_stream;
+    ctx->pinned_cap = 1 << 16;
+    if (hipHostMalloc((void **)&ctx->pinned, ctx->pinned_cap, hipHostMallocDefault) != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return PCR_EHIP; }
+    for (int i = 0; i < 2; i++)
+        if (hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming) != hipSuccess) { delete ctx; return PCR_EHIP; }
+    *out = ctx;
+    return PCR_OK;
+}
+
+extern "C" int pcr_destroy(pcr_context *ctx) {
+    if (!ctx) return PCR_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (int i = 0; i < 2; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return PCR_OK;
+}
+
+extern "C" int pcr_set_stream(pcr_context *ctx, void *s) {
+    if (!ctx) return PCR_EINVAL;
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    return PCR_OK;
+}
+
+extern "C" const char *pcr_last_error(const pcr_context *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int pcr_arena_reserve(pcr_context *ctx, size_t bytes) {
+    ctx->arena_off = 0;
+    if (bytes <= ctx->arena_cap) return PCR_OK;
+    PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->arena) { PCR_HIP_CHECK(ctx, hipFree(ctx->arena)); ctx->arena = nullptr; ctx->arena_cap = 0; }
+    size_t cap = bytes + bytes / 4;
+    hipError_t e = hipMalloc((void **)&ctx->arena, cap);
+    if (e != hipSuccess) { ctx->err = std::string("hipMalloc(arena): ") + hipGetErrorString(e); return PCR_ENOMEM; }
+    ctx->arena_cap = cap;
+    return PCR_OK;
+}
+
+void *pcr_arena_alloc(pcr_context *ctx, size_t bytes) {
+    size_t off = (ctx->arena_off + 255) & ~(size_t)255;
+    if (off + bytes > ctx->arena_cap) { ctx->err = "scratch arena exhausted"; return nullptr; }
+    ctx->arena_off = off + bytes;
+    return ctx->arena + off;
+}
+
+#define ENTER(ctx)                                                               \
+    if (!(ctx)) return PCR_EINVAL;                                               \
+    if (hipSetDevice((ctx)->device) != hipSuccess) return PCR_EHIP;              \
+    (ctx)->err.clear();
+
+static int alloc_cloud(pcr_context *ctx, DevCloud *c, int cap, bool with_nrm, bool with_bvh) {
+    const int cc = cap > 0 ? cap : 1;
+    c->cap = cap;
+    c->pts = arena<float4>(ctx, cc);
+    c->nrm = with_nrm ? arena<float4>(ctx, cc) : nullptr;
+    c->n = arena<int>(ctx, 1);
+    c->boxes = with_bvh ? arena<float4>(ctx, 2 * bvh_node_capacity(cc)) : nullptr;
+    if (!c->pts || !c->n || (with_nrm && !c->nrm) || (with_bvh && !c->boxes)) return PCR_ENOMEM;
+    return PCR_OK;
+}
+
+// Morton-sorted copy of a caller cloud (+ optional normals) with its BVH; perm maps sorted -> caller index
+static int import_cloud(pcr_context *ctx, const float *xyz, const float *nrm, int64_t n, DevCloud *c, uint32_t **perm_out) {
+    double b6[6];
+    PCR_TRY(pcr_dev_bounds(ctx, xyz, n, b6));
+    PCR_TRY(alloc_cloud(ctx, c, (int)n, nrm != nullptr, true));
+    uint32_t *perm = arena<uint32_t>(ctx, n > 0 ? n : 1);
+    if (!perm) return PCR_ENOMEM;
+    PCR_TRY(pcr_dev_sort_cloud(ctx, xyz, n, b6, c, perm));
+    if (nrm) PCR_TRY(pcr_dev_gather_f3_to_f4(ctx, nrm, perm, n, c->nrm));
+    PCR_TRY(pcr_dev_build_bvh(ctx, c));
+    if (perm_out) *perm_out = perm;
+    return PCR_OK;
+}
+
+// -------------------------------------------------------------------------------------- geometry API
+extern "C" int pcr_bounds(pcr_context *ctx, const float *xyz, int64_t n, double *b6) {
+    ENTER(ctx);
+    if (n < 0 || !b6 || (n > 0 && !xyz)) return PCR_EINVAL;
+    PCR_TRY(pcr_arena_reserve(ctx, 1 << 20));
+    return pcr_dev_bounds(ctx, xyz, n, b6);
+}
+
+extern "C" int pcr_voxel_down_sample(pcr_context *ctx, const float *xyz, const float *normals_in, int64_t n, double voxel,
+                                     float *out_xyz, float *out_normals, int64_t *out_n) {
+    ENTER(ctx);
+    if (n < 0 || !out_n || (n > 0 && (!xyz || !out_xyz))) return PCR_EINVAL;
+    if (!(voxel > 0.0)) { ctx->err = "voxel_size <= 0"; return PCR_EINVAL; }
+    *out_n = 0;
+    if (n == 0) return PCR_OK;
+    PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n)));
+    double b6[6];
+    PCR_TRY(pcr_dev_bounds(ctx, xyz, n, b6));
+    DevCloud v;
+    PCR_TRY(alloc_cloud(ctx, &v, (int)n, normals_in != nullptr, false));
+    PCR_TRY(pcr_dev_voxel(ctx, xyz, normals_in, n, b6, voxel, &v));
+    PCR_TRY(pcr_dev_pack_f4_to_f3(ctx, v.pts, v.n, v.cap, out_xyz));
+    if (normals_in && out_normals) PCR_TRY(pcr_dev_pack_f4_to_f3(ctx, v.nrm, v.n, v.cap, out_normals));
+    return pcr_read_count(ctx, v.n, out_n);
+}
+
+__global__ void k_keep_to_caller(const uint8_t *__restrict__ keep_sorted, const uint32_t *__restrict__ perm, int n, uint8_t *__restrict__ keep_caller) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) keep_caller[perm[i]] = keep_sorted[i];
+}
+__global__ void k_emit_kept(const float *__restrict__ xyz, const uint8_t *__restrict__ keep, const int *__restrict__ pos, int n, float *__restrict__ out_xyz, int64_t *__restrict__ out_index) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    const int o = pos[i];
+    if (out_xyz) { out_xyz[o * 3] = xyz[i * 3]; out_xyz[o * 3 + 1] = xyz[i * 3 + 1]; out_xyz[o * 3 + 2] = xyz[i * 3 + 2]; }
+    if (out_index) out_index[o] = i;
+}
+
+extern "C" int pcr_remove_statistical_outlier(pcr_context *ctx, const float *xyz, int64_t n, int nb_neighbors, double std_ratio,
+                                              uint8_t *keep_mask, float *out_xyz, int64_t *out_index, int64_t *out_n) {
+    ENTER(ctx);
+    if (n < 0 || (n > 0 && !xyz)) return PCR_EINVAL;
+    if (nb_neighbors < 1 || !(std_ratio > 0.0)) { ctx->err = "nb_neighbors < 1 or std_ratio <= 0"; return PCR_EINVAL; }
+    if (out_n) *out_n = 0;
+    if (n == 0) return PCR_OK;
+    PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n) + (size_t)n * 64));
+    DevCloud c, kept; uint32_t *perm = nullptr;
+    PCR_TRY(import_cloud(ctx, xyz, nullptr, n, &c, &perm));
+    PCR_TRY(alloc_cloud(ctx, &kept, (int)n, false, false));
+    uint8_t *keep_sorted = arena<uint8_t>(ctx, n);
+    uint8_t *keep_caller = keep_mask ? keep_mask : arena<uint8_t>(ctx, n);
+    int *pos = arena<int>(ctx, n);
+    int *total = arena<int>(ctx, 1);
+    if (!keep_sorted || !keep_caller || !pos || !total) return PCR_ENOMEM;
+    PCR_TRY(pcr_dev_sor(ctx, &c, nb_neighbors, std_ratio, &kept, keep_sorted, nullptr));
+    const int nb = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(k_keep_to_caller, dim3(nb), dim3(256), 0, ctx->stream, keep_sorted, perm, (int)n, keep_caller);
+    // emit the kept points in CALLER order (select_by_index semantics)
+    PCR_TRY(pcr_dev_flag_scan(ctx, keep_caller, nullptr, (int)n, pos, total));
+    if (out_xyz || out_index) hipLaunchKernelGGL(k_emit_kept, dim3(nb), dim3(256), 0, ctx->stream, xyz, keep_caller, pos, (int)n, out_xyz, out_index);
+    int64_t m = 0;
+    PCR_TRY(pcr_read_count(ctx, total, &m));
+    if (out_n) *out_n = m;
+    return PCR_OK;
+}
+
+extern "C" int pcr_estimate_normals(pcr_context *ctx, const float *xyz, int64_t n, int search_kind, int knn, double radius,
+                                    const float *prior_normals, float *normals) {
+    ENTER(ctx);
+    if (n < 0 || (n > 0 && (!xyz || !normals))) return PCR_EINVAL;
+    if (n == 0) return PCR_OK;
+    PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n) + (size_t)n * 64));
+    DevCloud c; uint32_t *perm = nullptr;
+    PCR_TRY(import_cloud(ctx, xyz, prior_normals, n, &c, &perm));
+    float4 *nout = arena<float4>(ctx, n);
+    if (!nout) return PCR_ENOMEM;
+    PCR_TRY(pcr_dev_normals(ctx, &c, search_kind, knn, radius, c.nrm, nout, nullptr));
+    PCR_TRY(pcr_dev_scatter_rows_f4_to_f3(ctx, nout, perm, c.n, c.cap, normals));
+    PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return PCR_OK;
+}
+
+__global__ void k_scatter_cov6(const float *__restrict__ src, const uint32_t *__restrict__ perm, int n, float *__restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = perm[i];
+    for (int t = 0; t < 6; t++) dst[(size_t)v * 6 + t] = src[(size_t)i * 6 + t];
+}
+
+extern "C" int pcr_estimate_covariances(pcr_context *ctx, const float *xyz, int64_t n, int search_kind, int knn, double radius, float *cov6) {
+    ENTER(ctx);
+    if (n < 0 || (n > 0 && (!xyz || !cov6))) return PCR_EINVAL;
+    if (n == 0) return PCR_OK;
+    PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n) + (size_t)n * 64));
+    DevCloud c; uint32_t *perm = nullptr;
+    PCR_TRY(import_cloud(ctx, xyz, nullptr, n, &c, &perm));
+    float *cs = arena<float>(ctx, (size_t)n * 6);
+    if (!cs) return PCR_ENOMEM;
+    PCR_TRY(pcr_dev_normals(ctx, &c, search_kind, knn, radius, nullptr, nullptr, cs));
+    hipLaunchKernelGGL(k_scatter_cov6, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, cs, perm, (int)n, cov6);
+    PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return PCR_OK;
+}
+
+__global__ void k_knn_unpermute(const int32_t *si, const float *sd, const int32_t *sc, const uint32_t *perm, int n, int k, int32_t *idx, float *d2, int32_t *counts) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t o = perm[i];
+    for (int t = 0; t < k; t++) {
+        const int32_t v = si[(size_t)i * k + t];
+        idx[(size_t)o * k + t] = v >= 0 ? (int32_t)perm[v] : -1;
+        d2[(size_t)o * k + t] = sd[(size_t)i * k + t];
+    }
+    if (counts) counts[o] = sc[i];
+}
+__global__ void k_match_unpermute(const int32_t *m, const uint32_t *sp, const uint32_t *tp, int n, int32_t *out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[sp[i]] = m[i] >= 0 ? (int32_t)tp[m[i]] : -1;
+}
+
+extern "C" int pcr_debug_knn(pcr_context *ctx, const float *xyz, int64_t n, int k, double radius, int32_t *idx, float *d2, int32_t *counts) {
+    ENTER(ctx);
+    if (n <= 0 || !xyz || !idx || !d2) return PCR_EINVAL;
+    // sort, search over the BVH, then report rows and indices in the CALLER's point order
+    PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n) + (size_t)n * (size_t)k * 16 + (size_t)n * 64));
+    DevCloud c; uint32_t *perm = nullptr;
+    PCR_TRY(import_cloud(ctx, xyz, nullptr, n, &c, &perm));
+    int32_t *si = arena<int32_t>(ctx, (size_t)n * k);
+    float *sd = arena<float>(ctx, (size_t)n * k);
+    int32_t *sc = arena<int32_t>(ctx, n);
+    if (!si || !sd || !sc) return PCR_ENOMEM;
+    PCR_TRY(pcr_dev_knn_debug(ctx, &c, k, radius, si, sd, sc));
+    hipLaunchKernelGGL(k_knn_unpermute, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, si, sd, sc, perm, (int)n, k, idx, d2, counts);
+    PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return PCR_OK;
+}
+
+// ---------------------------------------------------------------------------------- registration API
+static int check_T(pcr_context *ctx, const double *T) {
+    if (!T) return PCR_EINVAL;
+    for (int k = 0; k < 16; k++) if (!std::isfinite(T[k])) { ctx->err = "non-finite init pose"; return PCR_EINVAL; }
+    return PCR_OK;
+}
+
+extern "C" int pcr_registration_generalized_icp(pcr_context *ctx, const float *src_xyz, const float *src_normals, int64_t n_src,
+                                                const float *tgt_xyz, const float *tgt_normals, int64_t n_tgt, double max_dist,
+                                                const double *init_T, const pcr_gicp_params *params, pcr_result *result,
+                                                int32_t *correspondences) {
+    ENTER(ctx);
+    if (!params || !result || n_src < 0 || n_tgt < 0) return PCR_EINVAL;
+    if (!(max_dist > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
+    if ((n_src > 0 && (!src_xyz || !src_normals)) || (n_tgt > 0 && (!tgt_xyz || !tgt_normals))) { ctx->err = "missing cloud or normals"; return PCR_EINVAL; }
+    PCR_TRY(check_T(ctx, init_T));
+    PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n_src) + pcr_scratch_bytes_for(n_tgt)));
+    DevCloud s, t; uint32_t *sperm = nullptr, *tperm = nullptr;
+    PCR_TRY(import_cloud(ctx, src_xyz, src_normals, n_src, &s, &sperm));
+    PCR_TRY(import_cloud(ctx, tgt_xyz, tgt_normals, n_tgt, &t, &tperm));
+    int32_t *match = arena<int32_t>(ctx, n_src > 0 ? n_src : 1);
+    if (!match) return PCR_ENOMEM;
+    PCR_TRY(pcr_dev_gicp(ctx, &s, &t, max_dist, init_T, params, result, match));
+    if (correspondences) {
+        int64_t nc = 0;
+        PCR_TRY(pcr_dev_compact_matches(ctx, match, s.n, s.cap, sperm, tperm, correspondences, &nc));
+    }
+    return PCR_OK;
+}
+
+extern "C" int pcr_debug_gicp_linearize(pcr_context *ctx, const float *src_xyz, const float *src_normals, int64_t n_src,
+                                        const float *tgt_xyz, const float *tgt_normals, int64_t n_tgt, double max_dist,
+                                        const double *T, const pcr_gicp_params *params, double *JTJ36, double *JTr6,
+                                        double *stats3, int32_t *match_out) {
+    ENTER(ctx);
+    if (!params || !JTJ36 || !JTr6 || !stats3 || n_src <= 0 || n_tgt <= 0) return PCR_EINVAL;
+    PCR_TRY(check_T(ctx, T));
+    PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n_src) + pcr_scratch_bytes_for(n_tgt)));
+    DevCloud s, t; uint32_t *sperm = nullptr, *tperm = nullptr;
+    PCR_TRY(import_cloud(ctx, src_xyz, src_normals, n_src, &s, &sperm));
+    PCR_TRY(import_cloud(ctx, tgt_xyz, tgt_normals, n_tgt, &t, &tperm));
+    int32_t *match = arena<int32_t>(ctx, n_src);
+    if (!match) return PCR_ENOMEM;
+    PCR_TRY(pcr_dev_linearize_once(ctx, &s, &t, max_dist, T, params, JTJ36, JTr6, stats3, match));
+    if (match_out) {
+        hipLaunchKernelGGL(k_match_unpermute, dim3((unsigned)((n_src + 255) / 256)), dim3(256), 0, ctx->stream, match, sperm, tperm, (int)n_src, match_out);
+        PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return PCR_OK;
+}
+
+// one cloud of one scale: voxel -> BVH -> SOR -> BVH -> normals   (ALL_FUNCTIONS.py:293-302)
+static int prep_scale(pcr_context *ctx, const float *xyz, const float *nrm, int64_t n, const double *b6, double voxel, int sor_k,
+                      double sor_std, int normal_k, DevCloud *clean, int **n_voxel_dev) {
+    DevCloud v;
+    PCR_TRY(alloc_cloud(ctx, clean, (int)n, true, true));        // survives the mark below (allocated first)
+    float4 *prior = nrm ? arena<float4>(ctx, n > 0 ? n : 1) : nullptr;
+    int *nv_keep = arena<int>(ctx, 1);
+    if (!nv_keep || (nrm && !prior)) return PCR_ENOMEM;
+    {
+        ArenaMark mark(ctx);
+        PCR_TRY(alloc_cloud(ctx, &v, (int)n, nrm != nullptr, true));
+        PCR_TRY(pcr_dev_voxel(ctx, xyz, nrm, n, b6, voxel, &v));
+        PCR_TRY(pcr_dev_build_bvh(ctx, &v));
+        DevCloud tmp = *clean;
+        tmp.nrm = prior;                                         // compacted voxel-mean normals = orientation prior
+        PCR_TRY(pcr_dev_sor(ctx, &v, sor_k, sor_std, &tmp, nullptr, nullptr));
+        PCR_HIP_CHECK(ctx, hipMemcpyAsync(nv_keep, v.n, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    PCR_TRY(pcr_dev_build_bvh(ctx, clean));
+    PCR_TRY(pcr_dev_normals(ctx, clean, PCR_SEARCH_KNN, normal_k, 0.0, prior, clean->nrm, nullptr));
+    *n_voxel_dev = nv_keep;
+    return PCR_OK;
+}
+
+extern "C" int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const float *src_normals, int64_t n_src,
+                                   const float *tgt_xyz, const float *tgt_normals, int64_t n_tgt, const double *voxels,
+                                   const double *dists, int n_scales, int sor_k, double sor_std, int normal_k,
+                                   const double *init_T, const pcr_gicp_params *params, pcr_scale_record *records,
+                                   int32_t *correspondences) {
+    ENTER(ctx);
+    if (!params || !records || !voxels || !dists || n_scales < 1 || n_src < 0 || n_tgt < 0) return PCR_EINVAL;
+    if ((n_src > 0 && !src_xyz) || (n_tgt > 0 && !tgt_xyz)) return PCR_EINVAL;
+    PCR_TRY(check_T(ctx, init_T));
+    for (int s = 0; s < n_scales; s++) {
+        if (!(voxels[s] > 0.0)) { ctx->err = "voxel_size <= 0"; return PCR_EINVAL; }
+        if (!(dists[s] > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
+    }
+    if (sor_k < 1 || !(sor_std > 0.0) || normal_k < 1) { ctx->err = "nb_neighbors < 1, std_ratio <= 0 or knn < 1"; return PCR_EINVAL; }
+    PCR_TRY(pcr_arena_reserve(ctx, 2 * (pcr_scratch_bytes_for(n_src) + pcr_scratch_bytes_for(n_tgt))));
+    double bs[6], bt[6];
+    PCR_TRY(pcr_dev_bounds(ctx, src_xyz, n_src, bs));
+    PCR_TRY(pcr_dev_bounds(ctx, tgt_xyz, n_tgt, bt));
+    double T[16];
+    memcpy(T, init_T, sizeof T);
+    for (int s = 0; s < n_scales; s++) {
+        ArenaMark mark(ctx);
+        DevCloud cs, ct; int *nvs = nullptr, *nvt = nullptr;
+        PCR_TRY(prep_scale(ctx, src_xyz, src_normals, n_src, bs, voxels[s], sor_k, sor_std, normal_k, &cs, &nvs));
+        PCR_TRY(prep_scale(ctx, tgt_xyz, tgt_normals, n_tgt, bt, voxels[s], sor_k, sor_std, normal_k, &ct, &nvt));
+        int32_t *match = arena<int32_t>(ctx, n_src > 0 ? n_src : 1);
+        if (!match) return PCR_ENOMEM;
+        PCR_TRY(pcr_dev_gicp(ctx, &cs, &ct, dists[s], T, params, &records[s].icp, match));
+        int h[4];
+        PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h[0], nvs, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h[1], nvt, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h[2], cs.n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h[3], ct.n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        records[s].n_voxel[0] = h[0]; records[s].n_voxel[1] = h[1]; records[s].n_clean[0] = h[2]; records[s].n_clean[1] = h[3];
+        memcpy(T, records[s].icp.transformation, sizeof T);
+        if (s == n_scales - 1 && correspondences) {
+            int64_t nc = 0;
+            PCR_TRY(pcr_dev_compact_matches(ctx, match, cs.n, cs.cap, nullptr, nullptr, correspondences, &nc));
+        }
+    }
+    return PCR_OK;
+}
+
+extern "C" int pcr_evaluate_registration(pcr_context *ctx, const float *src_xyz, int64_t n_src, const float *tgt_xyz, int64_t n_tgt,
+                                         double max_dist, const double *T, pcr_result *result, int32_t *correspondences) {
+    ENTER(ctx);
+    if (!result || n_src < 0 || n_tgt < 0) return PCR_EINVAL;
+    if (!(max_dist > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
+    PCR_TRY(check_T(ctx, T));
+    PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n_src) + pcr_scratch_bytes_for(n_tgt)));
+    DevCloud s, t; uint32_t *sperm = nullptr, *tperm = nullptr;
+    PCR_TRY(import_cloud(ctx, src_xyz, nullptr, n_src, &s, &sperm));
+    PCR_TRY(import_cloud(ctx, tgt_xyz, nullptr, n_tgt, &t, &tperm));
+    int32_t *match = arena<int32_t>(ctx, n_src > 0 ? n_src : 1);
+    if (!match) return PCR_ENOMEM;
+    PCR_TRY(pcr_dev_evaluate(ctx, &s, &t, max_dist, T, result, match, nullptr));
+    for (int k = 0; k < 16; k++) result->transformation[k] = T[k];
+    if (correspondences) {
+        int64_t nc = 0;
+        PCR_TRY(pcr_dev_compact_matches(ctx, match, s.n, s.cap, sperm, tperm, correspondences, &nc));
+    }
+    return PCR_OK;
+}
+
+extern "C" int pcr_information_matrix(pcr_context *ctx, const float *src_xyz, int64_t n_src, const float *tgt_xyz, int64_t n_tgt,
+                                      double max_dist, const double *T, double *info36) {
+    ENTER(ctx);
+    if (!info36 || n_src < 0 || n_tgt < 0) return PCR_EINVAL;
+    if (!(max_dist > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
+    PCR_TRY(check_T(ctx, T));
+    PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n_src) + pcr_scratch_bytes_for(n_tgt)));
+    DevCloud s, t;
+    PCR_TRY(import_cloud(ctx, src_xyz, nullptr, n_src, &s, nullptr));
+    PCR_TRY(import_cloud(ctx, tgt_xyz, nullptr, n_tgt, &t, nullptr));
+    pcr_result r;
+    return pcr_dev_evaluate(ctx, &s, &t, max_dist, T, &r, nullptr, info36);
+}

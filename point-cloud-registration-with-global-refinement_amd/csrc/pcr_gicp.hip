@@ -1,0 +1,448 @@
+// pcr_gicp.hip -- the GICP inner loop on gfx950 (K10 + K11 + K12 fused into ONE kernel per iteration):
+//   transform -> exact 1-NN within max_dist over the target BVH (warm-started from the previous match)
+//   -> plane-to-plane whitening W = (Cs+Ct)^(-1/2) in closed form -> 3 robustly weighted rows
+//   -> wavefront/LDS reduction of the 21+6 normal-equation sums -> last-arriving workgroup sums the
+//   per-workgroup partials in fixed order, tests convergence, solves the 6x6 system (pivoted LDL^T) and
+//   left-multiplies the pose, all on the device.  The host only polls a 'done' word every few launches.
+// Reference behaviour: Open3D RegistrationGeneralizedICP / RegistrationICP /
+// TransformationEstimationForGeneralizedICP::ComputeTransformation as called at ALL_FUNCTIONS.py:304-311 and
+// 2_MGICP_refinement_in_NCLT_dataset.py:155-162.
+#include <cmath>
+#include <cstring>
+#include "pcr_device.h"
+
+#define ICP_BS 256
+#define NV 30            // 21 (upper JTJ) + 6 (JTr) + sum r^2 + sum d^2 + count
+#define NVP 32           // padded row of a partial
+
+enum { ICP_MODE_GICP = 0, ICP_MODE_EVAL = 1 };
+
+struct IcpState {
+    double T[16];
+    double fitness, rmse;       // of the most recent search
+    double sums[NVP];           // reduced sums of the most recent launch
+    long long count;
+    int iter;                   // pose updates applied
+    int launches;               // searches done
+    int done, converged;
+    unsigned int ticket;
+    int pad;
+};
+
+struct IcpArgs {
+    const float4 *src_pts, *src_nrm; const int *ns_ptr;
+    const float4 *tgt_pts, *tgt_nrm, *tgt_boxes; const int *nt_ptr;
+    int32_t *match;
+    IcpState *state;
+    double *partials;
+    double max_dist2; float r2f;
+    int loss; double loss_k; double a;          // a = 1 - epsilon
+    double rel_fit, rel_rmse; int max_it;
+    int single;                                  // 1: linearise once, never update (debug / evaluate)
+};
+
+struct IcpInit { double T[16]; };
+__global__ void k_icp_init(IcpState *st, IcpInit in) {
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 16; k++) st->T[k] = in.T[k];
+        st->fitness = 0; st->rmse = 0; st->count = 0; st->iter = 0; st->launches = 0; st->done = 0; st->converged = 0; st->ticket = 0; st->pad = 0;
+        for (int k = 0; k < NVP; k++) st->sums[k] = 0;
+    }
+}
+
+struct NnVisitor {
+    const float4 *__restrict__ pts;
+    int n, best;
+    float qx, qy, qz, bestd;
+    __device__ float bound() const { return bestd; }
+    __device__ void leaf(int l) {
+        const int b = l * PCR_LEAF;
+#pragma unroll
+        for (int j = 0; j < PCR_LEAF; j++) {
+            const int idx = b + j;
+            if (idx < n) {
+                const float4 p = pts[idx];
+                const float d = pcr_d2(p.x - qx, p.y - qy, p.z - qz);
+                if (d < bestd) { bestd = d; best = idx; }
+            }
+        }
+    }
+};
+
+__device__ static inline double icp_weight(int loss, double k, double r) {
+    if (loss == PCR_LOSS_L1) return 1.0 / fmax(fabs(r), 1e-300);    // Open3D: 1/|r| (unguarded); guard only against r == 0
+    if (loss == PCR_LOSS_GM) { const double d = k + r * r; return k / (d * d); }
+    return 1.0;
+}
+
+// 6x6 symmetric solve, LDL^T with diagonal pivoting (as Eigen::LDLT), one lane
+__device__ static bool icp_ldlt6(const double *A36, const double *b6, double *x6) {
+    double A[36], L[36], D[6], y[6], z[6]; int perm[6];
+    for (int i = 0; i < 36; i++) { A[i] = A36[i]; L[i] = 0; }
+    for (int i = 0; i < 6; i++) perm[i] = i;
+    for (int k = 0; k < 6; k++) {
+        int piv = k; double best = fabs(A[k * 6 + k]);
+        for (int i = k + 1; i < 6; i++) if (fabs(A[i * 6 + i]) > best) { best = fabs(A[i * 6 + i]); piv = i; }
+        if (piv != k) {
+            for (int j = 0; j < 6; j++) { double t = A[k * 6 + j]; A[k * 6 + j] = A[piv * 6 + j]; A[piv * 6 + j] = t; }
+            for (int j = 0; j < 6; j++) { double t = A[j * 6 + k]; A[j * 6 + k] = A[j * 6 + piv]; A[j * 6 + piv] = t; }
+            for (int j = 0; j < k; j++) { double t = L[k * 6 + j]; L[k * 6 + j] = L[piv * 6 + j]; L[piv * 6 + j] = t; }
+            int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+        }
+        const double d = A[k * 6 + k];
+        D[k] = d; L[k * 6 + k] = 1.0;
+        if (d == 0.0 || !isfinite(d)) return false;
+        for (int i = k + 1; i < 6; i++) L[i * 6 + k] = A[i * 6 + k] / d;
+        for (int i = k + 1; i < 6; i++)
+            for (int j = k + 1; j < 6; j++) A[i * 6 + j] -= L[i * 6 + k] * d * L[j * 6 + k];
+    }
+    for (int i = 0; i < 6; i++) { double s = b6[perm[i]]; for (int j = 0; j < i; j++) s -= L[i * 6 + j] * y[j]; y[i] = s; }
+    for (int i = 0; i < 6; i++) y[i] /= D[i];
+    for (int i = 5; i >= 0; i--) { double s = y[i]; for (int j = i + 1; j < 6; j++) s -= L[j * 6 + i] * z[j]; z[i] = s; }
+    bool ok = true;
+    for (int i = 0; i < 6; i++) { x6[perm[i]] = z[i]; }
+    for (int i = 0; i < 6; i++) ok = ok && isfinite(x6[i]);
+    return ok;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
+    IcpState *st = a.state;
+    if (st->done) return;
+    __shared__ BvhMeta m;
+    __shared__ double red[ICP_BS / PCR_WAVE][NVP];
+    __shared__ double fin[8][NVP];
+    __shared__ int is_last;
+    const int ns = *a.ns_ptr, nt = *a.nt_ptr;
+    int nb = (ns + ICP_BS - 1) / ICP_BS;
+    if (nb < 1) nb = 1;
+    if ((int)blockIdx.x >= nb) return;
+    if (threadIdx.x == 0) pcr_bvh_meta(nt, m);
+    __syncthreads();
+    const int launches = st->launches;
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = st->T[k];
+
+    double acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) acc[k] = 0.0;
+
+    const int i = blockIdx.x * ICP_BS + threadIdx.x;
+    if (i < ns) {
+        const float4 pf = a.src_pts[i];
+        const double px = pf.x, py = pf.y, pz = pf.z;
+        const double qx = T[0] * px + T[1] * py + T[2] * pz + T[3];
+        const double qy = T[4] * px + T[5] * py + T[6] * pz + T[7];
+        const double qz = T[8] * px + T[9] * py + T[10] * pz + T[11];
+        NnVisitor v;
+        v.pts = a.tgt_pts; v.n = nt; v.best = -1; v.bestd = a.r2f;
+        v.qx = (float)qx; v.qy = (float)qy; v.qz = (float)qz;
+        if (nt > 0) {
+            int seed = launches > 0 ? a.match[i] : -1;
+            if (seed >= 0) {
+                const float4 c = a.tgt_pts[seed];
+                const float d = pcr_d2(c.x - v.qx, c.y - v.qy, c.z - v.qz);
+                if (d < v.bestd) { v.bestd = d; v.best = seed; }
+            } else {
+                v.leaf(pcr_bvh_greedy_leaf(a.tgt_boxes, m, v.qx, v.qy, v.qz));
+            }
+            pcr_bvh_traverse(a.tgt_boxes, m, v.qx, v.qy, v.qz, v);
+        }
+        int best = v.best;
+        if (best >= 0) {
+            const float4 tf = a.tgt_pts[best];
+            const double dx = qx - (double)tf.x, dy = qy - (double)tf.y, dz = qz - (double)tf.z;
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 < a.max_dist2) {
+                acc[28] = d2; acc[29] = 1.0;
+                if (MODE == ICP_MODE_GICP) {
+                    // effective covariance normals: C = I - a m m^T, m = e1 when n.x < -0.99 (Open3D GetRotationFromE1ToX)
+                    const float4 sn = a.src_nrm[i], tn = a.tgt_nrm[best];
+                    double sx = sn.x, sy = sn.y, sz = sn.z, tx = tn.x, ty = tn.y, tz = tn.z;
+                    if (sx < -0.99) { sx = 1; sy = 0; sz = 0; }
+                    if (tx < -0.99) { tx = 1; ty = 0; tz = 0; }
+                    double inv = 1.0 / sqrt(sx * sx + sy * sy + sz * sz);
+                    sx *= inv; sy *= inv; sz *= inv;
+                    inv = 1.0 / sqrt(tx * tx + ty * ty + tz * tz);
+                    tx *= inv; ty *= inv; tz *= inv;
+                    // rotate the source normal into the target frame (covariance R C R^T)
+                    const double ux = T[0] * sx + T[1] * sy + T[2] * sz, uy = T[4] * sx + T[5] * sy + T[6] * sz, uz = T[8] * sx + T[9] * sy + T[10] * sz;
+                    const double c = ux * tx + uy * ty + uz * tz;
+                    // M = 2I - a(uu^T + vv^T): eigenpairs (2 - a(1+c), u+v), (2 - a(1-c), u-v), (2, u x v)
+                    const double SQ2 = 1.4142135623730951;
+                    const double lp = 2.0 - a.a * (1.0 + c), lm = 2.0 - a.a * (1.0 - c);
+                    const double slp = sqrt(lp), slm = sqrt(lm);
+                    const double gp = a.a / (2.0 * SQ2 * slp * (SQ2 + slp)), gm = a.a / (2.0 * SQ2 * slm * (SQ2 + slm));
+                    const double ex = ux + tx, ey = uy + ty, ez = uz + tz, fx = ux - tx, fy = uy - ty, fz = uz - tz;
+                    const double w0 = 1.0 / SQ2;
+                    double W[9];
+                    W[0] = w0 + gp * ex * ex + gm * fx * fx; W[1] = gp * ex * ey + gm * fx * fy; W[2] = gp * ex * ez + gm * fx * fz;
+                    W[4] = w0 + gp * ey * ey + gm * fy * fy; W[5] = gp * ey * ez + gm * fy * fz; W[8] = w0 + gp * ez * ez + gm * fz * fz;
+                    W[3] = W[1]; W[6] = W[2]; W[7] = W[5];
+                    double r2 = 0;
+#pragma unroll
+                    for (int row = 0; row < 3; row++) {
+                        const double wx = W[row * 3], wy = W[row * 3 + 1], wz = W[row * 3 + 2];
+                        double J[6];
+                        J[0] = qy * wz - qz * wy; J[1] = qz * wx - qx * wz; J[2] = qx * wy - qy * wx;   // q x W_row
+                        J[3] = wx; J[4] = wy; J[5] = wz;
+                        const double r = wx * dx + wy * dy + wz * dz;
+                        const double w = icp_weight(a.loss, a.loss_k, r);
+                        int t = 0;
+#pragma unroll
+                        for (int p = 0; p < 6; p++) {
+                            const double wj = w * J[p];
+#pragma unroll
+                            for (int q = p; q < 6; q++) acc[t++] += wj * J[q];
+                            acc[21 + p] += wj * r;
+                        }
+                        r2 += r * r;
+                    }
+                    acc[27] = r2;
+                } else {
+                    // GetInformationMatrixFromPointClouds: sum G^T G over matched TARGET points
+                    const double x = tf.x, y = tf.y, z = tf.z;
+                    const double G[3][6] = {{0, z, -y, 1, 0, 0}, {-z, 0, x, 0, 1, 0}, {y, -x, 0, 0, 0, 1}};
+#pragma unroll
+                    for (int row = 0; row < 3; row++) {
+                        int t = 0;
+#pragma unroll
+                        for (int p = 0; p < 6; p++)
+#pragma unroll
+                            for (int q = p; q < 6; q++) acc[t++] += G[row][p] * G[row][q];
+                    }
+                }
+            } else best = -1;
+        }
+        a.match[i] = best;
+    }
+
+    // ---- workgroup reduction: fixed shuffle tree, then waves in order
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; k++) { const double s = pcr_wave_sum(acc[k]); if (lane == 0) red[wv][k] = s; }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = red[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < ICP_BS / PCR_WAVE; w++) s += red[w][threadIdx.x];
+        a.partials[(size_t)blockIdx.x * NVP + threadIdx.x] = s;
+        __threadfence();                       // release this workgroup's partial (agent scope)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int t = atomicAdd(&st->ticket, 1u);
+        is_last = (t == (unsigned int)(nb - 1));
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();                           // acquire: other workgroups' partials
+
+    // ---- last workgroup: sum the partials in workgroup order (deterministic), then finish the iteration
+    {
+        const int vcol = threadIdx.x & 31, chunk = threadIdx.x >> 5;      // 8 chunks x 32 columns
+        const int per = (nb + 7) / 8;
+        const int b0 = chunk * per, b1 = min(nb, b0 + per);
+        double s = 0;
+        if (vcol < NV) for (int b = b0; b < b1; b++) s += a.partials[(size_t)b * NVP + vcol];
+        fin[chunk][vcol] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NVP) {
+        double s = 0;
+#pragma unroll
+        for (int c = 0; c < 8; c++) s += fin[c][threadIdx.x];
+        fin[0][threadIdx.x] = s;
+        st->sums[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double *S = fin[0];
+        const long long count = (long long)(S[29] + 0.5);
+        const double fit = ns > 0 ? (double)count / (double)ns : 0.0;
+        const double rmse = count > 0 ? sqrt(S[28] / (double)count) : 0.0;
+        bool stop = false, conv = false;
+        if (a.single) stop = true;
+        else if (launches > 0 && fabs(st->fitness - fit) < a.rel_fit && fabs(st->rmse - rmse) < a.rel_rmse) { stop = true; conv = true; }
+        else if (st->iter >= a.max_it) stop = true;
+        st->fitness = fit; st->rmse = rmse; st->count = count;
+        if (!stop && MODE == ICP_MODE_GICP) {
+            double U[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+            if (count > 0) {
+                double A[36], nb6[6], x[6];
+                int t = 0;
+                for (int p = 0; p < 6; p++) for (int q = p; q < 6; q++) { A[p * 6 + q] = S[t]; A[q * 6 + p] = S[t]; t++; }
+                for (int p = 0; p < 6; p++) nb6[p] = -S[21 + p];
+                if (icp_ldlt6(A, nb6, x)) {
+                    const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]), sg = sin(x[2]);
+                    U[0] = cg * cb; U[1] = cg * sb * sa - sg * ca; U[2] = cg * sb * ca + sg * sa; U[3] = x[3];
+                    U[4] = sg * cb; U[5] = sg * sb * sa + cg * ca; U[6] = sg * sb * ca - cg * sa; U[7] = x[4];
+                    U[8] = -sb;     U[9] = cb * sa;                U[10] = cb * ca;               U[11] = x[5];
+                }
+            }
+            double Tn[16];
+            for (int r = 0; r < 4; r++)
+                for (int c = 0; c < 4; c++) {
+                    double s = 0;
+                    for (int k = 0; k < 4; k++) s += U[r * 4 + k] * st->T[k * 4 + c];
+                    Tn[r * 4 + c] = s;
+                }
+            for (int k = 0; k < 16; k++) st->T[k] = Tn[k];
+            st->iter = st->iter + 1;
+        }
+        st->launches = launches + 1;
+        st->converged = conv ? 1 : 0;
+        st->ticket = 0;
+        __threadfence();
+        st->done = stop ? 1 : 0;
+    }
+}
+
+static void fill_args(IcpArgs &a, const DevCloud *src, const DevCloud *tgt, double max_dist, const pcr_gicp_params *p,
+                      int32_t *match, IcpState *st, double *partials, int single) {
+    a.src_pts = src->pts; a.src_nrm = src->nrm; a.ns_ptr = src->n;
+    a.tgt_pts = tgt->pts; a.tgt_nrm = tgt->nrm; a.tgt_boxes = tgt->boxes; a.nt_ptr = tgt->n;
+    a.match = match; a.state = st; a.partials = partials;
+    a.max_dist2 = max_dist * max_dist;
+    const double r2w = a.max_dist2 * (1.0 + 1e-6);
+    a.r2f = r2w < 3.0e38 ? (float)r2w : 3.0e38f;
+    a.loss = p ? p->loss : 0; a.loss_k = p ? p->loss_k : 1.0; a.a = 1.0 - (p ? p->epsilon : 1e-3);
+    a.rel_fit = p ? p->relative_fitness : 1e-6; a.rel_rmse = p ? p->relative_rmse : 1e-6; a.max_it = p ? p->max_iteration : 30;
+    a.single = single;
+}
+
+static int read_state(pcr_context *ctx, const IcpState *st_dev, IcpState *host) {
+    PCR_HIP_CHECK(ctx, hipMemcpyAsync(ctx->pinned, st_dev, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(host, ctx->pinned, sizeof(IcpState));
+    return PCR_OK;
+}
+
+static void state_to_result(const IcpState &s, pcr_result *out) {
+    for (int k = 0; k < 16; k++) out->transformation[k] = s.T[k];
+    out->fitness = s.fitness; out->inlier_rmse = s.rmse; out->n_correspondences = s.count;
+    out->iterations = s.iter; out->converged = s.converged;
+}
+
+int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, double max_dist, const double *T0,
+                 const pcr_gicp_params *p, pcr_result *out, int32_t *match_dev) {
+    if (!(max_dist > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
+    if (!src->nrm || !tgt->nrm) { ctx->err = "GICP needs normals (or covariances) on both clouds"; return PCR_EINVAL; }
+    ArenaMark mark(ctx);
+    const int cap = src->cap > 0 ? src->cap : 1;
+    const int nbmax = (cap + ICP_BS - 1) / ICP_BS;
+    IcpState *st = arena<IcpState>(ctx, 1);
+    double *partials = arena<double>(ctx, (size_t)nbmax * NVP);
+    int32_t *match = match_dev ? match_dev : arena<int32_t>(ctx, cap);
+    if (!st || !partials || !match) return PCR_ENOMEM;
+    IcpArgs a; fill_args(a, src, tgt, max_dist, p, match, st, partials, 0);
+    IcpInit in; memcpy(in.T, T0, sizeof in.T);
+    hipLaunchKernelGGL(k_icp_init, dim3(1), dim3(64), 0, ctx->stream, st, in);
+
+    // Launch in chunks; the state of chunk c is copied back while chunk c+1 is already queued, so the GPU never
+    // idles on the host.  Launches after 'done' return at their first instruction.
+    const int total = a.max_it + 1, CHUNK = 8;
+    IcpState *slots = (IcpState *)ctx->pinned;      // two read-back slots
+    int launched = 0, cur = 0, prev = -1;
+    IcpState fin; bool have = false;
+    for (;;) {
+        const bool enq = launched < total;
+        if (enq) {
+            const int c = total - launched < CHUNK ? total - launched : CHUNK;
+            for (int k = 0; k < c; k++) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP>), dim3(nbmax), dim3(ICP_BS), 0, ctx->stream, a);
+            launched += c;
+            PCR_HIP_CHECK(ctx, hipMemcpyAsync(&slots[cur], st, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
+            PCR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[cur], ctx->stream));
+        }
+        if (prev >= 0) {
+            PCR_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev[prev]));
+            if (slots[prev].done) { fin = slots[prev]; have = true; break; }
+        }
+        if (!enq) break;
+        prev = cur; cur ^= 1;
+    }
+    if (!have) { ctx->err = "GICP loop ended without a final state"; return PCR_EHIP; }
+    // drain the (no-op) tail so the pinned slots and the arena can be reused safely
+    PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    state_to_result(fin, out);
+    for (int k = 0; k < 16; k++) if (!std::isfinite(fin.T[k])) { ctx->err = "non-finite pose"; return PCR_ENUMERIC; }
+    return PCR_OK;
+}
+
+int pcr_dev_linearize_once(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, double max_dist, const double *T,
+                           const pcr_gicp_params *p, double *JTJ36, double *JTr6, double *stats3, int32_t *match_dev) {
+    if (!(max_dist > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
+    ArenaMark mark(ctx);
+    const int cap = src->cap > 0 ? src->cap : 1;
+    const int nbmax = (cap + ICP_BS - 1) / ICP_BS;
+    IcpState *st = arena<IcpState>(ctx, 1);
+    double *partials = arena<double>(ctx, (size_t)nbmax * NVP);
+    int32_t *match = match_dev ? match_dev : arena<int32_t>(ctx, cap);
+    if (!st || !partials || !match) return PCR_ENOMEM;
+    IcpArgs a; fill_args(a, src, tgt, max_dist, p, match, st, partials, 1);
+    IcpInit in; memcpy(in.T, T, sizeof in.T);
+    hipLaunchKernelGGL(k_icp_init, dim3(1), dim3(64), 0, ctx->stream, st, in);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP>), dim3(nbmax), dim3(ICP_BS), 0, ctx->stream, a);
+    IcpState h;
+    PCR_TRY(read_state(ctx, st, &h));
+    int t = 0;
+    for (int r = 0; r < 6; r++) for (int c = r; c < 6; c++) { JTJ36[r * 6 + c] = h.sums[t]; JTJ36[c * 6 + r] = h.sums[t]; t++; }
+    for (int r = 0; r < 6; r++) JTr6[r] = h.sums[21 + r];
+    stats3[0] = (double)h.count; stats3[1] = h.sums[28]; stats3[2] = h.sums[27];
+    return PCR_OK;
+}
+
+int pcr_dev_evaluate(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, double max_dist, const double *T,
+                     pcr_result *out, int32_t *match_dev, double *info36) {
+    if (!(max_dist > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
+    ArenaMark mark(ctx);
+    const int cap = src->cap > 0 ? src->cap : 1;
+    const int nbmax = (cap + ICP_BS - 1) / ICP_BS;
+    IcpState *st = arena<IcpState>(ctx, 1);
+    double *partials = arena<double>(ctx, (size_t)nbmax * NVP);
+    int32_t *match = match_dev ? match_dev : arena<int32_t>(ctx, cap);
+    if (!st || !partials || !match) return PCR_ENOMEM;
+    IcpArgs a; fill_args(a, src, tgt, max_dist, nullptr, match, st, partials, 1);
+    IcpInit in; memcpy(in.T, T, sizeof in.T);
+    hipLaunchKernelGGL(k_icp_init, dim3(1), dim3(64), 0, ctx->stream, st, in);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_EVAL>), dim3(nbmax), dim3(ICP_BS), 0, ctx->stream, a);
+    IcpState h;
+    PCR_TRY(read_state(ctx, st, &h));
+    if (out) { state_to_result(h, out); out->iterations = 0; out->converged = 0; }
+    if (info36) {
+        int t = 0;
+        for (int r = 0; r < 6; r++) for (int c = r; c < 6; c++) { info36[r * 6 + c] = h.sums[t]; info36[c * 6 + r] = h.sums[t]; t++; }
+    }
+    return PCR_OK;
+}
+
+// ---- correspondence_set: (source index, target index) rows, mapped back to the caller's point order
+__global__ void __launch_bounds__(256) k_match_flags(const int32_t *__restrict__ match, const int *__restrict__ n_ptr, uint8_t *__restrict__ flags) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < *n_ptr) flags[i] = match[i] >= 0 ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_match_emit(const int32_t *__restrict__ match, const int *__restrict__ n_ptr, const uint8_t *__restrict__ flags, const int *__restrict__ pos,
+                                                    const uint32_t *__restrict__ sperm, const uint32_t *__restrict__ tperm, int32_t *__restrict__ corr) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= *n_ptr || !flags[i]) return;
+    const int o = pos[i], t = match[i];
+    corr[2 * (size_t)o] = sperm ? (int32_t)sperm[i] : i;
+    corr[2 * (size_t)o + 1] = tperm ? (int32_t)tperm[t] : t;
+}
+
+int pcr_dev_compact_matches(pcr_context *ctx, const int32_t *match, const int *n, int cap, const uint32_t *src_perm,
+                            const uint32_t *tgt_perm, int32_t *corr_out, int64_t *n_corr) {
+    if (cap <= 0) { if (n_corr) *n_corr = 0; return PCR_OK; }
+    ArenaMark mark(ctx);
+    uint8_t *flags = arena<uint8_t>(ctx, cap);
+    int *pos = arena<int>(ctx, cap);
+    int *total = arena<int>(ctx, 1);
+    if (!flags || !pos || !total) return PCR_ENOMEM;
+    const int nb = (cap + 255) / 256;
+    hipLaunchKernelGGL(k_match_flags, dim3(nb), dim3(256), 0, ctx->stream, match, n, flags);
+    PCR_TRY(pcr_dev_flag_scan(ctx, flags, n, cap, pos, total));
+    hipLaunchKernelGGL(k_match_emit, dim3(nb), dim3(256), 0, ctx->stream, match, n, flags, pos, src_perm, tgt_perm, corr_out);
+    if (n_corr) PCR_TRY(pcr_read_count(ctx, total, n_corr));
+    return PCR_OK;
+}

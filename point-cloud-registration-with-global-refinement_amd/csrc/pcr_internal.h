@@ -1,0 +1,103 @@
+// pcr_internal.h -- host-side internals of libpcr_hip.so (context, scratch arena, device cloud records).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/pcr_hip.h"
+
+#define PCR_LEAF 8          // points per BVH leaf
+#define PCR_FANOUT 8        // children per BVH node
+#define PCR_MAX_LEVELS 12
+
+struct pcr_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    char *arena = nullptr;
+    size_t arena_cap = 0, arena_off = 0;
+    char *pinned = nullptr;        // host-pinned read-back window
+    size_t pinned_cap = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    std::string err;
+};
+
+#define PCR_HIP_CHECK(ctx, expr)                                                                   \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                        \
+            return PCR_EHIP;                                                                       \
+        }                                                                                          \
+    } while (0)
+
+#define PCR_TRY(expr)                                                                              \
+    do {                                                                                           \
+        int _rc = (expr);                                                                          \
+        if (_rc != PCR_OK) return _rc;                                                             \
+    } while (0)
+
+// ---- arena ------------------------------------------------------------------------------------
+int pcr_arena_reserve(pcr_context *ctx, size_t bytes);       // grow (sync + realloc) if needed, reset offset
+void *pcr_arena_alloc(pcr_context *ctx, size_t bytes);       // bump, 256-B aligned; nullptr if exhausted
+template <class T> static inline T *arena(pcr_context *ctx, size_t count) {
+    return (T *)pcr_arena_alloc(ctx, count * sizeof(T));
+}
+struct ArenaMark { pcr_context *ctx; size_t off; ArenaMark(pcr_context *c) : ctx(c), off(c->arena_off) {} ~ArenaMark() { ctx->arena_off = off; } };
+
+// ---- device-resident cloud: Morton-ordered float4 points (+ optional normals) with a device-side count ----
+struct DevCloud {
+    float4 *pts = nullptr;       // xyz, w = bit pattern of the original index (or 0)
+    float4 *nrm = nullptr;       // optional
+    int *n = nullptr;            // device count
+    int cap = 0;                 // host upper bound of *n
+    float4 *boxes = nullptr;     // implicit BVH: node i -> boxes[2i] = lo, boxes[2i+1] = hi
+};
+
+static inline size_t bvh_node_capacity(int cap_points) {
+    size_t c = ((size_t)cap_points + PCR_LEAF - 1) / PCR_LEAF, tot = c;
+    while (c > PCR_FANOUT) { c = (c + PCR_FANOUT - 1) / PCR_FANOUT; tot += c; }
+    return tot + 8;
+}
+
+// ---- sort (pcr_sort.hip; rocPRIM device radix sort, the one library primitive used) -------------
+size_t pcr_sort_temp_bytes(size_t n);
+int pcr_sort_pairs(pcr_context *ctx, void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
+                   const uint32_t *vals_in, uint32_t *vals_out, size_t n, int end_bit);
+
+// ---- cloud ops (pcr_cloud.hip) -------------------------------------------------------------------
+size_t pcr_scratch_bytes_for(int64_t n);                       // generous per-cloud scratch estimate
+int pcr_dev_bounds(pcr_context *ctx, const float *xyz, int64_t n, double *bounds6_host);
+// voxel grid mean in Morton order of the voxel index; out.cap must be >= n
+int pcr_dev_voxel(pcr_context *ctx, const float *xyz, const float *nrm_in, int64_t n, const double *bounds6,
+                  double voxel, DevCloud *out);
+// Morton-sort a raw packed cloud (for kNN on un-voxelised input); perm[i] = original index of sorted point i
+int pcr_dev_sort_cloud(pcr_context *ctx, const float *xyz, int64_t n, const double *bounds6, DevCloud *out,
+                       uint32_t *perm);
+int pcr_dev_build_bvh(pcr_context *ctx, DevCloud *c);
+// SOR: keep flags + compaction into `out` (out.cap >= in.cap); returns nothing to the host
+int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double std_ratio, DevCloud *out,
+                uint8_t *keep_sorted /*optional device, in.cap*/, double *avg_sorted /*optional*/);
+// normals (and optionally covariances) by k-NN / hybrid / radius neighbourhoods over the BVH
+int pcr_dev_normals(pcr_context *ctx, DevCloud *c, int search_kind, int knn, double radius, const float4 *prior,
+                    float4 *normals_out, float *cov6_out /*optional, sorted order, 6 per point*/);
+int pcr_dev_knn_debug(pcr_context *ctx, const DevCloud *c, int k, double radius, int32_t *idx, float *d2, int32_t *counts);
+int pcr_read_count(pcr_context *ctx, const int *dev_n, int64_t *out);
+// pos[i] = number of set flags before i, *total_dev = number of set flags (n from device pointer or n_cap)
+int pcr_dev_flag_scan(pcr_context *ctx, const uint8_t *flags, const int *n_ptr, int n_cap, int *pos, int *total_dev);
+// gather helpers between caller order and Morton order
+int pcr_dev_scatter_rows_f4_to_f3(pcr_context *ctx, const float4 *src_sorted, const uint32_t *perm, const int *n, int cap, float *dst_packed);
+int pcr_dev_pack_f4_to_f3(pcr_context *ctx, const float4 *src, const int *n, int cap, float *dst_packed);
+int pcr_dev_unpack_f3_to_f4(pcr_context *ctx, const float *src, int64_t n, float4 *dst);
+int pcr_dev_gather_f3_to_f4(pcr_context *ctx, const float *src_packed, const uint32_t *perm, int64_t n, float4 *dst);
+
+// ---- gicp (pcr_gicp.hip) --------------------------------------------------------------------------
+struct IcpOutputs { pcr_result res; };
+int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, double max_dist, const double *T0,
+                 const pcr_gicp_params *p, pcr_result *out, int32_t *match_dev /*optional src.cap*/);
+int pcr_dev_linearize_once(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, double max_dist, const double *T,
+                           const pcr_gicp_params *p, double *JTJ36, double *JTr6, double *stats3, int32_t *match_dev);
+int pcr_dev_evaluate(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, double max_dist, const double *T,
+                     pcr_result *out, int32_t *match_dev, double *info36 /*optional*/);
+int pcr_dev_compact_matches(pcr_context *ctx, const int32_t *match, const int *n, int cap, const uint32_t *src_perm,
+                            const uint32_t *tgt_perm, int32_t *corr_out, int64_t *n_corr);

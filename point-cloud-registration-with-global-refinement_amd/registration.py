@@ -1,0 +1,257 @@
+"""Stand-ins for ``o3d.pipelines.registration`` as used on the reference's hot path.
+
+``registration_generalized_icp`` ALL_FUNCTIONS.py:304-311 / 2_MGICP...py:155-162; ``registration_icp`` with
+``TransformationEstimationForGeneralizedICP`` :220-226; ``L1Loss`` :284, ``GMLoss`` :219;
+``ICPConvergenceCriteria`` :309-311; ``evaluate_registration`` :809-820;
+``get_information_matrix_from_point_clouds`` :327-331; ``compute_fpfh_feature`` :186-187;
+``FastGlobalRegistrationOption`` :189-196; ``registration_fgr_based_on_feature_matching`` :198-202.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .geometry import PointCloud, _ptr, _torch
+
+
+class RobustKernel:
+    kind = _lib.LOSS_L2
+    k = 1.0
+
+
+class L2Loss(RobustKernel):
+    pass
+
+
+class L1Loss(RobustKernel):
+    kind = _lib.LOSS_L1
+
+
+class GMLoss(RobustKernel):
+    kind = _lib.LOSS_GM
+
+    def __init__(self, k: float = 1.0):
+        self.k = float(k)
+
+
+class TransformationEstimationForGeneralizedICP:
+    def __init__(self, kernel: RobustKernel | None = None, epsilon: float = 1e-3):
+        self.kernel = kernel if kernel is not None else L2Loss()
+        self.epsilon = float(epsilon)
+
+
+class ICPConvergenceCriteria:
+    def __init__(self, relative_fitness: float = 1e-6, relative_rmse: float = 1e-6, max_iteration: int = 30):
+        self.relative_fitness = float(relative_fitness)
+        self.relative_rmse = float(relative_rmse)
+        self.max_iteration = int(max_iteration)
+
+
+class FastGlobalRegistrationOption:
+    def __init__(self, division_factor=1.4, use_absolute_scale=False, decrease_mu=False,
+                 maximum_correspondence_distance=0.025, iteration_number=64, tuple_scale=0.95,
+                 maximum_tuple_count=1000, tuple_test=True, seed=None):
+        self.division_factor = float(division_factor)
+        self.use_absolute_scale = bool(use_absolute_scale)
+        self.decrease_mu = bool(decrease_mu)
+        self.maximum_correspondence_distance = float(maximum_correspondence_distance)
+        self.iteration_number = int(iteration_number)
+        self.tuple_scale = float(tuple_scale)
+        self.maximum_tuple_count = int(maximum_tuple_count)
+        self.tuple_test = bool(tuple_test)
+        self.seed = seed
+
+
+class RegistrationResult:
+    """``transformation`` (4x4 float64, source->target), ``fitness``, ``inlier_rmse``, ``correspondence_set``."""
+
+    def __init__(self, transformation=None, fitness=0.0, inlier_rmse=0.0, correspondence_set=None, iterations=0,
+                 converged=False, scales=None):
+        self.transformation = np.eye(4) if transformation is None else np.array(transformation, dtype=np.float64).reshape(4, 4)
+        self.fitness = float(fitness)
+        self.inlier_rmse = float(inlier_rmse)
+        self._corr = correspondence_set           # torch int32 (K,2) on device, materialised lazily
+        self.iterations = int(iterations)
+        self.converged = bool(converged)
+        self.scales = scales or []
+
+    @property
+    def correspondence_set(self):
+        if self._corr is None:
+            return np.zeros((0, 2), np.int32)
+        if not isinstance(self._corr, np.ndarray):
+            self._corr = self._corr.cpu().numpy()
+        return self._corr
+
+    def __repr__(self):
+        return (f"RegistrationResult with fitness={self.fitness:e}, inlier_rmse={self.inlier_rmse:e}, "
+                f"and correspondence_set size of {len(self.correspondence_set)}")
+
+
+class Feature:
+    """``o3d.pipelines.registration.Feature``: ``data`` is (dimension, N) float64 like Open3D's."""
+
+    def __init__(self, dev):
+        self._dev = dev            # torch (N,33) float32 cuda
+
+    @property
+    def data(self):
+        return self._dev.detach().cpu().numpy().astype(np.float64).T
+
+    def dimension(self):
+        return int(self._dev.shape[1])
+
+    def num(self):
+        return int(self._dev.shape[0])
+
+
+def _params(estimation, criteria) -> _lib.PcrGicpParams:
+    return _lib.PcrGicpParams(int(estimation.kernel.kind), float(estimation.kernel.k), float(estimation.epsilon),
+                              float(criteria.relative_fitness), float(criteria.relative_rmse), int(criteria.max_iteration))
+
+
+def _result(r: _lib.PcrResult, corr=None, scales=None) -> RegistrationResult:
+    if corr is not None:
+        corr = corr[: r.n_correspondences]
+    return RegistrationResult(np.array(r.transformation, dtype=np.float64).reshape(4, 4), r.fitness, r.inlier_rmse, corr,
+                              r.iterations, bool(r.converged), scales)
+
+
+def _T(init):
+    T = np.ascontiguousarray(np.asarray(init, dtype=np.float64).reshape(4, 4))
+    return T, T.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ensure_gicp_normals(pc: PointCloud):
+    """Open3D InitializePointCloudForGeneralizedICP: clouds without covariances and without normals get
+    ``estimate_normals()`` with the default search (KNN 30) first."""
+    if not pc.has_normals():
+        pc = pc.__deepcopy__({})
+        pc.estimate_normals()
+    return pc
+
+
+def registration_generalized_icp(source: PointCloud, target: PointCloud, max_correspondence_distance: float,
+                                 init=np.eye(4), estimation_method=None, criteria=None) -> RegistrationResult:
+    estimation = estimation_method or TransformationEstimationForGeneralizedICP()
+    criteria = criteria or ICPConvergenceCriteria()
+    ctx = _lib.Context.current()
+    torch = _torch()
+    if max_correspondence_distance <= 0:
+        raise RuntimeError("Invalid max_correspondence_distance.")
+    source = _ensure_gicp_normals(source); target = _ensure_gicp_normals(target)
+    ns, nt = len(source), len(target)
+    corr = torch.empty((max(ns, 1), 2), dtype=torch.int32, device="cuda")
+    res = _lib.PcrResult()
+    T, Tp = _T(init)
+    p = _params(estimation, criteria)
+    ctx.check(ctx.lib.pcr_registration_generalized_icp(
+        ctx.handle, _ptr(source.device_xyz()), _ptr(source.device_normals()), C.c_int64(ns), _ptr(target.device_xyz()),
+        _ptr(target.device_normals()), C.c_int64(nt), C.c_double(max_correspondence_distance), Tp, C.byref(p), C.byref(res),
+        _ptr(corr)), "registration_generalized_icp")
+    return _result(res, corr)
+
+
+def registration_icp(source, target, max_correspondence_distance, init=np.eye(4), estimation_method=None, criteria=None):
+    """Only the GICP estimator is on the hot path (ALL_FUNCTIONS.py:220-226)."""
+    if not isinstance(estimation_method, TransformationEstimationForGeneralizedICP):
+        raise RuntimeError("registration_icp: only TransformationEstimationForGeneralizedICP is implemented on the MI355X path")
+    return registration_generalized_icp(source, target, max_correspondence_distance, init, estimation_method, criteria)
+
+
+def multiscale_gicp(source: PointCloud, target: PointCloud, voxel_sizes, max_correspondence_distances, init=np.eye(4),
+                    estimation_method=None, criteria=None, nb_neighbors: int = 30, std_ratio: float = 1.0,
+                    normal_knn: int = 20) -> RegistrationResult:
+    """Device-resident body of the reference's ``Multiscale_GICP`` loops (one C-ABI call for all scales)."""
+    estimation = estimation_method or TransformationEstimationForGeneralizedICP()
+    criteria = criteria or ICPConvergenceCriteria()
+    ctx = _lib.Context.current()
+    torch = _torch()
+    vox = np.ascontiguousarray(np.asarray(voxel_sizes, dtype=np.float64).reshape(-1))
+    dst = np.ascontiguousarray(np.asarray(max_correspondence_distances, dtype=np.float64).reshape(-1))
+    if vox.size != dst.size or vox.size < 1:
+        raise RuntimeError("multiscale_gicp: voxel_sizes and max_correspondence_distances must have the same length >= 1")
+    ns, nt = len(source), len(target)
+    recs = (_lib.PcrScaleRecord * vox.size)()
+    corr = torch.empty((max(ns, 1), 2), dtype=torch.int32, device="cuda")
+    T, Tp = _T(init)
+    p = _params(estimation, criteria)
+    sn = source.device_normals() if source.has_normals() else None
+    tn = target.device_normals() if target.has_normals() else None
+    ctx.check(ctx.lib.pcr_multiscale_gicp(
+        ctx.handle, _ptr(source.device_xyz()), _ptr(sn), C.c_int64(ns), _ptr(target.device_xyz()), _ptr(tn), C.c_int64(nt),
+        vox.ctypes.data_as(C.POINTER(C.c_double)), dst.ctypes.data_as(C.POINTER(C.c_double)), C.c_int(vox.size),
+        C.c_int(nb_neighbors), C.c_double(std_ratio), C.c_int(normal_knn), Tp, C.byref(p), recs, _ptr(corr)),
+        "multiscale_gicp")
+    scales = [dict(voxel=float(vox[i]), max_dist=float(dst[i]), n_voxel=tuple(recs[i].n_voxel), n_clean=tuple(recs[i].n_clean),
+                   iterations=int(recs[i].icp.iterations), fitness=recs[i].icp.fitness, inlier_rmse=recs[i].icp.inlier_rmse,
+                   converged=bool(recs[i].icp.converged), n_corr=int(recs[i].icp.n_correspondences),
+                   T=np.array(recs[i].icp.transformation).reshape(4, 4)) for i in range(vox.size)]
+    return _result(recs[vox.size - 1].icp, corr, scales)
+
+
+def evaluate_registration(source: PointCloud, target: PointCloud, max_correspondence_distance: float,
+                          transformation=np.eye(4)) -> RegistrationResult:
+    ctx = _lib.Context.current()
+    torch = _torch()
+    if max_correspondence_distance <= 0:
+        raise RuntimeError("Invalid max_correspondence_distance.")
+    ns, nt = len(source), len(target)
+    corr = torch.empty((max(ns, 1), 2), dtype=torch.int32, device="cuda")
+    res = _lib.PcrResult()
+    T, Tp = _T(transformation)
+    ctx.check(ctx.lib.pcr_evaluate_registration(ctx.handle, _ptr(source.device_xyz()), C.c_int64(ns), _ptr(target.device_xyz()),
+                                                C.c_int64(nt), C.c_double(max_correspondence_distance), Tp, C.byref(res),
+                                                _ptr(corr)), "evaluate_registration")
+    return _result(res, corr)
+
+
+def get_information_matrix_from_point_clouds(source: PointCloud, target: PointCloud, max_correspondence_distance: float,
+                                             transformation) -> np.ndarray:
+    ctx = _lib.Context.current()
+    info = np.zeros(36, dtype=np.float64)
+    T, Tp = _T(transformation)
+    ctx.check(ctx.lib.pcr_information_matrix(ctx.handle, _ptr(source.device_xyz()), C.c_int64(len(source)),
+                                             _ptr(target.device_xyz()), C.c_int64(len(target)),
+                                             C.c_double(max_correspondence_distance), Tp,
+                                             info.ctypes.data_as(C.POINTER(C.c_double))), "get_information_matrix_from_point_clouds")
+    return info.reshape(6, 6)
+
+
+def compute_fpfh_feature(cloud: PointCloud, search_param) -> Feature:
+    ctx = _lib.Context.current()
+    torch = _torch()
+    if not cloud.has_normals():
+        raise RuntimeError("Failed because input point cloud has no normal.")
+    kind, knn, radius = search_param._spec()
+    n = len(cloud)
+    feat = torch.zeros((max(n, 1), 33), dtype=torch.float32, device="cuda")
+    ctx.check(ctx.lib.pcr_compute_fpfh_feature(ctx.handle, _ptr(cloud.device_xyz()), _ptr(cloud.device_normals()), C.c_int64(n),
+                                               C.c_int(kind), C.c_int(knn), C.c_double(radius), _ptr(feat)), "compute_fpfh_feature")
+    return Feature(feat[:n].contiguous())
+
+
+_fgr_seed_counter = [0x9E3779B97F4A7C15]
+
+
+def registration_fgr_based_on_feature_matching(source: PointCloud, target: PointCloud, source_feature: Feature,
+                                               target_feature: Feature, option: FastGlobalRegistrationOption | None = None):
+    ctx = _lib.Context.current()
+    torch = _torch()
+    option = option or FastGlobalRegistrationOption()
+    seed = option.seed
+    if seed is None:                       # Open3D draws from std::random_device; here a process-local counter
+        _fgr_seed_counter[0] = (_fgr_seed_counter[0] * 6364136223846793005 + 1442695040888963407) & (2 ** 64 - 1)
+        seed = _fgr_seed_counter[0]
+    o = _lib.PcrFgrOption(option.division_factor, int(option.use_absolute_scale), int(option.decrease_mu),
+                          option.maximum_correspondence_distance, option.iteration_number, option.tuple_scale,
+                          option.maximum_tuple_count, int(option.tuple_test), int(seed))
+    ns, nt = len(source), len(target)
+    corr = torch.empty((max(ns, 1), 2), dtype=torch.int32, device="cuda")
+    res = _lib.PcrResult()
+    ctx.check(ctx.lib.pcr_registration_fgr(ctx.handle, _ptr(source.device_xyz()), _ptr(source_feature._dev), C.c_int64(ns),
+                                           _ptr(target.device_xyz()), _ptr(target_feature._dev), C.c_int64(nt), C.byref(o),
+                                           C.byref(res), _ptr(corr)), "registration_fgr_based_on_feature_matching")
+    return _result(res, corr)
