@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""bench.py -- pairs registered per second on synthetic 200k-point NCLT-shaped clouds, 3 GICP scales
+(BASELINE.json metric, config 2).
+
+One "step" = one call of the hot path on one pair already resident in HBM: the whole Multiscale_GICP body
+(voxel_down_sample -> remove_statistical_outlier(30, 1.0) -> estimate_normals(KNN 20) ->
+registration_generalized_icp(L1, 1e-6/1e-6/100) for voxels 0.4/0.2/0.1 m, search radii 1.2/0.4/0.1 m), exactly the
+reference's pair-time definition (2_MGICP...py:190-199).  N>1: one process per GPU, each registers its own pairs
+(no data-path collective); one all-gather of the fixed-size pose records closes the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--points 200000] [--pairs 2] [--no-cpu-baseline]
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "point-cloud-registration-with-global-refinement_amd"
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=200_000)
+    ap.add_argument("--pairs", type=int, default=2, help="distinct synthetic pairs cycled through the steps")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    P = importlib.import_module(PKG)
+    syn = importlib.import_module(PKG + ".synthetic")
+    shard = importlib.import_module(PKG + ".sharding")
+    ctypes = __import__("ctypes")
+
+    # ---- synthetic workload (same seeds on every rank; every rank registers its own copy: weak scaling)
+    pairs = [syn.make_pair(args.points, index=i) for i in range(args.pairs)]
+    clouds = [(P.PointCloud(p.source), P.PointCloud(p.target)) for p in pairs]       # resident in HBM before timing
+    est = P.registration.TransformationEstimationForGeneralizedICP(P.registration.L1Loss())
+    crit = P.registration.ICPConvergenceCriteria(relative_fitness=1e-6, relative_rmse=1e-6, max_iteration=100)
+
+    def step(i):
+        p = pairs[i % len(pairs)]; s, t = clouds[i % len(pairs)]
+        return P.registration.multiscale_gicp(s, t, p.voxel_sizes, p.max_distances_script, p.T_init, est, crit, 30, 1.0, 20)
+
+    ctx = P._lib.Context.current()
+    for i in range(args.warmup):
+        step(i)
+    prof = (ctypes.c_double * 8)()
+    ctx.lib.pcr_profile_enable(ctx.handle, 1)
+    ctx.lib.pcr_profile_read(ctx.handle, prof, 1)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    results = [step(i) for i in range(args.steps)]
+    recs = np.stack([shard.pack_record(rank * args.steps + i, r) for i, r in enumerate(results)])
+    gathered = shard.gather_records(recs, world * args.steps, device=torch.device("cuda", local_rank)) if world > 1 else recs
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ctx.lib.pcr_profile_read(ctx.handle, prof, 0)
+    ctx.lib.pcr_profile_enable(ctx.handle, 0)
+
+    if rank == 0:
+        res = results[-1]
+        # ---- roofline of the dominant kernel (k_icp_iter): algorithmic bytes / launch / launch duration
+        ev_ms, ev_launches, ik_us, live, alg_bytes, issued = (prof[i] for i in range(6))
+        bytes_per_launch = alg_bytes / live if live else 0.0
+        us_event = 1e3 * ev_ms / ev_launches if ev_launches else float("nan")     # HIP events over fully-live chunks
+        us_kernel = ik_us / live if live else float("nan")                         # kernel's own s_memrealtime stamps
+        achieved = bytes_per_launch / (us_event * 1e-6) / 1e9 if ev_launches else 0.0
+        # sanity of the result itself (planted motion) -- printed, not part of the contract
+        p_last = pairs[(args.steps - 1) % len(pairs)]
+        dR = res.transformation[:3, :3].T @ p_last.T_true[:3, :3]
+        ang = float(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))); dtr = float(np.linalg.norm(res.transformation[:3, 3] - p_last.T_true[:3, 3]))
+        line = {
+            "metric": "point-cloud pairs registered/sec (200k pts, 3 GICP scales)",
+            "value": world * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 points+search, f64 normal equations", "data": "synthetic",
+            "config": {"workload": f"single pair, {args.points}-pt synthetic NCLT-shaped clouds, 3-scale GICP "
+                                   "(voxels 0.4/0.2/0.1 m, radii 1.2/0.4/0.1 m, SOR(30,1.0), KNN-20 normals, L1, 1e-6/1e-6/100)",
+                       "points_per_cloud": args.points, "distinct_pairs": args.pairs, "parallelism": f"pairs x{world}",
+                       "scales": [dict(voxel=s["voxel"], max_dist=s["max_dist"], n_voxel=s["n_voxel"], n_clean=s["n_clean"],
+                                       iterations=s["iterations"]) for s in res.scales],
+                       "err_vs_planted": {"rad": ang, "m": dtr}, "gathered_records": int(len(gathered))},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_icp_iter<GICP>",
+                         "bytes_per_launch": bytes_per_launch, "us_per_launch_hip_events": us_event,
+                         "us_per_launch_in_kernel_clock": us_kernel, "live_launches": live, "launches_issued": issued},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(pairs[0], args.points)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pair, npts):
+    """The oracle ("port": float64 C/OpenMP restatement of the Open3D CPU path) on the SAME workload, timed on
+    this host's cores.  Bounded sample: as many repetitions of pair 0 as fit in ~20 s (at least one)."""
+    from oracle import oracle as orc
+    orc.build()
+    cores = os.cpu_count() or 1
+    orc.set_num_threads(cores)
+    t0 = time.perf_counter(); n = 0
+    while True:
+        orc.multiscale_gicp(pair.source, pair.target, pair.voxel_sizes, pair.max_distances_script, pair.T_init)
+        n += 1
+        if time.perf_counter() - t0 > 20.0 or n >= 5:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{n} x pair 0 of the same {npts}-pt workload (identical parameters), OpenMP threads = {cores}"}
+
+
+if __name__ == "__main__":
+    main()

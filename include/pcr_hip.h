@@ -149,6 +149,15 @@ int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, const float *sr
                          const float *tgt_xyz, const float *tgt_feat33, int64_t n_tgt, const pcr_fgr_option *option,
                          pcr_result *result, int32_t *correspondences);
 
+/* ---- measurement hooks (bench.py): no reference counterpart -------------------------- */
+/* While enabled, pcr_multiscale_gicp / pcr_registration_generalized_icp bracket every chunk of GICP-iteration
+ * launches with HIP events on the context stream and the kernel stamps itself with s_memrealtime.
+ * out8 = { [0] ms of HIP-event time over chunks whose launches were all live, [1] launches in those chunks,
+ *          [2] us of in-kernel time summed over live launches, [3] live launches,
+ *          [4] algorithmic bytes of the live launches (48 B x source points), [5] launches issued, 0, 0 } */
+int pcr_profile_enable(pcr_context *ctx, int on);
+int pcr_profile_read(pcr_context *ctx, double *out8, int reset);
+
 /* ---- test hooks (exercised by tests/ only) ----------------------------------------- */
 /* exact k nearest neighbours of every point of a cloud (self included), through the same index the
  * pipeline uses. idx: n x k int32, d2: n x k float32 (device), rows sorted ascending.              */

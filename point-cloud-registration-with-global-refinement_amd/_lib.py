@@ -46,6 +46,7 @@ EXPORTS = [
     "pcr_voxel_down_sample", "pcr_remove_statistical_outlier", "pcr_estimate_normals", "pcr_estimate_covariances",
     "pcr_registration_generalized_icp", "pcr_multiscale_gicp", "pcr_evaluate_registration", "pcr_information_matrix",
     "pcr_compute_fpfh_feature", "pcr_registration_fgr", "pcr_debug_knn", "pcr_debug_gicp_linearize",
+    "pcr_profile_enable", "pcr_profile_read",
 ]
 
 _lib = None
@@ -73,6 +74,9 @@ def load():
                 raise RuntimeError(
                     f"libpcr_hip.so not found at {SO_PATH}: the HIP extension is not built "
                     "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+            # torch bundles its own HIP runtime: load it FIRST so that libpcr_hip.so binds to the same one
+            # (two HIP runtimes in one process cannot share a device context)
+            import torch  # noqa: F401
             lib = C.CDLL(SO_PATH)
             lib.pcr_last_error.restype = C.c_char_p
             lib.pcr_last_error.argtypes = [C.c_void_p]

@@ -33,6 +33,7 @@ extern "C" int pcr_destroy(pcr_context *ctx) {
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (int i = 0; i < 2; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return PCR_OK;
@@ -42,6 +43,17 @@ extern "C" int pcr_set_stream(pcr_context *ctx, void *s) {
     if (!ctx) return PCR_EINVAL;
     (void)hipStreamSynchronize(ctx->stream);
     ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    return PCR_OK;
+}
+
+extern "C" int pcr_profile_enable(pcr_context *ctx, int on) {
+    if (!ctx) return PCR_EINVAL;
+    ctx->profiling = on ? 1 : 0;
+    return PCR_OK;
+}
+extern "C" int pcr_profile_read(pcr_context *ctx, double *out8, int reset) {
+    if (!ctx || !out8) return PCR_EINVAL;
+    for (int i = 0; i < 8; i++) { out8[i] = ctx->prof[i]; if (reset) ctx->prof[i] = 0; }
     return PCR_OK;
 }
 
@@ -83,10 +95,10 @@ static int alloc_cloud(pcr_context *ctx, DevCloud *c, int cap, bool with_nrm, bo
 }
 
 // Morton-sorted copy of a caller cloud (+ optional normals) with its BVH; perm maps sorted -> caller index
-static int import_cloud(pcr_context *ctx, const float *xyz, const float *nrm, int64_t n, DevCloud *c, uint32_t **perm_out) {
+static int import_cloud(pcr_context *ctx, const float *xyz, const float *nrm, int64_t n, DevCloud *c, uint32_t **perm_out, bool force_nrm = false) {
     double b6[6];
     PCR_TRY(pcr_dev_bounds(ctx, xyz, n, b6));
-    PCR_TRY(alloc_cloud(ctx, c, (int)n, nrm != nullptr, true));
+    PCR_TRY(alloc_cloud(ctx, c, (int)n, nrm != nullptr || force_nrm, true));
     uint32_t *perm = arena<uint32_t>(ctx, n > 0 ? n : 1);
     if (!perm) return PCR_ENOMEM;
     PCR_TRY(pcr_dev_sort_cloud(ctx, xyz, n, b6, c, perm));
@@ -251,8 +263,8 @@ extern "C" int pcr_registration_generalized_icp(pcr_context *ctx, const float *s
     PCR_TRY(check_T(ctx, init_T));
     PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n_src) + pcr_scratch_bytes_for(n_tgt)));
     DevCloud s, t; uint32_t *sperm = nullptr, *tperm = nullptr;
-    PCR_TRY(import_cloud(ctx, src_xyz, src_normals, n_src, &s, &sperm));
-    PCR_TRY(import_cloud(ctx, tgt_xyz, tgt_normals, n_tgt, &t, &tperm));
+    PCR_TRY(import_cloud(ctx, src_xyz, src_normals, n_src, &s, &sperm, true));
+    PCR_TRY(import_cloud(ctx, tgt_xyz, tgt_normals, n_tgt, &t, &tperm, true));
     int32_t *match = arena<int32_t>(ctx, n_src > 0 ? n_src : 1);
     if (!match) return PCR_ENOMEM;
     PCR_TRY(pcr_dev_gicp(ctx, &s, &t, max_dist, init_T, params, result, match));

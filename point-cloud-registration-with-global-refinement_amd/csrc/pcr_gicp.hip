@@ -26,7 +26,9 @@ struct IcpState {
     int launches;               // searches done
     int done, converged;
     unsigned int ticket;
-    int pad;
+    int ns;                     // source points of this problem (for the byte model)
+    unsigned long long t_start; // s_memrealtime (100 MHz) stamp of workgroup 0 at kernel entry
+    unsigned long long t_live;  // sum over live launches of (last workgroup's exit stamp - t_start)
 };
 
 struct IcpArgs {
@@ -45,7 +47,7 @@ struct IcpInit { double T[16]; };
 __global__ void k_icp_init(IcpState *st, IcpInit in) {
     if (threadIdx.x == 0) {
         for (int k = 0; k < 16; k++) st->T[k] = in.T[k];
-        st->fitness = 0; st->rmse = 0; st->count = 0; st->iter = 0; st->launches = 0; st->done = 0; st->converged = 0; st->ticket = 0; st->pad = 0;
+        st->fitness = 0; st->rmse = 0; st->count = 0; st->iter = 0; st->launches = 0; st->done = 0; st->converged = 0; st->ticket = 0; st->ns = 0; st->t_start = 0; st->t_live = 0;
         for (int k = 0; k < NVP; k++) st->sums[k] = 0;
     }
 }
@@ -117,6 +119,7 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
     int nb = (ns + ICP_BS - 1) / ICP_BS;
     if (nb < 1) nb = 1;
     if ((int)blockIdx.x >= nb) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->t_start = wall_clock64();   // published by this workgroup's release below
     if (threadIdx.x == 0) pcr_bvh_meta(nt, m);
     __syncthreads();
     const int launches = st->launches;
@@ -294,6 +297,8 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
         st->launches = launches + 1;
         st->converged = conv ? 1 : 0;
         st->ticket = 0;
+        st->ns = ns;
+        st->t_live += wall_clock64() - st->t_start;
         __threadfence();
         st->done = stop ? 1 : 0;
     }
@@ -344,13 +349,19 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     // idles on the host.  Launches after 'done' return at their first instruction.
     const int total = a.max_it + 1, CHUNK = 8;
     IcpState *slots = (IcpState *)ctx->pinned;      // two read-back slots
-    int launched = 0, cur = 0, prev = -1;
+    int launched = 0, cur = 0, prev = -1, n_chunks = 0;
     IcpState fin; bool have = false;
     for (;;) {
         const bool enq = launched < total;
         if (enq) {
             const int c = total - launched < CHUNK ? total - launched : CHUNK;
+            if (ctx->profiling) {
+                while ((int)ctx->prof_events.size() < 2 * (n_chunks + 1)) { hipEvent_t e; PCR_HIP_CHECK(ctx, hipEventCreate(&e)); ctx->prof_events.push_back(e); }
+                PCR_HIP_CHECK(ctx, hipEventRecord(ctx->prof_events[2 * n_chunks], ctx->stream));
+            }
             for (int k = 0; k < c; k++) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP>), dim3(nbmax), dim3(ICP_BS), 0, ctx->stream, a);
+            if (ctx->profiling) PCR_HIP_CHECK(ctx, hipEventRecord(ctx->prof_events[2 * n_chunks + 1], ctx->stream));
+            n_chunks++;
             launched += c;
             PCR_HIP_CHECK(ctx, hipMemcpyAsync(&slots[cur], st, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
             PCR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[cur], ctx->stream));
@@ -365,6 +376,21 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     if (!have) { ctx->err = "GICP loop ended without a final state"; return PCR_EHIP; }
     // drain the (no-op) tail so the pinned slots and the arena can be reused safely
     PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->profiling) {
+        // chunks whose launches were all live (before 'done'): HIP-event time / launches = launch-to-launch period
+        for (int c = 0; c < n_chunks; c++) {
+            const int first = c * CHUNK, last = first + CHUNK < total ? first + CHUNK : total;
+            if (last <= fin.launches) {
+                float ms = 0;
+                PCR_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->prof_events[2 * c], ctx->prof_events[2 * c + 1]));
+                ctx->prof[0] += ms; ctx->prof[1] += last - first;
+            }
+        }
+        ctx->prof[2] += (double)fin.t_live * 0.01;            // 100 MHz ticks -> microseconds
+        ctx->prof[3] += fin.launches;
+        ctx->prof[4] += 48.0 * (double)fin.ns * (double)fin.launches;   // 48 B per source point per launch
+        ctx->prof[5] += launched;
+    }
     state_to_result(fin, out);
     for (int k = 0; k < 16; k++) if (!std::isfinite(fin.T[k])) { ctx->err = "non-finite pose"; return PCR_ENUMERIC; }
     return PCR_OK;

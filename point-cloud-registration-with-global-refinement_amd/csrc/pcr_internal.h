@@ -19,6 +19,9 @@ struct pcr_context {
     char *pinned = nullptr;        // host-pinned read-back window
     size_t pinned_cap = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
+    int profiling = 0;             // bench instrumentation (pcr_profile_*)
+    double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<hipEvent_t> prof_events;
     std::string err;
 };
 

@@ -14,6 +14,7 @@ def test_library_exports_every_declared_symbol():
     P = pkg()
     if not os.path.exists(P._lib.SO_PATH):
         P._lib.build()
+    import torch  # noqa: F401  (same HIP runtime as torch; see _lib.load)
     lib = ctypes.CDLL(P._lib.SO_PATH)
     hdr = open(os.path.join(ROOT, "include", "pcr_hip.h")).read()
     declared = sorted(set(re.findall(r"\b(pcr_[a-z0-9_]+)\s*\(", hdr)))

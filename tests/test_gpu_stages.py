@@ -37,6 +37,7 @@ def test_voxel_with_normals_and_errors(P, oracle, small_pair):
     out = pc.voxel_down_sample(0.4)
     rp, rn = oracle.voxel_down_sample(src, 0.4, normals=nrm)
     key = np.lexsort((out.points[:, 2], out.points[:, 1], out.points[:, 0]))
+    rp = rp.astype(np.float32).astype(np.float64)        # order by the same float32-rounded coordinates
     rkey = np.lexsort((rp[:, 2], rp[:, 1], rp[:, 0]))
     assert np.array_equal(out.normals[key], rn[rkey].astype(np.float32).astype(np.float64))
     with pytest.raises(RuntimeError):
