@@ -128,7 +128,12 @@ def cpu_baseline(pair, npts):
     this host's cores.  Bounded sample: as many repetitions of pair 0 as fit in ~20 s (at least one)."""
     from oracle import oracle as orc
     orc.build()
-    cores = os.cpu_count() or 1
+    # a 1-GPU box grants this job a 16-core CPU share although os.cpu_count() reports the whole host
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, int(os.environ.get("PCR_CPU_BASELINE_THREADS", "16"))))
     orc.set_num_threads(cores)
     t0 = time.perf_counter(); n = 0
     while True:

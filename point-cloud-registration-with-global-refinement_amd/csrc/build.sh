@@ -8,7 +8,7 @@ OUT=../libpcr_hip.so
 objs=""
 for f in pcr_sort pcr_cloud pcr_gicp pcr_fpfh pcr_fgr pcr_api; do
   [ -f $f.hip ] || continue
-  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ pcr_internal.h -nt $f.o ] || [ pcr_device.h -nt $f.o ] || [ ../../include/pcr_hip.h -nt $f.o ]; then
+  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ pcr_internal.h -nt $f.o ] || [ pcr_device.h -nt $f.o ] || [ pcr_octree.h -nt $f.o ] || [ ../../include/pcr_hip.h -nt $f.o ]; then
     echo "hipcc $f.hip"
     hipcc $FLAGS -c $f.hip -o $f.o
   fi

@@ -2,7 +2,8 @@
 // scratch-arena plumbing.  Each entry point replaces one Open3D binding call of the reference; see the header.
 #include <cmath>
 #include <cstring>
-#include "pcr_device.h"
+#include <cstdlib>
+#include "pcr_octree.h"
 
 // ------------------------------------------------------------------------------------------- context
 extern "C" int pcr_version(void) { return 100; }
@@ -83,14 +84,24 @@ void *pcr_arena_alloc(pcr_context *ctx, size_t bytes) {
     if (hipSetDevice((ctx)->device) != hipSuccess) return PCR_EHIP;              \
     (ctx)->err.clear();
 
-static int alloc_cloud(pcr_context *ctx, DevCloud *c, int cap, bool with_nrm, bool with_bvh) {
+static int alloc_cloud(pcr_context *ctx, DevCloud *c, int cap, bool with_nrm, bool with_tree) {
     const int cc = cap > 0 ? cap : 1;
     c->cap = cap;
     c->pts = arena<float4>(ctx, cc);
     c->nrm = with_nrm ? arena<float4>(ctx, cc) : nullptr;
     c->n = arena<int>(ctx, 1);
-    c->boxes = with_bvh ? arena<float4>(ctx, 2 * bvh_node_capacity(cc)) : nullptr;
-    if (!c->pts || !c->n || (with_nrm && !c->nrm) || (with_bvh && !c->boxes)) return PCR_ENOMEM;
+    c->keys = arena<uint64_t>(ctx, cc);
+    if (!c->pts || !c->n || !c->keys || (with_nrm && !c->nrm)) return PCR_ENOMEM;
+    c->oct_child = nullptr; c->oct_nodes = nullptr; c->oct_parent = nullptr; c->oct_meta = nullptr; c->leaf_of = nullptr;
+    if (with_tree) {
+        const size_t nodes = oct_node_capacity(cc);
+        c->oct_child = arena<int>(ctx, nodes);
+        c->oct_nodes = arena<float4>(ctx, 2 * nodes);
+        c->oct_parent = arena<int>(ctx, nodes);
+        c->oct_meta = arena<OctMeta>(ctx, 1);
+        c->leaf_of = arena<int>(ctx, cc);
+        if (!c->oct_child || !c->oct_nodes || !c->oct_parent || !c->oct_meta || !c->leaf_of) return PCR_ENOMEM;
+    }
     return PCR_OK;
 }
 
@@ -223,9 +234,9 @@ __global__ void k_knn_unpermute(const int32_t *si, const float *sd, const int32_
     }
     if (counts) counts[o] = sc[i];
 }
-__global__ void k_match_unpermute(const int32_t *m, const uint32_t *sp, const uint32_t *tp, int n, int32_t *out) {
+__global__ void k_match_unpermute(const int32_t *m, const uint32_t *sp, const uint32_t *tp, int n, int32_t *out, int raw) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[sp[i]] = m[i] >= 0 ? (int32_t)tp[m[i]] : -1;
+    if (i < n) out[sp[i]] = raw ? m[i] : (m[i] >= 0 ? (int32_t)tp[m[i]] : -1);
 }
 
 extern "C" int pcr_debug_knn(pcr_context *ctx, const float *xyz, int64_t n, int k, double radius, int32_t *idx, float *d2, int32_t *counts) {
@@ -290,7 +301,7 @@ extern "C" int pcr_debug_gicp_linearize(pcr_context *ctx, const float *src_xyz, 
     if (!match) return PCR_ENOMEM;
     PCR_TRY(pcr_dev_linearize_once(ctx, &s, &t, max_dist, T, params, JTJ36, JTr6, stats3, match));
     if (match_out) {
-        hipLaunchKernelGGL(k_match_unpermute, dim3((unsigned)((n_src + 255) / 256)), dim3(256), 0, ctx->stream, match, sperm, tperm, (int)n_src, match_out);
+        hipLaunchKernelGGL(k_match_unpermute, dim3((unsigned)((n_src + 255) / 256)), dim3(256), 0, ctx->stream, match, sperm, tperm, (int)n_src, match_out, getenv("PCR_DEBUG_VISITS") ? 1 : 0);
         PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     }
     return PCR_OK;
@@ -312,6 +323,7 @@ static int prep_scale(pcr_context *ctx, const float *xyz, const float *nrm, int6
         DevCloud tmp = *clean;
         tmp.nrm = prior;                                         // compacted voxel-mean normals = orientation prior
         PCR_TRY(pcr_dev_sor(ctx, &v, sor_k, sor_std, &tmp, nullptr, nullptr));
+        for (int d = 0; d < 3; d++) { clean->key_org[d] = tmp.key_org[d]; clean->key_unit[d] = tmp.key_unit[d]; }
         PCR_HIP_CHECK(ctx, hipMemcpyAsync(nv_keep, v.n, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
     }
     PCR_TRY(pcr_dev_build_bvh(ctx, clean));

@@ -5,7 +5,8 @@
 // EstimateCovariances} as called at ALL_FUNCTIONS.py:293-302 / 2_MGICP_refinement_in_NCLT_dataset.py:146-153
 // (SURVEY.md A.1-A.4).  All kernels are count-driven by a DEVICE-side int so that no host round trip is
 // needed between stages.
-#include "pcr_device.h"
+#include <cstdlib>
+#include "pcr_octree.h"
 
 #define BS 256
 
@@ -148,7 +149,7 @@ __global__ void __launch_bounds__(BS) k_head_flags(const uint64_t *__restrict__ 
 }
 __global__ void __launch_bounds__(BS) k_voxel_mean(const float *__restrict__ xyz, const float *__restrict__ nrm_in, const uint64_t *__restrict__ keys,
                                                    const uint32_t *__restrict__ vals, const uint8_t *__restrict__ flags, const int *__restrict__ pos, int n,
-                                                   float4 *__restrict__ out_pts, float4 *__restrict__ out_nrm) {
+                                                   float4 *__restrict__ out_pts, float4 *__restrict__ out_nrm, uint64_t *__restrict__ out_keys) {
     const int i = blockIdx.x * BS + threadIdx.x;
     if (i >= n || !flags[i]) return;
     const uint64_t key = keys[i];
@@ -163,6 +164,7 @@ __global__ void __launch_bounds__(BS) k_voxel_mean(const float *__restrict__ xyz
     const double c = (double)(j - i);
     const int o = pos[i];
     out_pts[o] = make_float4((float)(sx / c), (float)(sy / c), (float)(sz / c), 0.0f);
+    out_keys[o] = key;
     if (nrm_in && out_nrm) out_nrm[o] = make_float4((float)(nx / c), (float)(ny / c), (float)(nz / c), 0.0f);
 }
 
@@ -180,6 +182,8 @@ int pcr_dev_voxel(pcr_context *ctx, const float *xyz, const float *nrm_in, int64
         if ((uint32_t)e > mx) mx = (uint32_t)e;
     }
     const int end_bit = 3 * bits_for(mx);
+    out->key_org[0] = (float)ox; out->key_org[1] = (float)oy; out->key_org[2] = (float)oz;
+    out->key_unit[0] = out->key_unit[1] = out->key_unit[2] = (float)voxel;
     ArenaMark mark(ctx);
     const int ni = (int)n;
     uint64_t *k0 = arena<uint64_t>(ctx, n), *k1 = arena<uint64_t>(ctx, n);
@@ -194,7 +198,7 @@ int pcr_dev_voxel(pcr_context *ctx, const float *xyz, const float *nrm_in, int64
     PCR_TRY(pcr_sort_pairs(ctx, temp, tb, k0, k1, v0, v1, n, end_bit));
     hipLaunchKernelGGL(k_head_flags, dim3(nb), dim3(BS), 0, ctx->stream, k1, ni, flags);
     PCR_TRY(pcr_dev_flag_scan(ctx, flags, nullptr, ni, pos, out->n));
-    hipLaunchKernelGGL(k_voxel_mean, dim3(nb), dim3(BS), 0, ctx->stream, xyz, nrm_in, k1, v1, flags, pos, ni, out->pts, out->nrm);
+    hipLaunchKernelGGL(k_voxel_mean, dim3(nb), dim3(BS), 0, ctx->stream, xyz, nrm_in, k1, v1, flags, pos, ni, out->pts, out->nrm, out->keys);
     return PCR_OK;
 }
 
@@ -244,13 +248,16 @@ int pcr_dev_sort_cloud(pcr_context *ctx, const float *xyz, int64_t n, const doub
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, ctx->stream, out->n, (int)n);
     if (n == 0) return PCR_OK;
     ArenaMark mark(ctx);
-    uint64_t *k0 = arena<uint64_t>(ctx, n), *k1 = arena<uint64_t>(ctx, n);
+    uint64_t *k0 = arena<uint64_t>(ctx, n), *k1 = out->keys;
     uint32_t *v0 = arena<uint32_t>(ctx, n);
     const size_t tb = pcr_sort_temp_bytes(n);
     void *temp = pcr_arena_alloc(ctx, tb);
     if (!k0 || !k1 || !v0 || !temp) return PCR_ENOMEM;
     float s[3];
-    for (int d = 0; d < 3; d++) { double e = b6[3 + d] - b6[d]; s[d] = e > 0 ? (float)(65535.0 / e) : 0.0f; }
+    for (int d = 0; d < 3; d++) {
+        double e = b6[3 + d] - b6[d]; s[d] = e > 0 ? (float)(65535.0 / e) : 0.0f;
+        out->key_org[d] = (float)b6[d]; out->key_unit[d] = e > 0 ? (float)(e / 65535.0) : 1.0f;
+    }
     const int nb = (int)((n + BS - 1) / BS);
     hipLaunchKernelGGL(k_raw_keys, dim3(nb), dim3(BS), 0, ctx->stream, xyz, (int)n, (float)b6[0], (float)b6[1], (float)b6[2], s[0], s[1], s[2], k0, v0);
     PCR_TRY(pcr_sort_pairs(ctx, temp, tb, k0, k1, v0, perm, n, 48));
@@ -258,96 +265,239 @@ int pcr_dev_sort_cloud(pcr_context *ctx, const float *xyz, int64_t n, const doub
     return PCR_OK;
 }
 
-// ====================================================================== implicit BVH build (K2, part 2)
-__global__ void __launch_bounds__(BS) k_bvh_leaves(const float4 *__restrict__ pts, const int *__restrict__ n_ptr, float4 *__restrict__ boxes) {
-    __shared__ BvhMeta m;
-    const int n = *n_ptr;
-    if (threadIdx.x == 0) pcr_bvh_meta(n, m);
+// ====================================================================== linear octree build (K2, part 2)
+// A: level of the highest Morton bit in which consecutive keys differ (-1: identical keys) + histogram
+__global__ void __launch_bounds__(BS) k_oct_lstar(const uint64_t *__restrict__ keys, const int *__restrict__ n_ptr, signed char *__restrict__ ls, int *__restrict__ hist) {
+    __shared__ int h[OCT_KEY_LEVELS];
+    if (threadIdx.x < OCT_KEY_LEVELS) h[threadIdx.x] = 0;
     __syncthreads();
-    const int leaf = blockIdx.x * BS + threadIdx.x;
-    float4 lo = make_float4(3.4e38f, 3.4e38f, 3.4e38f, 0), hi = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, 0);
-    if (leaf < m.cnt[0]) {
-        const int b = leaf * PCR_LEAF;
-#pragma unroll
-        for (int j = 0; j < PCR_LEAF; j++) {
-            if (b + j < n) {
-                const float4 p = pts[b + j];
-                lo.x = fminf(lo.x, p.x); lo.y = fminf(lo.y, p.y); lo.z = fminf(lo.z, p.z);
-                hi.x = fmaxf(hi.x, p.x); hi.y = fmaxf(hi.y, p.y); hi.z = fmaxf(hi.z, p.z);
-            }
+    const int n = *n_ptr, i = blockIdx.x * BS + threadIdx.x;
+    if (i < n) {
+        int v;
+        if (i == 0) v = OCT_KEY_LEVELS - 1;
+        else {
+            const uint64_t x = keys[i] ^ keys[i - 1];
+            v = x ? (63 - __builtin_clzll(x)) / 3 : -1;
         }
-        boxes[2 * (size_t)leaf] = lo; boxes[2 * (size_t)leaf + 1] = hi;
+        ls[i] = (signed char)v;
+        if (v >= 0) atomicAdd(&h[v], 1);
     }
-    // level 1 = 8 consecutive leaves = 8 consecutive lanes
+    __syncthreads();
+    if (threadIdx.x < OCT_KEY_LEVELS && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+// B: choose the leaf level (first level with <= n/4 cells: ~8 points per leaf), the root level, offsets
+struct OctGeom { float org[3]; float unit[3]; };
+__global__ void k_oct_meta(const int *__restrict__ n_ptr, const int *__restrict__ hist, int node_cap, OctMeta *__restrict__ meta, int *__restrict__ child, OctGeom g) {
+    if (threadIdx.x != 0) return;
+    const int n = *n_ptr;
+    OctMeta m;
+    for (int d = 0; d < 3; d++) { m.org[d] = g.org[d]; m.unit[d] = g.unit[d]; }
+    m.n = n; m.l0 = 0; m.nl = 0; m.total = 0;
+    for (int k = 0; k < OCT_MAXL; k++) { m.cnt[k] = 0; m.off[k] = 0; }
+    if (n > 0) {
+        int cnt[OCT_KEY_LEVELS + 1];
+        cnt[OCT_KEY_LEVELS] = 0;
+        for (int l = OCT_KEY_LEVELS - 1; l >= 0; l--) cnt[l] = cnt[l + 1] + hist[l];
+        const int want = n / 4 > 1 ? n / 4 : 1;
+        int l0 = 0;
+        while (l0 < OCT_KEY_LEVELS - 1 && cnt[l0] > want) l0++;
+        int top = l0;
+        while (top < OCT_KEY_LEVELS - 1 && cnt[top] > 1) top++;
+        for (;;) {      // respect the level and node budgets by coarsening the leaves
+            if (top - l0 + 1 > OCT_MAXL) { l0 = top - OCT_MAXL + 1; }
+            long long tot = 0;
+            for (int l = l0; l <= top; l++) tot += cnt[l] + 1;
+            if (tot <= node_cap || l0 == top) break;
+            l0++;
+        }
+        m.l0 = l0; m.nl = top - l0 + 1;
+        int off = 0;
+        for (int li = 0; li < m.nl; li++) { m.cnt[li] = cnt[l0 + li]; m.off[li] = off; off += m.cnt[li] + 1; }
+        m.total = off;
+        for (int li = 0; li < m.nl; li++) child[m.off[li] + m.cnt[li]] = li == 0 ? n : m.cnt[li - 1];
+    }
+    *meta = m;
+}
+// C: per tile, number of node starts per stored level
+__global__ void __launch_bounds__(BS) k_oct_tile_count(const signed char *__restrict__ ls, const OctMeta *__restrict__ meta, int *__restrict__ tile_cnt) {
+    __shared__ int h[OCT_KEY_LEVELS + 1];
+    if (threadIdx.x <= OCT_KEY_LEVELS) h[threadIdx.x] = 0;
+    __syncthreads();
+    const int n = meta->n, l0 = meta->l0, nl = meta->nl;
 #pragma unroll
-    for (int o = 1; o < PCR_FANOUT; o <<= 1) {
-        lo.x = fminf(lo.x, __shfl_xor(lo.x, o, PCR_WAVE)); lo.y = fminf(lo.y, __shfl_xor(lo.y, o, PCR_WAVE)); lo.z = fminf(lo.z, __shfl_xor(lo.z, o, PCR_WAVE));
-        hi.x = fmaxf(hi.x, __shfl_xor(hi.x, o, PCR_WAVE)); hi.y = fmaxf(hi.y, __shfl_xor(hi.y, o, PCR_WAVE)); hi.z = fmaxf(hi.z, __shfl_xor(hi.z, o, PCR_WAVE));
+    for (int j = 0; j < 4; j++) {
+        const int e = blockIdx.x * TILE + j * BS + threadIdx.x;
+        if (e < n) { const int v = ls[e]; if (v >= 0) atomicAdd(&h[v], 1); }
     }
-    if (m.n_levels > 1 && (threadIdx.x & 7) == 0) {
-        const int p = leaf >> 3;
-        if (p < m.cnt[1]) { boxes[2 * (size_t)(m.off[1] + p)] = lo; boxes[2 * (size_t)(m.off[1] + p) + 1] = hi; }
+    __syncthreads();
+    if (threadIdx.x < OCT_MAXL) {
+        int c = 0;
+        if ((int)threadIdx.x < nl) for (int l = l0 + threadIdx.x; l < OCT_KEY_LEVELS; l++) c += h[l];
+        tile_cnt[blockIdx.x * OCT_MAXL + threadIdx.x] = c;
     }
 }
-__global__ void __launch_bounds__(BS) k_bvh_level(const int *__restrict__ n_ptr, float4 *__restrict__ boxes, int level) {
-    __shared__ BvhMeta m;
-    if (threadIdx.x == 0) pcr_bvh_meta(*n_ptr, m);
+// D: exclusive scan over tiles, one lane per level
+__global__ void k_oct_tile_scan(int *__restrict__ tile_cnt, int n_tiles) {
+    if (threadIdx.x >= OCT_MAXL) return;
+    int run = 0;
+    for (int t = 0; t < n_tiles; t++) { const int v = tile_cnt[t * OCT_MAXL + threadIdx.x]; tile_cnt[t * OCT_MAXL + threadIdx.x] = run; run += v; }
+}
+// E: node ids by ballot ranking; write child links and the leaf of every point
+__global__ void __launch_bounds__(BS) k_oct_apply(const signed char *__restrict__ ls, const OctMeta *__restrict__ meta, const int *__restrict__ tile_cnt,
+                                                  int *__restrict__ child, int *__restrict__ leaf_of, int *__restrict__ parent) {
+    __shared__ int wtot[4][BS / PCR_WAVE][OCT_MAXL];
+    const int n = meta->n, l0 = meta->l0, nl = meta->nl;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const int e = blockIdx.x * TILE + j * BS + threadIdx.x; v[j] = e < n ? (int)ls[e] : -2; }
+    for (int li = 0; li < nl; li++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned long long b = __ballot(v[j] >= l0 + li);
+            if (lane == 0) wtot[j][w][li] = __popcll(b);
+        }
     __syncthreads();
-    if (level >= m.n_levels) return;
-    const int node = blockIdx.x * BS + threadIdx.x;
-    if (node >= m.cnt[level]) return;
-    float4 lo = make_float4(3.4e38f, 3.4e38f, 3.4e38f, 0), hi = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, 0);
-    const int first = node * PCR_FANOUT, cc = m.cnt[level - 1];
-    for (int c = 0; c < PCR_FANOUT && first + c < cc; c++) {
-        const float4 a = boxes[2 * (size_t)(m.off[level - 1] + first + c)], b = boxes[2 * (size_t)(m.off[level - 1] + first + c) + 1];
-        lo.x = fminf(lo.x, a.x); lo.y = fminf(lo.y, a.y); lo.z = fminf(lo.z, a.z);
-        hi.x = fmaxf(hi.x, b.x); hi.y = fmaxf(hi.y, b.y); hi.z = fmaxf(hi.z, b.z);
+    const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int e = blockIdx.x * TILE + j * BS + threadIdx.x;
+        int below = -1;
+        for (int li = 0; li < nl; li++) {
+            const bool f = v[j] >= l0 + li;
+            const unsigned long long b = __ballot(f);
+            int pre = tile_cnt[blockIdx.x * OCT_MAXL + li];
+            for (int jj = 0; jj < 4; jj++)
+                for (int ww = 0; ww < BS / PCR_WAVE; ww++)
+                    if (jj < j || (jj == j && ww < w)) pre += wtot[jj][ww][li];
+            const int id = pre + __popcll(b & lt);      // exclusive rank of this element among the starts of level li
+            if (li == 0 && e < n) leaf_of[e] = id + (f ? 1 : 0) - 1;
+            if (f) child[meta->off[li] + id] = li == 0 ? e : below;
+            // the node of level li-1 that starts here hangs under the node of level li that CONTAINS this element
+            if (li > 0 && v[j] >= l0 + li - 1) parent[meta->off[li - 1] + below] = id + (f ? 1 : 0) - 1;
+            below = id;
+        }
     }
-    boxes[2 * (size_t)(m.off[level] + node)] = lo; boxes[2 * (size_t)(m.off[level] + node) + 1] = hi;
+}
+// F/G: tight boxes, bottom-up
+__global__ void __launch_bounds__(BS) k_oct_leaf_boxes(const float4 *__restrict__ pts, const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int *__restrict__ parent) {
+    const int j = blockIdx.x * BS + threadIdx.x;
+    if (meta->nl < 1 || j >= meta->cnt[0]) return;
+    const int a = child[j], b = child[j + 1];
+    float4 lo = make_float4(3.4e38f, 3.4e38f, 3.4e38f, 0), hi = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, 0);
+    for (int i = a; i < b; i++) {
+        const float4 p = pts[i];
+        lo.x = fminf(lo.x, p.x); lo.y = fminf(lo.y, p.y); lo.z = fminf(lo.z, p.z);
+        hi.x = fmaxf(hi.x, p.x); hi.y = fmaxf(hi.y, p.y); hi.z = fmaxf(hi.z, p.z);
+    }
+    lo.w = __int_as_float(a); hi.w = __int_as_float(b - a);
+    boxes[2 * (size_t)j] = lo; boxes[2 * (size_t)j + 1] = hi;
+    if (meta->nl == 1) parent[j] = 0;
+}
+__device__ static inline void oct_node_box(const OctMeta &m, const int *__restrict__ child, float4 *__restrict__ boxes, int li, int j) {
+    const int a = child[m.off[li] + j], b = child[m.off[li] + j + 1];
+    float4 lo = make_float4(3.4e38f, 3.4e38f, 3.4e38f, 0), hi = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, 0);
+    for (int c = a; c < b; c++) {
+        const float4 x = boxes[2 * (size_t)(m.off[li - 1] + c)], y = boxes[2 * (size_t)(m.off[li - 1] + c) + 1];
+        lo.x = fminf(lo.x, x.x); lo.y = fminf(lo.y, x.y); lo.z = fminf(lo.z, x.z);
+        hi.x = fmaxf(hi.x, y.x); hi.y = fmaxf(hi.y, y.y); hi.z = fmaxf(hi.z, y.z);
+    }
+    lo.w = __int_as_float(a); hi.w = __int_as_float(b - a);
+    boxes[2 * (size_t)(m.off[li] + j)] = lo; boxes[2 * (size_t)(m.off[li] + j) + 1] = hi;
+}
+__global__ void __launch_bounds__(BS) k_oct_level_boxes(const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int li) {
+    const int j = blockIdx.x * BS + threadIdx.x;
+    if (li >= meta->nl || j >= meta->cnt[li]) return;
+    oct_node_box(*meta, child, boxes, li, j);
+}
+// remaining (small) levels in ONE workgroup, level by level
+__global__ void __launch_bounds__(1024) k_oct_upper_boxes(const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int first_li) {
+    __shared__ OctMeta m;
+    if (threadIdx.x == 0) m = *meta;
+    __syncthreads();
+    for (int li = first_li; li < m.nl; li++) {
+        for (int j = threadIdx.x; j < m.cnt[li]; j += 1024) oct_node_box(m, child, boxes, li, j);
+        __threadfence_block();
+        __syncthreads();
+    }
 }
 
 int pcr_dev_build_bvh(pcr_context *ctx, DevCloud *c) {
     if (c->cap <= 0) return PCR_OK;
-    BvhMeta m; pcr_bvh_meta(c->cap, m);
-    if (m.n_levels > 7) { ctx->err = "cloud too large for the 7-level BVH"; return PCR_EINVAL; }
-    hipLaunchKernelGGL(k_bvh_leaves, dim3((m.cnt[0] + BS - 1) / BS), dim3(BS), 0, ctx->stream, c->pts, c->n, c->boxes);
-    for (int l = 2; l < m.n_levels; l++)
-        hipLaunchKernelGGL(k_bvh_level, dim3((m.cnt[l] + BS - 1) / BS), dim3(BS), 0, ctx->stream, c->n, c->boxes, l);
+    ArenaMark mark(ctx);
+    const int cap = c->cap, n_tiles = (cap + TILE - 1) / TILE;
+    signed char *ls = arena<signed char>(ctx, cap);
+    int *hist = arena<int>(ctx, 32);
+    int *tile_cnt = arena<int>(ctx, (size_t)n_tiles * OCT_MAXL);
+    if (!ls || !hist || !tile_cnt) return PCR_ENOMEM;
+    PCR_HIP_CHECK(ctx, hipMemsetAsync(hist, 0, 32 * sizeof(int), ctx->stream));
+    const int nb = (cap + BS - 1) / BS;
+    hipLaunchKernelGGL(k_oct_lstar, dim3(nb), dim3(BS), 0, ctx->stream, c->keys, c->n, ls, hist);
+    OctGeom g; for (int d = 0; d < 3; d++) { g.org[d] = c->key_org[d]; g.unit[d] = c->key_unit[d]; }
+    hipLaunchKernelGGL(k_oct_meta, dim3(1), dim3(64), 0, ctx->stream, c->n, hist, (int)oct_node_capacity(cap), c->oct_meta, c->oct_child, g);
+    hipLaunchKernelGGL(k_oct_tile_count, dim3(n_tiles), dim3(BS), 0, ctx->stream, ls, c->oct_meta, tile_cnt);
+    hipLaunchKernelGGL(k_oct_tile_scan, dim3(1), dim3(64), 0, ctx->stream, tile_cnt, n_tiles);
+    hipLaunchKernelGGL(k_oct_apply, dim3(n_tiles), dim3(BS), 0, ctx->stream, ls, c->oct_meta, tile_cnt, c->oct_child, c->leaf_of, c->oct_parent);
+    const int nbl = (cap / 2 + 1 + BS - 1) / BS;       // <= n/2 leaves (or 1)
+    hipLaunchKernelGGL(k_oct_leaf_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->pts, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_parent);
+    hipLaunchKernelGGL(k_oct_level_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, 1);
+    hipLaunchKernelGGL(k_oct_level_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, 2);
+    hipLaunchKernelGGL(k_oct_upper_boxes, dim3(1), dim3(1024), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, 3);
     return PCR_OK;
 }
 
-// ====================================================================================== k-NN (K3)
-// One query per thread; the running k-best lives in LDS ([slot][thread], conflict-free), candidates come from
-// the stack-free BVH walk seeded with the query's Morton neighbours.
-#define KNN_BS 128
+static inline OctView oct_view(const DevCloud *c) {
+    OctView v; v.pts = c->pts; v.nodes = c->oct_nodes; v.parent = c->oct_parent; v.meta = c->oct_meta; v.leaf_of = c->leaf_of; v.keys = c->keys;
+    return v;
+}
 
-struct KnnVisitor {
-    const float4 *__restrict__ pts;
-    float *sd; int *si;        // LDS columns of this thread (stride KNN_BS)
-    int n, k, count, wslot, skip_lo, skip_hi;
-    float qx, qy, qz, worst, r2cap;
-    __device__ float bound() const { return count < k ? r2cap : worst; }
-    __device__ void rescan() {
-        float w = -1.0f; int ws = 0;
-        for (int s = 0; s < k; s++) { float v = sd[s * KNN_BS]; if (v > w) { w = v; ws = s; } }
-        worst = w; wslot = ws;
-    }
-    __device__ void point(int idx, float d2) {
-        if (count < k) {
-            if (d2 < r2cap) { sd[count * KNN_BS] = d2; si[count * KNN_BS] = idx; count++; if (count == k) rescan(); }
-        } else if (d2 < worst) {
-            sd[wslot * KNN_BS] = d2; si[wslot * KNN_BS] = idx; rescan();
-        }
-    }
-    __device__ void scan(int leaf) {
-        const int b = leaf * PCR_LEAF;
+// ====================================================================================== k-NN (K3)
+// "Octet" k-NN: 8 consecutive lanes cooperate on ONE query, a wavefront serves 8 Morton-consecutive queries.
+//   * node visit : lane c tests child c's box (one coalesced 256-B read per octet), the 8 verdicts come back
+//                  as one byte of a wave ballot -> the pending-children mask of the stack-free walk;
+//   * leaf visit : lane c tests point c of the leaf (one coalesced 128-B read), survivors are inserted one per
+//                  round into the octet's k-best, which is DISTRIBUTED over the 8 lanes (slot s lives in lane s%8,
+//                  register s/8); the current worst is an 8-lane arg-max (3 xor-shuffles);
+//   * no LDS, no per-lane divergence inside a query, ~50 VGPRs -> full occupancy.
+// The walk is seeded with the query's Morton neighbours (own leaf +- span), which already contain most of the
+// true neighbours, so the bound is tight before the first box test.
+#define KNN_BS 256
+
+template <int SLOTS>
+struct OctetKnn {
+    float sd[SLOTS]; int si[SLOTS];
+    float worst; int wlane;      // octet-wide worst distance and the octet-lane that owns it
+    int wj;                      // owner's register index of the worst
+    int ol;                      // lane within the octet
+    __device__ void init(int k, float cap, int ol_) {
+        ol = ol_;
 #pragma unroll
-        for (int j = 0; j < PCR_LEAF; j++) {
-            const int idx = b + j;
-            if (idx < n) { const float4 p = pts[idx]; point(idx, pcr_d2(p.x - qx, p.y - qy, p.z - qz)); }
+        for (int j = 0; j < SLOTS; j++) { sd[j] = (ol + OCT * j < k) ? cap : -1.0f; si[j] = -1; }
+        refresh();
+    }
+    __device__ void refresh() {
+        float m = sd[0]; int mj = 0;
+#pragma unroll
+        for (int j = 1; j < SLOTS; j++) if (sd[j] > m) { m = sd[j]; mj = j; }
+        wj = mj;
+        int ml = ol;
+#pragma unroll
+        for (int o = 1; o < OCT; o <<= 1) {
+            const float om = __shfl_xor(m, o, OCT); const int olane = __shfl_xor(ml, o, OCT);
+            if (om > m || (om == m && olane < ml)) { m = om; ml = olane; }
+        }
+        worst = m; wlane = ml;
+    }
+    // all 8 lanes call with the same candidate
+    __device__ void insert(float cd, int ci) {
+        if (cd < worst) {
+            if (ol == wlane) {
+#pragma unroll
+                for (int j = 0; j < SLOTS; j++) if (j == wj) { sd[j] = cd; si[j] = ci; }
+            }
+            refresh();
         }
     }
-    __device__ void leaf(int l) { if (l < skip_lo || l > skip_hi) scan(l); }
 };
 
 // ---- analytic symmetric 3x3 eigenvector of the smallest eigenvalue (Eberly's non-iterative solver)
@@ -437,107 +587,152 @@ __device__ static void d_fast_eigen3x3(const double *C6, double *nv) {
 enum { KNN_MODE_SOR = 0, KNN_MODE_NORMALS = 1, KNN_MODE_DEBUG = 2 };
 
 struct KnnArgs {
-    const float4 *pts; const float4 *boxes; const int *n_ptr;
+    OctView t; const int *n_ptr;
     int k; float r2cap_f; double r2cap;
     double *avg;                       // SOR
     const float4 *prior; float4 *normals; float *cov6;   // normals
-    int32_t *dbg_idx; float *dbg_d2; int32_t *dbg_cnt;   // debug
+    int32_t *dbg_idx; float *dbg_d2; int32_t *dbg_cnt;   // debug (rows unsorted)
+    int dbg_visits;                                      // debug: dbg_cnt <- traversal counters
 };
 
-template <int MODE>
+__device__ static inline double octet_sum(double v) {
+#pragma unroll
+    for (int o = 1; o < OCT; o <<= 1) v += __shfl_xor(v, o, OCT);
+    return v;
+}
+
+template <int MODE, int SLOTS>
 __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ BvhMeta m;
-    const int n = *a.n_ptr;
-    if (threadIdx.x == 0) pcr_bvh_meta(n, m);
+    constexpr int OPB = KNN_BS / OCT;
+    __shared__ OctMeta m;
+    __shared__ OctStack<OPB> stk;
+    if (threadIdx.x == 0) m = *a.t.meta;
     __syncthreads();
-    const int i = blockIdx.x * KNN_BS + threadIdx.x;
-    if (i >= n) return;
-    float *sd = (float *)smem + threadIdx.x;
-    int *si = (int *)(smem + sizeof(float) * (size_t)a.k * KNN_BS) + threadIdx.x;
-    const float4 q = a.pts[i];
-    KnnVisitor v;
-    v.pts = a.pts; v.sd = sd; v.si = si; v.n = n; v.k = a.k; v.count = 0; v.wslot = 0; v.worst = 3.4e38f; v.r2cap = a.r2cap_f;
-    v.qx = q.x; v.qy = q.y; v.qz = q.z;
-    // seed with the Morton neighbourhood: enough leaves around the query's own leaf to hold k points
-    const int own = i / PCR_LEAF, span = (a.k + PCR_LEAF - 1) / PCR_LEAF / 2 + 1;
-    int lo = own - span, hi = own + span;
-    if (lo < 0) lo = 0;
-    if (hi > m.cnt[0] - 1) hi = m.cnt[0] - 1;
-    v.skip_lo = 1; v.skip_hi = 0;
-    for (int l = lo; l <= hi; l++) v.scan(l);
-    v.skip_lo = lo; v.skip_hi = hi;
-    pcr_bvh_traverse(a.boxes, m, q.x, q.y, q.z, v);
+    const int n = m.n;
+    const int lane = threadIdx.x & 63, oct = lane >> 3, ol = lane & 7, ob = threadIdx.x >> 3;
+    const int qi = blockIdx.x * OPB + ob;
+    const bool live = qi < n;
+    if (__ballot(live) == 0ull) return;                      // whole wavefront beyond the cloud
+    const float4 q = a.t.pts[live ? qi : 0];
+    OctetKnn<SLOTS> tk;
+    tk.init(a.k, a.r2cap_f, ol);
+
+    // seed range of Morton neighbours [plo, phi] (by point index): already contains most true neighbours
+    int plo = 0, phi = -1;
+    if (live) { plo = qi - a.k < 0 ? 0 : qi - a.k; phi = qi + a.k > n - 1 ? n - 1 : qi + a.k; }
+    bool seeding = true;
+
+    // ---- wave-wide visit of `count` consecutive points from `first`, 8 at a time; survivors enter the k-best
+    auto visit = [&](int first, int count) {
+        int base = first; const int end = first + count;
+        while (__ballot(base < end) != 0ull) {
+            float d2 = 0.0f; bool pass = false;
+            const int idx = base + ol;
+            if (idx < end && (seeding || idx < plo || idx > phi)) {
+                const float4 p = a.t.pts[idx];
+                d2 = pcr_d2(p.x - q.x, p.y - q.y, p.z - q.z);
+                pass = d2 < tk.worst;
+            }
+            unsigned long long bal = __ballot(pass);
+            uint32_t surv = (uint32_t)(bal >> (oct * 8)) & 0xffu;
+            while (bal != 0ull) {
+                if (surv) {
+                    const int sl = __builtin_ctz(surv);
+                    surv &= surv - 1;
+                    const float cd = __shfl(d2, sl, OCT);
+                    tk.insert(cd, base + sl);
+                }
+                bal = __ballot(surv != 0);
+            }
+            base += OCT;
+        }
+    };
+    visit(plo, phi - plo + 1);
+    seeding = false;
+
+    // ---- exact completion: bottom-up from the query's own leaf
+    int nvis = 0;
+    oct_search<OPB>(a.t, m, stk, live, live ? a.t.leaf_of[qi] : 0, q.x, q.y, q.z, [&]() { return tk.worst; }, visit,
+                    [&](int f, int c) { return f >= plo && f + c - 1 <= phi; }, ol, oct, ob, (MODE == KNN_MODE_DEBUG && a.dbg_visits) ? &nvis : nullptr);
+    if (!live) return;
 
     // ---- epilogue in float64 on the selected neighbours (inputs are exact float32 -> same values as the oracle)
     const double qx = q.x, qy = q.y, qz = q.z;
     if (MODE == KNN_MODE_SOR) {
-        double s = 0; int c = 0;
-        for (int t = 0; t < v.count; t++) {
-            const float4 p = a.pts[si[t * KNN_BS]];
-            const double dx = (double)p.x - qx, dy = (double)p.y - qy, dz = (double)p.z - qz;
-            const double d2 = dx * dx + dy * dy + dz * dz;
-            if (d2 < a.r2cap) { s += sqrt(d2); c++; }
-        }
-        a.avg[i] = c > 0 ? s / (double)c : -1.0;
-    } else if (MODE == KNN_MODE_NORMALS) {
-        double cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; int c = 0;
-        for (int t = 0; t < v.count; t++) {
-            const float4 p = a.pts[si[t * KNN_BS]];
-            const double x = p.x, y = p.y, z = p.z;
-            const double dx = x - qx, dy = y - qy, dz = z - qz;
-            if (dx * dx + dy * dy + dz * dz < a.r2cap) {
-                cu[0] += x; cu[1] += y; cu[2] += z;
-                cu[3] += x * x; cu[4] += x * y; cu[5] += x * z; cu[6] += y * y; cu[7] += y * z; cu[8] += z * z;
-                c++;
+        double s = 0, c = 0;
+#pragma unroll
+        for (int j = 0; j < SLOTS; j++) {
+            if (tk.si[j] >= 0) {
+                const float4 p = a.t.pts[tk.si[j]];
+                const double dx = (double)p.x - qx, dy = (double)p.y - qy, dz = (double)p.z - qz;
+                const double d2 = dx * dx + dy * dy + dz * dz;
+                if (d2 < a.r2cap) { s += sqrt(d2); c += 1.0; }
             }
         }
-        double C6[6];
-        if (c >= 3) {
-            const double inv = 1.0 / (double)c;   // cumulants /= n, as Open3D
-            for (int t = 0; t < 9; t++) cu[t] = cu[t] / (double)c;
-            (void)inv;
-            C6[0] = cu[3] - cu[0] * cu[0]; C6[1] = cu[4] - cu[0] * cu[1]; C6[2] = cu[5] - cu[0] * cu[2];
-            C6[3] = cu[6] - cu[1] * cu[1]; C6[4] = cu[7] - cu[1] * cu[2]; C6[5] = cu[8] - cu[2] * cu[2];
-        } else { C6[0] = 1; C6[1] = 0; C6[2] = 0; C6[3] = 1; C6[4] = 0; C6[5] = 1; }
-        if (a.cov6) { for (int t = 0; t < 6; t++) a.cov6[(size_t)i * 6 + t] = (float)C6[t]; }
-        if (a.normals) {
-            double nv[3];
-            d_fast_eigen3x3(C6, nv);
-            const double nn = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
-            double px = 0, py = 0, pz = 0;
-            if (a.prior) { const float4 pr = a.prior[i]; px = pr.x; py = pr.y; pz = pr.z; }
-            if (nn == 0.0 || !(nn == nn)) { if (a.prior) { nv[0] = px; nv[1] = py; nv[2] = pz; } else { nv[0] = 0; nv[1] = 0; nv[2] = 1; } }
-            if (a.prior && nv[0] * px + nv[1] * py + nv[2] * pz < 0.0) { nv[0] = -nv[0]; nv[1] = -nv[1]; nv[2] = -nv[2]; }
-            a.normals[i] = make_float4((float)nv[0], (float)nv[1], (float)nv[2], 0.0f);
+        s = octet_sum(s); c = octet_sum(c);
+        if (ol == 0) a.avg[qi] = c > 0 ? s / c : -1.0;
+    } else if (MODE == KNN_MODE_NORMALS) {
+        double cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, c = 0;
+#pragma unroll
+        for (int j = 0; j < SLOTS; j++) {
+            if (tk.si[j] >= 0) {
+                const float4 p = a.t.pts[tk.si[j]];
+                const double x = p.x, y = p.y, z = p.z;
+                const double dx = x - qx, dy = y - qy, dz = z - qz;
+                if (dx * dx + dy * dy + dz * dz < a.r2cap) {
+                    cu[0] += x; cu[1] += y; cu[2] += z;
+                    cu[3] += x * x; cu[4] += x * y; cu[5] += x * z; cu[6] += y * y; cu[7] += y * z; cu[8] += z * z;
+                    c += 1.0;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; t++) cu[t] = octet_sum(cu[t]);
+        c = octet_sum(c);
+        if (ol == 0) {
+            double C6[6];
+            if (c >= 3.0) {
+                for (int t = 0; t < 9; t++) cu[t] = cu[t] / c;       // cumulants /= n, as Open3D
+                C6[0] = cu[3] - cu[0] * cu[0]; C6[1] = cu[4] - cu[0] * cu[1]; C6[2] = cu[5] - cu[0] * cu[2];
+                C6[3] = cu[6] - cu[1] * cu[1]; C6[4] = cu[7] - cu[1] * cu[2]; C6[5] = cu[8] - cu[2] * cu[2];
+            } else { C6[0] = 1; C6[1] = 0; C6[2] = 0; C6[3] = 1; C6[4] = 0; C6[5] = 1; }
+            if (a.cov6) { for (int t = 0; t < 6; t++) a.cov6[(size_t)qi * 6 + t] = (float)C6[t]; }
+            if (a.normals) {
+                double nv[3];
+                d_fast_eigen3x3(C6, nv);
+                const double nn = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+                double px = 0, py = 0, pz = 0;
+                if (a.prior) { const float4 pr = a.prior[qi]; px = pr.x; py = pr.y; pz = pr.z; }
+                if (nn == 0.0 || !(nn == nn)) { if (a.prior) { nv[0] = px; nv[1] = py; nv[2] = pz; } else { nv[0] = 0; nv[1] = 0; nv[2] = 1; } }
+                if (a.prior && nv[0] * px + nv[1] * py + nv[2] * pz < 0.0) { nv[0] = -nv[0]; nv[1] = -nv[1]; nv[2] = -nv[2]; }
+                a.normals[qi] = make_float4((float)nv[0], (float)nv[1], (float)nv[2], 0.0f);
+            }
         }
     } else {
-        // debug: selection-sort the k-best ascending (d2, idx) and emit
-        for (int t = 0; t < v.count; t++) {
-            int best = t; float bd = sd[t * KNN_BS]; int bi = si[t * KNN_BS];
-            for (int u = t + 1; u < v.count; u++) {
-                float d = sd[u * KNN_BS]; int ix = si[u * KNN_BS];
-                if (d < bd || (d == bd && ix < bi)) { best = u; bd = d; bi = ix; }
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < SLOTS; j++) {
+            const int slot = ol + OCT * j;
+            if (slot < a.k) {
+                a.dbg_idx[(size_t)qi * a.k + slot] = tk.si[j];
+                a.dbg_d2[(size_t)qi * a.k + slot] = tk.si[j] >= 0 ? tk.sd[j] : __builtin_inff();
+                c += tk.si[j] >= 0 ? 1 : 0;
             }
-            if (best != t) { sd[best * KNN_BS] = sd[t * KNN_BS]; si[best * KNN_BS] = si[t * KNN_BS]; sd[t * KNN_BS] = bd; si[t * KNN_BS] = bi; }
-            a.dbg_idx[(size_t)i * a.k + t] = bi; a.dbg_d2[(size_t)i * a.k + t] = bd;
         }
-        for (int t = v.count; t < a.k; t++) { a.dbg_idx[(size_t)i * a.k + t] = -1; a.dbg_d2[(size_t)i * a.k + t] = __builtin_inff(); }
-        if (a.dbg_cnt) a.dbg_cnt[i] = v.count;
+#pragma unroll
+        for (int o = 1; o < OCT; o <<= 1) c += __shfl_xor(c, o, OCT);
+        if (ol == 0 && a.dbg_cnt) a.dbg_cnt[qi] = a.dbg_visits ? nvis : c;
     }
 }
 
 template <int MODE>
 static int launch_knn(pcr_context *ctx, const DevCloud *c, KnnArgs a) {
     if (c->cap <= 0) return PCR_OK;
-    const size_t lds = (size_t)a.k * KNN_BS * 8;
-    if (a.k < 1 || lds > 150 * 1024) { ctx->err = "k out of range for the per-thread k-NN kernel (1..150)"; return PCR_EINVAL; }
-    static bool attr_set[3] = {false, false, false};
-    if (!attr_set[MODE]) {
-        PCR_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_knn<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set[MODE] = true;
-    }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn<MODE>), dim3((c->cap + KNN_BS - 1) / KNN_BS), dim3(KNN_BS), lds, ctx->stream, a);
+    if (a.k < 1 || a.k > 200) { ctx->err = "k out of range for the octet k-NN kernel (1..200)"; return PCR_EINVAL; }
+    const dim3 grid((unsigned)(((size_t)c->cap * OCT + KNN_BS - 1) / KNN_BS)), block(KNN_BS);
+    if (a.k <= 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn<MODE, 4>), grid, block, 0, ctx->stream, a);
+    else if (a.k <= 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn<MODE, 8>), grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn<MODE, 25>), grid, block, 0, ctx->stream, a);
     return PCR_OK;
 }
 
@@ -550,10 +745,10 @@ static void knn_radius(KnnArgs &a, int search_kind, double radius) {
 
 int pcr_dev_knn_debug(pcr_context *ctx, const DevCloud *c, int k, double radius, int32_t *idx, float *d2, int32_t *counts) {
     KnnArgs a = {};
-    a.pts = c->pts; a.boxes = c->boxes; a.n_ptr = c->n; a.k = k;
+    a.t = oct_view(c); a.n_ptr = c->n; a.k = k;
     knn_radius(a, radius > 0 ? PCR_SEARCH_HYBRID : PCR_SEARCH_KNN, radius);
     if (radius > 0) a.r2cap_f = (float)(radius * radius);
-    a.dbg_idx = idx; a.dbg_d2 = d2; a.dbg_cnt = counts;
+    a.dbg_idx = idx; a.dbg_d2 = d2; a.dbg_cnt = counts; a.dbg_visits = getenv("PCR_DEBUG_VISITS") ? 1 : 0;
     return launch_knn<KNN_MODE_DEBUG>(ctx, c, a);
 }
 
@@ -591,16 +786,19 @@ __global__ void __launch_bounds__(BS) k_sor_flags(const double *__restrict__ avg
     flags[i] = (v > 0 && v < stats3[2]) ? 1 : 0;
 }
 __global__ void __launch_bounds__(BS) k_compact_cloud(const float4 *__restrict__ pts, const float4 *__restrict__ nrm, const uint8_t *__restrict__ flags, const int *__restrict__ pos,
-                                                      const int *__restrict__ n_ptr, float4 *__restrict__ out_pts, float4 *__restrict__ out_nrm) {
+                                                      const int *__restrict__ n_ptr, float4 *__restrict__ out_pts, float4 *__restrict__ out_nrm,
+                                                      const uint64_t *__restrict__ keys, uint64_t *__restrict__ out_keys) {
     const int i = blockIdx.x * BS + threadIdx.x;
     if (i >= *n_ptr || !flags[i]) return;
     const int o = pos[i];
     out_pts[o] = pts[i];
+    out_keys[o] = keys[i];
     if (nrm && out_nrm) out_nrm[o] = nrm[i];
 }
 
 int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double std_ratio, DevCloud *out, uint8_t *keep_sorted, double *avg_sorted) {
     if (nb_neighbors < 1 || !(std_ratio > 0.0)) { ctx->err = "nb_neighbors < 1 or std_ratio <= 0"; return PCR_EINVAL; }
+    for (int d = 0; d < 3; d++) { out->key_org[d] = in->key_org[d]; out->key_unit[d] = in->key_unit[d]; }
     if (in->cap <= 0) { PCR_HIP_CHECK(ctx, hipMemsetAsync(out->n, 0, sizeof(int), ctx->stream)); return PCR_OK; }
     ArenaMark mark(ctx);
     double *avg = avg_sorted ? avg_sorted : arena<double>(ctx, in->cap);
@@ -609,14 +807,14 @@ int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double s
     int *pos = arena<int>(ctx, in->cap);
     if (!avg || !stats3 || !flags || !pos) return PCR_ENOMEM;
     KnnArgs a = {};
-    a.pts = in->pts; a.boxes = in->boxes; a.n_ptr = in->n; a.k = nb_neighbors; a.avg = avg;
+    a.t = oct_view(in); a.n_ptr = in->n; a.k = nb_neighbors; a.avg = avg;
     knn_radius(a, PCR_SEARCH_KNN, 0);
     PCR_TRY(launch_knn<KNN_MODE_SOR>(ctx, in, a));
     hipLaunchKernelGGL(k_sor_stats, dim3(1), dim3(1024), 0, ctx->stream, avg, in->n, std_ratio, stats3);
     const int nb = (in->cap + BS - 1) / BS;
     hipLaunchKernelGGL(k_sor_flags, dim3(nb), dim3(BS), 0, ctx->stream, avg, in->n, stats3, flags);
     PCR_TRY(pcr_dev_flag_scan(ctx, flags, in->n, in->cap, pos, out->n));
-    hipLaunchKernelGGL(k_compact_cloud, dim3(nb), dim3(BS), 0, ctx->stream, in->pts, in->nrm, flags, pos, in->n, out->pts, out->nrm);
+    hipLaunchKernelGGL(k_compact_cloud, dim3(nb), dim3(BS), 0, ctx->stream, in->pts, in->nrm, flags, pos, in->n, out->pts, out->nrm, in->keys, out->keys);
     return PCR_OK;
 }
 
@@ -626,12 +824,12 @@ int pcr_dev_normals(pcr_context *ctx, DevCloud *c, int search_kind, int knn, dou
     if (knn < 1) { ctx->err = "knn < 1"; return PCR_EINVAL; }
     if (search_kind == PCR_SEARCH_HYBRID && !(radius > 0)) { ctx->err = "radius <= 0"; return PCR_EINVAL; }
     KnnArgs a = {};
-    a.pts = c->pts; a.boxes = c->boxes; a.n_ptr = c->n; a.k = knn; a.prior = prior; a.normals = normals_out; a.cov6 = cov6_out;
+    a.t = oct_view(c); a.n_ptr = c->n; a.k = knn; a.prior = prior; a.normals = normals_out; a.cov6 = cov6_out;
     knn_radius(a, search_kind, radius);
     return launch_knn<KNN_MODE_NORMALS>(ctx, c, a);
 }
 
 size_t pcr_scratch_bytes_for(int64_t n) {
     // voxel/sort temporaries (2x u64 keys, 2x u32 vals, flags, pos, sort temp) + clouds + boxes, with slack
-    return (size_t)(n > 0 ? n : 1) * 160 + pcr_sort_temp_bytes((size_t)(n > 0 ? n : 1)) + (4u << 20);
+    return (size_t)(n > 0 ? n : 1) * 320 + pcr_sort_temp_bytes((size_t)(n > 0 ? n : 1)) + (4u << 20);
 }

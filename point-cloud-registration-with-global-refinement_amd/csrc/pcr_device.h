@@ -93,6 +93,7 @@ __device__ static inline void pcr_bvh_traverse(const float4 *__restrict__ boxes,
         if (lvl == 1) {
             v.leaf(child);
         } else {
+            v.on_node();
             pending = (pending & ~(0xffull << (8 * lvl))) | ((uint64_t)mask << (8 * lvl));
             lvl--; node = child;
             mask = pcr_child_mask(boxes, m, lvl, node, qx, qy, qz, v.bound());

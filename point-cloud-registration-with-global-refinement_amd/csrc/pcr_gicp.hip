@@ -9,7 +9,9 @@
 // 2_MGICP_refinement_in_NCLT_dataset.py:155-162.
 #include <cmath>
 #include <cstring>
-#include "pcr_device.h"
+#include <cstdio>
+#include <cstdlib>
+#include "pcr_octree.h"
 
 #define ICP_BS 256
 #define NV 30            // 21 (upper JTJ) + 6 (JTr) + sum r^2 + sum d^2 + count
@@ -29,11 +31,12 @@ struct IcpState {
     int ns;                     // source points of this problem (for the byte model)
     unsigned long long t_start; // s_memrealtime (100 MHz) stamp of workgroup 0 at kernel entry
     unsigned long long t_live;  // sum over live launches of (last workgroup's exit stamp - t_start)
+    unsigned long long t_dbg[4]; // diagnostic stamps (sum): wg0 after search, wg0 after reduce, last wg entering tail, last wg after partial sums
 };
 
 struct IcpArgs {
     const float4 *src_pts, *src_nrm; const int *ns_ptr;
-    const float4 *tgt_pts, *tgt_nrm, *tgt_boxes; const int *nt_ptr;
+    const float4 *tgt_pts, *tgt_nrm; OctView tgt; const int *nt_ptr;
     int32_t *match;
     IcpState *state;
     double *partials;
@@ -41,35 +44,58 @@ struct IcpArgs {
     int loss; double loss_k; double a;          // a = 1 - epsilon
     double rel_fit, rel_rmse; int max_it;
     int single;                                  // 1: linearise once, never update (debug / evaluate)
+    int dbg_visits;                              // diagnostics: store node/leaf visit counts instead of matches
 };
 
 struct IcpInit { double T[16]; };
 __global__ void k_icp_init(IcpState *st, IcpInit in) {
     if (threadIdx.x == 0) {
         for (int k = 0; k < 16; k++) st->T[k] = in.T[k];
-        st->fitness = 0; st->rmse = 0; st->count = 0; st->iter = 0; st->launches = 0; st->done = 0; st->converged = 0; st->ticket = 0; st->ns = 0; st->t_start = 0; st->t_live = 0;
+        st->fitness = 0; st->rmse = 0; st->count = 0; st->iter = 0; st->launches = 0; st->done = 0; st->converged = 0; st->ticket = 0; st->ns = 0; st->t_start = 0; st->t_live = 0; for (int k = 0; k < 4; k++) st->t_dbg[k] = 0;
         for (int k = 0; k < NVP; k++) st->sums[k] = 0;
     }
 }
 
-struct NnVisitor {
-    const float4 *__restrict__ pts;
-    int n, best;
-    float qx, qy, qz, bestd;
-    __device__ float bound() const { return bestd; }
-    __device__ void leaf(int l) {
-        const int b = l * PCR_LEAF;
-#pragma unroll
-        for (int j = 0; j < PCR_LEAF; j++) {
-            const int idx = b + j;
-            if (idx < n) {
-                const float4 p = pts[idx];
-                const float d = pcr_d2(p.x - qx, p.y - qy, p.z - qz);
-                if (d < bestd) { bestd = d; best = idx; }
+// ---- exact 1-NN of one query per octet over the target's linear octree.  Called by all 64 lanes of a wavefront;
+// `live` is octet-uniform.  hint >= 0: a target point near the answer (previous match, or the previous start point of
+// an unmatched query) -- the search starts bottom-up from its leaf; hint < 0: greedy nearest-box descent from the root.
+// Returns the best index within r2cap (or -1) and, through start_pt, a point of the start leaf (next launch's hint).
+template <int OPB>
+__device__ static inline int oct_nn_query(const OctView &t, const OctMeta &m, OctStack<OPB> &stk, bool live, float qx, float qy, float qz,
+                                          float r2cap, int hint, int ol, int oct, int ob, int *start_pt, int *visits) {
+    int best = -1; float bestd = r2cap;
+    const bool active = live && m.nl >= 1;
+    auto visit = [&](int first, int count) {                 // wave-wide; count == 0: octet idle
+        int base = first; const int end = first + count;
+        while (__ballot(base < end) != 0ull) {
+            float d = 3.4e38f; int id = -1;
+            if (base + ol < end) {
+                const float4 p = t.pts[base + ol];
+                d = pcr_d2(p.x - qx, p.y - qy, p.z - qz); id = base + ol;
             }
+#pragma unroll
+            for (int o = 1; o < OCT; o <<= 1) {               // octet arg-min (ties -> lower index)
+                const float od = __shfl_xor(d, o, OCT); const int oid = __shfl_xor(id, o, OCT);
+                if (od < d || (od == d && (unsigned)oid < (unsigned)id)) { d = od; id = oid; }
+            }
+            if (id >= 0 && d < bestd) { bestd = d; best = id; }
+            base += OCT;
         }
+    };
+    int leaf = 0;
+    const bool warm = active && hint >= 0;
+    if (warm) {
+        const float4 c = t.pts[hint];
+        const float d = pcr_d2(c.x - qx, c.y - qy, c.z - qz);
+        if (d < bestd) { bestd = d; best = hint; }
+        leaf = t.leaf_of[hint];
     }
-};
+    const bool cold = active && !warm;
+    if (__ballot(cold) != 0ull) { const int g = oct_greedy_leaf(t, m, cold, qx, qy, qz, ol); if (cold) leaf = g; }
+    if (active) *start_pt = __float_as_int(t.nodes[2 * (size_t)(m.off[0] + leaf)].w);
+    oct_search<OPB>(t, m, stk, active, leaf, qx, qy, qz, [&]() { return bestd; }, visit, [](int, int) { return false; }, ol, oct, ob, visits);
+    return best;
+}
 
 __device__ static inline double icp_weight(int loss, double k, double r) {
     if (loss == PCR_LOSS_L1) return 1.0 / fmax(fabs(r), 1e-300);    // Open3D: 1/|r| (unguarded); guard only against r == 0
@@ -77,10 +103,66 @@ __device__ static inline double icp_weight(int loss, double k, double r) {
     return 1.0;
 }
 
-// 6x6 symmetric solve, LDL^T with diagonal pivoting (as Eigen::LDLT), one lane
-__device__ static bool icp_ldlt6(const double *A36, const double *b6, double *x6) {
-    double A[36], L[36], D[6], y[6], z[6]; int perm[6];
-    for (int i = 0; i < 36; i++) { A[i] = A36[i]; L[i] = 0; }
+// 6x6 symmetric solve on ONE lane.  Fast path: LDL^T without pivoting, fully unrolled so that every array lives in
+// registers (no scratch traffic on the critical path of the iteration).  If a pivot is not strictly positive/finite
+// (semi-definite or indefinite system) fall back to the diagonally pivoted LDL^T of Eigen::LDLT on LDS arrays.
+__device__ static bool icp_ldlt6_fast(const double *S /*21 upper-triangular sums*/, const double *b /*6*/, double *x) {
+    double A[6][6];
+    {
+        int t = 0;
+#pragma unroll
+        for (int p = 0; p < 6; p++)
+#pragma unroll
+            for (int q = p; q < 6; q++) { A[q][p] = S[t]; t++; }      // lower triangle
+    }
+    double D[6], y[6];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const double d = A[k][k];
+        ok = ok && (d > 0.0) && isfinite(d);
+        D[k] = d;
+        const double inv = 1.0 / d;
+        double col[6];
+#pragma unroll
+        for (int i = k + 1; i < 6; i++) col[i] = A[i][k];            // original column k below the diagonal
+#pragma unroll
+        for (int i = k + 1; i < 6; i++) {
+            const double l = col[i] * inv;
+#pragma unroll
+            for (int j = k + 1; j <= i; j++) A[i][j] -= l * col[j];
+            A[i][k] = l;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double s = b[i];
+#pragma unroll
+        for (int j = 0; j < i; j++) s -= A[i][j] * y[j];
+        y[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) y[i] /= D[i];
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        double s = y[i];
+#pragma unroll
+        for (int j = i + 1; j < 6; j++) s -= A[j][i] * x[j];
+        x[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) ok = ok && isfinite(x[i]);
+    return ok;
+}
+
+// pivoted fallback; w = LDS workspace of >= 36+36+6+6+6 doubles and 6 ints
+__device__ static bool icp_ldlt6_pivoted(const double *S, const double *b6, double *x6, double *w, int *perm) {
+    double *A = w, *L = w + 36, *D = w + 72, *y = w + 78, *z = w + 84;
+    {
+        int t = 0;
+        for (int p = 0; p < 6; p++) for (int q = p; q < 6; q++) { A[p * 6 + q] = S[t]; A[q * 6 + p] = S[t]; t++; }
+    }
+    for (int i = 0; i < 36; i++) L[i] = 0;
     for (int i = 0; i < 6; i++) perm[i] = i;
     for (int k = 0; k < 6; k++) {
         int piv = k; double best = fabs(A[k * 6 + k]);
@@ -102,26 +184,60 @@ __device__ static bool icp_ldlt6(const double *A36, const double *b6, double *x6
     for (int i = 0; i < 6; i++) y[i] /= D[i];
     for (int i = 5; i >= 0; i--) { double s = y[i]; for (int j = i + 1; j < 6; j++) s -= L[j * 6 + i] * z[j]; z[i] = s; }
     bool ok = true;
-    for (int i = 0; i < 6; i++) { x6[perm[i]] = z[i]; }
-    for (int i = 0; i < 6; i++) ok = ok && isfinite(x6[i]);
+    for (int i = 0; i < 6; i++) { const double v = z[i]; ok = ok && isfinite(v); w[90 + perm[i]] = v; }
+    for (int i = 0; i < 6; i++) x6[i] = w[90 + i];
     return ok;
 }
 
+// ---- kernel 1 of an iteration: exact 1-NN of every transformed source point, ONE query per octet (32 per
+// workgroup).  Latency-bound pointer chasing, so it runs at full occupancy (few registers, many wavefronts).
+__global__ void __launch_bounds__(ICP_BS) k_icp_nn(IcpArgs a) {
+    IcpState *st = a.state;
+    if (st->done) return;
+    constexpr int OPB = ICP_BS / OCT;
+    __shared__ OctMeta m;
+    __shared__ OctStack<OPB> stk;
+    const int ns = *a.ns_ptr, nt = *a.nt_ptr;
+    if ((int)blockIdx.x * OPB >= ns) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->t_start = wall_clock64();
+    if (threadIdx.x == 0) m = *a.tgt.meta;
+    __syncthreads();
+    const int launches = st->launches;
+    const int lane = threadIdx.x & 63, oct = lane >> 3, ol = lane & 7, ob = threadIdx.x >> 3;
+    const int i = blockIdx.x * OPB + ob;
+    const bool live = i < ns && nt > 0;
+    float qx = 0, qy = 0, qz = 0; int hint = -1;
+    if (i < ns) {
+        const float4 pf = a.src_pts[i];
+        const double px = pf.x, py = pf.y, pz = pf.z;
+        qx = (float)(st->T[0] * px + st->T[1] * py + st->T[2] * pz + st->T[3]);
+        qy = (float)(st->T[4] * px + st->T[5] * py + st->T[6] * pz + st->T[7]);
+        qz = (float)(st->T[8] * px + st->T[9] * py + st->T[10] * pz + st->T[11]);
+        // match[] carries the warm-start hint across launches: >= 0 matched target point, <= -2 -> start point -(v+2)
+        const int mv = launches > 0 ? a.match[i] : -1;
+        hint = mv >= 0 ? mv : (mv <= -2 ? -(mv + 2) : -1);
+    }
+    int visits = 0, start_pt = 0;
+    const int best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.r2f, hint, ol, oct, ob, &start_pt, a.dbg_visits ? &visits : nullptr);
+    if (ol == 0 && i < ns) a.match[i] = a.dbg_visits ? visits : (best >= 0 ? best : -(start_pt + 2));
+}
+
+// ---- kernel 2 of an iteration: one correspondence per lane in float64 -> wave/LDS reduction -> last workgroup
+// finishes the iteration (sum partials, convergence test, 6x6 solve, pose update).
 template <int MODE>
 __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
     IcpState *st = a.state;
     if (st->done) return;
-    __shared__ BvhMeta m;
     __shared__ double red[ICP_BS / PCR_WAVE][NVP];
     __shared__ double fin[8][NVP];
     __shared__ int is_last;
-    const int ns = *a.ns_ptr, nt = *a.nt_ptr;
+    __shared__ double ldl_w[96];
+    __shared__ int ldl_perm[6];
+    const int ns = *a.ns_ptr;
     int nb = (ns + ICP_BS - 1) / ICP_BS;
     if (nb < 1) nb = 1;
     if ((int)blockIdx.x >= nb) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->t_start = wall_clock64();   // published by this workgroup's release below
-    if (threadIdx.x == 0) pcr_bvh_meta(nt, m);
-    __syncthreads();
+    const unsigned long long t_entry = wall_clock64();
     const int launches = st->launches;
     double T[12];
 #pragma unroll
@@ -132,28 +248,22 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
     for (int k = 0; k < NV; k++) acc[k] = 0.0;
 
     const int i = blockIdx.x * ICP_BS + threadIdx.x;
+    double qx = 0, qy = 0, qz = 0;
+    int cand = -1;
     if (i < ns) {
         const float4 pf = a.src_pts[i];
         const double px = pf.x, py = pf.y, pz = pf.z;
-        const double qx = T[0] * px + T[1] * py + T[2] * pz + T[3];
-        const double qy = T[4] * px + T[5] * py + T[6] * pz + T[7];
-        const double qz = T[8] * px + T[9] * py + T[10] * pz + T[11];
-        NnVisitor v;
-        v.pts = a.tgt_pts; v.n = nt; v.best = -1; v.bestd = a.r2f;
-        v.qx = (float)qx; v.qy = (float)qy; v.qz = (float)qz;
-        if (nt > 0) {
-            int seed = launches > 0 ? a.match[i] : -1;
-            if (seed >= 0) {
-                const float4 c = a.tgt_pts[seed];
-                const float d = pcr_d2(c.x - v.qx, c.y - v.qy, c.z - v.qz);
-                if (d < v.bestd) { v.bestd = d; v.best = seed; }
-            } else {
-                v.leaf(pcr_bvh_greedy_leaf(a.tgt_boxes, m, v.qx, v.qy, v.qz));
-            }
-            pcr_bvh_traverse(a.tgt_boxes, m, v.qx, v.qy, v.qz, v);
-        }
-        int best = v.best;
-        if (best >= 0) {
+        qx = T[0] * px + T[1] * py + T[2] * pz + T[3];
+        qy = T[4] * px + T[5] * py + T[6] * pz + T[7];
+        qz = T[8] * px + T[9] * py + T[10] * pz + T[11];
+        cand = a.match[i];
+    }
+    if (a.dbg_visits) cand = -1;
+
+    // ---- one correspondence per lane, float64
+    if (i < ns && cand >= 0) {
+        int best = cand;
+        {
             const float4 tf = a.tgt_pts[best];
             const double dx = qx - (double)tf.x, dy = qy - (double)tf.y, dz = qz - (double)tf.z;
             const double d2 = dx * dx + dy * dy + dz * dz;
@@ -218,9 +328,10 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
                 }
             } else best = -1;
         }
-        a.match[i] = best;
+        if (best < 0) a.match[i] = -(cand + 2);      // beyond max_dist in float64: keep the candidate as next start hint
     }
 
+    const unsigned long long t_search = wall_clock64() - t_entry;
     // ---- workgroup reduction: fixed shuffle tree, then waves in order
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -230,17 +341,27 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
         double s = red[0][threadIdx.x];
 #pragma unroll
         for (int w = 1; w < ICP_BS / PCR_WAVE; w++) s += red[w][threadIdx.x];
-        a.partials[(size_t)blockIdx.x * NVP + threadIdx.x] = s;
-        __threadfence();                       // release this workgroup's partial (agent scope)
+        // publish write-through (sc1): no per-workgroup release fence (a release = whole-L2 write-back; ~700 of
+        // them per launch serialised to >100 us).  cdna_hip_programming.md Guideline 16, recipe R1.
+        __hip_atomic_store(&a.partials[(size_t)blockIdx.x * NVP + threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
+    if (threadIdx.x == 63) {   // diagnostics in the two padding columns: ticks to end-of-search / end-of-reduction
+        __hip_atomic_store(&a.partials[(size_t)blockIdx.x * NVP + 30], (double)t_search, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.partials[(size_t)blockIdx.x * NVP + 31], (double)(wall_clock64() - t_entry), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its stores ...
+    __syncthreads();                                       // ... before ONE lane signals for the workgroup
     if (threadIdx.x == 0) {
-        const unsigned int t = atomicAdd(&st->ticket, 1u);
-        is_last = (t == (unsigned int)(nb - 1));
+        const unsigned int t = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == (unsigned int)(nb - 1));
+        if (last) {                                        // ONE acquire, in the last-arriving workgroup only
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        is_last = last;
     }
     __syncthreads();
     if (!is_last) return;
-    __threadfence();                           // acquire: other workgroups' partials
 
     // ---- last workgroup: sum the partials in workgroup order (deterministic), then finish the iteration
     {
@@ -248,19 +369,36 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
         const int per = (nb + 7) / 8;
         const int b0 = chunk * per, b1 = min(nb, b0 + per);
         double s = 0;
-        if (vcol < NV) for (int b = b0; b < b1; b++) s += a.partials[(size_t)b * NVP + vcol];
+        // plain loads behind the ONE agent acquire above: the hardware keeps many in flight (relaxed-atomic loads were
+        // issued one at a time: 50-100 us for ~600 rows).  Four interleaved accumulators, combined in a fixed order.
+        const double *P = a.partials;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        int b = b0;
+        if (vcol < NV) {
+            for (; b + 3 < b1; b += 4) {
+                s0 += P[(size_t)(b + 0) * NVP + vcol]; s1 += P[(size_t)(b + 1) * NVP + vcol];
+                s2 += P[(size_t)(b + 2) * NVP + vcol]; s3 += P[(size_t)(b + 3) * NVP + vcol];
+            }
+            for (; b < b1; b++) s0 += P[(size_t)b * NVP + vcol];
+            s = (s0 + s1) + (s2 + s3);
+        } else {
+            for (; b < b1; b++) s = fmax(s, P[(size_t)b * NVP + vcol]);
+        }
         fin[chunk][vcol] = s;
     }
     __syncthreads();
     if (threadIdx.x < NVP) {
         double s = 0;
 #pragma unroll
-        for (int c = 0; c < 8; c++) s += fin[c][threadIdx.x];
+        for (int c = 0; c < 8; c++) s = threadIdx.x < NV ? s + fin[c][threadIdx.x] : fmax(s, fin[c][threadIdx.x]);
         fin[0][threadIdx.x] = s;
         st->sums[threadIdx.x] = s;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        const unsigned long long t0k = st->t_start;    // stamped by k_icp_nn (previous kernel)
+        st->t_dbg[3] += wall_clock64() - t0k;
+        st->t_dbg[0] += (unsigned long long)fin[0][30]; st->t_dbg[1] += (unsigned long long)fin[0][31];
         const double *S = fin[0];
         const long long count = (long long)(S[29] + 0.5);
         const double fit = ns > 0 ? (double)count / (double)ns : 0.0;
@@ -273,11 +411,18 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
         if (!stop && MODE == ICP_MODE_GICP) {
             double U[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
             if (count > 0) {
-                double A[36], nb6[6], x[6];
-                int t = 0;
-                for (int p = 0; p < 6; p++) for (int q = p; q < 6; q++) { A[p * 6 + q] = S[t]; A[q * 6 + p] = S[t]; t++; }
+                double nb6[6], x[6];
+#pragma unroll
                 for (int p = 0; p < 6; p++) nb6[p] = -S[21 + p];
-                if (icp_ldlt6(A, nb6, x)) {
+                bool solved = icp_ldlt6_fast(S, nb6, x);
+                if (!solved) {                         // rare: indefinite / semi-definite system
+                    double *rhs = &fin[1][0];          // LDS copies (dynamic indexing must not touch scratch)
+                    double *sol = &fin[2][0];
+                    for (int p = 0; p < 6; p++) rhs[p] = -S[21 + p];
+                    solved = icp_ldlt6_pivoted(S, rhs, sol, ldl_w, ldl_perm);
+                    for (int p = 0; p < 6; p++) x[p] = sol[p];
+                }
+                if (solved) {
                     const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]), sg = sin(x[2]);
                     U[0] = cg * cb; U[1] = cg * sb * sa - sg * ca; U[2] = cg * sb * ca + sg * sa; U[3] = x[3];
                     U[4] = sg * cb; U[5] = sg * sb * sa + cg * ca; U[6] = sg * sb * ca - cg * sa; U[7] = x[4];
@@ -296,18 +441,18 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
         }
         st->launches = launches + 1;
         st->converged = conv ? 1 : 0;
-        st->ticket = 0;
+        __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         st->ns = ns;
-        st->t_live += wall_clock64() - st->t_start;
-        __threadfence();
-        st->done = stop ? 1 : 0;
+        st->t_live += wall_clock64() - t0k;
+        st->done = stop ? 1 : 0;          // visible to the next launch through the kernel boundary
     }
 }
 
 static void fill_args(IcpArgs &a, const DevCloud *src, const DevCloud *tgt, double max_dist, const pcr_gicp_params *p,
                       int32_t *match, IcpState *st, double *partials, int single) {
     a.src_pts = src->pts; a.src_nrm = src->nrm; a.ns_ptr = src->n;
-    a.tgt_pts = tgt->pts; a.tgt_nrm = tgt->nrm; a.tgt_boxes = tgt->boxes; a.nt_ptr = tgt->n;
+    a.tgt_pts = tgt->pts; a.tgt_nrm = tgt->nrm; a.nt_ptr = tgt->n;
+    a.tgt.pts = tgt->pts; a.tgt.nodes = tgt->oct_nodes; a.tgt.parent = tgt->oct_parent; a.tgt.meta = tgt->oct_meta; a.tgt.leaf_of = tgt->leaf_of; a.tgt.keys = tgt->keys;
     a.match = match; a.state = st; a.partials = partials;
     a.max_dist2 = max_dist * max_dist;
     const double r2w = a.max_dist2 * (1.0 + 1e-6);
@@ -315,6 +460,7 @@ static void fill_args(IcpArgs &a, const DevCloud *src, const DevCloud *tgt, doub
     a.loss = p ? p->loss : 0; a.loss_k = p ? p->loss_k : 1.0; a.a = 1.0 - (p ? p->epsilon : 1e-3);
     a.rel_fit = p ? p->relative_fitness : 1e-6; a.rel_rmse = p ? p->relative_rmse : 1e-6; a.max_it = p ? p->max_iteration : 30;
     a.single = single;
+    a.dbg_visits = (single && getenv("PCR_DEBUG_VISITS")) ? 1 : 0;
 }
 
 static int read_state(pcr_context *ctx, const IcpState *st_dev, IcpState *host) {
@@ -337,6 +483,7 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     ArenaMark mark(ctx);
     const int cap = src->cap > 0 ? src->cap : 1;
     const int nbmax = (cap + ICP_BS - 1) / ICP_BS;
+    const int nbnn = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT);
     IcpState *st = arena<IcpState>(ctx, 1);
     double *partials = arena<double>(ctx, (size_t)nbmax * NVP);
     int32_t *match = match_dev ? match_dev : arena<int32_t>(ctx, cap);
@@ -359,7 +506,10 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
                 while ((int)ctx->prof_events.size() < 2 * (n_chunks + 1)) { hipEvent_t e; PCR_HIP_CHECK(ctx, hipEventCreate(&e)); ctx->prof_events.push_back(e); }
                 PCR_HIP_CHECK(ctx, hipEventRecord(ctx->prof_events[2 * n_chunks], ctx->stream));
             }
-            for (int k = 0; k < c; k++) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP>), dim3(nbmax), dim3(ICP_BS), 0, ctx->stream, a);
+            for (int k = 0; k < c; k++) {
+                hipLaunchKernelGGL(k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP>), dim3(nbmax), dim3(ICP_BS), 0, ctx->stream, a);
+            }
             if (ctx->profiling) PCR_HIP_CHECK(ctx, hipEventRecord(ctx->prof_events[2 * n_chunks + 1], ctx->stream));
             n_chunks++;
             launched += c;
@@ -390,6 +540,8 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
         ctx->prof[3] += fin.launches;
         ctx->prof[4] += 48.0 * (double)fin.ns * (double)fin.launches;   // 48 B per source point per launch
         ctx->prof[5] += launched;
+        ctx->prof[6] += (double)fin.t_dbg[0] * 0.01; ctx->prof[7] += (double)fin.t_dbg[3] * 0.01;
+        if (getenv("PCR_DEBUG_STAMPS")) fprintf(stderr, "icp stamps (us/launch): slowest-wg search %.1f slowest-wg reduce %.1f (unused %.1f) sums-done %.1f end %.1f (launches %d ns %d)\n", fin.t_dbg[0] * 0.01 / fin.launches, fin.t_dbg[1] * 0.01 / fin.launches, fin.t_dbg[2] * 0.01 / fin.launches, fin.t_dbg[3] * 0.01 / fin.launches, fin.t_live * 0.01 / fin.launches, fin.launches, fin.ns);
     }
     state_to_result(fin, out);
     for (int k = 0; k < 16; k++) if (!std::isfinite(fin.T[k])) { ctx->err = "non-finite pose"; return PCR_ENUMERIC; }
@@ -402,6 +554,7 @@ int pcr_dev_linearize_once(pcr_context *ctx, const DevCloud *src, const DevCloud
     ArenaMark mark(ctx);
     const int cap = src->cap > 0 ? src->cap : 1;
     const int nbmax = (cap + ICP_BS - 1) / ICP_BS;
+    const int nbnn = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT);
     IcpState *st = arena<IcpState>(ctx, 1);
     double *partials = arena<double>(ctx, (size_t)nbmax * NVP);
     int32_t *match = match_dev ? match_dev : arena<int32_t>(ctx, cap);
@@ -409,6 +562,7 @@ int pcr_dev_linearize_once(pcr_context *ctx, const DevCloud *src, const DevCloud
     IcpArgs a; fill_args(a, src, tgt, max_dist, p, match, st, partials, 1);
     IcpInit in; memcpy(in.T, T, sizeof in.T);
     hipLaunchKernelGGL(k_icp_init, dim3(1), dim3(64), 0, ctx->stream, st, in);
+    hipLaunchKernelGGL(k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP>), dim3(nbmax), dim3(ICP_BS), 0, ctx->stream, a);
     IcpState h;
     PCR_TRY(read_state(ctx, st, &h));
@@ -425,6 +579,7 @@ int pcr_dev_evaluate(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt,
     ArenaMark mark(ctx);
     const int cap = src->cap > 0 ? src->cap : 1;
     const int nbmax = (cap + ICP_BS - 1) / ICP_BS;
+    const int nbnn = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT);
     IcpState *st = arena<IcpState>(ctx, 1);
     double *partials = arena<double>(ctx, (size_t)nbmax * NVP);
     int32_t *match = match_dev ? match_dev : arena<int32_t>(ctx, cap);
@@ -432,6 +587,7 @@ int pcr_dev_evaluate(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt,
     IcpArgs a; fill_args(a, src, tgt, max_dist, nullptr, match, st, partials, 1);
     IcpInit in; memcpy(in.T, T, sizeof in.T);
     hipLaunchKernelGGL(k_icp_init, dim3(1), dim3(64), 0, ctx->stream, st, in);
+    hipLaunchKernelGGL(k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_EVAL>), dim3(nbmax), dim3(ICP_BS), 0, ctx->stream, a);
     IcpState h;
     PCR_TRY(read_state(ctx, st, &h));

@@ -54,14 +54,17 @@ struct DevCloud {
     float4 *nrm = nullptr;       // optional
     int *n = nullptr;            // device count
     int cap = 0;                 // host upper bound of *n
-    float4 *boxes = nullptr;     // implicit BVH: node i -> boxes[2i] = lo, boxes[2i+1] = hi
+    uint64_t *keys = nullptr;    // sorted Morton keys of the points (voxel index / quantised position)
+    int *oct_child = nullptr;    // linear octree (pcr_octree.h): build-time child links,
+    float4 *oct_nodes = nullptr; //   packed node records (box + first/count),
+    int *oct_parent = nullptr;   //   parent links
+    struct OctMeta *oct_meta = nullptr;
+    int *leaf_of = nullptr;
+    float key_org[3] = {0, 0, 0};   // lattice of the Morton keys: coordinate i <-> [org + i*unit, org + (i+1)*unit)
+    float key_unit[3] = {1, 1, 1};
 };
 
-static inline size_t bvh_node_capacity(int cap_points) {
-    size_t c = ((size_t)cap_points + PCR_LEAF - 1) / PCR_LEAF, tot = c;
-    while (c > PCR_FANOUT) { c = (c + PCR_FANOUT - 1) / PCR_FANOUT; tot += c; }
-    return tot + 8;
-}
+static inline size_t oct_node_capacity(int cap_points) { return (size_t)cap_points + 256; }   // entries of child[] / box pairs
 
 // ---- sort (pcr_sort.hip; rocPRIM device radix sort, the one library primitive used) -------------
 size_t pcr_sort_temp_bytes(size_t n);

@@ -1,0 +1,203 @@
+// pcr_octree.h -- linear octree over a Morton-sorted cloud and its 8-lane ("octet") traversal.
+//
+// Nodes of level l are the runs of points that share the Morton prefix key >> 3l; the children of a node are the
+// <= 8 runs of level l-1 inside it, stored contiguously, each with the TIGHT axis-aligned box of its points.  Cells
+// of one level are disjoint, so a query ball only meets the few cells it geometrically touches -- unlike fixed
+// groups of consecutive Morton points, whose boxes straddle the curve's jumps (measured: p90 leaf diagonal 3.5 m at
+// 0.1 m voxels, ~500 box tests per 1-NN query; DESIGN.md "spatial index").
+//
+// Layout (device), level index li = Morton level - l0, node j of level li lives at slot off[li] + j:
+//   nodes[2 slot]     = (lo.x, lo.y, lo.z, int first)   first POINT (li = 0) / first CHILD in level li-1 (li > 0)
+//   nodes[2 slot + 1] = (hi.x, hi.y, hi.z, int count)   number of points / children (<= 8 children)
+//   parent[slot]      = node of level li+1 that contains it
+//   leaf_of[i]        = leaf (li = 0 node) holding point i ;  keys[i] = Morton key of point i
+//   meta              = OctMeta: levels, counts, offsets, key geometry (origin + unit of the integer lattice)
+//
+// Search = bottom-up from a start leaf (the query's own leaf, or the leaf of the previous match): scan the leaf,
+// then climb; at every ancestor test its other children and walk down those the ball meets; stop as soon as the
+// ball lies inside the ancestor's Morton cell (then nothing outside the subtree can be closer).  With a warm bound
+// this touches 2-4 nodes instead of a root-to-leaf spine per query.
+//
+// 8 consecutive lanes serve one query.  Lane c tests child c of a node (one coalesced 256-B read), the verdicts
+// return as one byte of a wave ballot; pending siblings live in a per-octet LDS stack (<= 16 levels).
+#pragma once
+#include "pcr_device.h"
+
+#define OCT 8
+#define OCT_MAXL 16          // stored levels (leaf level .. root)
+#define OCT_KEY_LEVELS 22    // Morton levels of a 63-bit key (+1)
+
+struct OctMeta {
+    int n;                   // points
+    int l0;                  // Morton level of the leaves
+    int nl;                  // stored levels; root = level index nl-1 (exactly one node)
+    int cnt[OCT_MAXL];
+    int off[OCT_MAXL];
+    int total;               // node slots used
+    float org[3];            // lattice origin:   integer coordinate i  <->  [org + i*unit, org + (i+1)*unit)
+    float unit[3];
+};
+
+struct OctView {             // what a kernel needs to walk a tree
+    const float4 *pts;
+    const float4 *nodes;
+    const int *parent;
+    const OctMeta *meta;
+    const int *leaf_of;
+    const uint64_t *keys;
+};
+
+__host__ __device__ static inline uint32_t pcr_compact21(uint64_t x) {
+    x &= 0x1249249249249249ull;
+    x = (x | (x >> 2)) & 0x10c30c30c30c30c3ull;
+    x = (x | (x >> 4)) & 0x100f00f00f00f00full;
+    x = (x | (x >> 8)) & 0x1f0000ff0000ffull;
+    x = (x | (x >> 16)) & 0x1f00000000ffffull;
+    x = (x | (x >> 32)) & 0x1fffffull;
+    return (uint32_t)x;
+}
+
+// per-octet traversal stack (LDS): [level][octet in block]
+template <int OPB>
+struct OctStack {
+    int cs[OCT_MAXL][OPB];
+    unsigned char mask[OCT_MAXL][OPB];
+};
+
+// Test the <= 8 nodes [cs, cs+cnt) of level li against the ball; returns the octet's byte of the wave ballot and,
+// through (first, count), this lane's node payload.  MUST be called by all 64 lanes.
+__device__ static inline uint32_t oct_test_nodes(const OctView &t, const OctMeta &m, bool want, int li, int cs, int cnt,
+                                                 float qx, float qy, float qz, float bound, int ol, int oct,
+                                                 int &first, int &count) {
+    bool pass = false;
+    first = 0; count = 0;
+    if (want && ol < cnt) {
+        const size_t j = (size_t)(m.off[li] + cs + ol);
+        const float4 lo = t.nodes[2 * j], hi = t.nodes[2 * j + 1];
+        pass = pcr_box_d2(lo, hi, qx, qy, qz) < bound;
+        first = __float_as_int(lo.w); count = __float_as_int(hi.w);
+    }
+    const unsigned long long bal = __ballot(pass);
+    return (uint32_t)(bal >> (oct * 8)) & 0xffu;
+}
+
+// Is the ball (q, sqrt(bound)) strictly inside the Morton cell of level `lvl` that contains lattice point (ix,iy,iz)?
+__device__ static inline bool oct_ball_in_cell(const OctMeta &m, uint32_t ix, uint32_t iy, uint32_t iz, int lvl, float qx, float qy,
+                                               float qz, float bound) {
+    if (!(bound < 3.0e38f)) return false;
+    const float r = sqrtf(bound) * 1.00001f;
+    const float w = (float)(1u << lvl);
+    const float q[3] = {qx, qy, qz};
+    const uint32_t ic[3] = {ix, iy, iz};
+    bool in = true;
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        const float side = w * m.unit[d];
+        const float cmin = m.org[d] + (float)((ic[d] >> lvl) << lvl) * m.unit[d];
+        const float eps = 1e-4f * side + 1e-6f * fabsf(cmin);
+        in = in && (q[d] - r > cmin + eps) && (q[d] + r < cmin + side - eps);
+    }
+    return in;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Bottom-up exact search driver for one query per octet.  All 64 lanes call it; `live`, `start_leaf` are
+// octet-uniform.  bound() -> current squared radius (octet-uniform, may shrink);  visit(first, count) is a WAVE-WIDE
+// operation that tests `count` points starting at `first` (count == 0: idle octet);  skip(first, count) -> true if a
+// leaf need not be scanned at all (e.g. already covered by the seed range).
+template <int OPB, class BoundFn, class VisitFn, class SkipFn>
+__device__ static inline void oct_search(const OctView &t, const OctMeta &m, OctStack<OPB> &stk, bool live, int start_leaf,
+                                         float qx, float qy, float qz, BoundFn bound, VisitFn visit, SkipFn skip, int ol, int oct, int ob,
+                                         int *visits) {
+    bool done = !live || m.nl < 1;
+    // ---- the start leaf itself
+    {
+        int f = 0, c = 0;
+        if (!done) {
+            const size_t j = (size_t)(m.off[0] + start_leaf);
+            f = __float_as_int(t.nodes[2 * j].w); c = __float_as_int(t.nodes[2 * j + 1].w);
+        }
+        visit(f, c);
+    }
+    uint32_t ix = 0, iy = 0, iz = 0;
+    if (!done) {
+        const uint64_t key = t.keys[__float_as_int(t.nodes[2 * (size_t)(m.off[0] + start_leaf)].w)];
+        ix = pcr_compact21(key); iy = pcr_compact21(key >> 1); iz = pcr_compact21(key >> 2);
+    }
+    int anc = start_leaf, anc_li = 0;       // subtree already covered
+    int li = 0, cs = 0, base_li = 0;        // current sibling list (nodes of level li starting at cs), pending mask
+    uint32_t mask = 0;
+    for (;;) {
+        bool ascend = false;
+        while (!done && mask == 0) {
+            if (li < base_li) { li++; cs = stk.cs[li][ob]; mask = stk.mask[li][ob]; }
+            else {
+                if (anc_li >= m.nl - 1 || oct_ball_in_cell(m, ix, iy, iz, m.l0 + anc_li, qx, qy, qz, bound())) done = true;
+                else ascend = true;
+                break;
+            }
+        }
+        if (__ballot(!done) == 0ull) break;
+        // ---- climb one level: the parent's other children become the sibling list
+        if (__ballot(ascend) != 0ull) {
+            int p = 0, pf = 0, pc = 0;
+            if (ascend) {
+                p = t.parent[m.off[anc_li] + anc];
+                const size_t j = (size_t)(m.off[anc_li + 1] + p);
+                pf = __float_as_int(t.nodes[2 * j].w); pc = __float_as_int(t.nodes[2 * j + 1].w);
+            }
+            int f, c;
+            const uint32_t nm = oct_test_nodes(t, m, ascend, anc_li, pf, pc, qx, qy, qz, bound(), ol, oct, f, c);
+            if (ascend) {
+                if (visits) *visits += 1 << 10;
+                li = anc_li; base_li = anc_li; cs = pf;
+                mask = nm & ~(1u << (anc - pf));
+                anc = p; anc_li++;
+            }
+        }
+        // ---- pop one pending sibling: a leaf is scanned, an inner node is opened
+        int vf = 0, vc = 0; bool descend = false; int dcs = 0, dcnt = 0;
+        if (!done && mask != 0) {
+            const int c = __builtin_ctz(mask);
+            mask &= mask - 1;
+            const size_t j = (size_t)(m.off[li] + cs + c);
+            const int nf = __float_as_int(t.nodes[2 * j].w), nc = __float_as_int(t.nodes[2 * j + 1].w);
+            if (visits) *visits += 1;
+            if (li == 0) { if (!skip(nf, nc)) { vf = nf; vc = nc; if (visits) *visits += 1 << 20; } }
+            else {
+                if (ol == 0) { stk.cs[li][ob] = cs; stk.mask[li][ob] = (unsigned char)mask; }
+                li--; cs = nf; dcs = nf; dcnt = nc; descend = true;
+            }
+        }
+        if (__ballot(vc > 0) != 0ull) visit(vf, vc);
+        if (__ballot(descend) != 0ull) {
+            int f, c;
+            const uint32_t nm = oct_test_nodes(t, m, descend, li, dcs, dcnt, qx, qy, qz, bound(), ol, oct, f, c);
+            if (descend) mask = nm;
+        }
+    }
+}
+
+// greedy nearest-box descent from the root (cold start of a 1-NN query): returns a leaf id (octet-uniform)
+__device__ static inline int oct_greedy_leaf(const OctView &t, const OctMeta &m, bool want, float qx, float qy, float qz, int ol) {
+    int li = m.nl - 1, node = 0;
+    while (__ballot(want && li > 0) != 0ull) {
+        float d = 3.4e38f; int c = 0, cs = 0;
+        if (want && li > 0) {
+            const size_t jn = (size_t)(m.off[li] + node);
+            cs = __float_as_int(t.nodes[2 * jn].w);
+            const int cnt = __float_as_int(t.nodes[2 * jn + 1].w);
+            if (ol < cnt) {
+                const size_t j = (size_t)(m.off[li - 1] + cs + ol);
+                d = pcr_box_d2(t.nodes[2 * j], t.nodes[2 * j + 1], qx, qy, qz); c = ol;
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < OCT; o <<= 1) {
+            const float od = __shfl_xor(d, o, OCT); const int oc = __shfl_xor(c, o, OCT);
+            if (od < d || (od == d && oc < c)) { d = od; c = oc; }
+        }
+        if (want && li > 0) { node = cs + c; li--; }
+    }
+    return node;
+}
