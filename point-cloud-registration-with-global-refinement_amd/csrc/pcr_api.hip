@@ -84,7 +84,7 @@ void *pcr_arena_alloc(pcr_context *ctx, size_t bytes) {
     if (hipSetDevice((ctx)->device) != hipSuccess) return PCR_EHIP;              \
     (ctx)->err.clear();
 
-static int alloc_cloud(pcr_context *ctx, DevCloud *c, int cap, bool with_nrm, bool with_tree) {
+int pcr_alloc_cloud(pcr_context *ctx, DevCloud *c, int cap, bool with_nrm, bool with_tree) {
     const int cc = cap > 0 ? cap : 1;
     c->cap = cap;
     c->pts = arena<float4>(ctx, cc);
@@ -106,10 +106,10 @@ static int alloc_cloud(pcr_context *ctx, DevCloud *c, int cap, bool with_nrm, bo
 }
 
 // Morton-sorted copy of a caller cloud (+ optional normals) with its BVH; perm maps sorted -> caller index
-static int import_cloud(pcr_context *ctx, const float *xyz, const float *nrm, int64_t n, DevCloud *c, uint32_t **perm_out, bool force_nrm = false) {
+int pcr_import_cloud(pcr_context *ctx, const float *xyz, const float *nrm, int64_t n, DevCloud *c, uint32_t **perm_out, bool force_nrm) {
     double b6[6];
     PCR_TRY(pcr_dev_bounds(ctx, xyz, n, b6));
-    PCR_TRY(alloc_cloud(ctx, c, (int)n, nrm != nullptr || force_nrm, true));
+    PCR_TRY(pcr_alloc_cloud(ctx, c, (int)n, nrm != nullptr || force_nrm, true));
     uint32_t *perm = arena<uint32_t>(ctx, n > 0 ? n : 1);
     if (!perm) return PCR_ENOMEM;
     PCR_TRY(pcr_dev_sort_cloud(ctx, xyz, n, b6, c, perm));
@@ -138,7 +138,7 @@ extern "C" int pcr_voxel_down_sample(pcr_context *ctx, const float *xyz, const f
     double b6[6];
     PCR_TRY(pcr_dev_bounds(ctx, xyz, n, b6));
     DevCloud v;
-    PCR_TRY(alloc_cloud(ctx, &v, (int)n, normals_in != nullptr, false));
+    PCR_TRY(pcr_alloc_cloud(ctx, &v, (int)n, normals_in != nullptr, false));
     PCR_TRY(pcr_dev_voxel(ctx, xyz, normals_in, n, b6, voxel, &v));
     PCR_TRY(pcr_dev_pack_f4_to_f3(ctx, v.pts, v.n, v.cap, out_xyz));
     if (normals_in && out_normals) PCR_TRY(pcr_dev_pack_f4_to_f3(ctx, v.nrm, v.n, v.cap, out_normals));
@@ -166,8 +166,8 @@ extern "C" int pcr_remove_statistical_outlier(pcr_context *ctx, const float *xyz
     if (n == 0) return PCR_OK;
     PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n) + (size_t)n * 64));
     DevCloud c, kept; uint32_t *perm = nullptr;
-    PCR_TRY(import_cloud(ctx, xyz, nullptr, n, &c, &perm));
-    PCR_TRY(alloc_cloud(ctx, &kept, (int)n, false, false));
+    PCR_TRY(pcr_import_cloud(ctx, xyz, nullptr, n, &c, &perm, false));
+    PCR_TRY(pcr_alloc_cloud(ctx, &kept, (int)n, false, false));
     uint8_t *keep_sorted = arena<uint8_t>(ctx, n);
     uint8_t *keep_caller = keep_mask ? keep_mask : arena<uint8_t>(ctx, n);
     int *pos = arena<int>(ctx, n);
@@ -192,7 +192,7 @@ extern "C" int pcr_estimate_normals(pcr_context *ctx, const float *xyz, int64_t 
     if (n == 0) return PCR_OK;
     PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n) + (size_t)n * 64));
     DevCloud c; uint32_t *perm = nullptr;
-    PCR_TRY(import_cloud(ctx, xyz, prior_normals, n, &c, &perm));
+    PCR_TRY(pcr_import_cloud(ctx, xyz, prior_normals, n, &c, &perm, false));
     float4 *nout = arena<float4>(ctx, n);
     if (!nout) return PCR_ENOMEM;
     PCR_TRY(pcr_dev_normals(ctx, &c, search_kind, knn, radius, c.nrm, nout, nullptr));
@@ -214,7 +214,7 @@ extern "C" int pcr_estimate_covariances(pcr_context *ctx, const float *xyz, int6
     if (n == 0) return PCR_OK;
     PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n) + (size_t)n * 64));
     DevCloud c; uint32_t *perm = nullptr;
-    PCR_TRY(import_cloud(ctx, xyz, nullptr, n, &c, &perm));
+    PCR_TRY(pcr_import_cloud(ctx, xyz, nullptr, n, &c, &perm, false));
     float *cs = arena<float>(ctx, (size_t)n * 6);
     if (!cs) return PCR_ENOMEM;
     PCR_TRY(pcr_dev_normals(ctx, &c, search_kind, knn, radius, nullptr, nullptr, cs));
@@ -245,7 +245,7 @@ extern "C" int pcr_debug_knn(pcr_context *ctx, const float *xyz, int64_t n, int 
     // sort, search over the BVH, then report rows and indices in the CALLER's point order
     PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n) + (size_t)n * (size_t)k * 16 + (size_t)n * 64));
     DevCloud c; uint32_t *perm = nullptr;
-    PCR_TRY(import_cloud(ctx, xyz, nullptr, n, &c, &perm));
+    PCR_TRY(pcr_import_cloud(ctx, xyz, nullptr, n, &c, &perm, false));
     int32_t *si = arena<int32_t>(ctx, (size_t)n * k);
     float *sd = arena<float>(ctx, (size_t)n * k);
     int32_t *sc = arena<int32_t>(ctx, n);
@@ -274,8 +274,8 @@ extern "C" int pcr_registration_generalized_icp(pcr_context *ctx, const float *s
     PCR_TRY(check_T(ctx, init_T));
     PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n_src) + pcr_scratch_bytes_for(n_tgt)));
     DevCloud s, t; uint32_t *sperm = nullptr, *tperm = nullptr;
-    PCR_TRY(import_cloud(ctx, src_xyz, src_normals, n_src, &s, &sperm, true));
-    PCR_TRY(import_cloud(ctx, tgt_xyz, tgt_normals, n_tgt, &t, &tperm, true));
+    PCR_TRY(pcr_import_cloud(ctx, src_xyz, src_normals, n_src, &s, &sperm, true));
+    PCR_TRY(pcr_import_cloud(ctx, tgt_xyz, tgt_normals, n_tgt, &t, &tperm, true));
     int32_t *match = arena<int32_t>(ctx, n_src > 0 ? n_src : 1);
     if (!match) return PCR_ENOMEM;
     PCR_TRY(pcr_dev_gicp(ctx, &s, &t, max_dist, init_T, params, result, match));
@@ -295,8 +295,8 @@ extern "C" int pcr_debug_gicp_linearize(pcr_context *ctx, const float *src_xyz, 
     PCR_TRY(check_T(ctx, T));
     PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n_src) + pcr_scratch_bytes_for(n_tgt)));
     DevCloud s, t; uint32_t *sperm = nullptr, *tperm = nullptr;
-    PCR_TRY(import_cloud(ctx, src_xyz, src_normals, n_src, &s, &sperm));
-    PCR_TRY(import_cloud(ctx, tgt_xyz, tgt_normals, n_tgt, &t, &tperm));
+    PCR_TRY(pcr_import_cloud(ctx, src_xyz, src_normals, n_src, &s, &sperm, false));
+    PCR_TRY(pcr_import_cloud(ctx, tgt_xyz, tgt_normals, n_tgt, &t, &tperm, false));
     int32_t *match = arena<int32_t>(ctx, n_src);
     if (!match) return PCR_ENOMEM;
     PCR_TRY(pcr_dev_linearize_once(ctx, &s, &t, max_dist, T, params, JTJ36, JTr6, stats3, match));
@@ -311,13 +311,13 @@ extern "C" int pcr_debug_gicp_linearize(pcr_context *ctx, const float *src_xyz, 
 static int prep_scale(pcr_context *ctx, const float *xyz, const float *nrm, int64_t n, const double *b6, double voxel, int sor_k,
                       double sor_std, int normal_k, DevCloud *clean, int **n_voxel_dev) {
     DevCloud v;
-    PCR_TRY(alloc_cloud(ctx, clean, (int)n, true, true));        // survives the mark below (allocated first)
+    PCR_TRY(pcr_alloc_cloud(ctx, clean, (int)n, true, true));        // survives the mark below (allocated first)
     float4 *prior = nrm ? arena<float4>(ctx, n > 0 ? n : 1) : nullptr;
     int *nv_keep = arena<int>(ctx, 1);
     if (!nv_keep || (nrm && !prior)) return PCR_ENOMEM;
     {
         ArenaMark mark(ctx);
-        PCR_TRY(alloc_cloud(ctx, &v, (int)n, nrm != nullptr, true));
+        PCR_TRY(pcr_alloc_cloud(ctx, &v, (int)n, nrm != nullptr, true));
         PCR_TRY(pcr_dev_voxel(ctx, xyz, nrm, n, b6, voxel, &v));
         PCR_TRY(pcr_dev_build_bvh(ctx, &v));
         DevCloud tmp = *clean;
@@ -384,8 +384,8 @@ extern "C" int pcr_evaluate_registration(pcr_context *ctx, const float *src_xyz,
     PCR_TRY(check_T(ctx, T));
     PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n_src) + pcr_scratch_bytes_for(n_tgt)));
     DevCloud s, t; uint32_t *sperm = nullptr, *tperm = nullptr;
-    PCR_TRY(import_cloud(ctx, src_xyz, nullptr, n_src, &s, &sperm));
-    PCR_TRY(import_cloud(ctx, tgt_xyz, nullptr, n_tgt, &t, &tperm));
+    PCR_TRY(pcr_import_cloud(ctx, src_xyz, nullptr, n_src, &s, &sperm, false));
+    PCR_TRY(pcr_import_cloud(ctx, tgt_xyz, nullptr, n_tgt, &t, &tperm, false));
     int32_t *match = arena<int32_t>(ctx, n_src > 0 ? n_src : 1);
     if (!match) return PCR_ENOMEM;
     PCR_TRY(pcr_dev_evaluate(ctx, &s, &t, max_dist, T, result, match, nullptr));
@@ -405,8 +405,8 @@ extern "C" int pcr_information_matrix(pcr_context *ctx, const float *src_xyz, in
     PCR_TRY(check_T(ctx, T));
     PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n_src) + pcr_scratch_bytes_for(n_tgt)));
     DevCloud s, t;
-    PCR_TRY(import_cloud(ctx, src_xyz, nullptr, n_src, &s, nullptr));
-    PCR_TRY(import_cloud(ctx, tgt_xyz, nullptr, n_tgt, &t, nullptr));
+    PCR_TRY(pcr_import_cloud(ctx, src_xyz, nullptr, n_src, &s, nullptr, false));
+    PCR_TRY(pcr_import_cloud(ctx, tgt_xyz, nullptr, n_tgt, &t, nullptr, false));
     pcr_result r;
     return pcr_dev_evaluate(ctx, &s, &t, max_dist, T, &r, nullptr, info36);
 }

@@ -1,15 +1,577 @@
-// pcr_fgr.hip -- FPFH + Fast Global Registration (K6-K9).  PLACEHOLDER entry points until the kernels land:
-// they fail loudly (no CPU fallback).
-#include "pcr_device.h"
+// pcr_fgr.hip -- FPFH features (K6) and Fast Global Registration (K7 feature matching, K8 tuple test,
+// K9 graduated-non-convexity Gauss-Newton) on gfx950.
+// Reference behaviour: Open3D ComputeFPFHFeature and FastGlobalRegistrationBasedOnFeatureMatching as called at
+// ALL_FUNCTIONS.py:186-187,198-202 / 1_FGR_pairwise_registration_in_NCLT_dataset.py:49-50,61-65.
+#include <cmath>
+#include <cstring>
+#include <cstdlib>
+#include "pcr_octree.h"
 
-extern "C" int pcr_compute_fpfh_feature(pcr_context *ctx, const float *, const float *, int64_t, int, int, double, float *) {
-    if (!ctx) return PCR_EINVAL;
-    ctx->err = "compute_fpfh_feature: not implemented on the MI355X path yet";
-    return PCR_EINVAL;
+#define FB 256
+#define PI_D 3.14159265358979323846
+
+// =============================================================================================== FPFH (K6)
+// Neighbour lists come from the octet k-NN (hybrid radius / max_nn, pcr_cloud.hip) in its distributed layout:
+// list[q*K + slot], slot = lane + 8*j.  The same 8 lanes then build the histogram of the point.
+
+__device__ static inline int bin11(double x) {
+    int h = (int)floor(x);
+    return h < 0 ? 0 : (h > 10 ? 10 : h);
 }
-extern "C" int pcr_registration_fgr(pcr_context *ctx, const float *, const float *, int64_t, const float *, const float *, int64_t,
-                                    const pcr_fgr_option *, pcr_result *, int32_t *) {
+
+// Open3D ComputePairFeatures(p1,n1,p2,n2) -> the three histogram bins (degenerate pairs vote in the bins of f = 0)
+__device__ static inline void pair_bins(const double *p1, const double *n1, const double *p2, const double *n2, int *b0, int *b1, int *b2) {
+    double dx = p2[0] - p1[0], dy = p2[1] - p1[1], dz = p2[2] - p1[2];
+    double f0 = 0, f1 = 0, f2 = 0;
+    const double len = sqrt(dx * dx + dy * dy + dz * dz);
+    if (len != 0.0) {
+        double ax = n1[0], ay = n1[1], az = n1[2], bx = n2[0], by = n2[1], bz = n2[2];
+        const double angle1 = (ax * dx + ay * dy + az * dz) / len, angle2 = (bx * dx + by * dy + bz * dz) / len;
+        double g2;
+        if (acos(fabs(angle1)) > acos(fabs(angle2))) {
+            ax = n2[0]; ay = n2[1]; az = n2[2]; bx = n1[0]; by = n1[1]; bz = n1[2];
+            dx = -dx; dy = -dy; dz = -dz;
+            g2 = -angle2;
+        } else g2 = angle1;
+        double vx = dy * az - dz * ay, vy = dz * ax - dx * az, vz = dx * ay - dy * ax;      // dp x n1
+        const double vn = sqrt(vx * vx + vy * vy + vz * vz);
+        if (vn != 0.0) {
+            vx /= vn; vy /= vn; vz /= vn;
+            const double wx = ay * vz - az * vy, wy = az * vx - ax * vz, wz = ax * vy - ay * vx;   // n1 x v
+            f2 = g2;
+            f1 = vx * bx + vy * by + vz * bz;
+            f0 = atan2(wx * bx + wy * by + wz * bz, ax * bx + ay * by + az * bz);
+        }
+    }
+    *b0 = bin11(11.0 * (f0 + PI_D) / (2.0 * PI_D));
+    *b1 = bin11(11.0 * (f1 + 1.0) * 0.5) + 11;
+    *b2 = bin11(11.0 * (f2 + 1.0) * 0.5) + 22;
+}
+
+struct FpfhArgs {
+    const float4 *pts, *nrm; const int *n_ptr;
+    const int32_t *nbr; int k; double r2;       // neighbour lists (sorted-cloud indices, -1 padded)
+    double *spfh;                               // n x 33
+    const uint32_t *perm; float *feat;          // output rows in caller order
+};
+
+__global__ void __launch_bounds__(FB) k_spfh(FpfhArgs a) {
+    __shared__ int hist[FB / OCT][33];
+    const int n = *a.n_ptr;
+    const int ol = threadIdx.x & 7, ob = threadIdx.x >> 3;
+    const int qi = blockIdx.x * (FB / OCT) + ob;
+    for (int b = ol; b < 33; b += OCT) hist[ob][b] = 0;
+    __syncthreads();
+    int cnt = 0;
+    if (qi < n) {
+        const float4 pf = a.pts[qi], nf = a.nrm[qi];
+        const double p1[3] = {pf.x, pf.y, pf.z}, n1[3] = {nf.x, nf.y, nf.z};
+        for (int slot = ol; slot < a.k; slot += OCT) {
+            const int id = a.nbr[(size_t)qi * a.k + slot];
+            if (id < 0 || id == qi) continue;
+            const float4 qf = a.pts[id], mf = a.nrm[id];
+            const double p2[3] = {qf.x, qf.y, qf.z}, n2[3] = {mf.x, mf.y, mf.z};
+            const double dx = p2[0] - p1[0], dy = p2[1] - p1[1], dz = p2[2] - p1[2];
+            if (!(dx * dx + dy * dy + dz * dz < a.r2)) continue;
+            int b0, b1, b2;
+            pair_bins(p1, n1, p2, n2, &b0, &b1, &b2);
+            atomicAdd(&hist[ob][b0], 1); atomicAdd(&hist[ob][b1], 1); atomicAdd(&hist[ob][b2], 1);
+            cnt++;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < OCT; o <<= 1) cnt += __shfl_xor(cnt, o, OCT);
+    __syncthreads();
+    if (qi < n) {
+        const double inc = cnt > 0 ? 100.0 / (double)cnt : 0.0;       // 100 / (m - 1), m counts the point itself
+        for (int b = ol; b < 33; b += OCT) a.spfh[(size_t)qi * 33 + b] = (double)hist[ob][b] * inc;
+    }
+}
+
+__global__ void __launch_bounds__(FB) k_fpfh(FpfhArgs a) {
+    const int n = *a.n_ptr;
+    const int ol = threadIdx.x & 7, ob = threadIdx.x >> 3;
+    const int qi = blockIdx.x * (FB / OCT) + ob;
+    double acc[33];
+#pragma unroll
+    for (int j = 0; j < 33; j++) acc[j] = 0.0;
+    int cnt = 0;
+    if (qi < n) {
+        const float4 pf = a.pts[qi];
+        for (int slot = ol; slot < a.k; slot += OCT) {
+            const int id = a.nbr[(size_t)qi * a.k + slot];
+            if (id < 0 || id == qi) continue;
+            const float4 qf = a.pts[id];
+            const double dx = (double)qf.x - (double)pf.x, dy = (double)qf.y - (double)pf.y, dz = (double)qf.z - (double)pf.z;
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            if (!(d2 < a.r2)) continue;
+            cnt++;
+            if (d2 == 0.0) continue;
+            const double inv = 1.0 / d2;
+            const double *s = a.spfh + (size_t)id * 33;
+#pragma unroll
+            for (int j = 0; j < 33; j++) acc[j] += s[j] * inv;
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < OCT; o <<= 1) cnt += __shfl_xor(cnt, o, OCT);
+#pragma unroll
+    for (int j = 0; j < 33; j++) {
+#pragma unroll
+        for (int o = 1; o < OCT; o <<= 1) acc[j] += __shfl_xor(acc[j], o, OCT);
+    }
+    if (qi < n && ol == 0) {
+        float *out = a.feat + (size_t)a.perm[qi] * 33;
+        if (cnt > 0) {
+            double sum[3] = {0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 33; j++) sum[j / 11] += acc[j];
+#pragma unroll
+            for (int g = 0; g < 3; g++) if (sum[g] != 0.0) sum[g] = 100.0 / sum[g];
+#pragma unroll
+            for (int j = 0; j < 33; j++) out[j] = (float)(acc[j] * sum[j / 11] + a.spfh[(size_t)qi * 33 + j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 33; j++) out[j] = 0.0f;
+        }
+    }
+}
+
+extern "C" int pcr_compute_fpfh_feature(pcr_context *ctx, const float *xyz, const float *normals, int64_t n, int search_kind, int knn,
+                                        double radius, float *feat33) {
     if (!ctx) return PCR_EINVAL;
-    ctx->err = "registration_fgr_based_on_feature_matching: not implemented on the MI355X path yet";
-    return PCR_EINVAL;
+    if (hipSetDevice(ctx->device) != hipSuccess) return PCR_EHIP;
+    ctx->err.clear();
+    if (n < 0 || (n > 0 && (!xyz || !normals || !feat33))) return PCR_EINVAL;
+    if (search_kind == PCR_SEARCH_RADIUS) { ctx->err = "compute_fpfh_feature: pure radius search not implemented (use Hybrid or KNN)"; return PCR_EINVAL; }
+    if (knn < 1 || knn > 200) { ctx->err = "compute_fpfh_feature: max_nn must be in 1..200"; return PCR_EINVAL; }
+    if (search_kind == PCR_SEARCH_HYBRID && !(radius > 0)) { ctx->err = "radius <= 0"; return PCR_EINVAL; }
+    if (n == 0) return PCR_OK;
+    PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n) + (size_t)n * ((size_t)knn * 8 + 33 * 8 + 64)));
+    DevCloud c; uint32_t *perm = nullptr;
+    PCR_TRY(pcr_import_cloud(ctx, xyz, normals, n, &c, &perm, false));
+    int32_t *nbr = arena<int32_t>(ctx, (size_t)n * knn);
+    float *nd2 = arena<float>(ctx, (size_t)n * knn);
+    double *spfh = arena<double>(ctx, (size_t)n * 33);
+    if (!nbr || !nd2 || !spfh) return PCR_ENOMEM;
+    PCR_TRY(pcr_dev_knn_debug(ctx, &c, knn, search_kind == PCR_SEARCH_HYBRID ? radius : 0.0, nbr, nd2, nullptr));
+    FpfhArgs a;
+    a.pts = c.pts; a.nrm = c.nrm; a.n_ptr = c.n; a.nbr = nbr; a.k = knn;
+    a.r2 = search_kind == PCR_SEARCH_HYBRID ? radius * radius : 1e300;
+    a.spfh = spfh; a.perm = perm; a.feat = feat33;
+    const dim3 grid((unsigned)(((size_t)n * OCT + FB - 1) / FB));
+    hipLaunchKernelGGL(k_spfh, grid, dim3(FB), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_fpfh, grid, dim3(FB), 0, ctx->stream, a);
+    PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return PCR_OK;
+}
+
+// ======================================================================== feature matching (K7)
+// Exact nearest row in 33-D, (a-b)^2 evaluated directly in float32 (no |a|^2+|b|^2-2ab cancellation), ties -> the
+// smaller index.  One query per lane, database rows staged through LDS in tiles and broadcast to all lanes.
+#define FEAT_D 33
+#define NN_TILE 64
+__global__ void __launch_bounds__(FB) k_feature_nn(const float *__restrict__ db, int n_db, const float *__restrict__ q, int n_q, int32_t *__restrict__ out) {
+    __shared__ float tile[NN_TILE][FEAT_D + 3];
+    const int qi = blockIdx.x * FB + threadIdx.x;
+    float f[FEAT_D];
+#pragma unroll
+    for (int j = 0; j < FEAT_D; j++) f[j] = qi < n_q ? q[(size_t)qi * FEAT_D + j] : 0.0f;
+    float best = 3.4e38f; int bi = -1;
+    for (int base = 0; base < n_db; base += NN_TILE) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < NN_TILE * FEAT_D; t += FB) {
+            const int r = t / FEAT_D, cidx = t % FEAT_D;
+            tile[r][cidx] = base + r < n_db ? db[(size_t)(base + r) * FEAT_D + cidx] : 0.0f;
+        }
+        __syncthreads();
+        const int lim = n_db - base < NN_TILE ? n_db - base : NN_TILE;
+        for (int r = 0; r < lim; r++) {
+            float d = 0.0f;
+#pragma unroll
+            for (int j = 0; j < FEAT_D; j++) { const float e = f[j] - tile[r][j]; d = __fmaf_rn(e, e, d); }
+            if (d < best) { best = d; bi = base + r; }
+        }
+    }
+    if (qi < n_q) out[qi] = bi;
+}
+
+// cross check: pair (i, i_to_j[i]) survives iff j_to_i[i_to_j[i]] == i      
+__global__ void __launch_bounds__(FB) k_cross_flags(const int32_t *__restrict__ i_to_j, const int32_t *__restrict__ j_to_i, int n_i, uint8_t *__restrict__ flags) {
+    const int i = blockIdx.x * FB + threadIdx.x;
+    if (i >= n_i) return;
+    const int j = i_to_j[i];
+    flags[i] = (j >= 0 && j_to_i[j] == i) ? 1 : 0;
+}
+__global__ void __launch_bounds__(FB) k_cross_emit(const int32_t *__restrict__ i_to_j, const uint8_t *__restrict__ flags, const int *__restrict__ pos, int n_i, int32_t *__restrict__ cross) {
+    const int i = blockIdx.x * FB + threadIdx.x;
+    if (i >= n_i || !flags[i]) return;
+    cross[2 * (size_t)pos[i]] = i; cross[2 * (size_t)pos[i] + 1] = i_to_j[i];
+}
+
+// ======================================================================== tuple test (K8)
+__host__ __device__ static inline uint64_t pcr_splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+struct TupleArgs {
+    const double *pi, *pj;          // normalised clouds i (larger) and j, n x 3 float64
+    const int32_t *cross; int ncross;
+    uint64_t seed; double tuple_scale; long long trials;
+};
+__device__ static inline bool tuple_ok(const TupleArgs &a, long long t, int *r) {
+    const double *pi[3], *pj[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        r[k] = (int)(pcr_splitmix64(a.seed + 3ull * (uint64_t)t + (uint64_t)k) % (uint64_t)a.ncross);
+        pi[k] = a.pi + (size_t)a.cross[2 * r[k]] * 3; pj[k] = a.pj + (size_t)a.cross[2 * r[k] + 1] * 3;
+    }
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double *p = pi[k], *q = pi[(k + 1) % 3], *u = pj[k], *v = pj[(k + 1) % 3];
+        const double li = sqrt((p[0] - q[0]) * (p[0] - q[0]) + (p[1] - q[1]) * (p[1] - q[1]) + (p[2] - q[2]) * (p[2] - q[2]));
+        const double lj = sqrt((u[0] - v[0]) * (u[0] - v[0]) + (u[1] - v[1]) * (u[1] - v[1]) + (u[2] - v[2]) * (u[2] - v[2]));
+        ok = ok && (li * a.tuple_scale < lj) && (lj < li / a.tuple_scale);
+    }
+    return ok;
+}
+__global__ void __launch_bounds__(FB) k_tuple_flags(TupleArgs a, uint8_t *__restrict__ flags) {
+    const long long t = (long long)blockIdx.x * FB + threadIdx.x;
+    if (t >= a.trials) return;
+    int r[3];
+    flags[t] = tuple_ok(a, t, r) ? 1 : 0;
+}
+// keep the first max_tuples accepted trials IN TRIAL ORDER (what the serial loop of the reference does)
+__global__ void __launch_bounds__(FB) k_tuple_emit(TupleArgs a, const uint8_t *__restrict__ flags, const int *__restrict__ pos, int max_tuples, int swapped,
+                                                   int32_t *__restrict__ corr /* (cloud0 idx, cloud1 idx) x 3 per tuple */) {
+    const long long t = (long long)blockIdx.x * FB + threadIdx.x;
+    if (t >= a.trials || !flags[t]) return;
+    const int rank = pos[t];
+    if (rank >= max_tuples) return;
+    int r[3];
+    (void)tuple_ok(a, t, r);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int ii = a.cross[2 * r[k]], jj = a.cross[2 * r[k] + 1];
+        corr[((size_t)rank * 3 + k) * 2] = swapped ? jj : ii;
+        corr[((size_t)rank * 3 + k) * 2 + 1] = swapped ? ii : jj;
+    }
+}
+
+// ======================================================================== normalisation
+__global__ void __launch_bounds__(FB) k_sum3(const float *__restrict__ xyz, int n, double *__restrict__ part) {
+    double s[3] = {0, 0, 0};
+    for (int i = blockIdx.x * FB + threadIdx.x; i < n; i += gridDim.x * FB) { s[0] += xyz[i * 3]; s[1] += xyz[i * 3 + 1]; s[2] += xyz[i * 3 + 2]; }
+    __shared__ double sh[FB / PCR_WAVE][3];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 0; d < 3; d++) { const double v = pcr_wave_sum(s[d]); if (lane == 0) sh[w][d] = v; }
+    __syncthreads();
+    if (threadIdx.x < 3) { double v = 0; for (int k = 0; k < FB / PCR_WAVE; k++) v += sh[k][threadIdx.x]; part[blockIdx.x * 3 + threadIdx.x] = v; }
+}
+__global__ void k_sum3_final(const double *__restrict__ part, int nb, int n, double *__restrict__ mean3) {
+    if (threadIdx.x < 3) { double v = 0; for (int k = 0; k < nb; k++) v += part[k * 3 + threadIdx.x]; mean3[threadIdx.x] = n > 0 ? v / (double)n : 0.0; }
+}
+// centred float64 copy + max norm (per block)
+__global__ void __launch_bounds__(FB) k_center(const float *__restrict__ xyz, int n, const double *__restrict__ mean3, double *__restrict__ out, double *__restrict__ part_max) {
+    double mx = 0;
+    for (int i = blockIdx.x * FB + threadIdx.x; i < n; i += gridDim.x * FB) {
+        const double x = (double)xyz[i * 3] - mean3[0], y = (double)xyz[i * 3 + 1] - mean3[1], z = (double)xyz[i * 3 + 2] - mean3[2];
+        out[(size_t)i * 3] = x; out[(size_t)i * 3 + 1] = y; out[(size_t)i * 3 + 2] = z;
+        mx = fmax(mx, sqrt(x * x + y * y + z * z));
+    }
+    __shared__ double sh[FB];
+    sh[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = FB / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]); __syncthreads(); }
+    if (threadIdx.x == 0) part_max[blockIdx.x] = sh[0];
+}
+__global__ void __launch_bounds__(FB) k_scale(double *__restrict__ p, long long n3, double inv) {
+    const long long i = (long long)blockIdx.x * FB + threadIdx.x;
+    if (i < n3) p[i] = p[i] / inv;
+}
+
+// ======================================================================== GNC Gauss-Newton (K9)
+#define FNV 27
+#define FNVP 32
+struct FgrState {
+    double trans[16];
+    double par;
+    unsigned int ticket;
+    int itr;
+};
+struct FgrOptArgs {
+    const double *p0, *q0;           // normalised cloud 0 (source) and cloud 1 (target)
+    const int32_t *corr; int ncorr;
+    FgrState *st; double *partials;
+    int decrease_mu; double max_corr_dist, division_factor;
+};
+__global__ void k_fgr_init(FgrState *st, double par) {
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < 16; k++) st->trans[k] = (k % 5 == 0) ? 1.0 : 0.0;
+        st->par = par; st->ticket = 0; st->itr = 0;
+    }
+}
+// 6x6 LDL^T without pivoting in registers (as in pcr_gicp.hip); the system here is -JTJ x = JTr
+__device__ static bool fgr_solve6(const double *S, const double *b, double *x) {
+    double A[6][6];
+    { int t = 0;
+#pragma unroll
+      for (int p = 0; p < 6; p++)
+#pragma unroll
+          for (int q = p; q < 6; q++) { A[q][p] = S[t]; t++; } }
+    double D[6], y[6];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const double d = A[k][k];
+        ok = ok && (d > 0.0) && isfinite(d);
+        D[k] = d;
+        const double inv = 1.0 / d;
+        double col[6];
+#pragma unroll
+        for (int i = k + 1; i < 6; i++) col[i] = A[i][k];
+#pragma unroll
+        for (int i = k + 1; i < 6; i++) {
+            const double l = col[i] * inv;
+#pragma unroll
+            for (int j = k + 1; j <= i; j++) A[i][j] -= l * col[j];
+            A[i][k] = l;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) { double s = b[i];
+#pragma unroll
+        for (int j = 0; j < i; j++) s -= A[i][j] * y[j];
+        y[i] = s; }
+#pragma unroll
+    for (int i = 0; i < 6; i++) y[i] /= D[i];
+#pragma unroll
+    for (int i = 5; i >= 0; i--) { double s = y[i];
+#pragma unroll
+        for (int j = i + 1; j < 6; j++) s -= A[j][i] * x[j];
+        x[i] = s; }
+#pragma unroll
+    for (int i = 0; i < 6; i++) ok = ok && isfinite(x[i]);
+    return ok;
+}
+
+__global__ void __launch_bounds__(FB) k_fgr_iter(FgrOptArgs a) {
+    __shared__ double red[FB / PCR_WAVE][FNVP];
+    __shared__ double fin[8][FNVP];
+    __shared__ int is_last;
+    FgrState *st = a.st;
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = st->trans[k];
+    const double par = st->par;
+    double acc[FNV];
+#pragma unroll
+    for (int k = 0; k < FNV; k++) acc[k] = 0.0;
+    for (int c = blockIdx.x * FB + threadIdx.x; c < a.ncorr; c += gridDim.x * FB) {
+        const double *p = a.p0 + (size_t)a.corr[2 * c] * 3, *q0 = a.q0 + (size_t)a.corr[2 * c + 1] * 3;
+        const double qx = T[0] * q0[0] + T[1] * q0[1] + T[2] * q0[2] + T[3];
+        const double qy = T[4] * q0[0] + T[5] * q0[1] + T[6] * q0[2] + T[7];
+        const double qz = T[8] * q0[0] + T[9] * q0[1] + T[10] * q0[2] + T[11];
+        const double rx = p[0] - qx, ry = p[1] - qy, rz = p[2] - qz;
+        const double temp = par / (rx * rx + ry * ry + rz * rz + par), s = temp * temp;
+        const double J[3][6] = {{0, -qz, qy, -1, 0, 0}, {qz, 0, -qx, 0, -1, 0}, {-qy, qx, 0, 0, 0, -1}};
+        const double r[3] = {rx, ry, rz};
+#pragma unroll
+        for (int row = 0; row < 3; row++) {
+            int t = 0;
+#pragma unroll
+            for (int u = 0; u < 6; u++) {
+                const double wj = s * J[row][u];
+#pragma unroll
+                for (int v = u; v < 6; v++) acc[t++] += wj * J[row][v];
+                acc[21 + u] += wj * r[row];
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < FNV; k++) { const double s = pcr_wave_sum(acc[k]); if (lane == 0) red[wv][k] = s; }
+    __syncthreads();
+    if (threadIdx.x < FNV) {
+        double s = red[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < FB / PCR_WAVE; w++) s += red[w][threadIdx.x];
+        __hip_atomic_store(&a.partials[(size_t)blockIdx.x * FNVP + threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == gridDim.x - 1);
+        if (last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        is_last = last;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    {
+        const int vcol = threadIdx.x & 31, chunk = threadIdx.x >> 5;
+        const int nb = gridDim.x, per = (nb + 7) / 8;
+        const int b0 = chunk * per, b1 = min(nb, b0 + per);
+        double s = 0;
+        if (vcol < FNV) for (int b = b0; b < b1; b++) s += a.partials[(size_t)b * FNVP + vcol];
+        fin[chunk][vcol] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < FNVP) {
+        double s = 0;
+#pragma unroll
+        for (int c = 0; c < 8; c++) s += fin[c][threadIdx.x];
+        fin[0][threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double *S = fin[0];
+        // Open3D: SolveLinearSystemPSD(-JTJ, JTr)  ==  JTJ x = -JTr
+        double nb6[6], x[6];
+#pragma unroll
+        for (int p = 0; p < 6; p++) nb6[p] = -S[21 + p];
+        double U[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        if (fgr_solve6(S, nb6, x)) {
+            const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]), sg = sin(x[2]);
+            U[0] = cg * cb; U[1] = cg * sb * sa - sg * ca; U[2] = cg * sb * ca + sg * sa; U[3] = x[3];
+            U[4] = sg * cb; U[5] = sg * sb * sa + cg * ca; U[6] = sg * sb * ca - cg * sa; U[7] = x[4];
+            U[8] = -sb;     U[9] = cb * sa;                U[10] = cb * ca;               U[11] = x[5];
+        }
+        double Tn[16];
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) { double s = 0; for (int k = 0; k < 4; k++) s += U[r * 4 + k] * st->trans[k * 4 + c]; Tn[r * 4 + c] = s; }
+        for (int k = 0; k < 16; k++) st->trans[k] = Tn[k];
+        if (a.decrease_mu && (st->itr % 4 == 0) && st->par > a.max_corr_dist) st->par = st->par / a.division_factor;
+        st->itr = st->itr + 1;
+        __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ======================================================================== driver
+static int normalise(pcr_context *ctx, const float *xyz, int64_t n, double *out64, double *mean_host, double *max_host) {
+    const int nb = (int)((n + FB - 1) / FB < 256 ? (n + FB - 1) / FB : 256);
+    double *part = arena<double>(ctx, (size_t)nb * 3 + 3 + nb);
+    if (!part) return PCR_ENOMEM;
+    double *mean3 = part + (size_t)nb * 3, *pmax = mean3 + 3;
+    hipLaunchKernelGGL(k_sum3, dim3(nb), dim3(FB), 0, ctx->stream, xyz, (int)n, part);
+    hipLaunchKernelGGL(k_sum3_final, dim3(1), dim3(64), 0, ctx->stream, part, nb, (int)n, mean3);
+    hipLaunchKernelGGL(k_center, dim3(nb), dim3(FB), 0, ctx->stream, xyz, (int)n, mean3, out64, pmax);
+    std::vector<double> h((size_t)3 + nb);
+    PCR_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), mean3, sizeof(double) * (3 + (size_t)nb), hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int d = 0; d < 3; d++) mean_host[d] = h[d];
+    double mx = 0; for (int k = 0; k < nb; k++) mx = h[3 + k] > mx ? h[3 + k] : mx;
+    *max_host = mx;
+    return PCR_OK;
+}
+
+extern "C" int pcr_evaluate_registration(pcr_context *ctx, const float *src_xyz, int64_t n_src, const float *tgt_xyz, int64_t n_tgt,
+                                         double max_dist, const double *T, pcr_result *result, int32_t *correspondences);
+
+extern "C" int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, const float *src_feat, int64_t ns, const float *tgt_xyz,
+                                    const float *tgt_feat, int64_t nt, const pcr_fgr_option *opt, pcr_result *result, int32_t *correspondences) {
+    if (!ctx) return PCR_EINVAL;
+    if (hipSetDevice(ctx->device) != hipSuccess) return PCR_EHIP;
+    ctx->err.clear();
+    if (!opt || !result || ns < 0 || nt < 0) return PCR_EINVAL;
+    if ((ns > 0 && (!src_xyz || !src_feat)) || (nt > 0 && (!tgt_xyz || !tgt_feat))) return PCR_EINVAL;
+    if (ns > 0x7fffffff / 8 || nt > 0x7fffffff / 8) { ctx->err = "cloud too large"; return PCR_EINVAL; }
+    double Tsrc2tgt[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    if (ns > 0 && nt > 0) {
+        const int64_t nmax = ns > nt ? ns : nt;
+        const long long trial_cap = opt->tuple_test ? 100ll * nmax : 0;
+        PCR_TRY(pcr_arena_reserve(ctx, (size_t)(ns + nt) * (24 + 8 + 16) + (size_t)nmax * 32 + (size_t)trial_cap * 5 + (size_t)nmax * 64 + (64u << 20)));
+        // ---- NormalizePointCloud
+        double *P[2] = {arena<double>(ctx, (size_t)ns * 3), arena<double>(ctx, (size_t)nt * 3)};
+        if (!P[0] || !P[1]) return PCR_ENOMEM;
+        double mean[2][3], mx[2];
+        PCR_TRY(normalise(ctx, src_xyz, ns, P[0], mean[0], &mx[0]));
+        PCR_TRY(normalise(ctx, tgt_xyz, nt, P[1], mean[1], &mx[1]));
+        const double scale = mx[0] > mx[1] ? mx[0] : mx[1];
+        const double scale_global = opt->use_absolute_scale ? 1.0 : scale, scale_start = opt->use_absolute_scale ? scale : 1.0;
+        if (scale_global != 1.0) {
+            hipLaunchKernelGGL(k_scale, dim3((unsigned)((ns * 3 + FB - 1) / FB)), dim3(FB), 0, ctx->stream, P[0], (long long)ns * 3, scale_global);
+            hipLaunchKernelGGL(k_scale, dim3((unsigned)((nt * 3 + FB - 1) / FB)), dim3(FB), 0, ctx->stream, P[1], (long long)nt * 3, scale_global);
+        }
+        // ---- AdvancedMatching: mutual nearest neighbours in feature space; i = the larger cloud
+        const int swapped = nt > ns ? 1 : 0;
+        const float *fi = swapped ? tgt_feat : src_feat, *fj = swapped ? src_feat : tgt_feat;
+        const int nPti = (int)(swapped ? nt : ns), nPtj = (int)(swapped ? ns : nt);
+        int32_t *j_to_i = arena<int32_t>(ctx, nPtj), *i_to_j = arena<int32_t>(ctx, nPti);
+        uint8_t *cflags = arena<uint8_t>(ctx, nPti);
+        int *cpos = arena<int>(ctx, nPti), *ncross_dev = arena<int>(ctx, 1);
+        int32_t *cross = arena<int32_t>(ctx, (size_t)nPti * 2);
+        if (!j_to_i || !i_to_j || !cflags || !cpos || !ncross_dev || !cross) return PCR_ENOMEM;
+        hipLaunchKernelGGL(k_feature_nn, dim3((nPtj + FB - 1) / FB), dim3(FB), 0, ctx->stream, fi, nPti, fj, nPtj, j_to_i);
+        hipLaunchKernelGGL(k_feature_nn, dim3((nPti + FB - 1) / FB), dim3(FB), 0, ctx->stream, fj, nPtj, fi, nPti, i_to_j);
+        hipLaunchKernelGGL(k_cross_flags, dim3((nPti + FB - 1) / FB), dim3(FB), 0, ctx->stream, i_to_j, j_to_i, nPti, cflags);
+        PCR_TRY(pcr_dev_flag_scan(ctx, cflags, nullptr, nPti, cpos, ncross_dev));
+        hipLaunchKernelGGL(k_cross_emit, dim3((nPti + FB - 1) / FB), dim3(FB), 0, ctx->stream, i_to_j, cflags, cpos, nPti, cross);
+        int64_t ncross = 0;
+        PCR_TRY(pcr_read_count(ctx, ncross_dev, &ncross));
+        // ---- tuple test
+        int32_t *corr = nullptr; int64_t ncorr = 0;
+        if (opt->tuple_test && ncross > 0 && opt->maximum_tuple_count > 0) {
+            const long long trials = 100ll * ncross;
+            uint8_t *tflags = arena<uint8_t>(ctx, trials);
+            int *tpos = arena<int>(ctx, trials), *ntup_dev = arena<int>(ctx, 1);
+            corr = arena<int32_t>(ctx, (size_t)opt->maximum_tuple_count * 6);
+            if (!tflags || !tpos || !ntup_dev || !corr) return PCR_ENOMEM;
+            TupleArgs ta;
+            ta.pi = swapped ? P[1] : P[0]; ta.pj = swapped ? P[0] : P[1]; ta.cross = cross; ta.ncross = (int)ncross;
+            ta.seed = opt->seed; ta.tuple_scale = opt->tuple_scale; ta.trials = trials;
+            const unsigned gb = (unsigned)((trials + FB - 1) / FB);
+            hipLaunchKernelGGL(k_tuple_flags, dim3(gb), dim3(FB), 0, ctx->stream, ta, tflags);
+            PCR_TRY(pcr_dev_flag_scan(ctx, tflags, nullptr, (int)trials, tpos, ntup_dev));
+            hipLaunchKernelGGL(k_tuple_emit, dim3(gb), dim3(FB), 0, ctx->stream, ta, tflags, tpos, opt->maximum_tuple_count, swapped, corr);
+            int64_t nacc = 0;
+            PCR_TRY(pcr_read_count(ctx, ntup_dev, &nacc));
+            if (nacc > opt->maximum_tuple_count) nacc = opt->maximum_tuple_count;
+            ncorr = nacc * 3;
+        } else if (ncross > 0) {
+            // tuple_test = false: every cross-checked pair (Open3D newer versions); (cloud0, cloud1) order
+            corr = arena<int32_t>(ctx, (size_t)ncross * 2);
+            if (!corr) return PCR_ENOMEM;
+            PCR_HIP_CHECK(ctx, hipMemcpyAsync(corr, cross, sizeof(int32_t) * 2 * (size_t)ncross, hipMemcpyDeviceToDevice, ctx->stream));
+            ncorr = ncross;
+            if (swapped) { ctx->err = "tuple_test=false with a larger target is not supported yet"; return PCR_EINVAL; }
+        }
+        // ---- OptimizePairwiseRegistration (moves cloud 1 = target onto cloud 0 = source)
+        double trans[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        if (ncorr >= 10) {
+            int nb = (int)((ncorr + FB - 1) / FB);
+            if (nb > 256) nb = 256;
+            FgrState *st = arena<FgrState>(ctx, 1);
+            double *partials = arena<double>(ctx, (size_t)nb * FNVP);
+            if (!st || !partials) return PCR_ENOMEM;
+            FgrOptArgs oa;
+            oa.p0 = P[0]; oa.q0 = P[1]; oa.corr = corr; oa.ncorr = (int)ncorr; oa.st = st; oa.partials = partials;
+            oa.decrease_mu = opt->decrease_mu; oa.max_corr_dist = opt->maximum_correspondence_distance; oa.division_factor = opt->division_factor;
+            hipLaunchKernelGGL(k_fgr_init, dim3(1), dim3(64), 0, ctx->stream, st, scale_start);
+            for (int it = 0; it < opt->iteration_number; it++) hipLaunchKernelGGL(k_fgr_iter, dim3(nb), dim3(FB), 0, ctx->stream, oa);
+            FgrState h;
+            PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+            PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            memcpy(trans, h.trans, sizeof trans);
+        }
+        // ---- GetTransformationOriginalScale, then invert: source -> target
+        double To[16] = {0};
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) To[r * 4 + c] = trans[r * 4 + c];
+            To[r * 4 + 3] = -(trans[r * 4 + 0] * mean[1][0] + trans[r * 4 + 1] * mean[1][1] + trans[r * 4 + 2] * mean[1][2]) + trans[r * 4 + 3] * scale_global + mean[0][r];
+        }
+        To[15] = 1;
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) Tsrc2tgt[r * 4 + c] = To[c * 4 + r];
+            Tsrc2tgt[r * 4 + 3] = -(To[0 * 4 + r] * To[3] + To[1 * 4 + r] * To[7] + To[2 * 4 + r] * To[11]);
+        }
+        for (int k = 0; k < 16; k++) if (!std::isfinite(Tsrc2tgt[k])) { ctx->err = "non-finite FGR pose"; return PCR_ENUMERIC; }
+    }
+    // ---- EvaluateRegistration(source, target, maximum_correspondence_distance, T)
+    if (!(opt->maximum_correspondence_distance > 0.0)) { ctx->err = "maximum_correspondence_distance <= 0"; return PCR_EINVAL; }
+    return pcr_evaluate_registration(ctx, src_xyz, ns, tgt_xyz, nt, opt->maximum_correspondence_distance, Tsrc2tgt, result, correspondences);
 }

@@ -97,6 +97,11 @@ int pcr_dev_pack_f4_to_f3(pcr_context *ctx, const float4 *src, const int *n, int
 int pcr_dev_unpack_f3_to_f4(pcr_context *ctx, const float *src, int64_t n, float4 *dst);
 int pcr_dev_gather_f3_to_f4(pcr_context *ctx, const float *src_packed, const uint32_t *perm, int64_t n, float4 *dst);
 
+// ---- shared by the API layer and the FGR stage (pcr_api.hip)
+int pcr_alloc_cloud(pcr_context *ctx, DevCloud *c, int cap, bool with_nrm, bool with_tree);
+// Morton-sorted copy of a caller cloud (+ optional normals) with its octree; perm maps sorted -> caller index
+int pcr_import_cloud(pcr_context *ctx, const float *xyz, const float *nrm, int64_t n, DevCloud *c, uint32_t **perm_out, bool force_nrm);
+
 // ---- gicp (pcr_gicp.hip) --------------------------------------------------------------------------
 struct IcpOutputs { pcr_result res; };
 int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, double max_dist, const double *T0,
