@@ -336,15 +336,28 @@ __global__ void __launch_bounds__(BS) k_oct_tile_count(const signed char *__rest
         tile_cnt[blockIdx.x * OCT_MAXL + threadIdx.x] = c;
     }
 }
-// D: exclusive scan over tiles, one lane per level
-__global__ void k_oct_tile_scan(int *__restrict__ tile_cnt, int n_tiles) {
-    if (threadIdx.x >= OCT_MAXL) return;
-    int run = 0;
-    for (int t = 0; t < n_tiles; t++) { const int v = tile_cnt[t * OCT_MAXL + threadIdx.x]; tile_cnt[t * OCT_MAXL + threadIdx.x] = run; run += v; }
+// D: exclusive scan over tiles for every level (one workgroup, block-wide scan per level)
+__global__ void __launch_bounds__(BS) k_oct_tile_scan(int *__restrict__ tile_cnt, int n_tiles) {
+    __shared__ int carry;
+    for (int li = 0; li < OCT_MAXL; li++) {
+        if (threadIdx.x == 0) carry = 0;
+        __syncthreads();
+        for (int b = 0; b < n_tiles; b += BS) {
+            const int t = b + threadIdx.x;
+            const int v = t < n_tiles ? tile_cnt[t * OCT_MAXL + li] : 0;
+            int tot;
+            const int ex = block_exclusive_scan(v, &tot);
+            const int c = carry;
+            if (t < n_tiles) tile_cnt[t * OCT_MAXL + li] = c + ex;
+            __syncthreads();
+            if (threadIdx.x == 0) carry = c + tot;
+            __syncthreads();
+        }
+    }
 }
 // E: node ids by ballot ranking; write child links and the leaf of every point
 __global__ void __launch_bounds__(BS) k_oct_apply(const signed char *__restrict__ ls, const OctMeta *__restrict__ meta, const int *__restrict__ tile_cnt,
-                                                  int *__restrict__ child, int *__restrict__ leaf_of, int *__restrict__ parent) {
+                                                  int *__restrict__ child, int *__restrict__ leaf_of) {
     __shared__ int wtot[4][BS / PCR_WAVE][OCT_MAXL];
     const int n = meta->n, l0 = meta->l0, nl = meta->nl;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -373,14 +386,12 @@ __global__ void __launch_bounds__(BS) k_oct_apply(const signed char *__restrict_
             const int id = pre + __popcll(b & lt);      // exclusive rank of this element among the starts of level li
             if (li == 0 && e < n) leaf_of[e] = id + (f ? 1 : 0) - 1;
             if (f) child[meta->off[li] + id] = li == 0 ? e : below;
-            // the node of level li-1 that starts here hangs under the node of level li that CONTAINS this element
-            if (li > 0 && v[j] >= l0 + li - 1) parent[meta->off[li - 1] + below] = id + (f ? 1 : 0) - 1;
             below = id;
         }
     }
 }
 // F/G: tight boxes, bottom-up
-__global__ void __launch_bounds__(BS) k_oct_leaf_boxes(const float4 *__restrict__ pts, const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int *__restrict__ parent) {
+__global__ void __launch_bounds__(BS) k_oct_leaf_boxes(const float4 *__restrict__ pts, const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up) {
     const int j = blockIdx.x * BS + threadIdx.x;
     if (meta->nl < 1 || j >= meta->cnt[0]) return;
     const int a = child[j], b = child[j + 1];
@@ -392,31 +403,33 @@ __global__ void __launch_bounds__(BS) k_oct_leaf_boxes(const float4 *__restrict_
     }
     lo.w = __int_as_float(a); hi.w = __int_as_float(b - a);
     boxes[2 * (size_t)j] = lo; boxes[2 * (size_t)j + 1] = hi;
-    if (meta->nl == 1) parent[j] = 0;
+    if (meta->nl == 1) up[j] = make_int4(0, 0, 1, 0);
 }
-__device__ static inline void oct_node_box(const OctMeta &m, const int *__restrict__ child, float4 *__restrict__ boxes, int li, int j) {
+__device__ static inline void oct_node_box(const OctMeta &m, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up, int li, int j) {
     const int a = child[m.off[li] + j], b = child[m.off[li] + j + 1];
     float4 lo = make_float4(3.4e38f, 3.4e38f, 3.4e38f, 0), hi = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, 0);
     for (int c = a; c < b; c++) {
         const float4 x = boxes[2 * (size_t)(m.off[li - 1] + c)], y = boxes[2 * (size_t)(m.off[li - 1] + c) + 1];
         lo.x = fminf(lo.x, x.x); lo.y = fminf(lo.y, x.y); lo.z = fminf(lo.z, x.z);
         hi.x = fmaxf(hi.x, y.x); hi.y = fmaxf(hi.y, y.y); hi.z = fmaxf(hi.z, y.z);
+        up[m.off[li - 1] + c] = make_int4(j, a, b - a, 0);          // child -> (parent, first sibling, sibling count)
     }
+    if (li == m.nl - 1) up[m.off[li] + j] = make_int4(0, 0, 1, 0);
     lo.w = __int_as_float(a); hi.w = __int_as_float(b - a);
     boxes[2 * (size_t)(m.off[li] + j)] = lo; boxes[2 * (size_t)(m.off[li] + j) + 1] = hi;
 }
-__global__ void __launch_bounds__(BS) k_oct_level_boxes(const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int li) {
+__global__ void __launch_bounds__(BS) k_oct_level_boxes(const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up, int li) {
     const int j = blockIdx.x * BS + threadIdx.x;
     if (li >= meta->nl || j >= meta->cnt[li]) return;
-    oct_node_box(*meta, child, boxes, li, j);
+    oct_node_box(*meta, child, boxes, up, li, j);
 }
 // remaining (small) levels in ONE workgroup, level by level
-__global__ void __launch_bounds__(1024) k_oct_upper_boxes(const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int first_li) {
+__global__ void __launch_bounds__(1024) k_oct_upper_boxes(const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up, int first_li) {
     __shared__ OctMeta m;
     if (threadIdx.x == 0) m = *meta;
     __syncthreads();
     for (int li = first_li; li < m.nl; li++) {
-        for (int j = threadIdx.x; j < m.cnt[li]; j += 1024) oct_node_box(m, child, boxes, li, j);
+        for (int j = threadIdx.x; j < m.cnt[li]; j += 1024) oct_node_box(m, child, boxes, up, li, j);
         __threadfence_block();
         __syncthreads();
     }
@@ -436,18 +449,18 @@ int pcr_dev_build_bvh(pcr_context *ctx, DevCloud *c) {
     OctGeom g; for (int d = 0; d < 3; d++) { g.org[d] = c->key_org[d]; g.unit[d] = c->key_unit[d]; }
     hipLaunchKernelGGL(k_oct_meta, dim3(1), dim3(64), 0, ctx->stream, c->n, hist, (int)oct_node_capacity(cap), c->oct_meta, c->oct_child, g);
     hipLaunchKernelGGL(k_oct_tile_count, dim3(n_tiles), dim3(BS), 0, ctx->stream, ls, c->oct_meta, tile_cnt);
-    hipLaunchKernelGGL(k_oct_tile_scan, dim3(1), dim3(64), 0, ctx->stream, tile_cnt, n_tiles);
-    hipLaunchKernelGGL(k_oct_apply, dim3(n_tiles), dim3(BS), 0, ctx->stream, ls, c->oct_meta, tile_cnt, c->oct_child, c->leaf_of, c->oct_parent);
+    hipLaunchKernelGGL(k_oct_tile_scan, dim3(1), dim3(BS), 0, ctx->stream, tile_cnt, n_tiles);
+    hipLaunchKernelGGL(k_oct_apply, dim3(n_tiles), dim3(BS), 0, ctx->stream, ls, c->oct_meta, tile_cnt, c->oct_child, c->leaf_of);
     const int nbl = (cap / 2 + 1 + BS - 1) / BS;       // <= n/2 leaves (or 1)
-    hipLaunchKernelGGL(k_oct_leaf_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->pts, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_parent);
-    hipLaunchKernelGGL(k_oct_level_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, 1);
-    hipLaunchKernelGGL(k_oct_level_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, 2);
-    hipLaunchKernelGGL(k_oct_upper_boxes, dim3(1), dim3(1024), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, 3);
+    hipLaunchKernelGGL(k_oct_leaf_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->pts, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up);
+    hipLaunchKernelGGL(k_oct_level_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, 1);
+    hipLaunchKernelGGL(k_oct_level_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, 2);
+    hipLaunchKernelGGL(k_oct_upper_boxes, dim3(1), dim3(1024), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, 3);
     return PCR_OK;
 }
 
 static inline OctView oct_view(const DevCloud *c) {
-    OctView v; v.pts = c->pts; v.nodes = c->oct_nodes; v.parent = c->oct_parent; v.meta = c->oct_meta; v.leaf_of = c->leaf_of; v.keys = c->keys;
+    OctView v; v.pts = c->pts; v.nodes = c->oct_nodes; v.up = c->oct_up; v.meta = c->oct_meta; v.leaf_of = c->leaf_of; v.keys = c->keys;
     return v;
 }
 
@@ -605,7 +618,7 @@ template <int MODE, int SLOTS>
 __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) {
     constexpr int OPB = KNN_BS / OCT;
     __shared__ OctMeta m;
-    __shared__ OctStack<OPB> stk;
+    __shared__ OctGroupStack gstk[KNN_BS / 64];
     if (threadIdx.x == 0) m = *a.t.meta;
     __syncthreads();
     const int n = m.n;
@@ -617,18 +630,19 @@ __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) {
     OctetKnn<SLOTS> tk;
     tk.init(a.k, a.r2cap_f, ol);
 
-    // seed range of Morton neighbours [plo, phi] (by point index): already contains most true neighbours
-    int plo = 0, phi = -1;
-    if (live) { plo = qi - a.k < 0 ? 0 : qi - a.k; phi = qi + a.k > n - 1 ? n - 1 : qi + a.k; }
+    // the wavefront's 8 queries are Morton-consecutive points g0..g0+7: seed every query with the index range
+    // [g0-k, g0+7+k] (it already holds most true neighbours), then ONE shared bottom-up walk completes all 8 exactly
+    const int g0 = blockIdx.x * OPB + (threadIdx.x >> 6) * OCT;
+    const int glast = g0 + OCT - 1 < n - 1 ? g0 + OCT - 1 : n - 1;
+    const int plo = g0 - a.k < 0 ? 0 : g0 - a.k, phi = glast + a.k > n - 1 ? n - 1 : glast + a.k;
     bool seeding = true;
 
-    // ---- wave-wide visit of `count` consecutive points from `first`, 8 at a time; survivors enter the k-best
+    // ---- scan `count` consecutive points from `first` for all 8 queries, 8 candidates at a time; survivors enter the k-best
     auto visit = [&](int first, int count) {
-        int base = first; const int end = first + count;
-        while (__ballot(base < end) != 0ull) {
+        for (int base = first; base < first + count; base += OCT) {
             float d2 = 0.0f; bool pass = false;
             const int idx = base + ol;
-            if (idx < end && (seeding || idx < plo || idx > phi)) {
+            if (live && idx < first + count && (seeding || idx < plo || idx > phi)) {
                 const float4 p = a.t.pts[idx];
                 d2 = pcr_d2(p.x - q.x, p.y - q.y, p.z - q.z);
                 pass = d2 < tk.worst;
@@ -644,16 +658,15 @@ __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) {
                 }
                 bal = __ballot(surv != 0);
             }
-            base += OCT;
         }
     };
     visit(plo, phi - plo + 1);
     seeding = false;
 
-    // ---- exact completion: bottom-up from the query's own leaf
     int nvis = 0;
-    oct_search<OPB>(a.t, m, stk, live, live ? a.t.leaf_of[qi] : 0, q.x, q.y, q.z, [&]() { return tk.worst; }, visit,
-                    [&](int f, int c) { return f >= plo && f + c - 1 <= phi; }, ol, oct, ob, (MODE == KNN_MODE_DEBUG && a.dbg_visits) ? &nvis : nullptr);
+    oct_search_group(a.t, m, gstk[threadIdx.x >> 6], live, a.t.leaf_of[g0], q.x, q.y, q.z, [&]() { return tk.worst; }, visit,
+                     [&](int f, int c) { return f >= plo && f + c - 1 <= phi; }, ol,
+                     (MODE == KNN_MODE_DEBUG && a.dbg_visits) ? &nvis : nullptr);
     if (!live) return;
 
     // ---- epilogue in float64 on the selected neighbours (inputs are exact float32 -> same values as the oracle)

@@ -16,6 +16,7 @@
 #define ICP_BS 256
 #define NV 30            // 21 (upper JTJ) + 6 (JTr) + sum r^2 + sum d^2 + count
 #define NVP 32           // padded row of a partial
+#define LIN_MAX_BLOCKS 256
 
 enum { ICP_MODE_GICP = 0, ICP_MODE_EVAL = 1 };
 
@@ -236,6 +237,7 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
     const int ns = *a.ns_ptr;
     int nb = (ns + ICP_BS - 1) / ICP_BS;
     if (nb < 1) nb = 1;
+    if (nb > (int)gridDim.x) nb = gridDim.x;
     if ((int)blockIdx.x >= nb) return;
     const unsigned long long t_entry = wall_clock64();
     const int launches = st->launches;
@@ -247,10 +249,10 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
 #pragma unroll
     for (int k = 0; k < NV; k++) acc[k] = 0.0;
 
-    const int i = blockIdx.x * ICP_BS + threadIdx.x;
+    for (int i = blockIdx.x * ICP_BS + threadIdx.x; i < ns; i += nb * ICP_BS) {
     double qx = 0, qy = 0, qz = 0;
     int cand = -1;
-    if (i < ns) {
+    {
         const float4 pf = a.src_pts[i];
         const double px = pf.x, py = pf.y, pz = pf.z;
         qx = T[0] * px + T[1] * py + T[2] * pz + T[3];
@@ -268,7 +270,7 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
             const double dx = qx - (double)tf.x, dy = qy - (double)tf.y, dz = qz - (double)tf.z;
             const double d2 = dx * dx + dy * dy + dz * dz;
             if (d2 < a.max_dist2) {
-                acc[28] = d2; acc[29] = 1.0;
+                acc[28] += d2; acc[29] += 1.0;
                 if (MODE == ICP_MODE_GICP) {
                     // effective covariance normals: C = I - a m m^T, m = e1 when n.x < -0.99 (Open3D GetRotationFromE1ToX)
                     const float4 sn = a.src_nrm[i], tn = a.tgt_nrm[best];
@@ -312,7 +314,7 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
                         }
                         r2 += r * r;
                     }
-                    acc[27] = r2;
+                    acc[27] += r2;
                 } else {
                     // GetInformationMatrixFromPointClouds: sum G^T G over matched TARGET points
                     const double x = tf.x, y = tf.y, z = tf.z;
@@ -329,6 +331,7 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
             } else best = -1;
         }
         if (best < 0) a.match[i] = -(cand + 2);      // beyond max_dist in float64: keep the candidate as next start hint
+    }
     }
 
     const unsigned long long t_search = wall_clock64() - t_entry;
@@ -452,7 +455,7 @@ static void fill_args(IcpArgs &a, const DevCloud *src, const DevCloud *tgt, doub
                       int32_t *match, IcpState *st, double *partials, int single) {
     a.src_pts = src->pts; a.src_nrm = src->nrm; a.ns_ptr = src->n;
     a.tgt_pts = tgt->pts; a.tgt_nrm = tgt->nrm; a.nt_ptr = tgt->n;
-    a.tgt.pts = tgt->pts; a.tgt.nodes = tgt->oct_nodes; a.tgt.parent = tgt->oct_parent; a.tgt.meta = tgt->oct_meta; a.tgt.leaf_of = tgt->leaf_of; a.tgt.keys = tgt->keys;
+    a.tgt.pts = tgt->pts; a.tgt.nodes = tgt->oct_nodes; a.tgt.up = tgt->oct_up; a.tgt.meta = tgt->oct_meta; a.tgt.leaf_of = tgt->leaf_of; a.tgt.keys = tgt->keys;
     a.match = match; a.state = st; a.partials = partials;
     a.max_dist2 = max_dist * max_dist;
     const double r2w = a.max_dist2 * (1.0 + 1e-6);
@@ -482,7 +485,7 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     if (!src->nrm || !tgt->nrm) { ctx->err = "GICP needs normals (or covariances) on both clouds"; return PCR_EINVAL; }
     ArenaMark mark(ctx);
     const int cap = src->cap > 0 ? src->cap : 1;
-    const int nbmax = (cap + ICP_BS - 1) / ICP_BS;
+    const int nbmax = (cap + ICP_BS - 1) / ICP_BS < LIN_MAX_BLOCKS ? (cap + ICP_BS - 1) / ICP_BS : LIN_MAX_BLOCKS;
     const int nbnn = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT);
     IcpState *st = arena<IcpState>(ctx, 1);
     double *partials = arena<double>(ctx, (size_t)nbmax * NVP);
@@ -553,7 +556,7 @@ int pcr_dev_linearize_once(pcr_context *ctx, const DevCloud *src, const DevCloud
     if (!(max_dist > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
     ArenaMark mark(ctx);
     const int cap = src->cap > 0 ? src->cap : 1;
-    const int nbmax = (cap + ICP_BS - 1) / ICP_BS;
+    const int nbmax = (cap + ICP_BS - 1) / ICP_BS < LIN_MAX_BLOCKS ? (cap + ICP_BS - 1) / ICP_BS : LIN_MAX_BLOCKS;
     const int nbnn = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT);
     IcpState *st = arena<IcpState>(ctx, 1);
     double *partials = arena<double>(ctx, (size_t)nbmax * NVP);
@@ -578,7 +581,7 @@ int pcr_dev_evaluate(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt,
     if (!(max_dist > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
     ArenaMark mark(ctx);
     const int cap = src->cap > 0 ? src->cap : 1;
-    const int nbmax = (cap + ICP_BS - 1) / ICP_BS;
+    const int nbmax = (cap + ICP_BS - 1) / ICP_BS < LIN_MAX_BLOCKS ? (cap + ICP_BS - 1) / ICP_BS : LIN_MAX_BLOCKS;
     const int nbnn = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT);
     IcpState *st = arena<IcpState>(ctx, 1);
     double *partials = arena<double>(ctx, (size_t)nbmax * NVP);

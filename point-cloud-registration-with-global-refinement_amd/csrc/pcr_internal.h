@@ -57,7 +57,7 @@ struct DevCloud {
     uint64_t *keys = nullptr;    // sorted Morton keys of the points (voxel index / quantised position)
     int *oct_child = nullptr;    // linear octree (pcr_octree.h): build-time child links,
     float4 *oct_nodes = nullptr; //   packed node records (box + first/count),
-    int *oct_parent = nullptr;   //   parent links
+    int4 *oct_up = nullptr;      //   (parent, first sibling, sibling count) per node
     struct OctMeta *oct_meta = nullptr;
     int *leaf_of = nullptr;
     float key_org[3] = {0, 0, 0};   // lattice of the Morton keys: coordinate i <-> [org + i*unit, org + (i+1)*unit)

@@ -9,7 +9,7 @@
 // Layout (device), level index li = Morton level - l0, node j of level li lives at slot off[li] + j:
 //   nodes[2 slot]     = (lo.x, lo.y, lo.z, int first)   first POINT (li = 0) / first CHILD in level li-1 (li > 0)
 //   nodes[2 slot + 1] = (hi.x, hi.y, hi.z, int count)   number of points / children (<= 8 children)
-//   parent[slot]      = node of level li+1 that contains it
+//   up[slot]          = (parent node of level li+1, first sibling, number of siblings, 0): one read per climb
 //   leaf_of[i]        = leaf (li = 0 node) holding point i ;  keys[i] = Morton key of point i
 //   meta              = OctMeta: levels, counts, offsets, key geometry (origin + unit of the integer lattice)
 //
@@ -41,7 +41,7 @@ struct OctMeta {
 struct OctView {             // what a kernel needs to walk a tree
     const float4 *pts;
     const float4 *nodes;
-    const int *parent;
+    const int4 *up;
     const OctMeta *meta;
     const int *leaf_of;
     const uint64_t *keys;
@@ -141,11 +141,7 @@ __device__ static inline void oct_search(const OctView &t, const OctMeta &m, Oct
         // ---- climb one level: the parent's other children become the sibling list
         if (__ballot(ascend) != 0ull) {
             int p = 0, pf = 0, pc = 0;
-            if (ascend) {
-                p = t.parent[m.off[anc_li] + anc];
-                const size_t j = (size_t)(m.off[anc_li + 1] + p);
-                pf = __float_as_int(t.nodes[2 * j].w); pc = __float_as_int(t.nodes[2 * j + 1].w);
-            }
+            if (ascend) { const int4 u = t.up[m.off[anc_li] + anc]; p = u.x; pf = u.y; pc = u.z; }
             int f, c;
             const uint32_t nm = oct_test_nodes(t, m, ascend, anc_li, pf, pc, qx, qy, qz, bound(), ol, oct, f, c);
             if (ascend) {
@@ -200,4 +196,104 @@ __device__ static inline int oct_greedy_leaf(const OctView &t, const OctMeta &m,
         if (want && li > 0) { node = cs + c; li--; }
     }
     return node;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// GROUP search: the 8 queries of a wavefront (8 Morton-consecutive points) share ONE walk.  All state is
+// wave-uniform (plain control flow, no ballots to agree on phases); a node is opened when ANY of the 8 queries can
+// still improve inside it, and all 64 lanes work on every step: node test = 8 queries x 8 children, leaf scan =
+// 8 queries x 8 candidates.  Used by the k-NN kernels, where the 8 balls overlap almost completely.
+struct OctGroupStack {            // per wavefront (LDS)
+    int cs[OCT_MAXL];
+    int mask[OCT_MAXL];
+    int first[OCT_MAXL][OCT];
+    int count[OCT_MAXL][OCT];
+};
+
+__device__ static inline float wave_or_octets_max(float v) {     // max over the 8 octets (v is octet-uniform)
+#pragma unroll
+    for (int o = OCT; o < 64; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// worst() -> this lane's (octet-uniform) squared bound; visit(first, count) scans points for all 8 queries;
+// skip(first, count) -> leaf already covered.  q*: this lane's query; live: octet-uniform.
+template <class WorstFn, class VisitFn, class SkipFn>
+__device__ static inline void oct_search_group(const OctView &t, const OctMeta &m, OctGroupStack &stk, bool live, int start_leaf,
+                                               float qx, float qy, float qz, WorstFn worst, VisitFn visit, SkipFn skip, int ol, int *visits) {
+    if (m.nl < 1 || __ballot(live) == 0ull) return;
+    // group box (live queries only)
+    float glo[3] = {live ? qx : 3.4e38f, live ? qy : 3.4e38f, live ? qz : 3.4e38f};
+    float ghi[3] = {live ? qx : -3.4e38f, live ? qy : -3.4e38f, live ? qz : -3.4e38f};
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+#pragma unroll
+        for (int o = OCT; o < 64; o <<= 1) { glo[d] = fminf(glo[d], __shfl_xor(glo[d], o, 64)); ghi[d] = fmaxf(ghi[d], __shfl_xor(ghi[d], o, 64)); }
+    start_leaf = __builtin_amdgcn_readfirstlane(start_leaf);
+
+    // children [cs, cs+cnt) of level li: bit c set when any live query can still improve inside child c
+    auto test = [&](int li, int cs, int cnt) -> int {
+        bool pass = false; int f = 0, c = 0;
+        if (ol < cnt) {
+            const size_t j = (size_t)(m.off[li] + cs + ol);
+            const float4 lo = t.nodes[2 * j], hi = t.nodes[2 * j + 1];
+            pass = live && pcr_box_d2(lo, hi, qx, qy, qz) < worst();
+            f = __float_as_int(lo.w); c = __float_as_int(hi.w);
+        }
+        unsigned long long bal = __ballot(pass);
+        bal |= bal >> 32; bal |= bal >> 16; bal |= bal >> 8;
+        if ((threadIdx.x & 63) < OCT) { stk.first[li][ol] = f; stk.count[li][ol] = c; }
+        return (int)(bal & 0xffull);
+    };
+    auto contained = [&](int lvl, uint32_t ix, uint32_t iy, uint32_t iz) -> bool {
+        const float wmax = wave_or_octets_max(live ? worst() : 0.0f);
+        if (!(wmax < 3.0e38f)) return false;
+        const float r = sqrtf(wmax) * 1.00001f;
+        const float w = (float)(1u << lvl);
+        const uint32_t ic[3] = {ix, iy, iz};
+        bool in = true;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const float side = w * m.unit[d];
+            const float cmin = m.org[d] + (float)((ic[d] >> lvl) << lvl) * m.unit[d];
+            const float eps = 1e-4f * side + 1e-6f * fabsf(cmin);
+            in = in && (glo[d] - r > cmin + eps) && (ghi[d] + r < cmin + side - eps);
+        }
+        return in;
+    };
+
+    // ---- the start leaf
+    int lf, lc;
+    {
+        const size_t j = (size_t)(m.off[0] + start_leaf);
+        lf = __float_as_int(t.nodes[2 * j].w); lc = __float_as_int(t.nodes[2 * j + 1].w);
+    }
+    if (!skip(lf, lc)) visit(lf, lc);
+    const uint64_t key = t.keys[lf];
+    const uint32_t ix = pcr_compact21(key), iy = pcr_compact21(key >> 1), iz = pcr_compact21(key >> 2);
+    int anc = start_leaf, anc_li = 0, li = 0, cs = 0, base_li = 0, mask = 0;
+    for (;;) {
+        while (mask == 0) {
+            if (li < base_li) { li++; cs = stk.cs[li]; mask = stk.mask[li]; }
+            else {
+                if (anc_li >= m.nl - 1 || contained(m.l0 + anc_li, ix, iy, iz)) return;
+                const int4 u = t.up[m.off[anc_li] + anc];
+                const int nm = test(anc_li, u.y, u.z);
+                li = anc_li; base_li = anc_li; cs = u.y;
+                mask = nm & ~(1 << (anc - u.y));
+                anc = u.x; anc_li++;
+            }
+        }
+        const int c = __builtin_ctz((unsigned)mask);
+        mask &= mask - 1;
+        const int nf = stk.first[li][c], nc = stk.count[li][c];
+        if (visits) *visits += 1;
+        if (li == 0) { if (!skip(nf, nc)) visit(nf, nc); }
+        else {
+            stk.cs[li] = cs; stk.mask[li] = mask;
+            li--; cs = nf;
+            mask = test(li, nf, nc);
+        }
+    }
 }

@@ -1,0 +1,76 @@
+"""Pair-level sharding and the single record all-gather, exercised with gloo on CPU ranks."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, pkg
+
+
+def test_partition_covers_every_pair_once():
+    sh = pkg("sharding")
+    for n_pairs, world in ((901, 8), (7, 2), (3, 8), (16, 4)):
+        got = []
+        for r in range(world):
+            rg = sh.partition(n_pairs, world, r)
+            got += list(rg)
+            assert len(rg) in (n_pairs // world, n_pairs // world + 1)
+        assert got == list(range(n_pairs))
+    assert sh.circuit_pair(0, 901) == (1, 0) and sh.circuit_pair(899, 901) == (900, 899)
+    assert sh.circuit_pair(900, 901) == (0, 900)                 # loop closure: cloud 0 onto cloud n-1 (2_MGICP...py:204-208)
+    assert list(sh.partition(901, 8, 7))[-1] == 900               # the closure pair falls to the last rank
+
+
+def _worker(rank, world, port, n_pairs, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from conftest import pkg as _pkg
+    sh = _pkg("sharding")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = sh.partition(n_pairs, world, rank)
+        recs = []
+        for i in mine:
+            T = np.eye(4); T[0, 3] = i; T[1, 3] = rank
+            res = type("R", (), dict(transformation=T, fitness=0.5 + i * 1e-3, inlier_rmse=0.1, correspondence_set=np.zeros((i, 2)),
+                                     iterations=i % 7, converged=bool(i % 2), _corr=None))()
+            recs.append(sh.pack_record(i, res))
+        out = sh.gather_records(np.stack(recs) if recs else np.zeros((0, sh.RECORD_DOUBLES)), n_pairs)
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_pairs", [7, 2])
+def test_gather_records_world_size_2(n_pairs):
+    import torch.multiprocessing as mp
+    sh = pkg("sharding")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_pairs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert np.array_equal(outs[0], outs[1])                       # every rank holds the full, ordered table
+    assert outs[0].shape == (n_pairs, sh.RECORD_DOUBLES)
+    for i in range(n_pairs):
+        rec = sh.unpack_record(outs[0][i])
+        assert rec["pair"] == i and rec["transformation"][0, 3] == i and rec["n_corr"] == i
+        owner = [r for r in range(2) if i in sh.partition(n_pairs, 2, r)][0]
+        assert rec["transformation"][1, 3] == owner
+
+
+def test_gather_records_single_process_identity():
+    sh = pkg("sharding")
+    recs = np.zeros((3, sh.RECORD_DOUBLES)); recs[:, 21] = [2, 0, 1]
+    out = sh.gather_records(recs, 3)
+    assert list(out[:, 21]) == [0, 1, 2]
+    with pytest.raises(RuntimeError):
+        sh.gather_records(recs[:2], 3)
