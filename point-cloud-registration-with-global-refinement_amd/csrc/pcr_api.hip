@@ -313,8 +313,9 @@ static int prep_scale(pcr_context *ctx, const float *xyz, const float *nrm, int6
     DevCloud v;
     PCR_TRY(pcr_alloc_cloud(ctx, clean, (int)n, true, true));        // survives the mark below (allocated first)
     float4 *prior = nrm ? arena<float4>(ctx, n > 0 ? n : 1) : nullptr;
-    int *nv_keep = arena<int>(ctx, 1);
-    if (!nv_keep || (nrm && !prior)) return PCR_ENOMEM;
+    int *nv_keep = arena<int>(ctx, 2);
+    uint8_t *todo = arena<uint8_t>(ctx, n > 0 ? n : 1);
+    if (!nv_keep || !todo || (nrm && !prior)) return PCR_ENOMEM;
     {
         ArenaMark mark(ctx);
         PCR_TRY(pcr_alloc_cloud(ctx, &v, (int)n, nrm != nullptr, true));
@@ -322,12 +323,14 @@ static int prep_scale(pcr_context *ctx, const float *xyz, const float *nrm, int6
         PCR_TRY(pcr_dev_build_bvh(ctx, &v));
         DevCloud tmp = *clean;
         tmp.nrm = prior;                                         // compacted voxel-mean normals = orientation prior
-        PCR_TRY(pcr_dev_sor(ctx, &v, sor_k, sor_std, &tmp, nullptr, nullptr));
+        tmp.nrm_final = clean->nrm;                              // normals of the cleaned cloud, straight from the SOR lists
+        PCR_TRY(pcr_dev_sor(ctx, &v, sor_k, sor_std, &tmp, nullptr, nullptr, normal_k, prior, todo, nv_keep + 1));
         for (int d = 0; d < 3; d++) { clean->key_org[d] = tmp.key_org[d]; clean->key_unit[d] = tmp.key_unit[d]; }
         PCR_HIP_CHECK(ctx, hipMemcpyAsync(nv_keep, v.n, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
     }
     PCR_TRY(pcr_dev_build_bvh(ctx, clean));
-    PCR_TRY(pcr_dev_normals(ctx, clean, PCR_SEARCH_KNN, normal_k, 0.0, prior, clean->nrm, nullptr));
+    // the few points whose list could not be proven exact: full search over the cleaned tree
+    PCR_TRY(pcr_dev_normals(ctx, clean, PCR_SEARCH_KNN, normal_k, 0.0, prior, clean->nrm, nullptr, todo));
     *n_voxel_dev = nv_keep;
     return PCR_OK;
 }

@@ -606,6 +606,8 @@ struct KnnArgs {
     const float4 *prior; float4 *normals; float *cov6;   // normals
     int32_t *dbg_idx; float *dbg_d2; int32_t *dbg_cnt;   // debug (rows unsorted)
     int dbg_visits;                                      // debug: dbg_cnt <- traversal counters
+    int32_t *list_idx; float *list_d2;                   // SOR: optional k-best lists, 32 slots per query (octet layout)
+    const uint8_t *todo;                                 // optional: only queries with todo[q] != 0 are processed
 };
 
 __device__ static inline double octet_sum(double v) {
@@ -623,9 +625,10 @@ __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) {
     __syncthreads();
     const int n = m.n;
     const int lane = threadIdx.x & 63, oct = lane >> 3, ol = lane & 7, ob = threadIdx.x >> 3;
+    const unsigned long long t_begin = wall_clock64();
     const int qi = blockIdx.x * OPB + ob;
-    const bool live = qi < n;
-    if (__ballot(live) == 0ull) return;                      // whole wavefront beyond the cloud
+    const bool live = qi < n && (!a.todo || a.todo[qi]);
+    if (__ballot(live) == 0ull) return;                      // nothing to do for this wavefront
     const float4 q = a.t.pts[live ? qi : 0];
     OctetKnn<SLOTS> tk;
     tk.init(a.k, a.r2cap_f, ol);
@@ -660,11 +663,29 @@ __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) {
             }
         }
     };
-    visit(plo, phi - plo + 1);
+    // direct fill: the min(k, 8*SLOTS) seeds CENTRED on the group go straight into the slots (slot j of lane l <- candidate
+    // c0 + 8 j + l), no insertion rounds while the k-best is not yet full; the outer seeds then mostly fail the bound test
+    const int filled = a.k < OCT * SLOTS ? a.k : OCT * SLOTS;
+    int c0 = g0 + OCT / 2 - filled / 2;
+    if (c0 + filled - 1 > phi) c0 = phi - filled + 1;
+    if (c0 < plo) c0 = plo;
+#pragma unroll
+    for (int j = 0; j < SLOTS; j++) {
+        const int idx = c0 + OCT * j + ol;
+        if (live && OCT * j + ol < filled && idx <= phi) {
+            const float4 p = a.t.pts[idx];
+            const float d2 = pcr_d2(p.x - q.x, p.y - q.y, p.z - q.z);
+            if (d2 < a.r2cap_f) { tk.sd[j] = d2; tk.si[j] = idx; }
+        }
+    }
+    tk.refresh();
+    if (c0 > plo) visit(plo, c0 - plo);
+    if (c0 + filled <= phi) visit(c0 + filled, phi - (c0 + filled) + 1);
     seeding = false;
 
     int nvis = 0;
-    oct_search_group(a.t, m, gstk[threadIdx.x >> 6], live, a.t.leaf_of[g0], q.x, q.y, q.z, [&]() { return tk.worst; }, visit,
+    const int first_live = g0 + (__builtin_ctzll(__ballot(live)) >> 3);
+    oct_search_group(a.t, m, gstk[threadIdx.x >> 6], live, a.t.leaf_of[first_live], q.x, q.y, q.z, [&]() { return tk.worst; }, visit,
                      [&](int f, int c) { return f >= plo && f + c - 1 <= phi; }, ol,
                      (MODE == KNN_MODE_DEBUG && a.dbg_visits) ? &nvis : nullptr);
     if (!live) return;
@@ -684,6 +705,10 @@ __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) {
         }
         s = octet_sum(s); c = octet_sum(c);
         if (ol == 0) a.avg[qi] = c > 0 ? s / c : -1.0;
+        if (a.list_idx && SLOTS == 4) {
+#pragma unroll
+            for (int j = 0; j < SLOTS; j++) { a.list_idx[(size_t)qi * 32 + ol + OCT * j] = tk.si[j]; a.list_d2[(size_t)qi * 32 + ol + OCT * j] = tk.sd[j]; }
+        }
     } else if (MODE == KNN_MODE_NORMALS) {
         double cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, c = 0;
 #pragma unroll
@@ -734,7 +759,7 @@ __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) {
         }
 #pragma unroll
         for (int o = 1; o < OCT; o <<= 1) c += __shfl_xor(c, o, OCT);
-        if (ol == 0 && a.dbg_cnt) a.dbg_cnt[qi] = a.dbg_visits ? nvis : c;
+        if (ol == 0 && a.dbg_cnt) a.dbg_cnt[qi] = a.dbg_visits == 2 ? (int)(wall_clock64() - t_begin) : (a.dbg_visits ? nvis : c);
     }
 }
 
@@ -761,8 +786,96 @@ int pcr_dev_knn_debug(pcr_context *ctx, const DevCloud *c, int k, double radius,
     a.t = oct_view(c); a.n_ptr = c->n; a.k = k;
     knn_radius(a, radius > 0 ? PCR_SEARCH_HYBRID : PCR_SEARCH_KNN, radius);
     if (radius > 0) a.r2cap_f = (float)(radius * radius);
-    a.dbg_idx = idx; a.dbg_d2 = d2; a.dbg_cnt = counts; a.dbg_visits = getenv("PCR_DEBUG_VISITS") ? 1 : 0;
+    a.dbg_idx = idx; a.dbg_d2 = d2; a.dbg_cnt = counts; a.dbg_visits = getenv("PCR_DEBUG_VISITS") ? atoi(getenv("PCR_DEBUG_VISITS")) : 0;
     return launch_knn<KNN_MODE_DEBUG>(ctx, c, a);
+}
+
+// ============================================= normals of the CLEANED cloud from the SOR pass's k-best lists (K5')
+// The k_nrm nearest KEPT neighbours of a kept point are among its k_list nearest in the un-cleaned cloud whenever
+// at least k_nrm of those survive the filter (every kept point outside the list is farther than all list members):
+// then no second search is needed.  The (rare) other points are flagged `todo` and searched over the cleaned tree.
+struct NflArgs {
+    const float4 *pts; const int *n_ptr;             // un-cleaned (voxel) cloud
+    const int32_t *lidx; const float *ld2;           // 32 slots per point
+    const uint8_t *keep; const int *pos;             // filter result, old -> new index
+    int k_list, k_nrm;
+    const float4 *prior; float4 *normals;            // cleaned order
+    uint8_t *todo; int *todo_count;
+};
+__global__ void __launch_bounds__(KNN_BS) k_normals_from_lists(NflArgs a) {
+    const int n = *a.n_ptr;
+    const int ol = threadIdx.x & 7;
+    const int i = blockIdx.x * (KNN_BS / OCT) + (threadIdx.x >> 3);
+    const bool act = i < n && a.keep[i];
+    int id[4]; float d[4]; bool ok[4];
+    int lc = 0, vc = 0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int slot = ol + OCT * s;
+        id[s] = (act && slot < a.k_list) ? a.lidx[(size_t)i * 32 + slot] : -1;
+        d[s] = id[s] >= 0 ? a.ld2[(size_t)i * 32 + slot] : -1.0f;
+        ok[s] = id[s] >= 0 && a.keep[id[s]];
+        lc += id[s] >= 0 ? 1 : 0; vc += ok[s] ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 1; o < OCT; o <<= 1) { lc += __shfl_xor(lc, o, OCT); vc += __shfl_xor(vc, o, OCT); }
+    const bool exact = act && (vc >= a.k_nrm || lc < a.k_list);
+    const int j = act ? a.pos[i] : 0;
+    if (act && ol == 0) {
+        a.todo[j] = exact ? 0 : 1;
+        if (!exact) atomicAdd(a.todo_count, 1);
+    }
+    // drop the farthest survivors until k_nrm remain (octet arg-max rounds; octets that are done idle along)
+    int excess = exact ? vc - a.k_nrm : 0;
+    while (__ballot(excess > 0) != 0ull) {
+        float m = -1.0f; int ms = 0;
+#pragma unroll
+        for (int s = 0; s < 4; s++) if (ok[s] && d[s] > m) { m = d[s]; ms = s; }
+        int ml = ol;
+#pragma unroll
+        for (int o = 1; o < OCT; o <<= 1) {
+            const float om = __shfl_xor(m, o, OCT); const int olane = __shfl_xor(ml, o, OCT);
+            if (om > m || (om == m && olane < ml)) { m = om; ml = olane; }
+        }
+        if (excess > 0) {
+            if (ol == ml) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) if (s == ms) ok[s] = false;
+            }
+            excess--;
+        }
+    }
+    if (!exact) return;
+    double cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, c = 0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        if (ok[s]) {
+            const float4 p = a.pts[id[s]];
+            const double x = p.x, y = p.y, z = p.z;
+            cu[0] += x; cu[1] += y; cu[2] += z;
+            cu[3] += x * x; cu[4] += x * y; cu[5] += x * z; cu[6] += y * y; cu[7] += y * z; cu[8] += z * z;
+            c += 1.0;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; t++) cu[t] = octet_sum(cu[t]);
+    c = octet_sum(c);
+    if (ol == 0) {
+        double C6[6];
+        if (c >= 3.0) {
+            for (int t = 0; t < 9; t++) cu[t] = cu[t] / c;
+            C6[0] = cu[3] - cu[0] * cu[0]; C6[1] = cu[4] - cu[0] * cu[1]; C6[2] = cu[5] - cu[0] * cu[2];
+            C6[3] = cu[6] - cu[1] * cu[1]; C6[4] = cu[7] - cu[1] * cu[2]; C6[5] = cu[8] - cu[2] * cu[2];
+        } else { C6[0] = 1; C6[1] = 0; C6[2] = 0; C6[3] = 1; C6[4] = 0; C6[5] = 1; }
+        double nv[3];
+        d_fast_eigen3x3(C6, nv);
+        const double nn = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+        double px = 0, py = 0, pz = 0;
+        if (a.prior) { const float4 pr = a.prior[j]; px = pr.x; py = pr.y; pz = pr.z; }
+        if (nn == 0.0 || !(nn == nn)) { if (a.prior) { nv[0] = px; nv[1] = py; nv[2] = pz; } else { nv[0] = 0; nv[1] = 0; nv[2] = 1; } }
+        if (a.prior && nv[0] * px + nv[1] * py + nv[2] * pz < 0.0) { nv[0] = -nv[0]; nv[1] = -nv[1]; nv[2] = -nv[2]; }
+        a.normals[j] = make_float4((float)nv[0], (float)nv[1], (float)nv[2], 0.0f);
+    }
 }
 
 // ============================================================================ SOR (K4)
@@ -809,7 +922,8 @@ __global__ void __launch_bounds__(BS) k_compact_cloud(const float4 *__restrict__
     if (nrm && out_nrm) out_nrm[o] = nrm[i];
 }
 
-int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double std_ratio, DevCloud *out, uint8_t *keep_sorted, double *avg_sorted) {
+int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double std_ratio, DevCloud *out, uint8_t *keep_sorted, double *avg_sorted,
+                int normal_k, const float4 *prior_out, uint8_t *todo_out, int *todo_count) {
     if (nb_neighbors < 1 || !(std_ratio > 0.0)) { ctx->err = "nb_neighbors < 1 or std_ratio <= 0"; return PCR_EINVAL; }
     for (int d = 0; d < 3; d++) { out->key_org[d] = in->key_org[d]; out->key_unit[d] = in->key_unit[d]; }
     if (in->cap <= 0) { PCR_HIP_CHECK(ctx, hipMemsetAsync(out->n, 0, sizeof(int), ctx->stream)); return PCR_OK; }
@@ -819,8 +933,13 @@ int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double s
     uint8_t *flags = keep_sorted ? keep_sorted : arena<uint8_t>(ctx, in->cap);
     int *pos = arena<int>(ctx, in->cap);
     if (!avg || !stats3 || !flags || !pos) return PCR_ENOMEM;
+    // normals of the cleaned cloud straight from this pass's lists when they can be exact (see k_normals_from_lists)
+    const bool fuse = normal_k > 0 && todo_out && nb_neighbors <= 32 && normal_k <= nb_neighbors;
+    int32_t *lidx = fuse ? arena<int32_t>(ctx, (size_t)in->cap * 32) : nullptr;
+    float *ld2 = fuse ? arena<float>(ctx, (size_t)in->cap * 32) : nullptr;
+    if (fuse && (!lidx || !ld2)) return PCR_ENOMEM;
     KnnArgs a = {};
-    a.t = oct_view(in); a.n_ptr = in->n; a.k = nb_neighbors; a.avg = avg;
+    a.t = oct_view(in); a.n_ptr = in->n; a.k = nb_neighbors; a.avg = avg; a.list_idx = lidx; a.list_d2 = ld2;
     knn_radius(a, PCR_SEARCH_KNN, 0);
     PCR_TRY(launch_knn<KNN_MODE_SOR>(ctx, in, a));
     hipLaunchKernelGGL(k_sor_stats, dim3(1), dim3(1024), 0, ctx->stream, avg, in->n, std_ratio, stats3);
@@ -828,16 +947,28 @@ int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double s
     hipLaunchKernelGGL(k_sor_flags, dim3(nb), dim3(BS), 0, ctx->stream, avg, in->n, stats3, flags);
     PCR_TRY(pcr_dev_flag_scan(ctx, flags, in->n, in->cap, pos, out->n));
     hipLaunchKernelGGL(k_compact_cloud, dim3(nb), dim3(BS), 0, ctx->stream, in->pts, in->nrm, flags, pos, in->n, out->pts, out->nrm, in->keys, out->keys);
+    if (todo_out) {
+        if (fuse) {
+            PCR_HIP_CHECK(ctx, hipMemsetAsync(todo_count, 0, sizeof(int), ctx->stream));
+            NflArgs f;
+            f.pts = in->pts; f.n_ptr = in->n; f.lidx = lidx; f.ld2 = ld2; f.keep = flags; f.pos = pos; f.k_list = nb_neighbors; f.k_nrm = normal_k;
+            f.prior = prior_out; f.normals = out->nrm_final; f.todo = todo_out; f.todo_count = todo_count;
+            hipLaunchKernelGGL(k_normals_from_lists, dim3((unsigned)(((size_t)in->cap * OCT + KNN_BS - 1) / KNN_BS)), dim3(KNN_BS), 0, ctx->stream, f);
+        } else {
+            PCR_HIP_CHECK(ctx, hipMemsetAsync(todo_out, 1, (size_t)in->cap, ctx->stream));
+        }
+    }
     return PCR_OK;
 }
 
 // ================================================================== covariances / normals (K5)
-int pcr_dev_normals(pcr_context *ctx, DevCloud *c, int search_kind, int knn, double radius, const float4 *prior, float4 *normals_out, float *cov6_out) {
+int pcr_dev_normals(pcr_context *ctx, DevCloud *c, int search_kind, int knn, double radius, const float4 *prior, float4 *normals_out, float *cov6_out,
+                    const uint8_t *todo) {
     if (search_kind == PCR_SEARCH_RADIUS) { ctx->err = "pure radius search not implemented on device yet"; return PCR_EINVAL; }
     if (knn < 1) { ctx->err = "knn < 1"; return PCR_EINVAL; }
     if (search_kind == PCR_SEARCH_HYBRID && !(radius > 0)) { ctx->err = "radius <= 0"; return PCR_EINVAL; }
     KnnArgs a = {};
-    a.t = oct_view(c); a.n_ptr = c->n; a.k = knn; a.prior = prior; a.normals = normals_out; a.cov6 = cov6_out;
+    a.t = oct_view(c); a.n_ptr = c->n; a.k = knn; a.prior = prior; a.normals = normals_out; a.cov6 = cov6_out; a.todo = todo;
     knn_radius(a, search_kind, radius);
     return launch_knn<KNN_MODE_NORMALS>(ctx, c, a);
 }

@@ -52,6 +52,7 @@ struct ArenaMark { pcr_context *ctx; size_t off; ArenaMark(pcr_context *c) : ctx
 struct DevCloud {
     float4 *pts = nullptr;       // xyz, w = bit pattern of the original index (or 0)
     float4 *nrm = nullptr;       // optional
+    float4 *nrm_final = nullptr; // (pcr_dev_sor) where fused normals of the cleaned cloud go
     int *n = nullptr;            // device count
     int cap = 0;                 // host upper bound of *n
     uint64_t *keys = nullptr;    // sorted Morton keys of the points (voxel index / quantised position)
@@ -83,10 +84,11 @@ int pcr_dev_sort_cloud(pcr_context *ctx, const float *xyz, int64_t n, const doub
 int pcr_dev_build_bvh(pcr_context *ctx, DevCloud *c);
 // SOR: keep flags + compaction into `out` (out.cap >= in.cap); returns nothing to the host
 int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double std_ratio, DevCloud *out,
-                uint8_t *keep_sorted /*optional device, in.cap*/, double *avg_sorted /*optional*/);
+                uint8_t *keep_sorted /*optional device, in.cap*/, double *avg_sorted /*optional*/,
+                int normal_k = 0, const float4 *prior_out = nullptr, uint8_t *todo_out = nullptr, int *todo_count = nullptr);
 // normals (and optionally covariances) by k-NN / hybrid / radius neighbourhoods over the BVH
 int pcr_dev_normals(pcr_context *ctx, DevCloud *c, int search_kind, int knn, double radius, const float4 *prior,
-                    float4 *normals_out, float *cov6_out /*optional, sorted order, 6 per point*/);
+                    float4 *normals_out, float *cov6_out /*optional, sorted order, 6 per point*/, const uint8_t *todo = nullptr);
 int pcr_dev_knn_debug(pcr_context *ctx, const DevCloud *c, int k, double radius, int32_t *idx, float *d2, int32_t *counts);
 int pcr_read_count(pcr_context *ctx, const int *dev_n, int64_t *out);
 // pos[i] = number of set flags before i, *total_dev = number of set flags (n from device pointer or n_cap)

@@ -297,3 +297,4 @@ __device__ static inline void oct_search_group(const OctView &t, const OctMeta &
         }
     }
 }
+

@@ -2,7 +2,7 @@
 import ctypes as C, importlib, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["PCR_DEBUG_VISITS"] = "1"
+os.environ.setdefault("PCR_DEBUG_VISITS", "1")
 import torch
 P = importlib.import_module("point-cloud-registration-with-global-refinement_amd")
 syn = importlib.import_module("point-cloud-registration-with-global-refinement_amd.synthetic")
@@ -35,4 +35,8 @@ for voxel in p.voxel_sizes:
                                         C.c_void_p(idx.data_ptr()), C.c_void_p(d2.data_ptr()), C.c_void_p(cnt.data_ptr())), "knn")
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         v = cnt.cpu().numpy(); pops, asc, leafs = v & 1023, (v >> 10) & 1023, v >> 20
+        if os.environ["PCR_DEBUG_VISITS"] == "2":
+            us = v.reshape(-1)[: (n // 8) * 8].reshape(-1, 8).max(1) * 0.01       # per wavefront (8 queries), 100 MHz ticks
+            print(f"kNN voxel {voxel} k {k}: per-wave us mean {us.mean():.1f} p50 {np.percentile(us,50):.1f} p90 {np.percentile(us,90):.1f} p99 {np.percentile(us,99):.1f} max {us.max():.1f}; waves {len(us)}  (call {dt*1e3:.2f} ms)")
+            continue
         print(f"kNN voxel {voxel} k {k} n {n}: pops mean {pops.mean():.1f} p99 {np.percentile(pops,99):.0f} | ascents mean {asc.mean():.1f} p99 {np.percentile(asc,99):.0f} | leaf pops mean {leafs.mean():.1f} p99 {np.percentile(leafs,99):.0f}  ({dt*1e3:.2f} ms incl. sort/build)")
