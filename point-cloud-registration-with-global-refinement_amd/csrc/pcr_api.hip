@@ -19,6 +19,9 @@ extern "C" int pcr_create(int device, pcr_context **out) {
     ctx->device = device;
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PCR_EHIP; }
     ctx->stream = ctx->own_stream;
+    if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PCR_EHIP; }
+    for (int i = 0; i < 2; i++)
+        if (hipEventCreateWithFlags(&ctx->side_ev[i], hipEventDisableTiming) != hipSuccess) { delete ctx; return PCR_EHIP; }
     ctx->pinned_cap = 1 << 16;
     if (hipHostMalloc((void **)&ctx->pinned, ctx->pinned_cap, hipHostMallocDefault) != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return PCR_EHIP; }
     for (int i = 0; i < 2; i++)
@@ -36,6 +39,8 @@ extern "C" int pcr_destroy(pcr_context *ctx) {
     for (int i = 0; i < 2; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+    for (int i = 0; i < 2; i++) if (ctx->side_ev[i]) (void)hipEventDestroy(ctx->side_ev[i]);
     delete ctx;
     return PCR_OK;
 }
@@ -349,7 +354,7 @@ extern "C" int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const
         if (!(dists[s] > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
     }
     if (sor_k < 1 || !(sor_std > 0.0) || normal_k < 1) { ctx->err = "nb_neighbors < 1, std_ratio <= 0 or knn < 1"; return PCR_EINVAL; }
-    PCR_TRY(pcr_arena_reserve(ctx, 2 * (pcr_scratch_bytes_for(n_src) + pcr_scratch_bytes_for(n_tgt))));
+    PCR_TRY(pcr_arena_reserve(ctx, 2 * pcr_scratch_bytes_for(n_src) + 3 * pcr_scratch_bytes_for(n_tgt)));
     double bs[6], bt[6];
     PCR_TRY(pcr_dev_bounds(ctx, src_xyz, n_src, bs));
     PCR_TRY(pcr_dev_bounds(ctx, tgt_xyz, n_tgt, bt));
@@ -358,8 +363,21 @@ extern "C" int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const
     for (int s = 0; s < n_scales; s++) {
         ArenaMark mark(ctx);
         DevCloud cs, ct; int *nvs = nullptr, *nvt = nullptr;
+        // the two clouds are independent until the GICP loop: the target's pipeline is enqueued on the side lane so its
+        // many small latency-bound launches (sort passes, octree levels, scans, the fallback search) hide under the
+        // source's k-NN kernels and vice versa
+        const size_t side_bytes = pcr_scratch_bytes_for(n_tgt) * 2;
+        char *side = (char *)pcr_arena_alloc(ctx, side_bytes);
+        if (!side) return PCR_ENOMEM;
+        PCR_HIP_CHECK(ctx, hipEventRecord(ctx->side_ev[0], ctx->stream));
+        PCR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_ev[0], 0));
+        {
+            SideLane lane(ctx, side, side_bytes);
+            PCR_TRY(prep_scale(ctx, tgt_xyz, tgt_normals, n_tgt, bt, voxels[s], sor_k, sor_std, normal_k, &ct, &nvt));
+            PCR_HIP_CHECK(ctx, hipEventRecord(ctx->side_ev[1], ctx->stream));
+        }
         PCR_TRY(prep_scale(ctx, src_xyz, src_normals, n_src, bs, voxels[s], sor_k, sor_std, normal_k, &cs, &nvs));
-        PCR_TRY(prep_scale(ctx, tgt_xyz, tgt_normals, n_tgt, bt, voxels[s], sor_k, sor_std, normal_k, &ct, &nvt));
+        PCR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev[1], 0));
         int32_t *match = arena<int32_t>(ctx, n_src > 0 ? n_src : 1);
         if (!match) return PCR_ENOMEM;
         PCR_TRY(pcr_dev_gicp(ctx, &cs, &ct, dists[s], T, params, &records[s].icp, match));

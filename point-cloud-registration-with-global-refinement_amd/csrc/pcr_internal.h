@@ -14,6 +14,8 @@ struct pcr_context {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
+    hipStream_t side_stream = nullptr;   // second lane: the other cloud's preprocessing runs concurrently on it
+    hipEvent_t side_ev[2] = {nullptr, nullptr};
     char *arena = nullptr;
     size_t arena_cap = 0, arena_off = 0;
     char *pinned = nullptr;        // host-pinned read-back window
@@ -46,6 +48,15 @@ void *pcr_arena_alloc(pcr_context *ctx, size_t bytes);       // bump, 256-B alig
 template <class T> static inline T *arena(pcr_context *ctx, size_t count) {
     return (T *)pcr_arena_alloc(ctx, count * sizeof(T));
 }
+// Run a scope on the side lane: a private sub-arena carved out of the main one + the side stream, so that two
+// independent pipelines can be enqueued without sharing (and prematurely recycling) scratch memory.
+struct SideLane {
+    pcr_context *ctx; char *arena; size_t cap, off; hipStream_t stream;
+    SideLane(pcr_context *c, char *base, size_t bytes) : ctx(c), arena(c->arena), cap(c->arena_cap), off(c->arena_off), stream(c->stream) {
+        c->arena = base; c->arena_cap = bytes; c->arena_off = 0; c->stream = c->side_stream;
+    }
+    ~SideLane() { ctx->arena = arena; ctx->arena_cap = cap; ctx->arena_off = off; ctx->stream = stream; }
+};
 struct ArenaMark { pcr_context *ctx; size_t off; ArenaMark(pcr_context *c) : ctx(c), off(c->arena_off) {} ~ArenaMark() { ctx->arena_off = off; } };
 
 // ---- device-resident cloud: Morton-ordered float4 points (+ optional normals) with a device-side count ----
