@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--points", type=int, default=200_000)
     ap.add_argument("--pairs", type=int, default=2, help="distinct synthetic pairs cycled through the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("PCR_BENCH_INFLIGHT", "3")),
+                    help="independent pairs in flight per GPU (one host thread + one HIP stream + one library context each)")
     args = ap.parse_args()
 
     import torch
@@ -61,12 +63,30 @@ def main():
         p = pairs[i % len(pairs)]; s, t = clouds[i % len(pairs)]
         return P.registration.multiscale_gicp(s, t, p.voxel_sizes, p.max_distances_script, p.T_init, est, crit, 30, 1.0, 20)
 
-    ctx = P._lib.Context.current()
-    for i in range(args.warmup):
-        step(i)
+    # ---- executor: `inflight` host threads, each with its own HIP stream and library context (pairs are independent)
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    ctxs = []
+    tls = threading.local()
+
+    def worker_init():
+        torch.cuda.set_device(local_rank)
+        tls.stream = torch.cuda.Stream()
+        with torch.cuda.stream(tls.stream):
+            c = P._lib.Context.current()
+        ctxs.append(c)
+
+    def run_step(i):
+        with torch.cuda.stream(tls.stream):
+            return step(i)
+
+    pool = ThreadPoolExecutor(max_workers=args.inflight, initializer=worker_init)
+    torch.cuda.synchronize()
+    list(pool.map(run_step, range(max(args.warmup, args.inflight))))            # warm-up (every worker at least once)
     prof = (ctypes.c_double * 8)()
-    ctx.lib.pcr_profile_enable(ctx.handle, 1)
-    ctx.lib.pcr_profile_read(ctx.handle, prof, 1)
+    for c in ctxs:
+        c.lib.pcr_profile_enable(c.handle, 1)
+        c.lib.pcr_profile_read(c.handle, prof, 1)
 
     def barrier():
         torch.cuda.synchronize()
@@ -76,7 +96,7 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    results = [step(i) for i in range(args.steps)]
+    results = list(pool.map(run_step, range(args.steps)))
     recs = np.stack([shard.pack_record(rank * args.steps + i, r) for i, r in enumerate(results)])
     gathered = shard.gather_records(recs, world * args.steps, device=torch.device("cuda", local_rank)) if world > 1 else recs
     barrier()
@@ -85,17 +105,27 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    ctx.lib.pcr_profile_read(ctx.handle, prof, 0)
-    ctx.lib.pcr_profile_enable(ctx.handle, 0)
+    acc = [0.0] * 8
+    for c in ctxs:
+        c.lib.pcr_profile_read(c.handle, prof, 0)
+        c.lib.pcr_profile_enable(c.handle, 0)
+        for k in range(8):
+            acc[k] += prof[k]
+    prof = acc
 
     if rank == 0:
         res = results[-1]
-        # ---- roofline of the dominant kernel (k_icp_iter): algorithmic bytes / launch / launch duration
+        # ---- roofline of the hot loop: ONE GICP iteration = k_icp_nn + k_icp_iter (SURVEY K10+K11), 48 B per source point
         ev_ms, ev_launches, ik_us, live, alg_bytes, issued = (prof[i] for i in range(6))
         bytes_per_launch = alg_bytes / live if live else 0.0
         us_event = 1e3 * ev_ms / ev_launches if ev_launches else float("nan")     # HIP events over fully-live chunks
-        us_kernel = ik_us / live if live else float("nan")                         # kernel's own s_memrealtime stamps
+        us_kernel = ik_us / live if live else float("nan")                         # kernels' own s_memrealtime stamps
         achieved = bytes_per_launch / (us_event * 1e-6) / 1e9 if ev_launches else 0.0
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")                    # rocprofv3 --pmc passes (profiles/README.md)
+        if os.path.exists(tj):
+            t = json.load(open(tj))
+            traffic = t.get("k_icp_nn", {}).get("hbm_bytes_per_launch", 0) + t.get("k_icp_iter<GICP>", {}).get("hbm_bytes_per_launch", 0)
         # sanity of the result itself (planted motion) -- printed, not part of the contract
         p_last = pairs[(args.steps - 1) % len(pairs)]
         dR = res.transformation[:3, :3].T @ p_last.T_true[:3, :3]
@@ -107,12 +137,12 @@ def main():
             "dtype": "f32 points+search, f64 normal equations", "data": "synthetic",
             "config": {"workload": f"single pair, {args.points}-pt synthetic NCLT-shaped clouds, 3-scale GICP "
                                    "(voxels 0.4/0.2/0.1 m, radii 1.2/0.4/0.1 m, SOR(30,1.0), KNN-20 normals, L1, 1e-6/1e-6/100)",
-                       "points_per_cloud": args.points, "distinct_pairs": args.pairs, "parallelism": f"pairs x{world}",
+                       "points_per_cloud": args.points, "distinct_pairs": args.pairs, "parallelism": f"pairs x{world}", "pairs_in_flight_per_gpu": args.inflight,
                        "scales": [dict(voxel=s["voxel"], max_dist=s["max_dist"], n_voxel=s["n_voxel"], n_clean=s["n_clean"],
                                        iterations=s["iterations"]) for s in res.scales],
                        "err_vs_planted": {"rad": ang, "m": dtr}, "gathered_records": int(len(gathered))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_icp_iter<GICP>",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_icp_nn + k_icp_iter<GICP> (one GICP iteration)",
                          "bytes_per_launch": bytes_per_launch, "us_per_launch_hip_events": us_event,
                          "us_per_launch_in_kernel_clock": us_kernel, "live_launches": live, "launches_issued": issued},
         }

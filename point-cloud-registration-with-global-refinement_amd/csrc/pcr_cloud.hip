@@ -391,7 +391,8 @@ __global__ void __launch_bounds__(BS) k_oct_apply(const signed char *__restrict_
     }
 }
 // F/G: tight boxes, bottom-up
-__global__ void __launch_bounds__(BS) k_oct_leaf_boxes(const float4 *__restrict__ pts, const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up) {
+__global__ void __launch_bounds__(BS) k_oct_leaf_boxes(const float4 *__restrict__ pts, const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up,
+                                                       int4 *__restrict__ pinfo) {
     const int j = blockIdx.x * BS + threadIdx.x;
     if (meta->nl < 1 || j >= meta->cnt[0]) return;
     const int a = child[j], b = child[j + 1];
@@ -400,6 +401,7 @@ __global__ void __launch_bounds__(BS) k_oct_leaf_boxes(const float4 *__restrict_
         const float4 p = pts[i];
         lo.x = fminf(lo.x, p.x); lo.y = fminf(lo.y, p.y); lo.z = fminf(lo.z, p.z);
         hi.x = fmaxf(hi.x, p.x); hi.y = fmaxf(hi.y, p.y); hi.z = fmaxf(hi.z, p.z);
+        pinfo[i] = make_int4(j, a, b - a, 0);                   // point -> (leaf, first point, point count)
     }
     lo.w = __int_as_float(a); hi.w = __int_as_float(b - a);
     boxes[2 * (size_t)j] = lo; boxes[2 * (size_t)j + 1] = hi;
@@ -452,7 +454,7 @@ int pcr_dev_build_bvh(pcr_context *ctx, DevCloud *c) {
     hipLaunchKernelGGL(k_oct_tile_scan, dim3(1), dim3(BS), 0, ctx->stream, tile_cnt, n_tiles);
     hipLaunchKernelGGL(k_oct_apply, dim3(n_tiles), dim3(BS), 0, ctx->stream, ls, c->oct_meta, tile_cnt, c->oct_child, c->leaf_of);
     const int nbl = (cap / 2 + 1 + BS - 1) / BS;       // <= n/2 leaves (or 1)
-    hipLaunchKernelGGL(k_oct_leaf_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->pts, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up);
+    hipLaunchKernelGGL(k_oct_leaf_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->pts, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, c->pinfo);
     hipLaunchKernelGGL(k_oct_level_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, 1);
     hipLaunchKernelGGL(k_oct_level_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, 2);
     hipLaunchKernelGGL(k_oct_upper_boxes, dim3(1), dim3(1024), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, 3);
@@ -460,7 +462,7 @@ int pcr_dev_build_bvh(pcr_context *ctx, DevCloud *c) {
 }
 
 static inline OctView oct_view(const DevCloud *c) {
-    OctView v; v.pts = c->pts; v.nodes = c->oct_nodes; v.up = c->oct_up; v.meta = c->oct_meta; v.leaf_of = c->leaf_of; v.keys = c->keys;
+    OctView v; v.pts = c->pts; v.nodes = c->oct_nodes; v.up = c->oct_up; v.meta = c->oct_meta; v.leaf_of = c->leaf_of; v.keys = c->keys; v.pinfo = c->pinfo;
     return v;
 }
 

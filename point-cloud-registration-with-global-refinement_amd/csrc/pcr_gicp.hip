@@ -455,7 +455,7 @@ static void fill_args(IcpArgs &a, const DevCloud *src, const DevCloud *tgt, doub
                       int32_t *match, IcpState *st, double *partials, int single) {
     a.src_pts = src->pts; a.src_nrm = src->nrm; a.ns_ptr = src->n;
     a.tgt_pts = tgt->pts; a.tgt_nrm = tgt->nrm; a.nt_ptr = tgt->n;
-    a.tgt.pts = tgt->pts; a.tgt.nodes = tgt->oct_nodes; a.tgt.up = tgt->oct_up; a.tgt.meta = tgt->oct_meta; a.tgt.leaf_of = tgt->leaf_of; a.tgt.keys = tgt->keys;
+    a.tgt.pts = tgt->pts; a.tgt.nodes = tgt->oct_nodes; a.tgt.up = tgt->oct_up; a.tgt.meta = tgt->oct_meta; a.tgt.leaf_of = tgt->leaf_of; a.tgt.keys = tgt->keys; a.tgt.pinfo = tgt->pinfo;
     a.match = match; a.state = st; a.partials = partials;
     a.max_dist2 = max_dist * max_dist;
     const double r2w = a.max_dist2 * (1.0 + 1e-6);

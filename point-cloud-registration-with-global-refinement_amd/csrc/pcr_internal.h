@@ -72,6 +72,7 @@ struct DevCloud {
     int4 *oct_up = nullptr;      //   (parent, first sibling, sibling count) per node
     struct OctMeta *oct_meta = nullptr;
     int *leaf_of = nullptr;
+    int4 *pinfo = nullptr;       //   point -> (leaf, first point of the leaf, point count)
     float key_org[3] = {0, 0, 0};   // lattice of the Morton keys: coordinate i <-> [org + i*unit, org + (i+1)*unit)
     float key_unit[3] = {1, 1, 1};
 };

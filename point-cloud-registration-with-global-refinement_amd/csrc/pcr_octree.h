@@ -45,6 +45,7 @@ struct OctView {             // what a kernel needs to walk a tree
     const OctMeta *meta;
     const int *leaf_of;
     const uint64_t *keys;
+    const int4 *pinfo;       // point -> (leaf, first point of the leaf, point count)
 };
 
 __host__ __device__ static inline uint32_t pcr_compact21(uint64_t x) {
