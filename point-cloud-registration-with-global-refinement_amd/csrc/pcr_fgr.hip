@@ -196,6 +196,130 @@ __global__ void __launch_bounds__(FB) k_feature_nn(const float *__restrict__ db,
     if (qi < n_q) out[qi] = bi;
 }
 
+// ---- MFMA path (the 33-D distance contraction is the one GEMM-shaped step of the pipeline) -------------------
+// d2(q, b) = |q|^2 + |b|^2 - 2 q.b with S = B_db * Q^T on v_mfma_f64_16x16x4_f64.  In float32 the expanded form
+// cancels (|f|^2 ~ 1e5 against d2 ~ 1) and dense feature sets have many neighbours inside the rounding margin, so the
+// contraction runs in FLOAT64: exact to ~1e-11 on these inputs, i.e. the true nearest row of the float32 features
+// (what Open3D's float64 kd-tree returns), ties -> smaller index.  Rows = 16 database points, columns = 16 queries per
+// MFMA; a wavefront keeps 4 column blocks (64 queries) in registers and reuses every database operand 4 times; a
+// lane owns one query column per block and 4 database rows, so the running arg-min needs no cross-lane traffic.
+#define FK 36                      // 33 padded to a multiple of 4
+#define QB 4                       // query blocks of 16 per wavefront
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// FT[k][n_pad] (k-major, zero padded, float64) + squared norms (padded rows: +huge, can never win)
+__global__ void __launch_bounds__(FB) k_feat_transpose(const float *__restrict__ f, int n, int n_pad, double *__restrict__ ft, double *__restrict__ nrm2) {
+    const int i = blockIdx.x * FB + threadIdx.x;
+    if (i >= n_pad) return;
+    double s = 0.0;
+    for (int k = 0; k < FK; k++) {
+        const double v = (i < n && k < FEAT_D) ? (double)f[(size_t)i * FEAT_D + k] : 0.0;
+        ft[(size_t)k * n_pad + i] = v;
+        s += v * v;
+    }
+    nrm2[i] = i < n ? s : 1.0e300;
+}
+
+__global__ void __launch_bounds__(FB) k_feature_nn_mfma(const double *__restrict__ dbT, const double *__restrict__ dbn, int n_db_pad,
+                                                        const double *__restrict__ qT, const double *__restrict__ qn, int n_q_pad,
+                                                        int tiles_per_split, double *__restrict__ cand_d, int *__restrict__ cand_i) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = lane & 15, kk = lane >> 4;
+    const int q0 = (blockIdx.x * (FB / 64) + wv) * (16 * QB);
+    if (q0 >= n_q_pad) return;
+    double qb[QB][FK / 4], nq[QB];
+#pragma unroll
+    for (int b = 0; b < QB; b++) {
+#pragma unroll
+        for (int t = 0; t < FK / 4; t++) qb[b][t] = qT[(size_t)(4 * t + kk) * n_q_pad + q0 + 16 * b + col];    // B[k = 4t + kk][col]
+        nq[b] = qn[q0 + 16 * b + col];
+    }
+    double bd[QB]; int bi[QB];
+#pragma unroll
+    for (int b = 0; b < QB; b++) { bd[b] = 1.0e300; bi[b] = -1; }
+    const int n_tiles = n_db_pad / 16;
+    const int t0 = blockIdx.y * tiles_per_split, t1 = min(n_tiles, t0 + tiles_per_split);
+    // software pipeline: operands of tile t+1 are in flight while the MFMAs of tile t issue
+    double av[FK / 4], an[FK / 4], nbv[4], nbn[4];
+    if (t0 < t1) {
+#pragma unroll
+        for (int t = 0; t < FK / 4; t++) av[t] = dbT[(size_t)(4 * t + kk) * n_db_pad + t0 * 16 + col];           // A[row = col][k = 4t + kk]
+#pragma unroll
+        for (int r = 0; r < 4; r++) nbv[r] = dbn[t0 * 16 + kk + 4 * r];                                        // result rows kk + 4r
+    }
+    for (int tile = t0; tile < t1; tile++) {
+        const int r0 = tile * 16, rn = (tile + 1 < t1 ? tile + 1 : tile) * 16;
+#pragma unroll
+        for (int t = 0; t < FK / 4; t++) an[t] = dbT[(size_t)(4 * t + kk) * n_db_pad + rn + col];
+#pragma unroll
+        for (int r = 0; r < 4; r++) nbn[r] = dbn[rn + kk + 4 * r];
+#pragma unroll
+        for (int b = 0; b < QB; b++) {
+            f64x4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < FK / 4; t++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t], qb[b][t], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const double v = (nq[b] + nbv[r]) - 2.0 * acc[r];
+                const int row = r0 + kk + 4 * r;
+                if (v < bd[b]) { bd[b] = v; bi[b] = row; }       // rows ascend within a lane: first (smallest) index kept on ties
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < FK / 4; t++) av[t] = an[t];
+#pragma unroll
+        for (int r = 0; r < 4; r++) nbv[r] = nbn[r];
+    }
+    // combine the 4 row groups (lanes col, col+16, col+32, col+48): lexicographic (distance, index) minimum
+#pragma unroll
+    for (int b = 0; b < QB; b++) {
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+            const double od = __shfl_xor(bd[b], o, 64); const int oi = __shfl_xor(bi[b], o, 64);
+            if (od < bd[b] || (od == bd[b] && oi >= 0 && (bi[b] < 0 || oi < bi[b]))) { bd[b] = od; bi[b] = oi; }
+        }
+        if (kk == 0) {
+            const size_t o = (size_t)(q0 + 16 * b + col) * gridDim.y + blockIdx.y;
+            cand_d[o] = bd[b]; cand_i[o] = bi[b];
+        }
+    }
+}
+__global__ void __launch_bounds__(FB) k_feature_nn_pick(const double *__restrict__ cand_d, const int *__restrict__ cand_i, int n_q, int splits, int32_t *__restrict__ out) {
+    const int qi = blockIdx.x * FB + threadIdx.x;
+    if (qi >= n_q) return;
+    double best = 1.0e300; int bi = -1;
+    for (int sidx = 0; sidx < splits; sidx++) {          // splits cover ascending row ranges: strict '<' keeps the smaller index on ties
+        const double d = cand_d[(size_t)qi * splits + sidx]; const int id = cand_i[(size_t)qi * splits + sidx];
+        if (id >= 0 && d < best) { best = d; bi = id; }
+    }
+    out[qi] = bi;
+}
+
+// nearest database row for every query row (exact, float64 contraction on the matrix cores)
+static int feature_nn(pcr_context *ctx, const float *db, int n_db, const float *q, int n_q, int32_t *out) {
+    if (n_db < 64 || n_q < 64 || getenv("PCR_FEATURE_NN_BRUTE")) {
+        hipLaunchKernelGGL(k_feature_nn, dim3((n_q + FB - 1) / FB), dim3(FB), 0, ctx->stream, db, n_db, q, n_q, out);
+        return PCR_OK;
+    }
+    ArenaMark mark(ctx);
+    const int ndp = (n_db + 15) / 16 * 16, nqp = (n_q + 255) / 256 * 256;
+    const int n_tiles = ndp / 16, waves = nqp / (16 * QB);
+    int splits = (4096 + waves - 1) / waves;
+    if (splits > 32) splits = 32;
+    if (splits > n_tiles) splits = n_tiles;
+    if (splits < 1) splits = 1;
+    const int tps = (n_tiles + splits - 1) / splits;
+    double *dbT = arena<double>(ctx, (size_t)FK * ndp), *dbn = arena<double>(ctx, ndp);
+    double *qT = arena<double>(ctx, (size_t)FK * nqp), *qn = arena<double>(ctx, nqp);
+    double *cd = arena<double>(ctx, (size_t)nqp * splits); int *ci = arena<int>(ctx, (size_t)nqp * splits);
+    if (!dbT || !dbn || !qT || !qn || !cd || !ci) return PCR_ENOMEM;
+    hipLaunchKernelGGL(k_feat_transpose, dim3((ndp + FB - 1) / FB), dim3(FB), 0, ctx->stream, db, n_db, ndp, dbT, dbn);
+    hipLaunchKernelGGL(k_feat_transpose, dim3((nqp + FB - 1) / FB), dim3(FB), 0, ctx->stream, q, n_q, nqp, qT, qn);
+    hipLaunchKernelGGL(k_feature_nn_mfma, dim3(nqp / 256, splits), dim3(FB), 0, ctx->stream, dbT, dbn, ndp, qT, qn, nqp, tps, cd, ci);
+    hipLaunchKernelGGL(k_feature_nn_pick, dim3((n_q + FB - 1) / FB), dim3(FB), 0, ctx->stream, cd, ci, n_q, splits, out);
+    return PCR_OK;
+}
+
 // cross check: pair (i, i_to_j[i]) survives iff j_to_i[i_to_j[i]] == i      
 __global__ void __launch_bounds__(FB) k_cross_flags(const int32_t *__restrict__ i_to_j, const int32_t *__restrict__ j_to_i, int n_i, uint8_t *__restrict__ flags) {
     const int i = blockIdx.x * FB + threadIdx.x;
@@ -484,7 +608,7 @@ extern "C" int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, cons
     if (ns > 0 && nt > 0) {
         const int64_t nmax = ns > nt ? ns : nt;
         const long long trial_cap = opt->tuple_test ? 100ll * nmax : 0;
-        PCR_TRY(pcr_arena_reserve(ctx, (size_t)(ns + nt) * (24 + 8 + 16) + (size_t)nmax * 32 + (size_t)trial_cap * 5 + (size_t)nmax * 64 + (64u << 20)));
+        PCR_TRY(pcr_arena_reserve(ctx, (size_t)(ns + nt) * (24 + 8 + 16) + (size_t)nmax * 32 + (size_t)trial_cap * 5 + (size_t)nmax * 64 + (size_t)nmax * (FK * 16 + 32 * 12 + 64) + (64u << 20)));
         // ---- NormalizePointCloud
         double *P[2] = {arena<double>(ctx, (size_t)ns * 3), arena<double>(ctx, (size_t)nt * 3)};
         if (!P[0] || !P[1]) return PCR_ENOMEM;
@@ -506,8 +630,8 @@ extern "C" int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, cons
         int *cpos = arena<int>(ctx, nPti), *ncross_dev = arena<int>(ctx, 1);
         int32_t *cross = arena<int32_t>(ctx, (size_t)nPti * 2);
         if (!j_to_i || !i_to_j || !cflags || !cpos || !ncross_dev || !cross) return PCR_ENOMEM;
-        hipLaunchKernelGGL(k_feature_nn, dim3((nPtj + FB - 1) / FB), dim3(FB), 0, ctx->stream, fi, nPti, fj, nPtj, j_to_i);
-        hipLaunchKernelGGL(k_feature_nn, dim3((nPti + FB - 1) / FB), dim3(FB), 0, ctx->stream, fj, nPtj, fi, nPti, i_to_j);
+        PCR_TRY(feature_nn(ctx, fi, nPti, fj, nPtj, j_to_i));
+        PCR_TRY(feature_nn(ctx, fj, nPtj, fi, nPti, i_to_j));
         hipLaunchKernelGGL(k_cross_flags, dim3((nPti + FB - 1) / FB), dim3(FB), 0, ctx->stream, i_to_j, j_to_i, nPti, cflags);
         PCR_TRY(pcr_dev_flag_scan(ctx, cflags, nullptr, nPti, cpos, ncross_dev));
         hipLaunchKernelGGL(k_cross_emit, dim3((nPti + FB - 1) / FB), dim3(FB), 0, ctx->stream, i_to_j, cflags, cpos, nPti, cross);

@@ -56,9 +56,10 @@ def test_fgr_matches_oracle_on_identical_features(P, oracle, fgr_inputs, small_p
         ref = oracle.registration_fgr(src.points, fs.data.T, tgt.points, ft.data.T, 1.4, abs_scale, True, 0.2, 300, 0.95,
                                       int(n_pontos * 0.2), True, 4242)
         a, d = pose_error(res.transformation, ref.transformation)
-        # same features, same counter-based sampler: only float32-vs-float64 near-ties in the 33-D matching can differ
-        assert a < 2e-3 and d < 2e-2, (abs_scale, a, d)
-        assert abs(res.fitness - ref.fitness) < 0.02
+        # same features, same counter-based sampler, float64 feature distances on both sides: same mutual-NN set, same
+        # tuples, same 300 Gauss-Newton steps -> the poses agree to rounding
+        assert a < 1e-7 and d < 1e-6, (abs_scale, a, d)
+        assert abs(res.fitness - ref.fitness) < 1e-9
         # and both sit in the statistical band around the shipped FGR pose
         a, d = pose_error(res.transformation, small_pair["T_fgr"])
         assert a < 3e-2 and d < 0.5, (a, d)
@@ -100,3 +101,16 @@ def test_coarse_to_fine_library_flow(P, oracle, small_pair):
     assert a < 2e-2 and d < 0.15, (a, d)              # no fixture pins the AF variant
     rinfo = oracle.information_matrix(small_pair["source"], small_pair["target"], 0.1, res.transformation)
     assert np.allclose(info, rinfo, rtol=1e-6)
+
+
+def test_mfma_feature_matching_vs_float32_bruteforce(P, fgr_inputs, monkeypatch):
+    """The float64 MFMA contraction finds the exact nearest feature (Open3D's float64 semantics); the float32 (a-b)^2
+    brute-force kernel can only differ on float32 near-ties, so the two FGR results must be practically the same."""
+    (src, fs), (tgt, ft) = fgr_inputs
+    opt = P.registration.FastGlobalRegistrationOption(1.4, False, True, 0.2, 64, 0.95, 2000, seed=99)
+    a = P.registration.registration_fgr_based_on_feature_matching(src, tgt, fs, ft, opt)
+    monkeypatch.setenv("PCR_FEATURE_NN_BRUTE", "1")
+    b = P.registration.registration_fgr_based_on_feature_matching(src, tgt, fs, ft, opt)
+    ang, dt = pose_error(a.transformation, b.transformation)
+    assert ang < 2e-3 and dt < 2e-2, (ang, dt)
+    assert abs(a.fitness - b.fitness) < 0.01
