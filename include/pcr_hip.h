@@ -121,6 +121,14 @@ int pcr_registration_generalized_icp(pcr_context *ctx, const float *src_xyz, con
                                      double max_correspondence_distance, const double *init_T,
                                      const pcr_gicp_params *params, pcr_result *result, int32_t *correspondences);
 
+/* == registration_icp(..., TransformationEstimationForGeneralizedICP(loss), ...) on clouds that already carry
+ *    covariances (GICP_robusto, ALL_FUNCTIONS.py:216-226): the given covariances are used untouched.
+ *    cov6 = xx,xy,xz,yy,yz,zz per point, float32, device.                                                   */
+int pcr_registration_generalized_icp_cov(pcr_context *ctx, const float *src_xyz, const float *src_cov6, int64_t n_src,
+                                         const float *tgt_xyz, const float *tgt_cov6, int64_t n_tgt,
+                                         double max_correspondence_distance, const double *init_T,
+                                         const pcr_gicp_params *params, pcr_result *result, int32_t *correspondences);
+
 /* == the whole body of Multiscale_GICP (ALL_FUNCTIONS.py:286-312 / 2_MGICP...py:140-163), device resident:
  * per scale voxel_down_sample -> remove_statistical_outlier(sor_k, sor_std) -> estimate_normals(KNN normal_k)
  * -> registration_generalized_icp, chained.  src/tgt_normals optional (AF flow orientation prior).

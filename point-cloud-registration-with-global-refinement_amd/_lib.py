@@ -46,7 +46,7 @@ EXPORTS = [
     "pcr_voxel_down_sample", "pcr_remove_statistical_outlier", "pcr_estimate_normals", "pcr_estimate_covariances",
     "pcr_registration_generalized_icp", "pcr_multiscale_gicp", "pcr_evaluate_registration", "pcr_information_matrix",
     "pcr_compute_fpfh_feature", "pcr_registration_fgr", "pcr_debug_knn", "pcr_debug_gicp_linearize",
-    "pcr_profile_enable", "pcr_profile_read",
+    "pcr_profile_enable", "pcr_profile_read", "pcr_registration_generalized_icp_cov",
 ]
 
 _lib = None

@@ -292,6 +292,40 @@ extern "C" int pcr_registration_generalized_icp(pcr_context *ctx, const float *s
     return PCR_OK;
 }
 
+__global__ void k_gather_cov6(const float *__restrict__ src, const uint32_t *__restrict__ perm, int n, float *__restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = perm[i];
+    for (int t = 0; t < 6; t++) dst[(size_t)i * 6 + t] = src[(size_t)v * 6 + t];
+}
+
+extern "C" int pcr_registration_generalized_icp_cov(pcr_context *ctx, const float *src_xyz, const float *src_cov6, int64_t n_src,
+                                                    const float *tgt_xyz, const float *tgt_cov6, int64_t n_tgt, double max_dist,
+                                                    const double *init_T, const pcr_gicp_params *params, pcr_result *result,
+                                                    int32_t *correspondences) {
+    ENTER(ctx);
+    if (!params || !result || n_src < 0 || n_tgt < 0) return PCR_EINVAL;
+    if (!(max_dist > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
+    if ((n_src > 0 && (!src_xyz || !src_cov6)) || (n_tgt > 0 && (!tgt_xyz || !tgt_cov6))) { ctx->err = "missing cloud or covariances"; return PCR_EINVAL; }
+    PCR_TRY(check_T(ctx, init_T));
+    PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n_src) + pcr_scratch_bytes_for(n_tgt) + (size_t)(n_src + n_tgt) * 32));
+    DevCloud s, t; uint32_t *sperm = nullptr, *tperm = nullptr;
+    PCR_TRY(pcr_import_cloud(ctx, src_xyz, nullptr, n_src, &s, &sperm, false));
+    PCR_TRY(pcr_import_cloud(ctx, tgt_xyz, nullptr, n_tgt, &t, &tperm, false));
+    s.cov6 = arena<float>(ctx, (size_t)(n_src > 0 ? n_src : 1) * 6);
+    t.cov6 = arena<float>(ctx, (size_t)(n_tgt > 0 ? n_tgt : 1) * 6);
+    int32_t *match = arena<int32_t>(ctx, n_src > 0 ? n_src : 1);
+    if (!s.cov6 || !t.cov6 || !match) return PCR_ENOMEM;
+    if (n_src > 0) hipLaunchKernelGGL(k_gather_cov6, dim3((unsigned)((n_src + 255) / 256)), dim3(256), 0, ctx->stream, src_cov6, sperm, (int)n_src, s.cov6);
+    if (n_tgt > 0) hipLaunchKernelGGL(k_gather_cov6, dim3((unsigned)((n_tgt + 255) / 256)), dim3(256), 0, ctx->stream, tgt_cov6, tperm, (int)n_tgt, t.cov6);
+    PCR_TRY(pcr_dev_gicp(ctx, &s, &t, max_dist, init_T, params, result, match));
+    if (correspondences) {
+        int64_t nc = 0;
+        PCR_TRY(pcr_dev_compact_matches(ctx, match, s.n, s.cap, sperm, tperm, correspondences, &nc));
+    }
+    return PCR_OK;
+}
+
 extern "C" int pcr_debug_gicp_linearize(pcr_context *ctx, const float *src_xyz, const float *src_normals, int64_t n_src,
                                         const float *tgt_xyz, const float *tgt_normals, int64_t n_tgt, double max_dist,
                                         const double *T, const pcr_gicp_params *params, double *JTJ36, double *JTr6,

@@ -792,6 +792,70 @@ int pcr_dev_knn_debug(pcr_context *ctx, const DevCloud *c, int k, double radius,
     return launch_knn<KNN_MODE_DEBUG>(ctx, c, a);
 }
 
+// ============================================================== pure radius neighbourhoods (KDTreeSearchParamRadius)
+// All points with d^2 < r^2 contribute to the moments directly (no k-best): same shared walk, fixed bound.
+struct RadArgs {
+    OctView t; const int *n_ptr; float r2f; double r2;
+    const float4 *prior; float4 *normals; float *cov6;
+};
+__global__ void __launch_bounds__(KNN_BS) k_radius_moments(RadArgs a) {
+    constexpr int OPB = KNN_BS / OCT;
+    __shared__ OctMeta m;
+    __shared__ OctGroupStack gstk[KNN_BS / 64];
+    if (threadIdx.x == 0) m = *a.t.meta;
+    __syncthreads();
+    const int n = m.n;
+    const int lane = threadIdx.x & 63, ol = lane & 7, ob = threadIdx.x >> 3;
+    const int qi = blockIdx.x * OPB + ob;
+    const bool live = qi < n;
+    if (__ballot(live) == 0ull) return;
+    const float4 q = a.t.pts[live ? qi : 0];
+    const double qx = q.x, qy = q.y, qz = q.z;
+    double cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, c = 0;
+    auto visit = [&](int first, int count) {
+        for (int base = first; base < first + count; base += OCT) {
+            const int idx = base + ol;
+            if (live && idx < first + count) {
+                const float4 p = a.t.pts[idx];
+                if (pcr_d2(p.x - q.x, p.y - q.y, p.z - q.z) < a.r2f) {
+                    const double x = p.x, y = p.y, z = p.z;
+                    const double dx = x - qx, dy = y - qy, dz = z - qz;
+                    if (dx * dx + dy * dy + dz * dz < a.r2) {
+                        cu[0] += x; cu[1] += y; cu[2] += z;
+                        cu[3] += x * x; cu[4] += x * y; cu[5] += x * z; cu[6] += y * y; cu[7] += y * z; cu[8] += z * z;
+                        c += 1.0;
+                    }
+                }
+            }
+        }
+    };
+    const int g0 = blockIdx.x * OPB + (threadIdx.x >> 6) * OCT;
+    oct_search_group(a.t, m, gstk[threadIdx.x >> 6], live, a.t.leaf_of[g0], q.x, q.y, q.z, [&]() { return a.r2f; }, visit,
+                     [](int, int) { return false; }, ol, nullptr);
+#pragma unroll
+    for (int t = 0; t < 9; t++) cu[t] = octet_sum(cu[t]);
+    c = octet_sum(c);
+    if (live && ol == 0) {
+        double C6[6];
+        if (c >= 3.0) {
+            for (int t = 0; t < 9; t++) cu[t] = cu[t] / c;
+            C6[0] = cu[3] - cu[0] * cu[0]; C6[1] = cu[4] - cu[0] * cu[1]; C6[2] = cu[5] - cu[0] * cu[2];
+            C6[3] = cu[6] - cu[1] * cu[1]; C6[4] = cu[7] - cu[1] * cu[2]; C6[5] = cu[8] - cu[2] * cu[2];
+        } else { C6[0] = 1; C6[1] = 0; C6[2] = 0; C6[3] = 1; C6[4] = 0; C6[5] = 1; }
+        if (a.cov6) { for (int t = 0; t < 6; t++) a.cov6[(size_t)qi * 6 + t] = (float)C6[t]; }
+        if (a.normals) {
+            double nv[3];
+            d_fast_eigen3x3(C6, nv);
+            const double nn = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+            double px = 0, py = 0, pz = 0;
+            if (a.prior) { const float4 pr = a.prior[qi]; px = pr.x; py = pr.y; pz = pr.z; }
+            if (nn == 0.0 || !(nn == nn)) { if (a.prior) { nv[0] = px; nv[1] = py; nv[2] = pz; } else { nv[0] = 0; nv[1] = 0; nv[2] = 1; } }
+            if (a.prior && nv[0] * px + nv[1] * py + nv[2] * pz < 0.0) { nv[0] = -nv[0]; nv[1] = -nv[1]; nv[2] = -nv[2]; }
+            a.normals[qi] = make_float4((float)nv[0], (float)nv[1], (float)nv[2], 0.0f);
+        }
+    }
+}
+
 // ============================================= normals of the CLEANED cloud from the SOR pass's k-best lists (K5')
 // The k_nrm nearest KEPT neighbours of a kept point are among its k_list nearest in the un-cleaned cloud whenever
 // at least k_nrm of those survive the filter (every kept point outside the list is farther than all list members):
@@ -966,7 +1030,15 @@ int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double s
 // ================================================================== covariances / normals (K5)
 int pcr_dev_normals(pcr_context *ctx, DevCloud *c, int search_kind, int knn, double radius, const float4 *prior, float4 *normals_out, float *cov6_out,
                     const uint8_t *todo) {
-    if (search_kind == PCR_SEARCH_RADIUS) { ctx->err = "pure radius search not implemented on device yet"; return PCR_EINVAL; }
+    if (search_kind == PCR_SEARCH_RADIUS) {
+        if (!(radius > 0)) { ctx->err = "radius <= 0"; return PCR_EINVAL; }
+        if (c->cap <= 0) return PCR_OK;
+        RadArgs r;
+        r.t = oct_view(c); r.n_ptr = c->n; r.r2 = radius * radius; r.r2f = (float)(r.r2 * (1.0 + 1e-6));
+        r.prior = prior; r.normals = normals_out; r.cov6 = cov6_out;
+        hipLaunchKernelGGL(k_radius_moments, dim3((unsigned)(((size_t)c->cap * OCT + KNN_BS - 1) / KNN_BS)), dim3(KNN_BS), 0, ctx->stream, r);
+        return PCR_OK;
+    }
     if (knn < 1) { ctx->err = "knn < 1"; return PCR_EINVAL; }
     if (search_kind == PCR_SEARCH_HYBRID && !(radius > 0)) { ctx->err = "radius <= 0"; return PCR_EINVAL; }
     KnnArgs a = {};

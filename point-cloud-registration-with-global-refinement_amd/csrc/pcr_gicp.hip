@@ -18,7 +18,7 @@
 #define NVP 32           // padded row of a partial
 #define LIN_MAX_BLOCKS 256
 
-enum { ICP_MODE_GICP = 0, ICP_MODE_EVAL = 1 };
+enum { ICP_MODE_GICP = 0, ICP_MODE_EVAL = 1, ICP_MODE_GICP_COV = 2 };   // _COV: per-point covariances given (GICP_robusto path)
 
 struct IcpState {
     double T[16];
@@ -37,6 +37,7 @@ struct IcpState {
 
 struct IcpArgs {
     const float4 *src_pts, *src_nrm; const int *ns_ptr;
+    const float *src_cov6, *tgt_cov6;            // optional raw covariances (xx,xy,xz,yy,yz,zz), Morton order
     const float4 *tgt_pts, *tgt_nrm; OctView tgt; const int *nt_ptr;
     int32_t *match;
     IcpState *state;
@@ -102,6 +103,37 @@ __device__ static inline double icp_weight(int loss, double k, double r) {
     if (loss == PCR_LOSS_L1) return 1.0 / fmax(fabs(r), 1e-300);    // Open3D: 1/|r| (unguarded); guard only against r == 0
     if (loss == PCR_LOSS_GM) { const double d = k + r * r; return k / (d * d); }
     return 1.0;
+}
+
+// W = (M^-1)^(1/2), symmetric principal root of an SPD 3x3 (general covariances: no closed form): cyclic Jacobi in
+// float64, fully unrolled (static indexing only -> registers)
+__device__ static inline void icp_sym3_inv_sqrt(const double *M6 /*xx,xy,xz,yy,yz,zz*/, double *W) {
+    double a[3][3] = {{M6[0], M6[1], M6[2]}, {M6[1], M6[3], M6[4]}, {M6[2], M6[4], M6[5]}};
+    double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+#pragma unroll
+    for (int sweep = 0; sweep < 6; sweep++) {
+#pragma unroll
+        for (int pq = 0; pq < 3; pq++) {
+            const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+            const double apq = a[p][q];
+            if (apq != 0.0) {
+                const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const double akp = a[k][p], akq = a[k][q]; a[k][p] = c * akp - sn * akq; a[k][q] = sn * akp + c * akq; }
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const double apk = a[p][k], aqk = a[q][k]; a[p][k] = c * apk - sn * aqk; a[q][k] = sn * apk + c * aqk; }
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const double vkp = v[k][p], vkq = v[k][q]; v[k][p] = c * vkp - sn * vkq; v[k][q] = sn * vkp + c * vkq; }
+            }
+        }
+    }
+    const double l0 = 1.0 / sqrt(a[0][0]), l1 = 1.0 / sqrt(a[1][1]), l2 = 1.0 / sqrt(a[2][2]);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) W[i * 3 + j] = v[i][0] * v[j][0] * l0 + v[i][1] * v[j][1] * l1 + v[i][2] * v[j][2] * l2;
 }
 
 // 6x6 symmetric solve on ONE lane.  Fast path: LDL^T without pivoting, fully unrolled so that every array lives in
@@ -271,7 +303,26 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
             const double d2 = dx * dx + dy * dy + dz * dz;
             if (d2 < a.max_dist2) {
                 acc[28] += d2; acc[29] += 1.0;
-                if (MODE == ICP_MODE_GICP) {
+                if (MODE == ICP_MODE_GICP || MODE == ICP_MODE_GICP_COV) {
+                    double W[9];
+                    if (MODE == ICP_MODE_GICP_COV) {
+                        // given covariances are used untouched (Open3D: HasCovariances): M = R Cs R^T + Ct
+                        const float *cs = a.src_cov6 + (size_t)i * 6, *ct = a.tgt_cov6 + (size_t)best * 6;
+                        const double C[3][3] = {{cs[0], cs[1], cs[2]}, {cs[1], cs[3], cs[4]}, {cs[2], cs[4], cs[5]}};
+                        const double R[3][3] = {{T[0], T[1], T[2]}, {T[4], T[5], T[6]}, {T[8], T[9], T[10]}};
+                        double RC[3][3], M[3][3];
+#pragma unroll
+                        for (int r_ = 0; r_ < 3; r_++)
+#pragma unroll
+                            for (int c_ = 0; c_ < 3; c_++) RC[r_][c_] = R[r_][0] * C[0][c_] + R[r_][1] * C[1][c_] + R[r_][2] * C[2][c_];
+#pragma unroll
+                        for (int r_ = 0; r_ < 3; r_++)
+#pragma unroll
+                            for (int c_ = 0; c_ < 3; c_++) M[r_][c_] = RC[r_][0] * R[c_][0] + RC[r_][1] * R[c_][1] + RC[r_][2] * R[c_][2];
+                        const double M6[6] = {M[0][0] + ct[0], 0.5 * (M[0][1] + M[1][0]) + ct[1], 0.5 * (M[0][2] + M[2][0]) + ct[2],
+                                              M[1][1] + ct[3], 0.5 * (M[1][2] + M[2][1]) + ct[4], M[2][2] + ct[5]};
+                        icp_sym3_inv_sqrt(M6, W);
+                    } else {
                     // effective covariance normals: C = I - a m m^T, m = e1 when n.x < -0.99 (Open3D GetRotationFromE1ToX)
                     const float4 sn = a.src_nrm[i], tn = a.tgt_nrm[best];
                     double sx = sn.x, sy = sn.y, sz = sn.z, tx = tn.x, ty = tn.y, tz = tn.z;
@@ -291,10 +342,10 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
                     const double gp = a.a / (2.0 * SQ2 * slp * (SQ2 + slp)), gm = a.a / (2.0 * SQ2 * slm * (SQ2 + slm));
                     const double ex = ux + tx, ey = uy + ty, ez = uz + tz, fx = ux - tx, fy = uy - ty, fz = uz - tz;
                     const double w0 = 1.0 / SQ2;
-                    double W[9];
                     W[0] = w0 + gp * ex * ex + gm * fx * fx; W[1] = gp * ex * ey + gm * fx * fy; W[2] = gp * ex * ez + gm * fx * fz;
                     W[4] = w0 + gp * ey * ey + gm * fy * fy; W[5] = gp * ey * ez + gm * fy * fz; W[8] = w0 + gp * ez * ez + gm * fz * fz;
                     W[3] = W[1]; W[6] = W[2]; W[7] = W[5];
+                    }
                     double r2 = 0;
 #pragma unroll
                     for (int row = 0; row < 3; row++) {
@@ -411,7 +462,7 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
         else if (launches > 0 && fabs(st->fitness - fit) < a.rel_fit && fabs(st->rmse - rmse) < a.rel_rmse) { stop = true; conv = true; }
         else if (st->iter >= a.max_it) stop = true;
         st->fitness = fit; st->rmse = rmse; st->count = count;
-        if (!stop && MODE == ICP_MODE_GICP) {
+        if (!stop && (MODE == ICP_MODE_GICP || MODE == ICP_MODE_GICP_COV)) {
             double U[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
             if (count > 0) {
                 double nb6[6], x[6];
@@ -454,6 +505,7 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
 static void fill_args(IcpArgs &a, const DevCloud *src, const DevCloud *tgt, double max_dist, const pcr_gicp_params *p,
                       int32_t *match, IcpState *st, double *partials, int single) {
     a.src_pts = src->pts; a.src_nrm = src->nrm; a.ns_ptr = src->n;
+    a.src_cov6 = src->cov6; a.tgt_cov6 = tgt->cov6;
     a.tgt_pts = tgt->pts; a.tgt_nrm = tgt->nrm; a.nt_ptr = tgt->n;
     a.tgt.pts = tgt->pts; a.tgt.nodes = tgt->oct_nodes; a.tgt.up = tgt->oct_up; a.tgt.meta = tgt->oct_meta; a.tgt.leaf_of = tgt->leaf_of; a.tgt.keys = tgt->keys; a.tgt.pinfo = tgt->pinfo;
     a.match = match; a.state = st; a.partials = partials;
@@ -482,7 +534,8 @@ static void state_to_result(const IcpState &s, pcr_result *out) {
 int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, double max_dist, const double *T0,
                  const pcr_gicp_params *p, pcr_result *out, int32_t *match_dev) {
     if (!(max_dist > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
-    if (!src->nrm || !tgt->nrm) { ctx->err = "GICP needs normals (or covariances) on both clouds"; return PCR_EINVAL; }
+    const bool use_cov = src->cov6 && tgt->cov6;
+    if (!use_cov && (!src->nrm || !tgt->nrm)) { ctx->err = "GICP needs normals (or covariances) on both clouds"; return PCR_EINVAL; }
     ArenaMark mark(ctx);
     const int cap = src->cap > 0 ? src->cap : 1;
     const int nbmax = (cap + ICP_BS - 1) / ICP_BS < LIN_MAX_BLOCKS ? (cap + ICP_BS - 1) / ICP_BS : LIN_MAX_BLOCKS;
@@ -511,7 +564,8 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
             }
             for (int k = 0; k < c; k++) {
                 hipLaunchKernelGGL(k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP>), dim3(nbmax), dim3(ICP_BS), 0, ctx->stream, a);
+                if (use_cov) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP_COV>), dim3(nbmax), dim3(ICP_BS), 0, ctx->stream, a);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP>), dim3(nbmax), dim3(ICP_BS), 0, ctx->stream, a);
             }
             if (ctx->profiling) PCR_HIP_CHECK(ctx, hipEventRecord(ctx->prof_events[2 * n_chunks + 1], ctx->stream));
             n_chunks++;

@@ -63,6 +63,7 @@ struct ArenaMark { pcr_context *ctx; size_t off; ArenaMark(pcr_context *c) : ctx
 struct DevCloud {
     float4 *pts = nullptr;       // xyz, w = bit pattern of the original index (or 0)
     float4 *nrm = nullptr;       // optional
+    float *cov6 = nullptr;       // optional raw covariances (xx,xy,xz,yy,yz,zz) in Morton order
     float4 *nrm_final = nullptr; // (pcr_dev_sor) where fused normals of the cleaned cloud go
     int *n = nullptr;            // device count
     int cap = 0;                 // host upper bound of *n

@@ -44,8 +44,17 @@ def registro_FGR(source, target, voxel_size, _use_absolute_scale=True, seed=None
 
 
 def GICP_robusto(source, target, max_corres_dist, initial_T, iterations):
-    """ALL_FUNCTIONS.py:211-227 (raw 30-NN covariances + GM loss).  SURVEY.md §8 f-4: not built yet."""
-    raise NotImplementedError("GICP_robusto (raw-covariance GICP with GMLoss, SURVEY.md §8 f-4) is not on the MI355X path yet")
+    """ALL_FUNCTIONS.py:211-227: radius-0.20 normals, raw 30-NN covariances (``estimate_covariances()`` default search),
+    GICP with ``GMLoss(k=1.0)``.  Mutates ``source``/``target`` (normals and covariances), like the reference."""
+    kd_tree_normais = _g.KDTreeSearchParamRadius(radius=0.20)
+    source.estimate_normals(kd_tree_normais)
+    target.estimate_normals(kd_tree_normais)
+    source.estimate_covariances()
+    target.estimate_covariances()
+    loss = _r.GMLoss(k=1.0)
+    return _r.registration_icp(source, target, max_corres_dist, initial_T,
+                               _r.TransformationEstimationForGeneralizedICP(loss),
+                               _r.ICPConvergenceCriteria(max_iteration=iterations))
 
 
 def create_scales(n_scales):

@@ -141,12 +141,21 @@ def registration_generalized_icp(source: PointCloud, target: PointCloud, max_cor
     torch = _torch()
     if max_correspondence_distance <= 0:
         raise RuntimeError("Invalid max_correspondence_distance.")
-    source = _ensure_gicp_normals(source); target = _ensure_gicp_normals(target)
     ns, nt = len(source), len(target)
     corr = torch.empty((max(ns, 1), 2), dtype=torch.int32, device="cuda")
     res = _lib.PcrResult()
     T, Tp = _T(init)
     p = _params(estimation, criteria)
+    if source.has_covariances() and target.has_covariances():
+        # Open3D InitializePointCloudForGeneralizedICP: clouds that already carry covariances keep them untouched
+        ctx.check(ctx.lib.pcr_registration_generalized_icp_cov(
+            ctx.handle, _ptr(source.device_xyz()), _ptr(source._cov), C.c_int64(ns), _ptr(target.device_xyz()), _ptr(target._cov),
+            C.c_int64(nt), C.c_double(max_correspondence_distance), Tp, C.byref(p), C.byref(res), _ptr(corr)),
+            "registration_generalized_icp")
+        return _result(res, corr)
+    if source.has_covariances() != target.has_covariances():
+        raise RuntimeError("registration_generalized_icp: either both clouds carry covariances or neither (mixed case not on the MI355X path)")
+    source = _ensure_gicp_normals(source); target = _ensure_gicp_normals(target)
     ctx.check(ctx.lib.pcr_registration_generalized_icp(
         ctx.handle, _ptr(source.device_xyz()), _ptr(source.device_normals()), C.c_int64(ns), _ptr(target.device_xyz()),
         _ptr(target.device_normals()), C.c_int64(nt), C.c_double(max_correspondence_distance), Tp, C.byref(p), C.byref(res),

@@ -166,3 +166,29 @@ def test_stepwise_call_sequence_equals_fused_call(P, small_pair):
         T = r.transformation
     ang, dt = pose_error(fused.transformation, T)
     assert ang < 1e-6 and dt < 1e-5, (ang, dt)
+
+
+def test_radius_normals_and_gicp_robusto_match_oracle(P, oracle, small_pair):
+    """GICP_robusto (ALL_FUNCTIONS.py:211-227): pure-radius normals, raw 30-NN covariances used untouched, GM loss."""
+    import copy
+    src = P.PointCloud(small_pair["source"]).voxel_down_sample(0.2)
+    tgt = P.PointCloud(small_pair["target"]).voxel_down_sample(0.2)
+    sp, tp = src.points, tgt.points
+    # radius search
+    s2 = copy.deepcopy(src); s2.estimate_normals(P.KDTreeSearchParamRadius(radius=0.6))
+    ref_n = oracle.estimate_normals(sp, oracle.SEARCH_RADIUS, 0, 0.6)
+    dots = (s2.normals * ref_n).sum(1)
+    assert (dots > 1 - 1e-5).mean() > 0.999
+    s2.estimate_covariances(P.KDTreeSearchParamRadius(radius=0.6))
+    ref_c = oracle.estimate_covariances(sp, oracle.SEARCH_RADIUS, 0, 0.6)
+    scale = np.abs(ref_c).max(axis=(1, 2), keepdims=True)
+    assert (np.abs(s2.covariances - ref_c) <= 2e-6 * scale + 1e-9).mean() > 0.999
+    # the function itself
+    T0 = small_pair["T_fgr"]
+    res = P.GICP_robusto(src, tgt, 0.6, T0, 25)
+    assert src.has_covariances() and tgt.has_covariances() and src.has_normals()
+    ref = oracle.registration_gicp(sp, tp, 0.6, T0, src_cov=src.covariances, tgt_cov=tgt.covariances, loss=oracle.LOSS_GM, loss_k=1.0,
+                                   max_it=25)
+    ang, dt = pose_error(res.transformation, ref.transformation)
+    assert ang < 1e-6 and dt < 1e-5, (ang, dt)
+    assert res.iterations == ref.iterations and abs(res.fitness - ref.fitness) < 1e-9
