@@ -6,6 +6,7 @@
 // (SURVEY.md A.1-A.4).  All kernels are count-driven by a DEVICE-side int so that no host round trip is
 // needed between stages.
 #include <cstdlib>
+#include <cstdio>
 #include "pcr_octree.h"
 
 #define BS 256
@@ -286,7 +287,7 @@ __global__ void __launch_bounds__(BS) k_oct_lstar(const uint64_t *__restrict__ k
     if (threadIdx.x < OCT_KEY_LEVELS && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
 // B: choose the leaf level (first level with <= n/4 cells: ~8 points per leaf), the root level, offsets
-struct OctGeom { float org[3]; float unit[3]; };
+struct OctGeom { float org[3]; float unit[3]; int leaf_div; };
 __global__ void k_oct_meta(const int *__restrict__ n_ptr, const int *__restrict__ hist, int node_cap, OctMeta *__restrict__ meta, int *__restrict__ child, OctGeom g) {
     if (threadIdx.x != 0) return;
     const int n = *n_ptr;
@@ -298,7 +299,7 @@ __global__ void k_oct_meta(const int *__restrict__ n_ptr, const int *__restrict_
         int cnt[OCT_KEY_LEVELS + 1];
         cnt[OCT_KEY_LEVELS] = 0;
         for (int l = OCT_KEY_LEVELS - 1; l >= 0; l--) cnt[l] = cnt[l + 1] + hist[l];
-        const int want = n / 4 > 1 ? n / 4 : 1;
+        const int want = n / g.leaf_div > 1 ? n / g.leaf_div : 1;
         int l0 = 0;
         while (l0 < OCT_KEY_LEVELS - 1 && cnt[l0] > want) l0++;
         int top = l0;
@@ -449,6 +450,7 @@ int pcr_dev_build_bvh(pcr_context *ctx, DevCloud *c) {
     const int nb = (cap + BS - 1) / BS;
     hipLaunchKernelGGL(k_oct_lstar, dim3(nb), dim3(BS), 0, ctx->stream, c->keys, c->n, ls, hist);
     OctGeom g; for (int d = 0; d < 3; d++) { g.org[d] = c->key_org[d]; g.unit[d] = c->key_unit[d]; }
+    { static const int div = getenv("PCR_OCT_DIV") ? atoi(getenv("PCR_OCT_DIV")) : 4; g.leaf_div = div; }
     hipLaunchKernelGGL(k_oct_meta, dim3(1), dim3(64), 0, ctx->stream, c->n, hist, (int)oct_node_capacity(cap), c->oct_meta, c->oct_child, g);
     hipLaunchKernelGGL(k_oct_tile_count, dim3(n_tiles), dim3(BS), 0, ctx->stream, ls, c->oct_meta, tile_cnt);
     hipLaunchKernelGGL(k_oct_tile_scan, dim3(1), dim3(BS), 0, ctx->stream, tile_cnt, n_tiles);
@@ -495,23 +497,17 @@ struct OctetKnn {
 #pragma unroll
         for (int j = 1; j < SLOTS; j++) if (sd[j] > m) { m = sd[j]; mj = j; }
         wj = mj;
-        int ml = ol;
-#pragma unroll
-        for (int o = 1; o < OCT; o <<= 1) {
-            const float om = __shfl_xor(m, o, OCT); const int olane = __shfl_xor(ml, o, OCT);
-            if (om > m || (om == m && olane < ml)) { m = om; ml = olane; }
-        }
-        worst = m; wlane = ml;
+        worst = pcr_octet_max(m);
+        // owner = lowest lane of the octet whose local maximum is the octet maximum (DPP + one ballot, no LDS hop)
+        const unsigned long long own = __ballot(m == worst);
+        wlane = __builtin_ctz((uint32_t)(own >> ((threadIdx.x & 56))) & 0xffu);
     }
-    // all 8 lanes call with the same candidate
+    // all 8 lanes call with the same candidate; branch-free (a candidate that no longer beats the bound changes nothing)
     __device__ void insert(float cd, int ci) {
-        if (cd < worst) {
-            if (ol == wlane) {
+        const bool own = cd < worst && ol == wlane;
 #pragma unroll
-                for (int j = 0; j < SLOTS; j++) if (j == wj) { sd[j] = cd; si[j] = ci; }
-            }
-            refresh();
-        }
+        for (int j = 0; j < SLOTS; j++) { const bool w = own && j == wj; sd[j] = w ? cd : sd[j]; si[j] = w ? ci : si[j]; }
+        refresh();
     }
 };
 
@@ -610,13 +606,11 @@ struct KnnArgs {
     int dbg_visits;                                      // debug: dbg_cnt <- traversal counters
     int32_t *list_idx; float *list_d2;                   // SOR: optional k-best lists, 32 slots per query (octet layout)
     const uint8_t *todo;                                 // optional: only queries with todo[q] != 0 are processed
+    unsigned long long *stamps;                          // diagnostics (PCR_KNN_STAMPS): 24 words per wavefront
+    int seed_span;                                       // Morton-index half-width of the seed range (-1: k)
 };
 
-__device__ static inline double octet_sum(double v) {
-#pragma unroll
-    for (int o = 1; o < OCT; o <<= 1) v += __shfl_xor(v, o, OCT);
-    return v;
-}
+__device__ static inline double octet_sum(double v) { return pcr_octet_sum(v); }
 
 template <int MODE, int SLOTS>
 __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) {
@@ -628,6 +622,7 @@ __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) {
     const int n = m.n;
     const int lane = threadIdx.x & 63, oct = lane >> 3, ol = lane & 7, ob = threadIdx.x >> 3;
     const unsigned long long t_begin = wall_clock64();
+    const unsigned long long c_begin = a.stamps ? __builtin_readcyclecounter() : 0ull;
     const int qi = blockIdx.x * OPB + ob;
     const bool live = qi < n && (!a.todo || a.todo[qi]);
     if (__ballot(live) == 0ull) return;                      // nothing to do for this wavefront
@@ -639,8 +634,12 @@ __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) {
     // [g0-k, g0+7+k] (it already holds most true neighbours), then ONE shared bottom-up walk completes all 8 exactly
     const int g0 = blockIdx.x * OPB + (threadIdx.x >> 6) * OCT;
     const int glast = g0 + OCT - 1 < n - 1 ? g0 + OCT - 1 : n - 1;
-    const int plo = g0 - a.k < 0 ? 0 : g0 - a.k, phi = glast + a.k > n - 1 ? n - 1 : glast + a.k;
+    const int span = a.seed_span >= 0 ? a.seed_span : a.k;
+    const int half = (a.k < OCT * SLOTS ? a.k : OCT * SLOTS) / 2 + OCT;      // the seed range must hold the direct fill
+    const int sp = span > half ? span : half;
+    const int plo = g0 - sp < 0 ? 0 : g0 - sp, phi = glast + sp > n - 1 ? n - 1 : glast + sp;
     bool seeding = true;
+    int st_scan = 0, st_rounds = 0;      // diagnostics: 8-point scan steps and insertion rounds of this wavefront
 
     // ---- scan `count` consecutive points from `first` for all 8 queries, 8 candidates at a time; survivors enter the k-best
     auto visit = [&](int first, int count) {
@@ -654,13 +653,13 @@ __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) {
             }
             unsigned long long bal = __ballot(pass);
             uint32_t surv = (uint32_t)(bal >> (oct * 8)) & 0xffu;
-            while (bal != 0ull) {
-                if (surv) {
-                    const int sl = __builtin_ctz(surv);
-                    surv &= surv - 1;
-                    const float cd = __shfl(d2, sl, OCT);
-                    tk.insert(cd, base + sl);
-                }
+            st_scan++;
+            while (bal != 0ull) {                      // one candidate per octet and round, no divergence inside
+                st_rounds++;
+                const int sl = __builtin_ctz(surv | 0x100u) & 7;
+                const float cd = __shfl(d2, sl, OCT);
+                tk.insert(surv ? cd : __builtin_inff(), base + sl);
+                surv &= surv - 1;
                 bal = __ballot(surv != 0);
             }
         }
@@ -685,11 +684,26 @@ __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) {
     if (c0 + filled <= phi) visit(c0 + filled, phi - (c0 + filled) + 1);
     seeding = false;
 
+    const float seed_worst = tk.worst;
     int nvis = 0;
     const int first_live = g0 + (__builtin_ctzll(__ballot(live)) >> 3);
     oct_search_group(a.t, m, gstk[threadIdx.x >> 6], live, a.t.leaf_of[first_live], q.x, q.y, q.z, [&]() { return tk.worst; }, visit,
                      [&](int f, int c) { return f >= plo && f + c - 1 <= phi; }, ol,
-                     (MODE == KNN_MODE_DEBUG && a.dbg_visits) ? &nvis : nullptr);
+                     ((MODE == KNN_MODE_DEBUG && a.dbg_visits) || a.stamps) ? &nvis : nullptr);
+    if (a.stamps && ol == 0) {
+        unsigned long long *w = a.stamps + 24 * ((size_t)blockIdx.x * (KNN_BS / 64) + (threadIdx.x >> 6));
+        w[8 + oct] = ((unsigned long long)__float_as_uint(seed_worst) << 32) | __float_as_uint(tk.worst);
+        w[16 + oct] = ((unsigned long long)__float_as_uint(q.x) << 32) | __float_as_uint(q.y);
+    }
+    if (a.stamps && lane == 0) {
+        unsigned long long *w = a.stamps + 24 * ((size_t)blockIdx.x * (KNN_BS / 64) + (threadIdx.x >> 6));
+        w[4] = ((unsigned long long)(unsigned)st_scan << 32) | (unsigned)st_rounds;
+        w[5] = ((unsigned long long)__float_as_uint(q.x) << 32) | __float_as_uint(q.y);
+        w[6] = ((unsigned long long)__float_as_uint(q.z) << 32) | __float_as_uint(tk.worst);
+        w[7] = (unsigned long long)nvis;
+        w[0] = t_begin; w[1] = wall_clock64(); w[2] = __builtin_readcyclecounter() - c_begin;
+        w[3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
     if (!live) return;
 
     // ---- epilogue in float64 on the selected neighbours (inputs are exact float32 -> same values as the oracle)
@@ -770,6 +784,27 @@ static int launch_knn(pcr_context *ctx, const DevCloud *c, KnnArgs a) {
     if (c->cap <= 0) return PCR_OK;
     if (a.k < 1 || a.k > 200) { ctx->err = "k out of range for the octet k-NN kernel (1..200)"; return PCR_EINVAL; }
     const dim3 grid((unsigned)(((size_t)c->cap * OCT + KNN_BS - 1) / KNN_BS)), block(KNN_BS);
+    const char *stamp_path = getenv("PCR_KNN_STAMPS");      // diagnostics only: per-wavefront begin/end clocks and hardware ids
+    const size_t stamp_words = (size_t)grid.x * (KNN_BS / 64) * 24;
+    if (stamp_path) {
+        if (hipMalloc(&a.stamps, stamp_words * 8) != hipSuccess) return PCR_ENOMEM;
+        hipMemsetAsync(a.stamps, 0, stamp_words * 8, ctx->stream);
+    }
+    struct StampDump {
+        pcr_context *ctx; const char *path; unsigned long long *dev; size_t words; int mode, k;
+        ~StampDump() {
+            if (!path) return;
+            hipStreamSynchronize(ctx->stream);
+            unsigned long long *h = (unsigned long long *)malloc(words * 8);
+            hipMemcpy(h, dev, words * 8, hipMemcpyDeviceToHost);
+            if (FILE *f = fopen(path, "ab")) {
+                const unsigned long long hdr[4] = {0x5354414d50ull, (unsigned long long)mode, (unsigned long long)k, words / 24};
+                fwrite(hdr, 8, 4, f); fwrite(h, 8, words, f); fclose(f);
+            }
+            free(h); hipFree(dev);
+        }
+    } dump{ctx, stamp_path, a.stamps, stamp_words, MODE, a.k};
+    { static const int ss = getenv("PCR_KNN_SEED") ? atoi(getenv("PCR_KNN_SEED")) : -1; a.seed_span = ss; }
     if (a.k <= 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn<MODE, 4>), grid, block, 0, ctx->stream, a);
     else if (a.k <= 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn<MODE, 8>), grid, block, 0, ctx->stream, a);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn<MODE, 25>), grid, block, 0, ctx->stream, a);

@@ -120,6 +120,41 @@ __device__ static inline int pcr_bvh_greedy_leaf(const float4 *__restrict__ boxe
     return node;
 }
 
+// ------------------------------------------------------------------------------ 8-lane (octet) DPP ops
+// Data-parallel-primitive moves stay inside the VALU (no LDS crossbar, no lgkmcnt wait), unlike __shfl_xor which
+// compiles to ds_bpermute.  quad_perm covers xor 1 / xor 2, row_half_mirror (lane i <-> 7-i of each 8) joins the
+// two quads of an octet; after the first two steps a quad is uniform, so the mirror acts as xor 4.
+template <int CTRL>
+__device__ static inline int pcr_dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ static inline float pcr_dpp_f(float v) { return __int_as_float(pcr_dpp_i<CTRL>(__float_as_int(v))); }
+#define PCR_DPP_XOR1 0xB1      // quad_perm [1,0,3,2]
+#define PCR_DPP_XOR2 0x4E      // quad_perm [2,3,0,1]
+#define PCR_DPP_HMIRROR 0x141  // row_half_mirror
+// max / min over the octet for values that are >= 0 or exactly -1 (the k-best sentinel): their float order equals the
+// signed-integer order of their bit patterns, and integer max needs no NaN canonicalisation
+__device__ static inline float pcr_octet_max(float v) {
+    int i = __float_as_int(v);
+    i = max(i, pcr_dpp_i<PCR_DPP_XOR1>(i));
+    i = max(i, pcr_dpp_i<PCR_DPP_XOR2>(i));
+    i = max(i, pcr_dpp_i<PCR_DPP_HMIRROR>(i));
+    return __int_as_float(i);
+}
+__device__ static inline float pcr_octet_min(float v) {
+    int i = __float_as_int(v);
+    i = min(i, pcr_dpp_i<PCR_DPP_XOR1>(i));
+    i = min(i, pcr_dpp_i<PCR_DPP_XOR2>(i));
+    i = min(i, pcr_dpp_i<PCR_DPP_HMIRROR>(i));
+    return __int_as_float(i);
+}
+__device__ static inline double pcr_octet_sum(double v) {       // fixed tree => deterministic; all 8 lanes get the sum
+    union { double d; int i[2]; } a, b;
+    a.d = v; b.i[0] = pcr_dpp_i<PCR_DPP_XOR1>(a.i[0]); b.i[1] = pcr_dpp_i<PCR_DPP_XOR1>(a.i[1]); v += b.d;
+    a.d = v; b.i[0] = pcr_dpp_i<PCR_DPP_XOR2>(a.i[0]); b.i[1] = pcr_dpp_i<PCR_DPP_XOR2>(a.i[1]); v += b.d;
+    a.d = v; b.i[0] = pcr_dpp_i<PCR_DPP_HMIRROR>(a.i[0]); b.i[1] = pcr_dpp_i<PCR_DPP_HMIRROR>(a.i[1]); v += b.d;
+    return v;
+}
+
 // ------------------------------------------------------------------------------------- reductions
 __device__ static inline double pcr_wave_sum(double v) {
 #pragma unroll

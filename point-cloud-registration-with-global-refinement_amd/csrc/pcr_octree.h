@@ -210,6 +210,7 @@ struct OctGroupStack {            // per wavefront (LDS)
     int mask[OCT_MAXL];
     int first[OCT_MAXL][OCT];
     int count[OCT_MAXL][OCT];
+    unsigned gd2[OCT_MAXL][OCT];   // per child: min over the group's live queries of the squared box distance (float bits)
 };
 
 __device__ static inline float wave_or_octets_max(float v) {     // max over the 8 octets (v is octet-uniform)
@@ -233,19 +234,34 @@ __device__ static inline void oct_search_group(const OctView &t, const OctMeta &
         for (int o = OCT; o < 64; o <<= 1) { glo[d] = fminf(glo[d], __shfl_xor(glo[d], o, 64)); ghi[d] = fmaxf(ghi[d], __shfl_xor(ghi[d], o, 64)); }
     start_leaf = __builtin_amdgcn_readfirstlane(start_leaf);
 
-    // children [cs, cs+cnt) of level li: bit c set when any live query can still improve inside child c
+    // children [cs, cs+cnt) of level li: bit c set when any live query can still improve inside child c; gd2[li][c] <- the
+    // smallest box distance over the group's queries (the pop order: nearest child first, so the bounds tighten before
+    // the farther children are looked at -- and are mostly gone by then)
     auto test = [&](int li, int cs, int cnt) -> int {
-        bool pass = false; int f = 0, c = 0;
+        bool pass = false; int f = 0, c = 0; float d2 = __builtin_inff();
+        if ((threadIdx.x & 63) < OCT) stk.gd2[li][ol] = 0x7f800000u;
         if (ol < cnt) {
             const size_t j = (size_t)(m.off[li] + cs + ol);
             const float4 lo = t.nodes[2 * j], hi = t.nodes[2 * j + 1];
-            pass = live && pcr_box_d2(lo, hi, qx, qy, qz) < worst();
+            if (live) d2 = pcr_box_d2(lo, hi, qx, qy, qz);
+            pass = d2 < worst();
             f = __float_as_int(lo.w); c = __float_as_int(hi.w);
         }
+        if (pass) atomicMin(&stk.gd2[li][ol], __float_as_uint(d2));
         unsigned long long bal = __ballot(pass);
         bal |= bal >> 32; bal |= bal >> 16; bal |= bal >> 8;
         if ((threadIdx.x & 63) < OCT) { stk.first[li][ol] = f; stk.count[li][ol] = c; }
         return (int)(bal & 0xffull);
+    };
+    // nearest pending child of level li (mask != 0); returns -1 when no query can improve in ANY pending child any more
+    auto pop = [&](int li, int mask) -> int {
+        const unsigned g = ((mask >> ol) & 1) ? stk.gd2[li][ol] : 0xffffffffu;
+        unsigned k = g;
+        k = min(k, (unsigned)pcr_dpp_i<PCR_DPP_XOR1>((int)k));
+        k = min(k, (unsigned)pcr_dpp_i<PCR_DPP_XOR2>((int)k));
+        k = min(k, (unsigned)pcr_dpp_i<PCR_DPP_HMIRROR>((int)k));
+        if (__ballot(live && __uint_as_float(k) < worst()) == 0ull) return -1;
+        return __builtin_ctz((unsigned)(__ballot(g == k) & 0xffull));
     };
     auto contained = [&](int lvl, uint32_t ix, uint32_t iy, uint32_t iz) -> bool {
         const float wmax = wave_or_octets_max(live ? worst() : 0.0f);
@@ -286,8 +302,9 @@ __device__ static inline void oct_search_group(const OctView &t, const OctMeta &
                 anc = u.x; anc_li++;
             }
         }
-        const int c = __builtin_ctz((unsigned)mask);
-        mask &= mask - 1;
+        const int c = pop(li, mask);
+        if (c < 0) { mask = 0; continue; }
+        mask &= ~(1 << c);
         const int nf = stk.first[li][c], nc = stk.count[li][c];
         if (visits) *visits += 1;
         if (li == 0) { if (!skip(nf, nc)) visit(nf, nc); }
