@@ -402,14 +402,20 @@ __global__ void __launch_bounds__(BS) k_oct_leaf_boxes(const float4 *__restrict_
         const float4 p = pts[i];
         lo.x = fminf(lo.x, p.x); lo.y = fminf(lo.y, p.y); lo.z = fminf(lo.z, p.z);
         hi.x = fmaxf(hi.x, p.x); hi.y = fmaxf(hi.y, p.y); hi.z = fmaxf(hi.z, p.z);
-        pinfo[i] = make_int4(j, a, b - a, 0);                   // point -> (leaf, first point, point count)
+        if (meta->nl == 1) pinfo[i] = make_int4(j, a, b - a, 0);     // one-level tree: the leaf is the start node
     }
     lo.w = __int_as_float(a); hi.w = __int_as_float(b - a);
     boxes[2 * (size_t)j] = lo; boxes[2 * (size_t)j + 1] = hi;
     if (meta->nl == 1) up[j] = make_int4(0, 0, 1, 0);
 }
-__device__ static inline void oct_node_box(const OctMeta &m, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up, int li, int j) {
+__device__ static inline void oct_node_box(const OctMeta &m, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up, int li, int j,
+                                           int4 *__restrict__ pinfo = nullptr) {
     const int a = child[m.off[li] + j], b = child[m.off[li] + j + 1];
+    if (li == 1 && pinfo) {       // point -> (level-1 node, its first point, its point count, 1)
+        const int pfirst = __float_as_int(boxes[2 * (size_t)(m.off[0] + a)].w);
+        const int plast = __float_as_int(boxes[2 * (size_t)(m.off[0] + b - 1)].w) + __float_as_int(boxes[2 * (size_t)(m.off[0] + b - 1) + 1].w);
+        for (int i = pfirst; i < plast; i++) pinfo[i] = make_int4(j, pfirst, plast - pfirst, 1);
+    }
     float4 lo = make_float4(3.4e38f, 3.4e38f, 3.4e38f, 0), hi = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, 0);
     for (int c = a; c < b; c++) {
         const float4 x = boxes[2 * (size_t)(m.off[li - 1] + c)], y = boxes[2 * (size_t)(m.off[li - 1] + c) + 1];
@@ -421,10 +427,11 @@ __device__ static inline void oct_node_box(const OctMeta &m, const int *__restri
     lo.w = __int_as_float(a); hi.w = __int_as_float(b - a);
     boxes[2 * (size_t)(m.off[li] + j)] = lo; boxes[2 * (size_t)(m.off[li] + j) + 1] = hi;
 }
-__global__ void __launch_bounds__(BS) k_oct_level_boxes(const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up, int li) {
+__global__ void __launch_bounds__(BS) k_oct_level_boxes(const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up, int li,
+                                                        int4 *__restrict__ pinfo) {
     const int j = blockIdx.x * BS + threadIdx.x;
     if (li >= meta->nl || j >= meta->cnt[li]) return;
-    oct_node_box(*meta, child, boxes, up, li, j);
+    oct_node_box(*meta, child, boxes, up, li, j, pinfo);
 }
 // remaining (small) levels in ONE workgroup, level by level
 __global__ void __launch_bounds__(1024) k_oct_upper_boxes(const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up, int first_li) {
@@ -457,8 +464,8 @@ int pcr_dev_build_bvh(pcr_context *ctx, DevCloud *c) {
     hipLaunchKernelGGL(k_oct_apply, dim3(n_tiles), dim3(BS), 0, ctx->stream, ls, c->oct_meta, tile_cnt, c->oct_child, c->leaf_of);
     const int nbl = (cap / 2 + 1 + BS - 1) / BS;       // <= n/2 leaves (or 1)
     hipLaunchKernelGGL(k_oct_leaf_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->pts, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, c->pinfo);
-    hipLaunchKernelGGL(k_oct_level_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, 1);
-    hipLaunchKernelGGL(k_oct_level_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, 2);
+    hipLaunchKernelGGL(k_oct_level_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, 1, c->pinfo);
+    hipLaunchKernelGGL(k_oct_level_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, 2, c->pinfo);
     hipLaunchKernelGGL(k_oct_upper_boxes, dim3(1), dim3(1024), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, 3);
     return PCR_OK;
 }

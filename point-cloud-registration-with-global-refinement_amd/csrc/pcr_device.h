@@ -155,6 +155,16 @@ __device__ static inline double pcr_octet_sum(double v) {       // fixed tree =>
     return v;
 }
 
+#define PCR_DPP_MIRROR 0x140   // row_mirror (lane i <-> 15-i of each 16-lane row)
+__device__ static inline double pcr_row16_sum(double v) {       // sum over each 16-lane DPP row, result in all 16 lanes
+    union { double d; int i[2]; } a, b;
+    a.d = v; b.i[0] = pcr_dpp_i<PCR_DPP_XOR1>(a.i[0]); b.i[1] = pcr_dpp_i<PCR_DPP_XOR1>(a.i[1]); v += b.d;
+    a.d = v; b.i[0] = pcr_dpp_i<PCR_DPP_XOR2>(a.i[0]); b.i[1] = pcr_dpp_i<PCR_DPP_XOR2>(a.i[1]); v += b.d;
+    a.d = v; b.i[0] = pcr_dpp_i<PCR_DPP_HMIRROR>(a.i[0]); b.i[1] = pcr_dpp_i<PCR_DPP_HMIRROR>(a.i[1]); v += b.d;
+    a.d = v; b.i[0] = pcr_dpp_i<PCR_DPP_MIRROR>(a.i[0]); b.i[1] = pcr_dpp_i<PCR_DPP_MIRROR>(a.i[1]); v += b.d;
+    return v;
+}
+
 // ------------------------------------------------------------------------------------- reductions
 __device__ static inline double pcr_wave_sum(double v) {
 #pragma unroll

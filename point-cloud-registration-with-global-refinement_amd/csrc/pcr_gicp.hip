@@ -16,7 +16,8 @@
 #define ICP_BS 256
 #define NV 30            // 21 (upper JTJ) + 6 (JTr) + sum r^2 + sum d^2 + count
 #define NVP 32           // padded row of a partial
-#define LIN_MAX_BLOCKS 256
+#define LIN_BS 512           // linearise kernel: few fat workgroups => few partial rows for the last one to gather
+#define LIN_MAX_BLOCKS 128
 
 enum { ICP_MODE_GICP = 0, ICP_MODE_EVAL = 1, ICP_MODE_GICP_COV = 2 };   // _COV: per-point covariances given (GICP_robusto path)
 
@@ -39,7 +40,7 @@ struct IcpArgs {
     const float4 *src_pts, *src_nrm; const int *ns_ptr;
     const float *src_cov6, *tgt_cov6;            // optional raw covariances (xx,xy,xz,yy,yz,zz), Morton order
     const float4 *tgt_pts, *tgt_nrm; OctView tgt; const int *nt_ptr;
-    int32_t *match;
+    int32_t *match; int src_cap;
     IcpState *state;
     double *partials;
     double max_dist2; float r2f;
@@ -47,7 +48,9 @@ struct IcpArgs {
     double rel_fit, rel_rmse; int max_it;
     int single;                                  // 1: linearise once, never update (debug / evaluate)
     int dbg_visits;                              // diagnostics: store node/leaf visit counts instead of matches
+    unsigned long long *stamps_nn, *stamps_it;   // diagnostics (PCR_ICP_STAMPS): per-wavefront clocks of the first 16 launches
 };
+#define ICP_STAMP_LAUNCHES 16
 
 struct IcpInit { double T[16]; };
 __global__ void k_icp_init(IcpState *st, IcpInit in) {
@@ -69,33 +72,53 @@ __device__ static inline int oct_nn_query(const OctView &t, const OctMeta &m, Oc
     const bool active = live && m.nl >= 1;
     auto visit = [&](int first, int count) {                 // wave-wide; count == 0: octet idle
         int base = first; const int end = first + count;
+        float d = 3.4e38f; int id = -1;                       // lane-local best over all steps (4 loads in flight per step)
         while (__ballot(base < end) != 0ull) {
-            float d = 3.4e38f; int id = -1;
-            if (base + ol < end) {
-                const float4 p = t.pts[base + ol];
-                d = pcr_d2(p.x - qx, p.y - qy, p.z - qz); id = base + ol;
-            }
+            float4 p[4];
 #pragma unroll
-            for (int o = 1; o < OCT; o <<= 1) {               // octet arg-min (ties -> lower index)
-                const float od = __shfl_xor(d, o, OCT); const int oid = __shfl_xor(id, o, OCT);
-                if (od < d || (od == d && (unsigned)oid < (unsigned)id)) { d = od; id = oid; }
+            for (int u = 0; u < 4; u++) { const int idx = base + OCT * u + ol; p[u] = t.pts[idx < end ? idx : (end > first ? end - 1 : 0)]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int idx = base + OCT * u + ol;
+                const float du = pcr_d2(p[u].x - qx, p[u].y - qy, p[u].z - qz);
+                if (idx < end && du < d) { d = du; id = idx; }      // increasing idx: ties keep the lower index
             }
-            if (id >= 0 && d < bestd) { bestd = d; best = id; }
-            base += OCT;
+            base += 4 * OCT;
         }
+        // octet arg-min (ties -> lower index) without the LDS crossbar: min distance, then min index among its holders
+        const float dmin = pcr_octet_min(d);
+        int cand = (d == dmin && id >= 0) ? id : 0x7fffffff;
+        cand = min(cand, pcr_dpp_i<PCR_DPP_XOR1>(cand)); cand = min(cand, pcr_dpp_i<PCR_DPP_XOR2>(cand)); cand = min(cand, pcr_dpp_i<PCR_DPP_HMIRROR>(cand));
+        if (cand != 0x7fffffff && (dmin < bestd || (dmin == bestd && (unsigned)cand < (unsigned)best))) { bestd = dmin; best = cand; }
     };
-    int leaf = 0;
+    int node = 0, node_li = 0;
     const bool warm = active && hint >= 0;
+    int s_first = 0, s_count = 0, s_parent = 0, s_sib = 0, s_nsib = 1; uint64_t s_key = 0;
     if (warm) {
+        // one hop: the hint point and the record of the level-1 node around it ("fat leaf"); next hop (issued here,
+        // consumed after the scan of the node's points): the node's up-link and key
+        const int4 pi = t.pinfo[hint];
         const float4 c = t.pts[hint];
+        node = pi.x; s_first = pi.y; s_count = pi.z; node_li = pi.w;
+        const int4 u = t.up[m.off[node_li] + node]; s_key = t.keys[pi.y];
+        s_parent = u.x; s_sib = u.y; s_nsib = u.z;
         const float d = pcr_d2(c.x - qx, c.y - qy, c.z - qz);
         if (d < bestd) { bestd = d; best = hint; }
-        leaf = t.leaf_of[hint];
     }
     const bool cold = active && !warm;
-    if (__ballot(cold) != 0ull) { const int g = oct_greedy_leaf(t, m, cold, qx, qy, qz, ol); if (cold) leaf = g; }
-    if (active) *start_pt = __float_as_int(t.nodes[2 * (size_t)(m.off[0] + leaf)].w);
-    oct_search<OPB>(t, m, stk, active, leaf, qx, qy, qz, [&]() { return bestd; }, visit, [](int, int) { return false; }, ol, oct, ob, visits);
+    if (__ballot(cold) != 0ull) {
+        const int g = oct_greedy_leaf(t, m, cold, qx, qy, qz, ol);
+        if (cold) {
+            node = g; node_li = 0;
+            const size_t j = (size_t)(m.off[0] + g);
+            s_first = __float_as_int(t.nodes[2 * j].w); s_count = __float_as_int(t.nodes[2 * j + 1].w);
+            const int4 u = t.up[j]; s_key = t.keys[s_first];
+            s_parent = u.x; s_sib = u.y; s_nsib = u.z;
+        }
+    }
+    if (active) *start_pt = s_first;
+    oct_search<OPB>(t, m, stk, active, node, node_li, s_first, s_count, s_key, s_parent, s_sib, s_nsib, qx, qy, qz, [&]() { return bestd; }, visit,
+                    [](int, int) { return false; }, ol, oct, ob, visits);
     return best;
 }
 
@@ -226,48 +249,61 @@ __device__ static bool icp_ldlt6_pivoted(const double *S, const double *b6, doub
 // workgroup).  Latency-bound pointer chasing, so it runs at full occupancy (few registers, many wavefronts).
 __global__ void __launch_bounds__(ICP_BS) k_icp_nn(IcpArgs a) {
     IcpState *st = a.state;
-    if (st->done) return;
     constexpr int OPB = ICP_BS / OCT;
     __shared__ OctMeta m;
     __shared__ OctStack<OPB> stk;
+    // everything the prologue needs is requested at once (each dependent hop costs ~1 us of wavefront life)
+    const int done = st->done, launches = st->launches;
     const int ns = *a.ns_ptr, nt = *a.nt_ptr;
-    if ((int)blockIdx.x * OPB >= ns) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->t_start = wall_clock64();
-    if (threadIdx.x == 0) m = *a.tgt.meta;
-    __syncthreads();
-    const int launches = st->launches;
     const int lane = threadIdx.x & 63, oct = lane >> 3, ol = lane & 7, ob = threadIdx.x >> 3;
     const int i = blockIdx.x * OPB + ob;
+    const int ic = i < a.src_cap ? i : 0;
+    const float4 pf = a.src_pts[ic];
+    const int mraw = a.match[ic];
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = st->T[k];
+    int mword = 0;
+    if (threadIdx.x < (int)(sizeof(OctMeta) / 4)) mword = ((const int *)a.tgt.meta)[threadIdx.x];
+    if (done) return;
+    if ((int)blockIdx.x * OPB >= ns) return;
+    const unsigned long long t_wave0 = wall_clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->t_start = t_wave0;
+    if (threadIdx.x < (int)(sizeof(OctMeta) / 4)) ((int *)&m)[threadIdx.x] = mword;
+    __syncthreads();
     const bool live = i < ns && nt > 0;
     float qx = 0, qy = 0, qz = 0; int hint = -1;
     if (i < ns) {
-        const float4 pf = a.src_pts[i];
         const double px = pf.x, py = pf.y, pz = pf.z;
-        qx = (float)(st->T[0] * px + st->T[1] * py + st->T[2] * pz + st->T[3]);
-        qy = (float)(st->T[4] * px + st->T[5] * py + st->T[6] * pz + st->T[7]);
-        qz = (float)(st->T[8] * px + st->T[9] * py + st->T[10] * pz + st->T[11]);
+        qx = (float)(T[0] * px + T[1] * py + T[2] * pz + T[3]);
+        qy = (float)(T[4] * px + T[5] * py + T[6] * pz + T[7]);
+        qz = (float)(T[8] * px + T[9] * py + T[10] * pz + T[11]);
         // match[] carries the warm-start hint across launches: >= 0 matched target point, <= -2 -> start point -(v+2)
-        const int mv = launches > 0 ? a.match[i] : -1;
+        const int mv = launches > 0 ? mraw : -1;
         hint = mv >= 0 ? mv : (mv <= -2 ? -(mv + 2) : -1);
     }
     int visits = 0, start_pt = 0;
     const int best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.r2f, hint, ol, oct, ob, &start_pt, a.dbg_visits ? &visits : nullptr);
     if (ol == 0 && i < ns) a.match[i] = a.dbg_visits ? visits : (best >= 0 ? best : -(start_pt + 2));
+    if (a.stamps_nn && lane == 0 && launches < ICP_STAMP_LAUNCHES) {
+        unsigned long long *w = a.stamps_nn + 2 * ((size_t)launches * gridDim.x * (ICP_BS / 64) + (size_t)blockIdx.x * (ICP_BS / 64) + (threadIdx.x >> 6));
+        w[0] = t_wave0; w[1] = wall_clock64();
+    }
 }
 
 // ---- kernel 2 of an iteration: one correspondence per lane in float64 -> wave/LDS reduction -> last workgroup
 // finishes the iteration (sum partials, convergence test, 6x6 solve, pose update).
 template <int MODE>
-__global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
+__global__ void __launch_bounds__(LIN_BS) k_icp_iter(IcpArgs a) {
     IcpState *st = a.state;
     if (st->done) return;
-    __shared__ double red[ICP_BS / PCR_WAVE][NVP];
-    __shared__ double fin[8][NVP];
+    __shared__ double red[LIN_BS / 16][NVP];       // one row per 16-lane DPP row
+    __shared__ double fin[16][NVP];
     __shared__ int is_last;
     __shared__ double ldl_w[96];
     __shared__ int ldl_perm[6];
     const int ns = *a.ns_ptr;
-    int nb = (ns + ICP_BS - 1) / ICP_BS;
+    int nb = (ns + LIN_BS - 1) / LIN_BS;
     if (nb < 1) nb = 1;
     if (nb > (int)gridDim.x) nb = gridDim.x;
     if ((int)blockIdx.x >= nb) return;
@@ -281,7 +317,7 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
 #pragma unroll
     for (int k = 0; k < NV; k++) acc[k] = 0.0;
 
-    for (int i = blockIdx.x * ICP_BS + threadIdx.x; i < ns; i += nb * ICP_BS) {
+    for (int i = blockIdx.x * LIN_BS + threadIdx.x; i < ns; i += nb * LIN_BS) {
     double qx = 0, qy = 0, qz = 0;
     int cand = -1;
     {
@@ -386,15 +422,16 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
     }
 
     const unsigned long long t_search = wall_clock64() - t_entry;
-    // ---- workgroup reduction: fixed shuffle tree, then waves in order
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // ---- workgroup reduction: DPP butterfly inside every 16-lane row (no LDS crossbar), then the 64 rows in order
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int k = 0; k < NV; k++) { const double s = pcr_wave_sum(acc[k]); if (lane == 0) red[wv][k] = s; }
+    for (int k = 0; k < NV; k++) { const double s = pcr_row16_sum(acc[k]); if ((lane & 15) == 0) red[threadIdx.x >> 4][k] = s; }
+    const unsigned long long t_ws = wall_clock64();
     __syncthreads();
     if (threadIdx.x < NV) {
         double s = red[0][threadIdx.x];
-#pragma unroll
-        for (int w = 1; w < ICP_BS / PCR_WAVE; w++) s += red[w][threadIdx.x];
+#pragma unroll 8
+        for (int w = 1; w < LIN_BS / 16; w++) s += red[w][threadIdx.x];
         // publish write-through (sc1): no per-workgroup release fence (a release = whole-L2 write-back; ~700 of
         // them per launch serialised to >100 us).  cdna_hip_programming.md Guideline 16, recipe R1.
         __hip_atomic_store(&a.partials[(size_t)blockIdx.x * NVP + threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -404,47 +441,45 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
         __hip_atomic_store(&a.partials[(size_t)blockIdx.x * NVP + 31], (double)(wall_clock64() - t_entry), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its stores ...
+    const unsigned long long t_drain = wall_clock64();
     __syncthreads();                                       // ... before ONE lane signals for the workgroup
     if (threadIdx.x == 0) {
         const unsigned int t = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = (t == (unsigned int)(nb - 1));
-        if (last) {                                        // ONE acquire, in the last-arriving workgroup only
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
         is_last = last;
     }
     __syncthreads();
+    if (a.stamps_it && (threadIdx.x & 63) == 0 && launches < ICP_STAMP_LAUNCHES) {
+        unsigned long long *w = a.stamps_it + 12 * ((size_t)launches * gridDim.x * (LIN_BS / 64) + (size_t)blockIdx.x * (LIN_BS / 64) + (threadIdx.x >> 6));
+        w[0] = t_entry; w[1] = t_entry + t_search; w[2] = wall_clock64(); w[3] = 0; w[4] = t_ws; w[5] = t_drain;
+    }
+    unsigned long long *wl = (a.stamps_it && launches < ICP_STAMP_LAUNCHES) ? a.stamps_it + 12 * ((size_t)launches * gridDim.x * (LIN_BS / 64) + (size_t)blockIdx.x * (LIN_BS / 64)) : nullptr;
     if (!is_last) return;
 
-    // ---- last workgroup: sum the partials in workgroup order (deterministic), then finish the iteration
+    // ---- last workgroup: gather the <= 128 partial rows with sc1 loads (coherent at agent scope without invalidating
+    // this XCD's L2: the acquire fence that plain loads would need took ~10 us here), eight rows per lane, one wait
     {
-        const int vcol = threadIdx.x & 31, chunk = threadIdx.x >> 5;      // 8 chunks x 32 columns
-        const int per = (nb + 7) / 8;
-        const int b0 = chunk * per, b1 = min(nb, b0 + per);
-        double s = 0;
-        // plain loads behind the ONE agent acquire above: the hardware keeps many in flight (relaxed-atomic loads were
-        // issued one at a time: 50-100 us for ~600 rows).  Four interleaved accumulators, combined in a fixed order.
-        const double *P = a.partials;
-        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        int b = b0;
-        if (vcol < NV) {
-            for (; b + 3 < b1; b += 4) {
-                s0 += P[(size_t)(b + 0) * NVP + vcol]; s1 += P[(size_t)(b + 1) * NVP + vcol];
-                s2 += P[(size_t)(b + 2) * NVP + vcol]; s3 += P[(size_t)(b + 3) * NVP + vcol];
-            }
-            for (; b < b1; b++) s0 += P[(size_t)b * NVP + vcol];
-            s = (s0 + s1) + (s2 + s3);
-        } else {
-            for (; b < b1; b++) s = fmax(s, P[(size_t)b * NVP + vcol]);
-        }
+        const int vcol = threadIdx.x & 31, chunk = threadIdx.x >> 5;      // 16 chunks x 32 columns; chunk c <- rows c, c+16, ...
+        const double *p[8]; double v[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) p[r] = a.partials + (size_t)(chunk + 16 * r < nb ? chunk + 16 * r : 0) * NVP + vcol;
+        asm volatile("global_load_dwordx2 %0, %8, off sc0 sc1\n\tglobal_load_dwordx2 %1, %9, off sc0 sc1\n\t"
+                     "global_load_dwordx2 %2, %10, off sc0 sc1\n\tglobal_load_dwordx2 %3, %11, off sc0 sc1\n\t"
+                     "global_load_dwordx2 %4, %12, off sc0 sc1\n\tglobal_load_dwordx2 %5, %13, off sc0 sc1\n\t"
+                     "global_load_dwordx2 %6, %14, off sc0 sc1\n\tglobal_load_dwordx2 %7, %15, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                     : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]) : "memory");
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; r++) { const double x = chunk + 16 * r < nb ? v[r] : 0.0; s = vcol < NV ? s + x : fmax(s, x); }
         fin[chunk][vcol] = s;
     }
+    if (wl && threadIdx.x == 0) wl[6] = wall_clock64();
     __syncthreads();
     if (threadIdx.x < NVP) {
         double s = 0;
 #pragma unroll
-        for (int c = 0; c < 8; c++) s = threadIdx.x < NV ? s + fin[c][threadIdx.x] : fmax(s, fin[c][threadIdx.x]);
+        for (int c = 0; c < 16; c++) s = threadIdx.x < NV ? s + fin[c][threadIdx.x] : fmax(s, fin[c][threadIdx.x]);
         fin[0][threadIdx.x] = s;
         st->sums[threadIdx.x] = s;
     }
@@ -453,6 +488,7 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
         const unsigned long long t0k = st->t_start;    // stamped by k_icp_nn (previous kernel)
         st->t_dbg[3] += wall_clock64() - t0k;
         st->t_dbg[0] += (unsigned long long)fin[0][30]; st->t_dbg[1] += (unsigned long long)fin[0][31];
+        if (wl) wl[7] = wall_clock64();
         const double *S = fin[0];
         const long long count = (long long)(S[29] + 0.5);
         const double fit = ns > 0 ? (double)count / (double)ns : 0.0;
@@ -483,11 +519,12 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
                     U[8] = -sb;     U[9] = cb * sa;                U[10] = cb * ca;               U[11] = x[5];
                 }
             }
+            if (wl) wl[8] = wall_clock64();
             double Tn[16];
             for (int r = 0; r < 4; r++)
                 for (int c = 0; c < 4; c++) {
                     double s = 0;
-                    for (int k = 0; k < 4; k++) s += U[r * 4 + k] * st->T[k * 4 + c];
+                    for (int k = 0; k < 4; k++) s += U[r * 4 + k] * (k < 3 ? T[k * 4 + c] : (c == 3 ? 1.0 : 0.0));
                     Tn[r * 4 + c] = s;
                 }
             for (int k = 0; k < 16; k++) st->T[k] = Tn[k];
@@ -498,6 +535,8 @@ __global__ void __launch_bounds__(ICP_BS) k_icp_iter(IcpArgs a) {
         __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         st->ns = ns;
         st->t_live += wall_clock64() - t0k;
+        if (a.stamps_it && launches < ICP_STAMP_LAUNCHES)
+            a.stamps_it[12 * ((size_t)launches * gridDim.x * (LIN_BS / 64) + (size_t)blockIdx.x * (LIN_BS / 64)) + 3] = wall_clock64();
         st->done = stop ? 1 : 0;          // visible to the next launch through the kernel boundary
     }
 }
@@ -508,7 +547,7 @@ static void fill_args(IcpArgs &a, const DevCloud *src, const DevCloud *tgt, doub
     a.src_cov6 = src->cov6; a.tgt_cov6 = tgt->cov6;
     a.tgt_pts = tgt->pts; a.tgt_nrm = tgt->nrm; a.nt_ptr = tgt->n;
     a.tgt.pts = tgt->pts; a.tgt.nodes = tgt->oct_nodes; a.tgt.up = tgt->oct_up; a.tgt.meta = tgt->oct_meta; a.tgt.leaf_of = tgt->leaf_of; a.tgt.keys = tgt->keys; a.tgt.pinfo = tgt->pinfo;
-    a.match = match; a.state = st; a.partials = partials;
+    a.match = match; a.src_cap = src->cap > 0 ? src->cap : 1; a.state = st; a.partials = partials;
     a.max_dist2 = max_dist * max_dist;
     const double r2w = a.max_dist2 * (1.0 + 1e-6);
     a.r2f = r2w < 3.0e38 ? (float)r2w : 3.0e38f;
@@ -516,6 +555,7 @@ static void fill_args(IcpArgs &a, const DevCloud *src, const DevCloud *tgt, doub
     a.rel_fit = p ? p->relative_fitness : 1e-6; a.rel_rmse = p ? p->relative_rmse : 1e-6; a.max_it = p ? p->max_iteration : 30;
     a.single = single;
     a.dbg_visits = (single && getenv("PCR_DEBUG_VISITS")) ? 1 : 0;
+    a.stamps_nn = nullptr; a.stamps_it = nullptr;
 }
 
 static int read_state(pcr_context *ctx, const IcpState *st_dev, IcpState *host) {
@@ -538,7 +578,7 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     if (!use_cov && (!src->nrm || !tgt->nrm)) { ctx->err = "GICP needs normals (or covariances) on both clouds"; return PCR_EINVAL; }
     ArenaMark mark(ctx);
     const int cap = src->cap > 0 ? src->cap : 1;
-    const int nbmax = (cap + ICP_BS - 1) / ICP_BS < LIN_MAX_BLOCKS ? (cap + ICP_BS - 1) / ICP_BS : LIN_MAX_BLOCKS;
+    const int nbmax = (cap + LIN_BS - 1) / LIN_BS < LIN_MAX_BLOCKS ? (cap + LIN_BS - 1) / LIN_BS : LIN_MAX_BLOCKS;
     const int nbnn = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT);
     IcpState *st = arena<IcpState>(ctx, 1);
     double *partials = arena<double>(ctx, (size_t)nbmax * NVP);
@@ -547,6 +587,12 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     IcpArgs a; fill_args(a, src, tgt, max_dist, p, match, st, partials, 0);
     IcpInit in; memcpy(in.T, T0, sizeof in.T);
     hipLaunchKernelGGL(k_icp_init, dim3(1), dim3(64), 0, ctx->stream, st, in);
+    const char *stamp_path = getenv("PCR_ICP_STAMPS");          // diagnostics only
+    const size_t sw_nn = (size_t)ICP_STAMP_LAUNCHES * nbnn * (ICP_BS / 64) * 2, sw_it = (size_t)ICP_STAMP_LAUNCHES * nbmax * (LIN_BS / 64) * 12;
+    if (stamp_path) {
+        if (hipMalloc(&a.stamps_nn, sw_nn * 8) != hipSuccess || hipMalloc(&a.stamps_it, sw_it * 8) != hipSuccess) return PCR_ENOMEM;
+        hipMemsetAsync(a.stamps_nn, 0, sw_nn * 8, ctx->stream); hipMemsetAsync(a.stamps_it, 0, sw_it * 8, ctx->stream);
+    }
 
     // Launch in chunks; the state of chunk c is copied back while chunk c+1 is already queued, so the GPU never
     // idles on the host.  Launches after 'done' return at their first instruction.
@@ -564,8 +610,8 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
             }
             for (int k = 0; k < c; k++) {
                 hipLaunchKernelGGL(k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
-                if (use_cov) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP_COV>), dim3(nbmax), dim3(ICP_BS), 0, ctx->stream, a);
-                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP>), dim3(nbmax), dim3(ICP_BS), 0, ctx->stream, a);
+                if (use_cov) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP_COV>), dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP>), dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
             }
             if (ctx->profiling) PCR_HIP_CHECK(ctx, hipEventRecord(ctx->prof_events[2 * n_chunks + 1], ctx->stream));
             n_chunks++;
@@ -600,6 +646,15 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
         ctx->prof[6] += (double)fin.t_dbg[0] * 0.01; ctx->prof[7] += (double)fin.t_dbg[3] * 0.01;
         if (getenv("PCR_DEBUG_STAMPS")) fprintf(stderr, "icp stamps (us/launch): slowest-wg search %.1f slowest-wg reduce %.1f (unused %.1f) sums-done %.1f end %.1f (launches %d ns %d)\n", fin.t_dbg[0] * 0.01 / fin.launches, fin.t_dbg[1] * 0.01 / fin.launches, fin.t_dbg[2] * 0.01 / fin.launches, fin.t_dbg[3] * 0.01 / fin.launches, fin.t_live * 0.01 / fin.launches, fin.launches, fin.ns);
     }
+    if (stamp_path) {
+        unsigned long long *h = (unsigned long long *)malloc((sw_nn + sw_it) * 8);
+        hipMemcpy(h, a.stamps_nn, sw_nn * 8, hipMemcpyDeviceToHost); hipMemcpy(h + sw_nn, a.stamps_it, sw_it * 8, hipMemcpyDeviceToHost);
+        if (FILE *f = fopen(stamp_path, "ab")) {
+            const unsigned long long hdr[6] = {0x49435053ull, (unsigned long long)nbnn * (ICP_BS / 64), (unsigned long long)nbmax * (LIN_BS / 64), ICP_STAMP_LAUNCHES, (unsigned long long)fin.launches, (unsigned long long)fin.ns};
+            fwrite(hdr, 8, 6, f); fwrite(h, 8, sw_nn + sw_it, f); fclose(f);
+        }
+        free(h); hipFree(a.stamps_nn); hipFree(a.stamps_it);
+    }
     state_to_result(fin, out);
     for (int k = 0; k < 16; k++) if (!std::isfinite(fin.T[k])) { ctx->err = "non-finite pose"; return PCR_ENUMERIC; }
     return PCR_OK;
@@ -610,7 +665,7 @@ int pcr_dev_linearize_once(pcr_context *ctx, const DevCloud *src, const DevCloud
     if (!(max_dist > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
     ArenaMark mark(ctx);
     const int cap = src->cap > 0 ? src->cap : 1;
-    const int nbmax = (cap + ICP_BS - 1) / ICP_BS < LIN_MAX_BLOCKS ? (cap + ICP_BS - 1) / ICP_BS : LIN_MAX_BLOCKS;
+    const int nbmax = (cap + LIN_BS - 1) / LIN_BS < LIN_MAX_BLOCKS ? (cap + LIN_BS - 1) / LIN_BS : LIN_MAX_BLOCKS;
     const int nbnn = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT);
     IcpState *st = arena<IcpState>(ctx, 1);
     double *partials = arena<double>(ctx, (size_t)nbmax * NVP);
@@ -620,7 +675,7 @@ int pcr_dev_linearize_once(pcr_context *ctx, const DevCloud *src, const DevCloud
     IcpInit in; memcpy(in.T, T, sizeof in.T);
     hipLaunchKernelGGL(k_icp_init, dim3(1), dim3(64), 0, ctx->stream, st, in);
     hipLaunchKernelGGL(k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP>), dim3(nbmax), dim3(ICP_BS), 0, ctx->stream, a);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP>), dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
     IcpState h;
     PCR_TRY(read_state(ctx, st, &h));
     int t = 0;
@@ -635,7 +690,7 @@ int pcr_dev_evaluate(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt,
     if (!(max_dist > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
     ArenaMark mark(ctx);
     const int cap = src->cap > 0 ? src->cap : 1;
-    const int nbmax = (cap + ICP_BS - 1) / ICP_BS < LIN_MAX_BLOCKS ? (cap + ICP_BS - 1) / ICP_BS : LIN_MAX_BLOCKS;
+    const int nbmax = (cap + LIN_BS - 1) / LIN_BS < LIN_MAX_BLOCKS ? (cap + LIN_BS - 1) / LIN_BS : LIN_MAX_BLOCKS;
     const int nbnn = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT);
     IcpState *st = arena<IcpState>(ctx, 1);
     double *partials = arena<double>(ctx, (size_t)nbmax * NVP);
@@ -645,7 +700,7 @@ int pcr_dev_evaluate(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt,
     IcpInit in; memcpy(in.T, T, sizeof in.T);
     hipLaunchKernelGGL(k_icp_init, dim3(1), dim3(64), 0, ctx->stream, st, in);
     hipLaunchKernelGGL(k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_EVAL>), dim3(nbmax), dim3(ICP_BS), 0, ctx->stream, a);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_EVAL>), dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
     IcpState h;
     PCR_TRY(read_state(ctx, st, &h));
     if (out) { state_to_result(h, out); out->iterations = 0; out->converged = 0; }

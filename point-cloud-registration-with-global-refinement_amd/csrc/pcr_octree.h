@@ -45,7 +45,8 @@ struct OctView {             // what a kernel needs to walk a tree
     const OctMeta *meta;
     const int *leaf_of;
     const uint64_t *keys;
-    const int4 *pinfo;       // point -> (leaf, first point of the leaf, point count)
+    const int4 *pinfo;       // point -> (node, its first point, its point count, level): the level-1 node holding the point
+                             // (the leaf when the tree has one level) -- the "fat leaf" a warm-started search scans first
 };
 
 __host__ __device__ static inline uint32_t pcr_compact21(uint64_t x) {
@@ -106,28 +107,25 @@ __device__ static inline bool oct_ball_in_cell(const OctMeta &m, uint32_t ix, ui
 // octet-uniform.  bound() -> current squared radius (octet-uniform, may shrink);  visit(first, count) is a WAVE-WIDE
 // operation that tests `count` points starting at `first` (count == 0: idle octet);  skip(first, count) -> true if a
 // leaf need not be scanned at all (e.g. already covered by the seed range).
+// s_*: what the walk needs about its start leaf (points, key of the first point, up-link).  Callers that know the leaf
+// one hop earlier (k_icp_nn: from the previous match) issue these loads together with their own, so that the record
+// arrives with the leaf's points instead of after them: the search is a chain of dependent loads and every hop costs
+// ~1 us of wavefront life.
 template <int OPB, class BoundFn, class VisitFn, class SkipFn>
-__device__ static inline void oct_search(const OctView &t, const OctMeta &m, OctStack<OPB> &stk, bool live, int start_leaf,
+__device__ static inline void oct_search(const OctView &t, const OctMeta &m, OctStack<OPB> &stk, bool live, int start_node, int start_li,
+                                         int s_first, int s_count, uint64_t s_key, int s_parent, int s_sib, int s_nsib,
                                          float qx, float qy, float qz, BoundFn bound, VisitFn visit, SkipFn skip, int ol, int oct, int ob,
                                          int *visits) {
     bool done = !live || m.nl < 1;
-    // ---- the start leaf itself
-    {
-        int f = 0, c = 0;
-        if (!done) {
-            const size_t j = (size_t)(m.off[0] + start_leaf);
-            f = __float_as_int(t.nodes[2 * j].w); c = __float_as_int(t.nodes[2 * j + 1].w);
-        }
-        visit(f, c);
-    }
+    // ---- the start node's own points (a leaf, or a level-1 node taken as one fat leaf)
+    visit(done ? 0 : s_first, done ? 0 : s_count);
     uint32_t ix = 0, iy = 0, iz = 0;
-    if (!done) {
-        const uint64_t key = t.keys[__float_as_int(t.nodes[2 * (size_t)(m.off[0] + start_leaf)].w)];
-        ix = pcr_compact21(key); iy = pcr_compact21(key >> 1); iz = pcr_compact21(key >> 2);
-    }
-    int anc = start_leaf, anc_li = 0;       // subtree already covered
-    int li = 0, cs = 0, base_li = 0;        // current sibling list (nodes of level li starting at cs), pending mask
+    if (!done) { ix = pcr_compact21(s_key); iy = pcr_compact21(s_key >> 1); iz = pcr_compact21(s_key >> 2); }
+    int anc = start_node, anc_li = start_li;              // subtree already covered
+    int li = start_li, cs = 0, base_li = start_li;        // current sibling list (nodes of level li starting at cs), pending mask
     uint32_t mask = 0;
+    bool first_ascent = true;
+    int pay_f = 0, pay_c = 0, pay_li = -1;                // lane c: (first, count) of child c of the list tested last (level pay_li)
     for (;;) {
         bool ascend = false;
         while (!done && mask == 0) {
@@ -142,7 +140,10 @@ __device__ static inline void oct_search(const OctView &t, const OctMeta &m, Oct
         // ---- climb one level: the parent's other children become the sibling list
         if (__ballot(ascend) != 0ull) {
             int p = 0, pf = 0, pc = 0;
-            if (ascend) { const int4 u = t.up[m.off[anc_li] + anc]; p = u.x; pf = u.y; pc = u.z; }
+            if (ascend) {
+                if (first_ascent) { p = s_parent; pf = s_sib; pc = s_nsib; }
+                else { const int4 u = t.up[m.off[anc_li] + anc]; p = u.x; pf = u.y; pc = u.z; }
+            }
             int f, c;
             const uint32_t nm = oct_test_nodes(t, m, ascend, anc_li, pf, pc, qx, qy, qz, bound(), ol, oct, f, c);
             if (ascend) {
@@ -150,15 +151,23 @@ __device__ static inline void oct_search(const OctView &t, const OctMeta &m, Oct
                 li = anc_li; base_li = anc_li; cs = pf;
                 mask = nm & ~(1u << (anc - pf));
                 anc = p; anc_li++;
+                first_ascent = false;
+                pay_f = f; pay_c = c; pay_li = li;
             }
         }
-        // ---- pop one pending sibling: a leaf is scanned, an inner node is opened
+        // ---- pop one pending sibling: a leaf is scanned, an inner node is opened.  Its (first, count) sit in lane c of
+        // the octet when the list was tested last (a shuffle instead of a dependent load), else they are re-read
         int vf = 0, vc = 0; bool descend = false; int dcs = 0, dcnt = 0;
-        if (!done && mask != 0) {
-            const int c = __builtin_ctz(mask);
+        const bool popping = !done && mask != 0;
+        const int pc_ = popping ? __builtin_ctz(mask) : 0;
+        const int sh_f = __shfl(pay_f, pc_, OCT), sh_c = __shfl(pay_c, pc_, OCT);
+        if (popping) {
             mask &= mask - 1;
-            const size_t j = (size_t)(m.off[li] + cs + c);
-            const int nf = __float_as_int(t.nodes[2 * j].w), nc = __float_as_int(t.nodes[2 * j + 1].w);
+            int nf = sh_f, nc = sh_c;
+            if (pay_li != li) {
+                const size_t j = (size_t)(m.off[li] + cs + pc_);
+                nf = __float_as_int(t.nodes[2 * j].w); nc = __float_as_int(t.nodes[2 * j + 1].w);
+            }
             if (visits) *visits += 1;
             if (li == 0) { if (!skip(nf, nc)) { vf = nf; vc = nc; if (visits) *visits += 1 << 20; } }
             else {
@@ -170,7 +179,7 @@ __device__ static inline void oct_search(const OctView &t, const OctMeta &m, Oct
         if (__ballot(descend) != 0ull) {
             int f, c;
             const uint32_t nm = oct_test_nodes(t, m, descend, li, dcs, dcnt, qx, qy, qz, bound(), ol, oct, f, c);
-            if (descend) mask = nm;
+            if (descend) { mask = nm; pay_f = f; pay_c = c; pay_li = li; }
         }
     }
 }
