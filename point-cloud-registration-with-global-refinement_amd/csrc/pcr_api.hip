@@ -17,13 +17,16 @@ extern "C" int pcr_create(int device, pcr_context **out) {
     if (hipSetDevice(device) != hipSuccess) return PCR_EHIP;
     pcr_context *ctx = new pcr_context();
     ctx->device = device;
-    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PCR_EHIP; }
-    ctx->stream = ctx->own_stream;
-    if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return PCR_EHIP; }
+    // Streams are created on first use and only as many as needed: the HIP runtime maps streams onto a small pool of
+    // hardware queues (GPU_MAX_HW_QUEUES, default 4) in creation order, and two streams that share a queue run their
+    // kernels one after the other -- an unused stream would push a busy one onto a shared queue (measured: 110 vs
+    // 180 pairs/s with three pairs in flight).
     for (int i = 0; i < 2; i++)
         if (hipEventCreateWithFlags(&ctx->side_ev[i], hipEventDisableTiming) != hipSuccess) { delete ctx; return PCR_EHIP; }
+    for (int i = 0; i < 4; i++)
+        if (hipEventCreateWithFlags(&ctx->lane_ev[i], hipEventDisableTiming) != hipSuccess) { delete ctx; return PCR_EHIP; }
     ctx->pinned_cap = 1 << 16;
-    if (hipHostMalloc((void **)&ctx->pinned, ctx->pinned_cap, hipHostMallocDefault) != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; return PCR_EHIP; }
+    if (hipHostMalloc((void **)&ctx->pinned, ctx->pinned_cap, hipHostMallocDefault) != hipSuccess) { delete ctx; return PCR_EHIP; }
     for (int i = 0; i < 2; i++)
         if (hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming) != hipSuccess) { delete ctx; return PCR_EHIP; }
     *out = ctx;
@@ -33,22 +36,24 @@ extern "C" int pcr_create(int device, pcr_context **out) {
 extern "C" int pcr_destroy(pcr_context *ctx) {
     if (!ctx) return PCR_OK;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (int i = 0; i < 2; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+    if (ctx->side_stream2) { (void)hipStreamSynchronize(ctx->side_stream2); (void)hipStreamDestroy(ctx->side_stream2); }
     for (int i = 0; i < 2; i++) if (ctx->side_ev[i]) (void)hipEventDestroy(ctx->side_ev[i]);
+    for (int i = 0; i < 4; i++) if (ctx->lane_ev[i]) (void)hipEventDestroy(ctx->lane_ev[i]);
     delete ctx;
     return PCR_OK;
 }
 
 extern "C" int pcr_set_stream(pcr_context *ctx, void *s) {
     if (!ctx) return PCR_EINVAL;
-    (void)hipStreamSynchronize(ctx->stream);
-    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;      // null: the context's own stream, created on first use
     return PCR_OK;
 }
 
@@ -84,10 +89,22 @@ void *pcr_arena_alloc(pcr_context *ctx, size_t bytes) {
     return ctx->arena + off;
 }
 
+static int ensure_stream(pcr_context *ctx) {
+    if (ctx->stream) return PCR_OK;
+    if (!ctx->own_stream && hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return PCR_EHIP; }
+    ctx->stream = ctx->own_stream;
+    return PCR_OK;
+}
+static int ensure_lanes(pcr_context *ctx, int lanes) {
+    if (!ctx->side_stream && hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return PCR_EHIP; }
+    if (lanes > 1 && !ctx->side_stream2 && hipStreamCreateWithFlags(&ctx->side_stream2, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return PCR_EHIP; }
+    return PCR_OK;
+}
 #define ENTER(ctx)                                                               \
     if (!(ctx)) return PCR_EINVAL;                                               \
     if (hipSetDevice((ctx)->device) != hipSuccess) return PCR_EHIP;              \
-    (ctx)->err.clear();
+    (ctx)->err.clear();                                                          \
+    if (ensure_stream(ctx) != PCR_OK) return PCR_EHIP;
 
 int pcr_alloc_cloud(pcr_context *ctx, DevCloud *c, int cap, bool with_nrm, bool with_tree) {
     const int cc = cap > 0 ? cap : 1;
@@ -389,44 +406,71 @@ extern "C" int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const
         if (!(dists[s] > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
     }
     if (sor_k < 1 || !(sor_std > 0.0) || normal_k < 1) { ctx->err = "nb_neighbors < 1, std_ratio <= 0 or knn < 1"; return PCR_EINVAL; }
-    PCR_TRY(pcr_arena_reserve(ctx, 2 * pcr_scratch_bytes_for(n_src) + 3 * pcr_scratch_bytes_for(n_tgt)));
+    const size_t blk_s = 2 * pcr_scratch_bytes_for(n_src), blk_t = 2 * pcr_scratch_bytes_for(n_tgt);
+    PCR_TRY(pcr_arena_reserve(ctx, 2 * (blk_s + blk_t) + pcr_scratch_bytes_for(n_src)));
     double bs[6], bt[6];
     PCR_TRY(pcr_dev_bounds(ctx, src_xyz, n_src, bs));
     PCR_TRY(pcr_dev_bounds(ctx, tgt_xyz, n_tgt, bt));
     double T[16];
     memcpy(T, init_T, sizeof T);
-    for (int s = 0; s < n_scales; s++) {
-        ArenaMark mark(ctx);
-        DevCloud cs, ct; int *nvs = nullptr, *nvt = nullptr;
-        // the two clouds are independent until the GICP loop: the target's pipeline is enqueued on the side lane so its
-        // many small latency-bound launches (sort passes, octree levels, scans, the fallback search) hide under the
-        // source's k-NN kernels and vice versa
-        const size_t side_bytes = pcr_scratch_bytes_for(n_tgt) * 2;
-        char *side = (char *)pcr_arena_alloc(ctx, side_bytes);
-        if (!side) return PCR_ENOMEM;
-        PCR_HIP_CHECK(ctx, hipEventRecord(ctx->side_ev[0], ctx->stream));
-        PCR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_ev[0], 0));
+    // Preprocessing never depends on the pose, so it runs one scale AHEAD of the GICP loop, each cloud on its own lane
+    // (stream + private block of the arena): the many small latency-bound launches of scale s+1 (sort passes, octree
+    // levels, scans) and its VALU-heavy k-NN kernels fill the machine while the latency-bound iterations of scale s run
+    // on the caller's stream.  Blocks form a ring of two scales; a block is recycled only after the GICP of its scale
+    // has been waited for on the host.
+    char *blocks[2][2];
+    for (int r = 0; r < 2; r++) {
+        blocks[r][0] = (char *)pcr_arena_alloc(ctx, blk_s); blocks[r][1] = (char *)pcr_arena_alloc(ctx, blk_t);
+        if (!blocks[r][0] || !blocks[r][1]) return PCR_ENOMEM;
+    }
+    static const int n_lanes = getenv("PCR_LANES") ? atoi(getenv("PCR_LANES")) : 2;
+    PCR_TRY(ensure_lanes(ctx, n_lanes));
+    hipStream_t lane_t = ctx->side_stream, lane_s = n_lanes > 1 ? ctx->side_stream2 : ctx->side_stream;
+    struct LaneGuard {            // an early error return must not leave lane work running over a recycled arena
+        hipStream_t a, b;
+        ~LaneGuard() { (void)hipStreamSynchronize(a); if (b != a) (void)hipStreamSynchronize(b); }
+    } guard{lane_t, lane_s};
+    PCR_HIP_CHECK(ctx, hipEventRecord(ctx->side_ev[0], ctx->stream));       // inputs are ready once the caller's stream gets here
+    PCR_HIP_CHECK(ctx, hipStreamWaitEvent(lane_t, ctx->side_ev[0], 0));
+    if (lane_s != lane_t) PCR_HIP_CHECK(ctx, hipStreamWaitEvent(lane_s, ctx->side_ev[0], 0));
+    DevCloud cs[2], ct[2]; int *nvs[2] = {nullptr, nullptr}, *nvt[2] = {nullptr, nullptr};
+    auto enqueue_prep = [&](int s) -> int {
+        const int r = s & 1;
         {
-            SideLane lane(ctx, side, side_bytes);
-            PCR_TRY(prep_scale(ctx, tgt_xyz, tgt_normals, n_tgt, bt, voxels[s], sor_k, sor_std, normal_k, &ct, &nvt));
-            PCR_HIP_CHECK(ctx, hipEventRecord(ctx->side_ev[1], ctx->stream));
+            SideLane lane(ctx, blocks[r][1], blk_t, lane_t);
+            PCR_TRY(prep_scale(ctx, tgt_xyz, tgt_normals, n_tgt, bt, voxels[s], sor_k, sor_std, normal_k, &ct[r], &nvt[r]));
+            PCR_HIP_CHECK(ctx, hipEventRecord(ctx->lane_ev[2 * r + 1], ctx->stream));
         }
-        PCR_TRY(prep_scale(ctx, src_xyz, src_normals, n_src, bs, voxels[s], sor_k, sor_std, normal_k, &cs, &nvs));
-        PCR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev[1], 0));
+        {
+            SideLane lane(ctx, blocks[r][0], blk_s, lane_s);
+            PCR_TRY(prep_scale(ctx, src_xyz, src_normals, n_src, bs, voxels[s], sor_k, sor_std, normal_k, &cs[r], &nvs[r]));
+            PCR_HIP_CHECK(ctx, hipEventRecord(ctx->lane_ev[2 * r], ctx->stream));
+        }
+        return PCR_OK;
+    };
+    static const bool ahead = !(getenv("PCR_PIPELINE") && atoi(getenv("PCR_PIPELINE")) == 0);
+    PCR_TRY(enqueue_prep(0));
+    for (int s = 0; s < n_scales; s++) {
+        const int r = s & 1;
+        if (!ahead && s > 0) PCR_TRY(enqueue_prep(s));
+        if (ahead && s + 1 < n_scales) PCR_TRY(enqueue_prep(s + 1));
+        ArenaMark mark(ctx);
+        PCR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_ev[2 * r], 0));
+        PCR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_ev[2 * r + 1], 0));
         int32_t *match = arena<int32_t>(ctx, n_src > 0 ? n_src : 1);
         if (!match) return PCR_ENOMEM;
-        PCR_TRY(pcr_dev_gicp(ctx, &cs, &ct, dists[s], T, params, &records[s].icp, match));
+        PCR_TRY(pcr_dev_gicp(ctx, &cs[r], &ct[r], dists[s], T, params, &records[s].icp, match));
         int h[4];
-        PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h[0], nvs, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h[1], nvt, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h[2], cs.n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h[3], ct.n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h[0], nvs[r], sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h[1], nvt[r], sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h[2], cs[r].n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h[3], ct[r].n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         records[s].n_voxel[0] = h[0]; records[s].n_voxel[1] = h[1]; records[s].n_clean[0] = h[2]; records[s].n_clean[1] = h[3];
         memcpy(T, records[s].icp.transformation, sizeof T);
         if (s == n_scales - 1 && correspondences) {
             int64_t nc = 0;
-            PCR_TRY(pcr_dev_compact_matches(ctx, match, cs.n, cs.cap, nullptr, nullptr, correspondences, &nc));
+            PCR_TRY(pcr_dev_compact_matches(ctx, match, cs[r].n, cs[r].cap, nullptr, nullptr, correspondences, &nc));
         }
     }
     return PCR_OK;

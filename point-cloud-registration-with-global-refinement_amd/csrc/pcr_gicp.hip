@@ -247,7 +247,7 @@ __device__ static bool icp_ldlt6_pivoted(const double *S, const double *b6, doub
 
 // ---- kernel 1 of an iteration: exact 1-NN of every transformed source point, ONE query per octet (32 per
 // workgroup).  Latency-bound pointer chasing, so it runs at full occupancy (few registers, many wavefronts).
-__global__ void __launch_bounds__(ICP_BS) k_icp_nn(IcpArgs a) {
+__global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_icp_nn(IcpArgs a) {
     IcpState *st = a.state;
     constexpr int OPB = ICP_BS / OCT;
     __shared__ OctMeta m;

@@ -14,8 +14,10 @@ struct pcr_context {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
-    hipStream_t side_stream = nullptr;   // second lane: the other cloud's preprocessing runs concurrently on it
+    hipStream_t side_stream = nullptr;   // preprocessing lanes: the two clouds of a scale are prepared concurrently on them,
+    hipStream_t side_stream2 = nullptr;  //   one scale ahead of the GICP loop that runs on `stream`
     hipEvent_t side_ev[2] = {nullptr, nullptr};
+    hipEvent_t lane_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // [ring slot][cloud]: prepared cloud ready
     char *arena = nullptr;
     size_t arena_cap = 0, arena_off = 0;
     char *pinned = nullptr;        // host-pinned read-back window
@@ -52,8 +54,8 @@ template <class T> static inline T *arena(pcr_context *ctx, size_t count) {
 // independent pipelines can be enqueued without sharing (and prematurely recycling) scratch memory.
 struct SideLane {
     pcr_context *ctx; char *arena; size_t cap, off; hipStream_t stream;
-    SideLane(pcr_context *c, char *base, size_t bytes) : ctx(c), arena(c->arena), cap(c->arena_cap), off(c->arena_off), stream(c->stream) {
-        c->arena = base; c->arena_cap = bytes; c->arena_off = 0; c->stream = c->side_stream;
+    SideLane(pcr_context *c, char *base, size_t bytes, hipStream_t lane = nullptr) : ctx(c), arena(c->arena), cap(c->arena_cap), off(c->arena_off), stream(c->stream) {
+        c->arena = base; c->arena_cap = bytes; c->arena_off = 0; c->stream = lane ? lane : c->side_stream;
     }
     ~SideLane() { ctx->arena = arena; ctx->arena_cap = cap; ctx->arena_off = off; ctx->stream = stream; }
 };
