@@ -1,0 +1,51 @@
+#!/bin/bash
+# Produces the round's committed profile evidence (run on the GPU box through gpurun):
+#   profiles/rNN_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the DEFAULT bench command
+#   profiles/rNN_pmc_hbm_traffic.csv      per-kernel HBM traffic from separate --pmc passes (FETCH_SIZE, WRITE_SIZE, TCC hit/miss)
+#   profiles/rNN_traffic.json             the same numbers keyed by kernel (bench.py reads it for roofline.traffic)
+# usage: tools/make_profiles.sh r01
+TAG=${1:-r01}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+export TMPDIR=/tmp
+OUT=$ROOT/gpurun_out/profiles_$TAG
+rm -rf "$OUT"; mkdir -p "$OUT" "$ROOT/profiles"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 12 > "$OUT/bench_stats.log" 2> "$OUT/bench_stats.err" || exit 1
+cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$ROOT/profiles/${TAG}_bench_kernel_stats.csv"
+for pass in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+  d=$OUT/pmc_$(echo $pass | tr ' ' '_')
+  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$d" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 4 --warmup 1 --inflight 1 > "$d.log" 2> "$d.err" || exit 1
+  echo "pmc pass [$pass] done"
+done
+python3 - "$OUT" "$ROOT/profiles/${TAG}" <<'PY'
+import csv, glob, json, sys, collections
+out, dst = sys.argv[1], sys.argv[2]
+def load(pat):
+    f = glob.glob(f"{out}/{pat}/**/*counter_collection.csv", recursive=True)[0]
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        d[r["Kernel_Name"]][r["Counter_Name"]].append((float(r["Counter_Value"]), dur))
+    return d
+fetch, write, tcc = load("pmc_FETCH_SIZE"), load("pmc_WRITE_SIZE"), load("pmc_TCC_HIT_sum_TCC_MISS_sum")
+short = {"k_icp_nn(IcpArgs)": "k_icp_nn", "void k_icp_iter<0>(IcpArgs)": "k_icp_iter<GICP>", "void k_knn<0, 4>(KnnArgs)": "k_knn<SOR,4>",
+         "void k_knn<1, 4>(KnnArgs)": "k_knn<NORMALS,4>", "k_normals_from_lists(NflArgs)": "k_normals_from_lists"}
+rows, js = [], {}
+for full, name in short.items():
+    live = lambda lst: [v for v, dur in lst if dur > 6.0]            # launches after 'done' return at once: not live
+    f = live(fetch[full]["FETCH_SIZE"]); w = live(write[full]["WRITE_SIZE"])
+    h = live(tcc[full]["TCC_HIT_sum"]); m = live(tcc[full]["TCC_MISS_sum"])
+    us = [dur for v, dur in fetch[full]["FETCH_SIZE"] if dur > 6.0]
+    if not f: continue
+    fk, wk = sum(f) / len(f), sum(w) / len(w)
+    hbm = int((2.0 * fk + wk) * 1024)                                # gfx950: FETCH_SIZE counts 64 B per 128-B request (guide, HBM section)
+    hit = sum(h) / max(1.0, sum(h) + sum(m))
+    rows.append([name, len(f), round(fk, 1), round(wk, 1), hbm, round(hit, 3), round(sum(us) / len(us), 1)])
+    js[name] = {"hbm_bytes_per_launch": hbm, "fetch_kb": fk, "write_kb": wk, "l2_hit": hit}
+with open(dst + "_pmc_hbm_traffic.csv", "w", newline="") as fcsv:
+    wr = csv.writer(fcsv); wr.writerow(["kernel", "live_launches", "FETCH_SIZE_KB_avg", "WRITE_SIZE_KB_avg", "hbm_bytes_per_launch_corrected", "L2_hit_rate", "avg_us_live_under_pmc"]); wr.writerows(rows)
+json.dump(js, open(dst + "_traffic.json", "w"), indent=1)
+for r in rows: print(r)
+PY
+grep '^{"metric' "$OUT/bench_stats.log" | tail -1 > "$ROOT/gpurun_out/bench_under_rocprof_$TAG.json"
+head -12 "$ROOT/profiles/${TAG}_bench_kernel_stats.csv" | cut -c1-150
