@@ -925,8 +925,7 @@ __global__ void __launch_bounds__(KNN_BS) k_normals_from_lists(NflArgs a) {
         ok[s] = id[s] >= 0 && a.keep[id[s]];
         lc += id[s] >= 0 ? 1 : 0; vc += ok[s] ? 1 : 0;
     }
-#pragma unroll
-    for (int o = 1; o < OCT; o <<= 1) { lc += __shfl_xor(lc, o, OCT); vc += __shfl_xor(vc, o, OCT); }
+    lc = pcr_octet_sum_i(lc); vc = pcr_octet_sum_i(vc);
     const bool exact = act && (vc >= a.k_nrm || lc < a.k_list);
     const int j = act ? a.pos[i] : 0;
     if (act && ol == 0) {
@@ -939,19 +938,12 @@ __global__ void __launch_bounds__(KNN_BS) k_normals_from_lists(NflArgs a) {
         float m = -1.0f; int ms = 0;
 #pragma unroll
         for (int s = 0; s < 4; s++) if (ok[s] && d[s] > m) { m = d[s]; ms = s; }
-        int ml = ol;
+        const float om = pcr_octet_max(m);                                   // DPP, no LDS hop; ties -> lowest lane
+        const int ml = __builtin_ctz((uint32_t)(__ballot(m == om) >> (threadIdx.x & 56)) & 0xffu);
+        const bool hit = excess > 0 && ol == ml;
 #pragma unroll
-        for (int o = 1; o < OCT; o <<= 1) {
-            const float om = __shfl_xor(m, o, OCT); const int olane = __shfl_xor(ml, o, OCT);
-            if (om > m || (om == m && olane < ml)) { m = om; ml = olane; }
-        }
-        if (excess > 0) {
-            if (ol == ml) {
-#pragma unroll
-                for (int s = 0; s < 4; s++) if (s == ms) ok[s] = false;
-            }
-            excess--;
-        }
+        for (int s = 0; s < 4; s++) ok[s] = ok[s] && !(hit && s == ms);
+        excess -= excess > 0 ? 1 : 0;
     }
     if (!exact) return;
     double cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, c = 0;
@@ -987,30 +979,49 @@ __global__ void __launch_bounds__(KNN_BS) k_normals_from_lists(NflArgs a) {
 }
 
 // ============================================================================ SOR (K4)
-// mean / Bessel std of the per-point mean neighbour distance, one block, fixed summation tree
-__global__ void __launch_bounds__(1024) k_sor_stats(const double *__restrict__ avg, const int *__restrict__ n_ptr, double std_ratio, double *__restrict__ out3) {
-    __shared__ double s[1024];
-    __shared__ long long sc[1024];
-    __shared__ double mean_s;
+// mean / Bessel std of the per-point mean neighbour distance in ONE pass over <= 128 workgroups: shifted moments
+// sum(v-c), sum((v-c)^2), count with c = the first valid value (no cancellation: |mean-c| ~ sigma), fixed summation
+// tree, write-through partial rows + ticket, the last workgroup gathers them with sc1 loads (no fence) and finishes.
+#define SOR_STAT_BLOCKS 128
+__global__ void __launch_bounds__(256) k_sor_stats(const double *__restrict__ avg, const int *__restrict__ n_ptr, double std_ratio, double *__restrict__ out3,
+                                                   double *__restrict__ partials /* SOR_STAT_BLOCKS x 4 */, unsigned int *__restrict__ ticket) {
+    __shared__ double red[16][3];
+    __shared__ double rows[SOR_STAT_BLOCKS * 3];
+    __shared__ int is_last;
     const int n = *n_ptr, t = threadIdx.x;
-    double a = 0; long long c = 0;
-    for (int i = t; i < n; i += 1024) { double v = avg[i]; if (v > 0) { a += v; c++; } }
-    s[t] = a; sc[t] = c;
+    double c = 0.0;
+    for (int i = 0; i < n && i < 64; i++) { const double v = avg[i]; if (v > 0) { c = v; break; } }     // same value in every workgroup
+    double a = 0, b = 0, cnt = 0;
+    for (int i = blockIdx.x * 256 + t; i < n; i += gridDim.x * 256) { const double v = avg[i]; if (v > 0) { const double d = v - c; a += d; b += d * d; cnt += 1.0; } }
+    a = pcr_row16_sum(a); b = pcr_row16_sum(b); cnt = pcr_row16_sum(cnt);
+    if ((t & 15) == 0) { red[t >> 4][0] = a; red[t >> 4][1] = b; red[t >> 4][2] = cnt; }
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) { if (t < o) { s[t] += s[t + o]; sc[t] += sc[t + o]; } __syncthreads(); }
-    const long long valid = sc[0];
-    if (t == 0) mean_s = valid > 0 ? s[0] / (double)valid : 0.0;
+    if (t < 3) {
+        double s = 0;
+        for (int r = 0; r < 16; r++) s += red[r][t];
+        __hip_atomic_store(&partials[blockIdx.x * 4 + t], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const double mean = mean_s;
-    a = 0;
-    for (int i = t; i < n; i += 1024) { double v = avg[i]; if (v > 0) a += (v - mean) * (v - mean); }
+    if (t == 0) is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     __syncthreads();
-    s[t] = a;
+    if (!is_last) return;
+    for (int e = t; e < 3 * (int)gridDim.x; e += 256) {
+        const double *p = partials + (e / 3) * 4 + (e % 3);
+        double v;
+        asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+        rows[e] = v;
+    }
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) { if (t < o) s[t] += s[t + o]; __syncthreads(); }
     if (t == 0) {
-        const double sd = sqrt(s[0] / (double)(valid - 1));
+        double sa = 0, sb = 0, sc = 0;
+        for (int r = 0; r < (int)gridDim.x; r++) { sa += rows[3 * r]; sb += rows[3 * r + 1]; sc += rows[3 * r + 2]; }
+        const double valid = sc;
+        const double mean = valid > 0 ? c + sa / valid : 0.0;
+        const double var = valid > 1 ? (sb - sa * sa / valid) / (valid - 1.0) : 0.0;
+        const double sd = sqrt(var > 0 ? var : 0.0);
         out3[0] = mean; out3[1] = sd; out3[2] = valid > 0 ? mean + std_ratio * sd : -1.0;
+        *ticket = 0u;
     }
 }
 __global__ void __launch_bounds__(BS) k_sor_flags(const double *__restrict__ avg, const int *__restrict__ n_ptr, const double *__restrict__ stats3, uint8_t *__restrict__ flags) {
@@ -1038,9 +1049,12 @@ int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double s
     ArenaMark mark(ctx);
     double *avg = avg_sorted ? avg_sorted : arena<double>(ctx, in->cap);
     double *stats3 = arena<double>(ctx, 4);
+    double *stat_partials = arena<double>(ctx, SOR_STAT_BLOCKS * 4);
+    unsigned int *stat_ticket = arena<unsigned int>(ctx, 1);
     uint8_t *flags = keep_sorted ? keep_sorted : arena<uint8_t>(ctx, in->cap);
     int *pos = arena<int>(ctx, in->cap);
-    if (!avg || !stats3 || !flags || !pos) return PCR_ENOMEM;
+    if (!avg || !stats3 || !stat_partials || !stat_ticket || !flags || !pos) return PCR_ENOMEM;
+    PCR_HIP_CHECK(ctx, hipMemsetAsync(stat_ticket, 0, sizeof(unsigned int), ctx->stream));
     // normals of the cleaned cloud straight from this pass's lists when they can be exact (see k_normals_from_lists)
     const bool fuse = normal_k > 0 && todo_out && nb_neighbors <= 32 && normal_k <= nb_neighbors;
     int32_t *lidx = fuse ? arena<int32_t>(ctx, (size_t)in->cap * 32) : nullptr;
@@ -1050,7 +1064,7 @@ int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double s
     a.t = oct_view(in); a.n_ptr = in->n; a.k = nb_neighbors; a.avg = avg; a.list_idx = lidx; a.list_d2 = ld2;
     knn_radius(a, PCR_SEARCH_KNN, 0);
     PCR_TRY(launch_knn<KNN_MODE_SOR>(ctx, in, a));
-    hipLaunchKernelGGL(k_sor_stats, dim3(1), dim3(1024), 0, ctx->stream, avg, in->n, std_ratio, stats3);
+    hipLaunchKernelGGL(k_sor_stats, dim3(SOR_STAT_BLOCKS), dim3(256), 0, ctx->stream, avg, in->n, std_ratio, stats3, stat_partials, stat_ticket);
     const int nb = (in->cap + BS - 1) / BS;
     hipLaunchKernelGGL(k_sor_flags, dim3(nb), dim3(BS), 0, ctx->stream, avg, in->n, stats3, flags);
     PCR_TRY(pcr_dev_flag_scan(ctx, flags, in->n, in->cap, pos, out->n));

@@ -147,6 +147,10 @@ __device__ static inline float pcr_octet_min(float v) {
     i = min(i, pcr_dpp_i<PCR_DPP_HMIRROR>(i));
     return __int_as_float(i);
 }
+__device__ static inline int pcr_octet_sum_i(int v) {
+    v += pcr_dpp_i<PCR_DPP_XOR1>(v); v += pcr_dpp_i<PCR_DPP_XOR2>(v); v += pcr_dpp_i<PCR_DPP_HMIRROR>(v);
+    return v;
+}
 __device__ static inline double pcr_octet_sum(double v) {       // fixed tree => deterministic; all 8 lanes get the sum
     union { double d; int i[2]; } a, b;
     a.d = v; b.i[0] = pcr_dpp_i<PCR_DPP_XOR1>(a.i[0]); b.i[1] = pcr_dpp_i<PCR_DPP_XOR1>(a.i[1]); v += b.d;
