@@ -1,0 +1,178 @@
+"""Script-equivalent drivers over a closed circuit of clouds: the three stages the reference runs as
+module-level code with hard-wired constants, as functions with the same data flow and on-disk formats.
+
+* stage 1 = `1_FGR_pairwise_registration_in_NCLT_dataset.py:125-177`: FGR on every pair of the circuit, poses saved
+  as `pose_{i+1}_{i}.txt` with `%.10f`;
+* stage 2 = `2_MGICP_refinement_in_NCLT_dataset.py:166-253`: multiscale GICP refinement of every pair from the stage-1
+  poses (5 scales, 100 iterations per scale);
+* stage 3 = `3_Global_Optimizations_in_NCLT_dataset.py:296-364`: LUM / SLERP / SLERP+LUM on the relative poses
+  (host side, `refinement.py`).
+
+Pair i registers cloud i+1 onto cloud i; the last pair closes the loop (cloud 0 onto cloud n-1).  Pairs are independent:
+under `torch.distributed` every rank takes a contiguous block of them (`sharding.partition`), keeps `inflight` pairs in
+flight on its GPU (host threads, one HIP stream each) and ONE all-gather leaves the ordered pose table on every rank.
+Nothing here is on the measured hot path; it only feeds it.
+"""
+from __future__ import annotations
+
+import os
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from . import functions, io, refinement, sharding
+from .geometry import PointCloud
+
+
+def load_circuit(cloud_dir: str, n_clouds: int, pattern: str = "s{i}.pcd", indices=None) -> dict:
+    """`{i: PointCloud}` for the requested cloud indices (all by default): `o3d.io.read_point_cloud(f".../s{i}.pcd")`."""
+    want = range(n_clouds) if indices is None else sorted(set(indices))
+    return {i: PointCloud(io.read_pcd_xyz(os.path.join(cloud_dir, pattern.format(i=i)))) for i in want}
+
+
+def _run_pairs(pair_indices, job, inflight: int):
+    """Run job(i) for every pair index with `inflight` host threads, each on its own stream."""
+    import torch
+    tls = threading.local()
+    dev = torch.cuda.current_device()
+
+    def init():
+        torch.cuda.set_device(dev)
+        tls.stream = torch.cuda.Stream()
+
+    def run(i):
+        with torch.cuda.stream(tls.stream):
+            t0 = time.perf_counter()
+            r = job(i)
+            torch.cuda.current_stream().synchronize()
+            return i, r, time.perf_counter() - t0
+
+    with ThreadPoolExecutor(max_workers=max(1, inflight), initializer=init) as pool:
+        return list(pool.map(run, list(pair_indices)))
+
+
+def _shard(n_pairs: int):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return sharding.partition(n_pairs, dist.get_world_size(), dist.get_rank()), dist.get_rank()
+    return range(n_pairs), 0
+
+
+def _clouds_of(pairs, n_clouds):
+    need = set()
+    for i in pairs:
+        s, t = sharding.circuit_pair(i, n_clouds)
+        need.update((s, t))
+    return need
+
+
+def _gather(results, n_pairs):
+    import torch
+    recs = np.stack([sharding.pack_record(i, r) for i, r, _ in results]) if results else np.zeros((0, sharding.RECORD_DOUBLES))
+    dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+    table = sharding.gather_records(recs, n_pairs, device=dev)
+    return [sharding.unpack_record(r) for r in table]
+
+
+def stage1_fgr(cloud_dir: str, out_dir: str, n_clouds: int, voxel_size: float = 0.1, pattern: str = "s{i}.pcd",
+               inflight: int = 3, seed=None, verbose: bool = True) -> list:
+    """FGR over the circuit (script 1).  Returns the n relative poses; rank 0 writes them under `out_dir` with the
+    names the later stages READ (`pose_0_{n-1}.txt` for the closure) and `%.10f` (S1:177)."""
+    mine, rank = _shard(n_clouds)
+    clouds = load_circuit(cloud_dir, n_clouds, pattern, _clouds_of(mine, n_clouds))
+
+    def job(i):
+        s, t = sharding.circuit_pair(i, n_clouds)
+        if verbose:
+            print(f"Registering cloud {s} in cloud {t}")
+        return functions.script1.registro_FGR(clouds[s], clouds[t], voxel_size, seed=None if seed is None else seed + i)
+
+    table = _gather(_run_pairs(mine, job, inflight), n_clouds)
+    poses = [r["transformation"] for r in table]
+    if rank == 0 and out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+        for i, T in enumerate(poses):
+            io.write_pose(os.path.join(out_dir, io.relative_pose_name(i, n_clouds)), T, fmt="%.10f")
+    return poses
+
+
+def stage2_mgicp(cloud_dir: str, init_dir: str, out_dir: str, n_clouds: int, n_scales: int = 5, iterations: int = 100,
+                 pattern: str = "s{i}.pcd", inflight: int = 3, absolute_dir: str = None, verbose: bool = True):
+    """Multiscale GICP over the circuit from the stage-1 poses (script 2).  Returns (relative poses, absolute poses,
+    per-pair records); rank 0 writes `pose_{i+1}_{i}.txt` (+ `pose_0_{n-1}.txt`) and, if asked, `pose{i}.txt`."""
+    initial_T = io.load_relative_poses(init_dir, n_clouds)
+    mine, rank = _shard(n_clouds)
+    clouds = load_circuit(cloud_dir, n_clouds, pattern, _clouds_of(mine, n_clouds))
+
+    def job(i):
+        s, t = sharding.circuit_pair(i, n_clouds)
+        r = functions.script2.Multiscale_GICP(clouds[s], clouds[t], n_scales, iterations, initial_T[i])
+        if verbose:
+            print(f"Pair {s}->{t} RMSE: {round(r.inlier_rmse, 3)} m")
+        return r
+
+    table = _gather(_run_pairs(mine, job, inflight), n_clouds)
+    rel = [r["transformation"] for r in table]
+    ab = refinement.poses_relativas_para_absolutas(rel)
+    if rank == 0 and out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+        for i, T in enumerate(rel):
+            io.write_pose(os.path.join(out_dir, io.relative_pose_name(i, n_clouds)), T)
+        if absolute_dir:
+            os.makedirs(absolute_dir, exist_ok=True)
+            for i, T in enumerate(ab):
+                io.write_pose(os.path.join(absolute_dir, f"pose{i}.txt"), T)
+    return rel, ab, table
+
+
+def stage3_refine(rel_dir: str, n_clouds: int, out_dir: str = None, groundtruth_dir: str = None) -> dict:
+    """Host-side global refinement of the circuit (script 3, steps 8-9): absolute poses by LUM, SLERP and SLERP+LUM
+    (the script-3 variants), optionally written as `out_dir/<method>/pose{i}.txt` and compared with a ground truth."""
+    rel = io.load_relative_poses(rel_dir, n_clouds)
+    out = {
+        "plain": refinement.poses_relativas_para_absolutas(rel),
+        "LUM": refinement.script3.reconstruir_Ts_para_origem_LUM(rel),
+        "SLERP": refinement.script3.reconstruir_Ts_para_origem_SLERP(rel),
+        "SLERP_LUM": refinement.script3.reconstruir_Ts_para_origem_SLERP_LUM(rel),
+        "closure": refinement.Calcular_Erro_LoopClosure(rel),
+    }
+    if out_dir:
+        for name in ("LUM", "SLERP", "SLERP_LUM"):
+            d = os.path.join(out_dir, name)
+            os.makedirs(d, exist_ok=True)
+            for i, T in enumerate(out[name]):
+                io.write_pose(os.path.join(d, f"pose{i}.txt"), T)
+    if groundtruth_dir:
+        gt = [io.read_pose(os.path.join(groundtruth_dir, f"pose{i}.txt")) for i in range(n_clouds)]
+        out["errors"] = {name: refinement.script3.subtract_squared_poses(gt, out[name]) for name in ("plain", "LUM", "SLERP", "SLERP_LUM")}
+    return out
+
+
+def main(argv=None) -> int:
+    import argparse
+    ap = argparse.ArgumentParser(description="circuit drivers (stages 1-3 of the reference's scripts)")
+    sub = ap.add_subparsers(dest="stage", required=True)
+    a = sub.add_parser("stage1"); a.add_argument("--clouds", required=True); a.add_argument("--out", required=True)
+    a.add_argument("--n", type=int, required=True); a.add_argument("--voxel", type=float, default=0.1); a.add_argument("--inflight", type=int, default=3)
+    a.add_argument("--seed", type=int, default=None)
+    b = sub.add_parser("stage2"); b.add_argument("--clouds", required=True); b.add_argument("--init", required=True); b.add_argument("--out", required=True)
+    b.add_argument("--absolute", default=None); b.add_argument("--n", type=int, required=True); b.add_argument("--scales", type=int, default=5)
+    b.add_argument("--iterations", type=int, default=100); b.add_argument("--inflight", type=int, default=3)
+    c = sub.add_parser("stage3"); c.add_argument("--relative", required=True); c.add_argument("--n", type=int, required=True)
+    c.add_argument("--out", default=None); c.add_argument("--groundtruth", default=None)
+    args = ap.parse_args(argv)
+    if args.stage in ("stage1", "stage2") and "RANK" in os.environ:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
+    if args.stage == "stage1":
+        stage1_fgr(args.clouds, args.out, args.n, args.voxel, inflight=args.inflight, seed=args.seed)
+    elif args.stage == "stage2":
+        stage2_mgicp(args.clouds, args.init, args.out, args.n, args.scales, args.iterations, inflight=args.inflight, absolute_dir=args.absolute)
+    else:
+        r = stage3_refine(args.relative, args.n, args.out, args.groundtruth)
+        print("closure error [R | t]:\n", r["closure"])
+    return 0

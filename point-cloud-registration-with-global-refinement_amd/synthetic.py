@@ -185,8 +185,35 @@ def perturbation(rng, ang_deg=0.5, dist=0.15):
     return T
 
 
-def make_pair(n_points: int = 200_000, seed: int = SEED, index: int = 0, n_scales: int = 3) -> SyntheticPair:
-    """Config 2 (n_points=200k, 3 scales) / config 5 (2M, 5 scales). ``index`` selects the pair of a stream."""
+def _scales(n_scales: int):
+    if n_scales == 3:
+        vox = [0.4, 0.2, 0.1]            # ALL_FUNCTIONS.py:260-264,274-275
+        dst = [3 * 0.4, 2 * 0.2, 0.1]    # 2_MGICP...py:115
+    else:
+        vox = [0.1 + 0.1 * i for i in range(n_scales)][::-1]
+        dst = {4: [3, 2.5, 2, 1], 5: [3, 2.5, 2, 1.5, 1]}[n_scales]
+        dst = [a * b for a, b in zip(dst, vox)]
+    return vox, dst
+
+
+def make_pair(n_points: int = 200_000, seed: int = SEED, index: int = 0, n_scales: int = 3, cache_dir: str = None) -> SyntheticPair:
+    """Config 2 (n_points=200k, 3 scales) / config 5 (2M, 5 scales). ``index`` selects the pair of a stream.
+    The sampler is deterministic but slow (rejection sampling, ~20 s per 200k pair on one core), so the clouds are
+    cached as .npz under ``cache_dir`` (default: $PCR_SYNTH_CACHE, else `<repo>/.synth_cache` if that directory exists, else
+    the system temp dir); the cache holds exactly what
+    the generator returns."""
+    import os
+    import tempfile
+    vox, dst = _scales(n_scales)
+    repo_cache = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".synth_cache")
+    cache_dir = cache_dir or os.environ.get("PCR_SYNTH_CACHE") or (repo_cache if os.path.isdir(repo_cache) else os.path.join(tempfile.gettempdir(), "pcr_synth_cache"))
+    path = os.path.join(cache_dir, f"pair_v1_{n_points}_{seed}_{index}.npz")
+    if os.path.exists(path):
+        try:
+            d = np.load(path)
+            return SyntheticPair(d["source"], d["target"], d["T_true"], d["T_init"], vox, dst)
+        except Exception:
+            pass
     half = 117.5 * np.sqrt(n_points / 200_000.0)
     scene = Scene(seed, half_extent=half)
     rng = np.random.default_rng([seed, 1000 + index])
@@ -196,11 +223,26 @@ def make_pair(n_points: int = 200_000, seed: int = SEED, index: int = 0, n_scale
     Ti = np.linalg.inv(T_true)
     source = (moved.astype(np.float64) @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32)
     T_init = perturbation(rng) @ T_true
-    if n_scales == 3:
-        vox = [0.4, 0.2, 0.1]            # ALL_FUNCTIONS.py:260-264,274-275
-        dst = [3 * 0.4, 2 * 0.2, 0.1]    # 2_MGICP...py:115
-    else:
-        vox = [0.1 + 0.1 * i for i in range(n_scales)][::-1]
-        dst = {4: [3, 2.5, 2, 1], 5: [3, 2.5, 2, 1.5, 1]}[n_scales]
-        dst = [a * b for a, b in zip(dst, vox)]
+    try:
+        os.makedirs(cache_dir, exist_ok=True)
+        tmp = path + f".{os.getpid()}.tmp.npz"
+        np.savez(tmp, source=source, target=target, T_true=T_true, T_init=T_init)
+        os.replace(tmp, path)
+    except OSError:
+        pass
     return SyntheticPair(source, target, T_true, T_init, vox, dst)
+
+
+def tile_pair(p: SyntheticPair, copies: int, pitch: float = 260.0, n_scales: int = None) -> SyntheticPair:
+    """A `copies`-times larger pair in about a second: the block is repeated on a square lattice of `pitch` metres (larger
+    than the block, so tiles do not touch) and the SAME planted motion relates the two big clouds.  Point spacing, and so
+    every per-scale retention ratio, stays that of the base pair -- the cheap stand-in for config 5's larger scene."""
+    side = int(np.ceil(np.sqrt(copies)))
+    offs = np.array([[(i % side) - (side - 1) / 2.0, (i // side) - (side - 1) / 2.0, 0.0] for i in range(copies)]) * pitch
+    moved = p.source.astype(np.float64) @ p.T_true[:3, :3].T + p.T_true[:3, 3]                 # source in the target frame
+    tgt = np.concatenate([p.target.astype(np.float64) + o for o in offs])
+    mov = np.concatenate([moved + o for o in offs])
+    Ti = np.linalg.inv(p.T_true)
+    src = mov @ Ti[:3, :3].T + Ti[:3, 3]
+    vox, dst = (p.voxel_sizes, p.max_distances_script) if n_scales is None else _scales(n_scales)
+    return SyntheticPair(src.astype(np.float32), tgt.astype(np.float32), p.T_true, p.T_init, vox, dst)

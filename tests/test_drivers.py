@@ -1,0 +1,63 @@
+"""Circuit drivers: script-equivalent stages over files in the reference's on-disk formats."""
+import os
+
+import numpy as np
+import pytest
+
+import pcr_amd
+from conftest import GOLDEN, pose_error
+
+H = np.load(os.path.join(GOLDEN, "host_pose_algebra.npz"))
+
+
+def test_stage3_on_shipped_facade_circuit(tmp_path):
+    rel = list(H["Facade_relative"]); n = len(rel)
+    d = tmp_path / "relative"; d.mkdir()
+    for i, T in enumerate(rel):
+        pcr_amd.io.write_pose(str(d / pcr_amd.io.relative_pose_name(i, n)), T)
+    assert (d / f"pose_0_{n - 1}.txt").exists() and (d / "pose_1_0.txt").exists()       # closure under the name stage 2/3 read
+    out = pcr_amd.drivers.stage3_refine(str(d), n, out_dir=str(tmp_path / "abs"))
+    np.testing.assert_allclose(np.stack(out["LUM"]), H["Facade_lum"], atol=1e-9)          # reference's own LUM (unit weights)
+    np.testing.assert_allclose(np.stack(out["plain"]), H["Facade_absolute"], atol=1e-12)
+    np.testing.assert_allclose(out["closure"], H["Facade_closure"], atol=1e-12)
+    for name in ("LUM", "SLERP", "SLERP_LUM"):
+        back = [pcr_amd.io.read_pose(str(tmp_path / "abs" / name / f"pose{i}.txt")) for i in range(n)]
+        np.testing.assert_allclose(np.stack(back), np.stack(out[name]), atol=1e-15)
+    # ground-truth comparison path (script 3, step 9) against the plain composition written as "ground truth"
+    gt = tmp_path / "gt"; gt.mkdir()
+    for i, T in enumerate(out["plain"]):
+        pcr_amd.io.write_pose(str(gt / f"pose{i}.txt"), T)
+    err = pcr_amd.drivers.stage3_refine(str(d), n, groundtruth_dir=str(gt))["errors"]
+    assert max(err["plain"][0]) < 1e-12 and max(err["plain"][1]) < 1e-12 and max(err["SLERP_LUM"][1]) > 1e-4
+
+
+def test_cli_stage3(tmp_path, capsys):
+    rel = list(H["Courtyard_relative"]); n = len(rel)
+    for i, T in enumerate(rel):
+        pcr_amd.io.write_pose(str(tmp_path / pcr_amd.io.relative_pose_name(i, n)), T)
+    assert pcr_amd.drivers.main(["stage3", "--relative", str(tmp_path), "--n", str(n), "--out", str(tmp_path / "o")]) == 0
+    assert "closure error" in capsys.readouterr().out
+    assert (tmp_path / "o" / "SLERP_LUM" / f"pose{n - 1}.txt").exists()
+
+
+@pytest.mark.gpu
+def test_stage1_stage2_on_a_two_cloud_circuit(tmp_path):
+    """Clouds s0 (target) and s1 (source) of golden pair 10 as a circuit of two: pair 0 = s1 -> s0, pair 1 closes the
+    loop (s0 -> s1).  Stage 1 writes %.10f FGR poses under the names stage 2 reads; stage 2 refines them."""
+    g = np.load(os.path.join(GOLDEN, "nclt_pair_010.npz"))
+    clouds = tmp_path / "clouds"; clouds.mkdir()
+    pcr_amd.io.write_pcd_xyz(str(clouds / "s0.pcd"), g["target"]); pcr_amd.io.write_pcd_xyz(str(clouds / "s1.pcd"), g["source"])
+    fgr = pcr_amd.drivers.stage1_fgr(str(clouds), str(tmp_path / "fgr"), 2, voxel_size=0.1, inflight=2, seed=2024, verbose=False)
+    assert sorted(os.listdir(tmp_path / "fgr")) == ["pose_0_1.txt", "pose_1_0.txt"]
+    a, d = pose_error(fgr[0], g["T_fgr"]); assert a < 2e-2 and d < 0.4, (a, d)
+    txt = open(tmp_path / "fgr" / "pose_1_0.txt").read().split()
+    assert all(len(v.split(".")[1]) == 10 for v in txt)                                   # S1:177 fmt="%.10f"
+    rel, ab, table = pcr_amd.drivers.stage2_mgicp(str(clouds), str(tmp_path / "fgr"), str(tmp_path / "gicp"), 2, n_scales=5, iterations=100,
+                                                  inflight=2, absolute_dir=str(tmp_path / "abs"), verbose=False)
+    a, d = pose_error(rel[0], g["T_gicp"]); assert a < 3e-4 and d < 3e-3, (a, d)
+    a, d = pose_error(rel[1], np.linalg.inv(g["T_gicp"])); assert a < 2e-3 and d < 2e-2, (a, d)     # the way back
+    assert [r["pair"] for r in table] == [0, 1] and all(r["fitness"] > 0.3 for r in table)
+    assert np.allclose(ab[0], np.eye(4)) and np.allclose(ab[1], rel[0])
+    assert sorted(os.listdir(tmp_path / "abs")) == ["pose0.txt", "pose1.txt"]
+    back = pcr_amd.io.load_relative_poses(str(tmp_path / "gicp"), 2)
+    np.testing.assert_allclose(np.stack(back), np.stack(rel), atol=1e-15)
