@@ -264,3 +264,8 @@ def registration_fgr_based_on_feature_matching(source: PointCloud, target: Point
                                            _ptr(target.device_xyz()), _ptr(target_feature._dev), C.c_int64(nt), C.byref(o),
                                            C.byref(res), _ptr(corr)), "registration_fgr_based_on_feature_matching")
     return _result(res, corr)
+
+
+# pose-graph slice of o3d.pipelines.registration (3_Global_Optimizations...py:292-358; host side, posegraph.py)
+from .posegraph import (GlobalOptimizationConvergenceCriteria, GlobalOptimizationLevenbergMarquardt,  # noqa: E402,F401
+                        GlobalOptimizationOption, PoseGraph, PoseGraphEdge, PoseGraphNode, global_optimization)
