@@ -58,7 +58,13 @@ def main():
     ctypes = __import__("ctypes")
 
     # ---- synthetic workload (same seeds on every rank; every rank registers its own copy: weak scaling)
-    pairs = [syn.make_pair(args.points, index=i) for i in range(args.pairs)]
+    if args.points < 200_000:       # diagnostic sizes: a random subset of the 200k pair (the generator needs a full-size scene)
+        import dataclasses
+        base = [syn.make_pair(200_000, index=i) for i in range(args.pairs)]
+        sub = np.random.default_rng(7).permutation(200_000)[: args.points]
+        pairs = [dataclasses.replace(b, source=b.source[sub], target=b.target[sub]) for b in base]
+    else:
+        pairs = [syn.make_pair(args.points, index=i) for i in range(args.pairs)]
     clouds = [(P.PointCloud(p.source), P.PointCloud(p.target)) for p in pairs]       # resident in HBM before timing
     est = P.registration.TransformationEstimationForGeneralizedICP(P.registration.L1Loss())
     crit = P.registration.ICPConvergenceCriteria(relative_fitness=1e-6, relative_rmse=1e-6, max_iteration=100)

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include "pcr_octree.h"
 
 #define ICP_BS 256
@@ -41,6 +42,9 @@ struct IcpArgs {
     const float *src_cov6, *tgt_cov6;            // optional raw covariances (xx,xy,xz,yy,yz,zz), Morton order
     const float4 *tgt_pts, *tgt_nrm; OctView tgt; const int *nt_ptr;
     int32_t *match; int src_cap;
+    float4 *ref; int32_t *rbest;                 // per source point: position and margin / nearest point of its last search (skip certificate)
+    float r2s, rs_minus_r;                       // search cap (r + g)^2 of the certificate mode and g = the unmatched margin
+    int verify;                                  // diagnostics (PCR_ICP_VERIFY): search certified queries too and report disagreements
     IcpState *state;
     double *partials;
     double max_dist2; float r2f;
@@ -67,12 +71,14 @@ __global__ void k_icp_init(IcpState *st, IcpInit in) {
 // Returns the best index within r2cap (or -1) and, through start_pt, a point of the start leaf (next launch's hint).
 template <int OPB>
 __device__ static inline int oct_nn_query(const OctView &t, const OctMeta &m, OctStack<OPB> &stk, bool live, float qx, float qy, float qz,
-                                          float r2cap, int hint, int ol, int oct, int ob, int *start_pt, int *visits) {
-    int best = -1; float bestd = r2cap;
+                                          float r2cap, int hint, int ol, int oct, int ob, int *start_pt, int *visits, float *d1_out, float *d2_out) {
+    // The walk keeps the TWO smallest squared distances (both capped at r2cap) and prunes with the second: the gap between
+    // them is the certificate that lets later launches skip this query while it has moved by less than half the gap.
+    int best = -1; float bestd = r2cap, secd = r2cap;
     const bool active = live && m.nl >= 1;
     auto visit = [&](int first, int count) {                 // wave-wide; count == 0: octet idle
         int base = first; const int end = first + count;
-        float d = 3.4e38f; int id = -1;                       // lane-local best over all steps (4 loads in flight per step)
+        float d = 3.4e38f, dd = 3.4e38f; int id = -1;         // lane-local best / second over all steps (4 loads in flight per step)
         while (__ballot(base < end) != 0ull) {
             float4 p[4];
 #pragma unroll
@@ -81,15 +87,23 @@ __device__ static inline int oct_nn_query(const OctView &t, const OctMeta &m, Oc
             for (int u = 0; u < 4; u++) {
                 const int idx = base + OCT * u + ol;
                 const float du = pcr_d2(p[u].x - qx, p[u].y - qy, p[u].z - qz);
-                if (idx < end && du < d) { d = du; id = idx; }      // increasing idx: ties keep the lower index
+                if (idx < end) {
+                    if (du < d) { dd = d; d = du; id = idx; }        // increasing idx: ties keep the lower index
+                    else dd = fminf(dd, du);
+                }
             }
             base += 4 * OCT;
         }
-        // octet arg-min (ties -> lower index) without the LDS crossbar: min distance, then min index among its holders
+        // octet arg-min (ties -> lower index) without the LDS crossbar: min distance, then min index among its holders;
+        // the runner-up is the smallest of the winner lane's second and the other lanes' best
         const float dmin = pcr_octet_min(d);
         int cand = (d == dmin && id >= 0) ? id : 0x7fffffff;
         cand = min(cand, pcr_dpp_i<PCR_DPP_XOR1>(cand)); cand = min(cand, pcr_dpp_i<PCR_DPP_XOR2>(cand)); cand = min(cand, pcr_dpp_i<PCR_DPP_HMIRROR>(cand));
-        if (cand != 0x7fffffff && (dmin < bestd || (dmin == bestd && (unsigned)cand < (unsigned)best))) { bestd = dmin; best = cand; }
+        const float sec = pcr_octet_min(id == cand ? dd : d);
+        if (cand != 0x7fffffff) {
+            if (dmin < bestd || (dmin == bestd && (unsigned)cand < (unsigned)best)) { secd = fminf(fminf(secd, bestd), sec); bestd = dmin; best = cand; }
+            else secd = fminf(secd, dmin);
+        }
     };
     int node = 0, node_li = 0;
     const bool warm = active && hint >= 0;
@@ -98,12 +112,9 @@ __device__ static inline int oct_nn_query(const OctView &t, const OctMeta &m, Oc
         // one hop: the hint point and the record of the level-1 node around it ("fat leaf"); next hop (issued here,
         // consumed after the scan of the node's points): the node's up-link and key
         const int4 pi = t.pinfo[hint];
-        const float4 c = t.pts[hint];
         node = pi.x; s_first = pi.y; s_count = pi.z; node_li = pi.w;
         const int4 u = t.up[m.off[node_li] + node]; s_key = t.keys[pi.y];
         s_parent = u.x; s_sib = u.y; s_nsib = u.z;
-        const float d = pcr_d2(c.x - qx, c.y - qy, c.z - qz);
-        if (d < bestd) { bestd = d; best = hint; }
     }
     const bool cold = active && !warm;
     if (__ballot(cold) != 0ull) {
@@ -117,8 +128,9 @@ __device__ static inline int oct_nn_query(const OctView &t, const OctMeta &m, Oc
         }
     }
     if (active) *start_pt = s_first;
-    oct_search<OPB>(t, m, stk, active, node, node_li, s_first, s_count, s_key, s_parent, s_sib, s_nsib, qx, qy, qz, [&]() { return bestd; }, visit,
+    oct_search<OPB>(t, m, stk, active, node, node_li, s_first, s_count, s_key, s_parent, s_sib, s_nsib, qx, qy, qz, [&]() { return secd; }, visit,
                     [](int, int) { return false; }, ol, oct, ob, visits);
+    *d1_out = bestd; *d2_out = secd;
     return best;
 }
 
@@ -260,6 +272,8 @@ __global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 
     const int ic = i < a.src_cap ? i : 0;
     const float4 pf = a.src_pts[ic];
     const int mraw = a.match[ic];
+    const float4 refv = a.ref ? a.ref[ic] : make_float4(0, 0, 0, 0);
+    const int rb = a.rbest ? a.rbest[ic] : -1;
     double T[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) T[k] = st->T[k];
@@ -269,10 +283,15 @@ __global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 
     if ((int)blockIdx.x * OPB >= ns) return;
     const unsigned long long t_wave0 = wall_clock64();
     if (blockIdx.x == 0 && threadIdx.x == 0) st->t_start = t_wave0;
+    __shared__ float4 rec_q[OPB];          // compacted work list of the workgroup: queries that really need a search
+    __shared__ int rec_i[OPB];
+    __shared__ int rec_c[OPB];             // diagnostics: certified claim of the record (-2: none)
+    __shared__ int n_rec;
     if (threadIdx.x < (int)(sizeof(OctMeta) / 4)) ((int *)&m)[threadIdx.x] = mword;
+    if (threadIdx.x == 0) n_rec = 0;
     __syncthreads();
-    const bool live = i < ns && nt > 0;
     float qx = 0, qy = 0, qz = 0; int hint = -1;
+    bool need = false, cert_flag = false;
     if (i < ns) {
         const double px = pf.x, py = pf.y, pz = pf.z;
         qx = (float)(T[0] * px + T[1] * py + T[2] * pz + T[3]);
@@ -281,10 +300,49 @@ __global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 
         // match[] carries the warm-start hint across launches: >= 0 matched target point, <= -2 -> start point -(v+2)
         const int mv = launches > 0 ? mraw : -1;
         hint = mv >= 0 ? mv : (mv <= -2 ? -(mv + 2) : -1);
+        // Certificate of the last search of this query: nearest target point rb at distance d1, every other one at >= d2,
+        // margin = (d2 - d1)/2 - slack.  While the query has moved by less than the margin since then, rb is still its
+        // unique nearest point (triangle inequality) and no search is needed; k_icp_iter re-tests the radius in float64.
+        const float ex = qx - refv.x, ey = qy - refv.y, ez = qz - refv.z;
+        const bool certified = launches > 0 && a.ref && !a.dbg_visits && refv.w > 0.0f && pcr_d2(ex, ey, ez) < refv.w * refv.w;
+        need = nt > 0 && (!certified || a.verify);
+        cert_flag = certified;
+        if (certified && ol == 0 && rb >= 0 && mraw != rb) a.match[i] = rb;     // k_icp_iter may have turned it into a hint (beyond max_dist)
     }
-    int visits = 0, start_pt = 0;
-    const int best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.r2f, hint, ol, oct, ob, &start_pt, a.dbg_visits ? &visits : nullptr);
-    if (ol == 0 && i < ns) a.match[i] = a.dbg_visits ? visits : (best >= 0 ? best : -(start_pt + 2));
+    // ---- compact the workgroup's pending queries to the front: wavefronts left without work retire at once
+    {
+        const unsigned long long nb = __ballot(need && ol == 0);
+        int base = 0;
+        if (lane == 0 && nb != 0ull) base = atomicAdd(&n_rec, __builtin_popcountll(nb));
+        base = __shfl(base, 0, 64);
+        if (need && ol == 0) {
+            const int slot = base + __builtin_popcountll(nb & ((1ull << lane) - 1ull));
+            rec_q[slot] = make_float4(qx, qy, qz, __int_as_float(hint)); rec_i[slot] = i; rec_c[slot] = cert_flag ? (rb >= 0 ? rb : -1) : -2;
+        }
+    }
+    __syncthreads();
+    const bool live = ob < n_rec;
+    if (__ballot(live) == 0ull) return;
+    int qi = 0;
+    if (live) { const float4 r = rec_q[ob]; qx = r.x; qy = r.y; qz = r.z; hint = __float_as_int(r.w); qi = rec_i[ob]; }
+    int visits = 0, start_pt = 0; float d1 = 0, d2 = 0;
+    const int best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.ref ? a.r2s : a.r2f, hint, ol, oct, ob, &start_pt, a.dbg_visits ? &visits : nullptr, &d1, &d2);
+    if (a.verify && ol == 0 && live && rec_c[ob] != -2) {
+        const int claim = rec_c[ob];
+        const bool bad = claim >= 0 ? best != claim : (best >= 0 && d1 < a.r2f);
+        if (bad) printf("certificate violated: launch %d query %d claim %d found %d d1 %.6f d2 %.6f ref margin %.6f moved %.6f\n", launches, qi, claim, best, sqrtf(d1), sqrtf(d2),
+                        a.ref[qi].w, sqrtf(pcr_d2(qx - a.ref[qi].x, qy - a.ref[qi].y, qz - a.ref[qi].z)));
+    }
+    if (ol == 0 && live) {
+        a.match[qi] = a.dbg_visits ? visits : (best >= 0 ? best : -(start_pt + 2));
+        if (a.ref) {
+            const float slack = 2e-5f + 1e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz));
+            // nothing within the (enlarged) search cap: still nothing within max_dist while the query moves by less than the gap
+            const float margin = best >= 0 ? 0.5f * (sqrtf(d2) - sqrtf(d1)) - slack : a.rs_minus_r - slack;
+            a.ref[qi] = make_float4(qx, qy, qz, margin > 0.0f ? margin : 0.0f);
+            a.rbest[qi] = best;
+        }
+    }
     if (a.stamps_nn && lane == 0 && launches < ICP_STAMP_LAUNCHES) {
         unsigned long long *w = a.stamps_nn + 2 * ((size_t)launches * gridDim.x * (ICP_BS / 64) + (size_t)blockIdx.x * (ICP_BS / 64) + (threadIdx.x >> 6));
         w[0] = t_wave0; w[1] = wall_clock64();
@@ -549,13 +607,18 @@ static void fill_args(IcpArgs &a, const DevCloud *src, const DevCloud *tgt, doub
     a.tgt.pts = tgt->pts; a.tgt.nodes = tgt->oct_nodes; a.tgt.up = tgt->oct_up; a.tgt.meta = tgt->oct_meta; a.tgt.leaf_of = tgt->leaf_of; a.tgt.keys = tgt->keys; a.tgt.pinfo = tgt->pinfo;
     a.match = match; a.src_cap = src->cap > 0 ? src->cap : 1; a.state = st; a.partials = partials;
     a.max_dist2 = max_dist * max_dist;
-    const double r2w = a.max_dist2 * (1.0 + 1e-6);
+    // The float32 search works on float32-rounded query positions (ulp 8e-6 m at 100 m), the radius itself is tested in
+    // float64 by k_icp_iter on the unrounded position: the search cap is widened by more than that rounding so that the
+    // float64 test alone decides (a cap of exactly r dropped ~1 in 1e5 borderline matches the oracle keeps).
+    const double rw = max_dist * (1.0 + 1e-4) + 3e-4;
+    const double r2w = max_dist < 1e18 ? rw * rw : 1e300;
     a.r2f = r2w < 3.0e38 ? (float)r2w : 3.0e38f;
     a.loss = p ? p->loss : 0; a.loss_k = p ? p->loss_k : 1.0; a.a = 1.0 - (p ? p->epsilon : 1e-3);
     a.rel_fit = p ? p->relative_fitness : 1e-6; a.rel_rmse = p ? p->relative_rmse : 1e-6; a.max_it = p ? p->max_iteration : 30;
     a.single = single;
     a.dbg_visits = (single && getenv("PCR_DEBUG_VISITS")) ? 1 : 0;
     a.stamps_nn = nullptr; a.stamps_it = nullptr;
+    a.ref = nullptr; a.rbest = nullptr;
 }
 
 static int read_state(pcr_context *ctx, const IcpState *st_dev, IcpState *host) {
@@ -584,7 +647,19 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     double *partials = arena<double>(ctx, (size_t)nbmax * NVP);
     int32_t *match = match_dev ? match_dev : arena<int32_t>(ctx, cap);
     if (!st || !partials || !match) return PCR_ENOMEM;
-    IcpArgs a; fill_args(a, src, tgt, max_dist, p, match, st, partials, 0);
+    IcpArgs a; memset(&a, 0, sizeof a); fill_args(a, src, tgt, max_dist, p, match, st, partials, 0);
+    static const bool use_skip = !(getenv("PCR_ICP_SKIP") && atoi(getenv("PCR_ICP_SKIP")) == 0);
+    if (use_skip && max_dist < 1e15) {
+        a.ref = arena<float4>(ctx, cap); a.rbest = arena<int32_t>(ctx, cap);
+        if (!a.ref || !a.rbest) return PCR_ENOMEM;
+        // certificate mode searches a slightly larger ball (r + g): a query with nothing inside it stays unmatched, without
+        // a search, until it has moved by g; candidates between r and r + g are rejected by k_icp_iter's float64 radius test
+        static const double gfrac = getenv("PCR_ICP_GAP") ? atof(getenv("PCR_ICP_GAP")) : 0.25;
+        double g = gfrac * max_dist; g = g < 0.01 ? 0.01 : (g > 0.05 ? 0.05 : g);
+        const double rs = max_dist + g;
+        a.r2s = (float)(rs * rs * (1.0 + 1e-6)); a.rs_minus_r = (float)g;
+        a.verify = getenv("PCR_ICP_VERIFY") ? 1 : 0;
+    }
     IcpInit in; memcpy(in.T, T0, sizeof in.T);
     hipLaunchKernelGGL(k_icp_init, dim3(1), dim3(64), 0, ctx->stream, st, in);
     const char *stamp_path = getenv("PCR_ICP_STAMPS");          // diagnostics only
@@ -597,6 +672,31 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     // Launch in chunks; the state of chunk c is copied back while chunk c+1 is already queued, so the GPU never
     // idles on the host.  Launches after 'done' return at their first instruction.
     const int total = a.max_it + 1, CHUNK = 8;
+    // One chunk = CHUNK x (k_icp_nn, k_icp_iter) replayed as ONE hipGraph launch: the loop is launch-bound (a 3000-point
+    // pair still takes 5 ms), and a graph costs one runtime call instead of 16.  The arena hands out the same addresses
+    // for the same problem sizes, so the instantiated graph is cached in the context under its argument bytes.
+    static const bool use_graph = !(getenv("PCR_ICP_GRAPH") && atoi(getenv("PCR_ICP_GRAPH")) == 0);
+    hipGraphExec_t chunk_exec = nullptr;
+    if (use_graph && !stamp_path) {
+        std::string key((const char *)&a, sizeof a);
+        const int extra[3] = {nbnn, nbmax, use_cov ? 1 : 0};
+        key.append((const char *)extra, sizeof extra);
+        for (auto &g : ctx->icp_graphs) if (g.first == key) { chunk_exec = g.second; break; }
+        if (!chunk_exec) {
+            hipGraph_t graph = nullptr;
+            PCR_HIP_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            for (int k = 0; k < CHUNK; k++) {
+                hipLaunchKernelGGL(k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
+                if (use_cov) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP_COV>), dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP>), dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
+            }
+            PCR_HIP_CHECK(ctx, hipStreamEndCapture(ctx->stream, &graph));
+            PCR_HIP_CHECK(ctx, hipGraphInstantiate(&chunk_exec, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+            if (ctx->icp_graphs.size() >= 16) { (void)hipGraphExecDestroy(ctx->icp_graphs.front().second); ctx->icp_graphs.erase(ctx->icp_graphs.begin()); }
+            ctx->icp_graphs.emplace_back(std::move(key), chunk_exec);
+        }
+    }
     IcpState *slots = (IcpState *)ctx->pinned;      // two read-back slots
     int launched = 0, cur = 0, prev = -1, n_chunks = 0;
     IcpState fin; bool have = false;
@@ -608,7 +708,8 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
                 while ((int)ctx->prof_events.size() < 2 * (n_chunks + 1)) { hipEvent_t e; PCR_HIP_CHECK(ctx, hipEventCreate(&e)); ctx->prof_events.push_back(e); }
                 PCR_HIP_CHECK(ctx, hipEventRecord(ctx->prof_events[2 * n_chunks], ctx->stream));
             }
-            for (int k = 0; k < c; k++) {
+            if (chunk_exec && c == CHUNK) PCR_HIP_CHECK(ctx, hipGraphLaunch(chunk_exec, ctx->stream));
+            else for (int k = 0; k < c; k++) {
                 hipLaunchKernelGGL(k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
                 if (use_cov) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP_COV>), dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
                 else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP>), dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
@@ -671,7 +772,7 @@ int pcr_dev_linearize_once(pcr_context *ctx, const DevCloud *src, const DevCloud
     double *partials = arena<double>(ctx, (size_t)nbmax * NVP);
     int32_t *match = match_dev ? match_dev : arena<int32_t>(ctx, cap);
     if (!st || !partials || !match) return PCR_ENOMEM;
-    IcpArgs a; fill_args(a, src, tgt, max_dist, p, match, st, partials, 1);
+    IcpArgs a; memset(&a, 0, sizeof a); fill_args(a, src, tgt, max_dist, p, match, st, partials, 1);
     IcpInit in; memcpy(in.T, T, sizeof in.T);
     hipLaunchKernelGGL(k_icp_init, dim3(1), dim3(64), 0, ctx->stream, st, in);
     hipLaunchKernelGGL(k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
@@ -696,7 +797,7 @@ int pcr_dev_evaluate(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt,
     double *partials = arena<double>(ctx, (size_t)nbmax * NVP);
     int32_t *match = match_dev ? match_dev : arena<int32_t>(ctx, cap);
     if (!st || !partials || !match) return PCR_ENOMEM;
-    IcpArgs a; fill_args(a, src, tgt, max_dist, nullptr, match, st, partials, 1);
+    IcpArgs a; memset(&a, 0, sizeof a); fill_args(a, src, tgt, max_dist, nullptr, match, st, partials, 1);
     IcpInit in; memcpy(in.T, T, sizeof in.T);
     hipLaunchKernelGGL(k_icp_init, dim3(1), dim3(64), 0, ctx->stream, st, in);
     hipLaunchKernelGGL(k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);

@@ -26,6 +26,7 @@ struct pcr_context {
     int profiling = 0;             // bench instrumentation (pcr_profile_*)
     double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<hipEvent_t> prof_events;
+    std::vector<std::pair<std::string, hipGraphExec_t>> icp_graphs;   // captured launch chunks of the GICP loop, keyed by their arguments
     std::string err;
 };
 

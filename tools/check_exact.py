@@ -1,0 +1,23 @@
+"""Diagnostic: are the correspondences of the LAST GICP launch (warm-started / certified) the exact nearest neighbours?
+Compares them with a cold evaluate_registration at the returned pose."""
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+P = importlib.import_module("point-cloud-registration-with-global-refinement_amd")
+syn = importlib.import_module("point-cloud-registration-with-global-refinement_amd.synthetic")
+reg = P.registration
+p = syn.make_pair(200000, index=int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+est = reg.TransformationEstimationForGeneralizedICP(reg.L1Loss()); crit = reg.ICPConvergenceCriteria(1e-6, 1e-6, 100)
+r01 = reg.multiscale_gicp(P.PointCloud(p.source), P.PointCloud(p.target), p.voxel_sizes[:2], p.max_distances_script[:2], p.T_init, estimation_method=est, criteria=crit)
+cl = []
+for c in (p.source, p.target):
+    pc = P.PointCloud(c).voxel_down_sample(0.1); pc, _ = pc.remove_statistical_outlier(30, 1.0); pc.estimate_normals(P.KDTreeSearchParamKNN(20)); cl.append(pc)
+for maxit in (1, 2, 3, 5, 8, 100):
+    r = reg.registration_generalized_icp(cl[0], cl[1], 0.1, r01.transformation, est, reg.ICPConvergenceCriteria(1e-6, 1e-6, maxit))
+    ev = reg.evaluate_registration(cl[0], cl[1], 0.1, r.transformation)
+    a = {tuple(x) for x in np.asarray(r.correspondence_set)}; b = {tuple(x) for x in np.asarray(ev.correspondence_set)}
+    print(f"max_it {maxit}: iterations {getattr(r, 'iterations', '?')} warm/cert set {len(a)} cold set {len(b)} only-warm {len(a - b)} only-cold {len(b - a)} fitness {r.fitness:.6f} vs {ev.fitness:.6f}")
+    if a != b:
+        da = sorted(a - b)[:5]; db = sorted(b - a)[:5]
+        print("   examples only-warm", da, "only-cold", db)
