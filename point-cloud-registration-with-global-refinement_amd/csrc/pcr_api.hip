@@ -23,7 +23,7 @@ extern "C" int pcr_create(int device, pcr_context **out) {
     // 180 pairs/s with three pairs in flight).
     for (int i = 0; i < 2; i++)
         if (hipEventCreateWithFlags(&ctx->side_ev[i], hipEventDisableTiming) != hipSuccess) { delete ctx; return PCR_EHIP; }
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 8; i++)
         if (hipEventCreateWithFlags(&ctx->lane_ev[i], hipEventDisableTiming) != hipSuccess) { delete ctx; return PCR_EHIP; }
     ctx->pinned_cap = 1 << 16;
     if (hipHostMalloc((void **)&ctx->pinned, ctx->pinned_cap, hipHostMallocDefault) != hipSuccess) { delete ctx; return PCR_EHIP; }
@@ -46,7 +46,7 @@ extern "C" int pcr_destroy(pcr_context *ctx) {
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
     if (ctx->side_stream2) { (void)hipStreamSynchronize(ctx->side_stream2); (void)hipStreamDestroy(ctx->side_stream2); }
     for (int i = 0; i < 2; i++) if (ctx->side_ev[i]) (void)hipEventDestroy(ctx->side_ev[i]);
-    for (int i = 0; i < 4; i++) if (ctx->lane_ev[i]) (void)hipEventDestroy(ctx->lane_ev[i]);
+    for (int i = 0; i < 8; i++) if (ctx->lane_ev[i]) (void)hipEventDestroy(ctx->lane_ev[i]);
     delete ctx;
     return PCR_OK;
 }
@@ -408,19 +408,22 @@ extern "C" int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const
     }
     if (sor_k < 1 || !(sor_std > 0.0) || normal_k < 1) { ctx->err = "nb_neighbors < 1, std_ratio <= 0 or knn < 1"; return PCR_EINVAL; }
     const size_t blk_s = 2 * pcr_scratch_bytes_for(n_src), blk_t = 2 * pcr_scratch_bytes_for(n_tgt);
-    PCR_TRY(pcr_arena_reserve(ctx, 2 * (blk_s + blk_t) + pcr_scratch_bytes_for(n_src)));
+    static const int ahead_env = getenv("PCR_PIPELINE") ? atoi(getenv("PCR_PIPELINE")) : 3;
+    constexpr int MAX_RING = 4;
+    const int ring = ahead_env < 1 ? 1 : (ahead_env > MAX_RING ? MAX_RING : ahead_env);      // scales prepared ahead (+ the one in use)
+    PCR_TRY(pcr_arena_reserve(ctx, (size_t)ring * (blk_s + blk_t) + pcr_scratch_bytes_for(n_src)));
     double bs[6], bt[6];
     PCR_TRY(pcr_dev_bounds(ctx, src_xyz, n_src, bs));
     PCR_TRY(pcr_dev_bounds(ctx, tgt_xyz, n_tgt, bt));
     double T[16];
     memcpy(T, init_T, sizeof T);
-    // Preprocessing never depends on the pose, so it runs one scale AHEAD of the GICP loop, each cloud on its own lane
-    // (stream + private block of the arena): the many small latency-bound launches of scale s+1 (sort passes, octree
-    // levels, scans) and its VALU-heavy k-NN kernels fill the machine while the latency-bound iterations of scale s run
-    // on the caller's stream.  Blocks form a ring of two scales; a block is recycled only after the GICP of its scale
-    // has been waited for on the host.
-    char *blocks[2][2];
-    for (int r = 0; r < 2; r++) {
+    // Preprocessing never depends on the pose, so it runs AHEAD of the GICP loop, each cloud on its own lane (stream +
+    // private block of the arena): the many small latency-bound launches of the coming scales (sort passes, octree
+    // levels, scans) and their VALU-heavy k-NN kernels fill the machine while the latency-bound iterations of scale s
+    // run on the caller's stream.  Blocks form a ring of `ring` scales; a block is recycled only after the GICP of its
+    // scale has been waited for on the host.
+    char *blocks[MAX_RING][2];
+    for (int r = 0; r < ring; r++) {
         blocks[r][0] = (char *)pcr_arena_alloc(ctx, blk_s); blocks[r][1] = (char *)pcr_arena_alloc(ctx, blk_t);
         if (!blocks[r][0] || !blocks[r][1]) return PCR_ENOMEM;
     }
@@ -434,9 +437,9 @@ extern "C" int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const
     PCR_HIP_CHECK(ctx, hipEventRecord(ctx->side_ev[0], ctx->stream));       // inputs are ready once the caller's stream gets here
     PCR_HIP_CHECK(ctx, hipStreamWaitEvent(lane_t, ctx->side_ev[0], 0));
     if (lane_s != lane_t) PCR_HIP_CHECK(ctx, hipStreamWaitEvent(lane_s, ctx->side_ev[0], 0));
-    DevCloud cs[2], ct[2]; int *nvs[2] = {nullptr, nullptr}, *nvt[2] = {nullptr, nullptr};
+    DevCloud cs[MAX_RING], ct[MAX_RING]; int *nvs[MAX_RING] = {}, *nvt[MAX_RING] = {};
     auto enqueue_prep = [&](int s) -> int {
-        const int r = s & 1;
+        const int r = s % ring;
         {
             SideLane lane(ctx, blocks[r][1], blk_t, lane_t);
             PCR_TRY(prep_scale(ctx, tgt_xyz, tgt_normals, n_tgt, bt, voxels[s], sor_k, sor_std, normal_k, &ct[r], &nvt[r]));
@@ -449,12 +452,10 @@ extern "C" int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const
         }
         return PCR_OK;
     };
-    static const bool ahead = !(getenv("PCR_PIPELINE") && atoi(getenv("PCR_PIPELINE")) == 0);
-    PCR_TRY(enqueue_prep(0));
+    int prepared = 0;
+    for (; prepared < n_scales && prepared < ring; prepared++) PCR_TRY(enqueue_prep(prepared));
     for (int s = 0; s < n_scales; s++) {
-        const int r = s & 1;
-        if (!ahead && s > 0) PCR_TRY(enqueue_prep(s));
-        if (ahead && s + 1 < n_scales) PCR_TRY(enqueue_prep(s + 1));
+        const int r = s % ring;
         ArenaMark mark(ctx);
         PCR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_ev[2 * r], 0));
         PCR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_ev[2 * r + 1], 0));
@@ -473,6 +474,8 @@ extern "C" int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const
             int64_t nc = 0;
             PCR_TRY(pcr_dev_compact_matches(ctx, match, cs[r].n, cs[r].cap, nullptr, nullptr, correspondences, &nc));
         }
+        // the block of scale s is free again (its GICP has been waited for): prepare the next scale not yet enqueued
+        if (prepared < n_scales) { PCR_TRY(enqueue_prep(prepared)); prepared++; }
     }
     return PCR_OK;
 }

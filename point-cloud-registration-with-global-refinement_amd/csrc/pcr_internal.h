@@ -17,7 +17,7 @@ struct pcr_context {
     hipStream_t side_stream = nullptr;   // preprocessing lanes: the two clouds of a scale are prepared concurrently on them,
     hipStream_t side_stream2 = nullptr;  //   one scale ahead of the GICP loop that runs on `stream`
     hipEvent_t side_ev[2] = {nullptr, nullptr};
-    hipEvent_t lane_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // [ring slot][cloud]: prepared cloud ready
+    hipEvent_t lane_ev[8] = {};   // [ring slot][cloud]: prepared cloud ready
     char *arena = nullptr;
     size_t arena_cap = 0, arena_off = 0;
     char *pinned = nullptr;        // host-pinned read-back window
