@@ -81,7 +81,7 @@ def main():
 
     def worker_init():
         torch.cuda.set_device(local_rank)
-        tls.stream = torch.cuda.Stream()
+        tls.stream = torch.cuda.Stream(priority=int(os.environ.get("PCR_BENCH_STREAM_PRIO", "0")))
         with torch.cuda.stream(tls.stream):
             c = P._lib.Context.current()
         ctxs.append(c)
@@ -123,10 +123,33 @@ def main():
             acc[k] += prof[k]
     prof = acc
 
+    # ---- roofline pass: the hot loop's launch period WITHOUT the other pairs' kernels in the way.  In the timed region
+    # three pairs share the GPU, so HIP events around a chunk of launches also count the time its kernels wait for
+    # wavefront slots taken by other streams (kept as `us_per_launch_in_flight`); the figure that rocprofv3's per-kernel
+    # durations can be checked against is measured here: a few extra steps, one pair at a time, same streams and contexts.
+    solo = [0.0] * 8
+    if rank == 0 and ctxs:
+        c0 = ctxs[0]
+        def solo_step(i):
+            with torch.cuda.stream(solo_stream):
+                return step(i)
+        solo_stream = torch.cuda.Stream()
+        with torch.cuda.stream(solo_stream):
+            cs = P._lib.Context.current()
+        solo_step(0)
+        cs.lib.pcr_profile_enable(cs.handle, 1); cs.lib.pcr_profile_read(cs.handle, prof_buf := (ctypes.c_double * 8)(), 1)
+        for i in range(4):
+            solo_step(i)
+        torch.cuda.synchronize()
+        cs.lib.pcr_profile_read(cs.handle, prof_buf, 0); cs.lib.pcr_profile_enable(cs.handle, 0)
+        solo = [prof_buf[k] for k in range(8)]
+
     if rank == 0:
         res = results[-1]
         # ---- roofline of the hot loop: ONE GICP iteration = k_icp_nn + k_icp_iter (SURVEY K10+K11), 48 B per source point
-        ev_ms, ev_launches, ik_us, live, alg_bytes, issued = (prof[i] for i in range(6))
+        ev_ms_f, ev_launches_f, ik_us_f, live_f, _, issued = (prof[i] for i in range(6))
+        us_in_flight = 1e3 * ev_ms_f / ev_launches_f if ev_launches_f else float("nan")
+        ev_ms, ev_launches, ik_us, live, alg_bytes, _ = (solo[i] for i in range(6))
         bytes_per_launch = alg_bytes / live if live else 0.0
         us_event = 1e3 * ev_ms / ev_launches if ev_launches else float("nan")     # HIP events over fully-live chunks
         us_kernel = ik_us / live if live else float("nan")                         # kernels' own s_memrealtime stamps
@@ -154,7 +177,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_icp_nn + k_icp_iter<GICP> (one GICP iteration)",
                          "bytes_per_launch": bytes_per_launch, "us_per_launch_hip_events": us_event,
-                         "us_per_launch_in_kernel_clock": us_kernel, "live_launches": live, "launches_issued": issued},
+                         "us_per_launch_in_kernel_clock": us_kernel, "us_per_launch_in_flight": us_in_flight,
+                         "measured_on": "4 extra single-pair steps after the timed region (same process, HIP events on the launch stream)",
+                         "live_launches": live, "launches_issued_timed_region": issued},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(pairs[0], args.points)

@@ -8,7 +8,7 @@ TAG=${1:-r01}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/profiles_$TAG
-rm -rf "$OUT"; mkdir -p "$OUT" "$ROOT/profiles"
+rm -rf "$OUT"; mkdir -p "$OUT" "$ROOT/profiles" "$ROOT/gpurun_out/profiles_export"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 12 > "$OUT/bench_stats.log" 2> "$OUT/bench_stats.err" || exit 1
 cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$ROOT/profiles/${TAG}_bench_kernel_stats.csv"
@@ -48,4 +48,6 @@ json.dump(js, open(dst + "_traffic.json", "w"), indent=1)
 for r in rows: print(r)
 PY
 grep '^{"metric' "$OUT/bench_stats.log" | tail -1 > "$ROOT/gpurun_out/bench_under_rocprof_$TAG.json"
+# gpurun only merges gpurun_out/ back: export the files to commit there as well
+cp "$ROOT/profiles/${TAG}_bench_kernel_stats.csv" "$ROOT/profiles/${TAG}_pmc_hbm_traffic.csv" "$ROOT/profiles/${TAG}_traffic.json" "$ROOT/gpurun_out/profiles_export/"
 head -12 "$ROOT/profiles/${TAG}_bench_kernel_stats.csv" | cut -c1-150
