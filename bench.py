@@ -47,10 +47,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # rehearsal of the N > 1 path on a one-GPU box: PCR_BENCH_REHEARSE=1 maps every rank onto device 0 and gathers over gloo
+    rehearse = os.environ.get("PCR_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     P = importlib.import_module(PKG)
     syn = importlib.import_module(PKG + ".synthetic")
@@ -108,11 +115,11 @@ def main():
     t0 = time.perf_counter()
     results = list(pool.map(run_step, range(args.steps)))
     recs = np.stack([shard.pack_record(rank * args.steps + i, r) for i, r in enumerate(results)])
-    gathered = shard.gather_records(recs, world * args.steps, device=torch.device("cuda", local_rank)) if world > 1 else recs
+    gathered = shard.gather_records(recs, world * args.steps, device=None if rehearse else torch.device("cuda", local_rank)) if world > 1 else recs
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     acc = [0.0] * 8

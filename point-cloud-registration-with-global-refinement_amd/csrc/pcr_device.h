@@ -1,6 +1,6 @@
-// pcr_device.h -- device-side helpers shared by the kernels: Morton keys, the implicit 8-ary BVH over a
-// Morton-ordered cloud, its stack-free traversal, and deterministic wave/block reductions.  gfx950 only
-// (64-lane wavefronts are hard-coded).
+// pcr_device.h -- device-side helpers shared by the kernels: Morton keys, point/box distances in a fixed operation
+// order, 8-lane (octet) and 16-lane (row) DPP reductions, deterministic wave reductions.  gfx950 only (64-lane
+// wavefronts are hard-coded).  The spatial index itself is in pcr_octree.h.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,26 +22,6 @@ __host__ __device__ static inline uint64_t pcr_morton3(uint32_t x, uint32_t y, u
     return pcr_spread21(x) | (pcr_spread21(y) << 1) | (pcr_spread21(z) << 2);
 }
 
-// ------------------------------------------------------------------------------- implicit BVH layout
-// Level 0 = leaves of PCR_LEAF consecutive points; level l+1 groups PCR_FANOUT consecutive nodes of level l.
-// The top level holds <= PCR_FANOUT nodes (children of a virtual root).
-struct BvhMeta {
-    int n;
-    int n_levels;
-    int off[PCR_MAX_LEVELS];
-    int cnt[PCR_MAX_LEVELS];
-};
-
-__host__ __device__ static inline void pcr_bvh_meta(int n, BvhMeta &m) {
-    int c = (n + PCR_LEAF - 1) / PCR_LEAF, l = 0, off = 0;
-    m.n = n; m.cnt[0] = c; m.off[0] = 0;
-    while (c > PCR_FANOUT && l + 1 < PCR_MAX_LEVELS) {
-        off += c; c = (c + PCR_FANOUT - 1) / PCR_FANOUT; l++;
-        m.cnt[l] = c; m.off[l] = off;
-    }
-    m.n_levels = l + 1;
-}
-
 // squared distance in a fixed operation order (the same helper is used for boxes and points so that the
 // box bound is monotone w.r.t. the point distances it guards)
 __device__ static inline float pcr_d2(float dx, float dy, float dz) { return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx)); }
@@ -51,73 +31,6 @@ __device__ static inline float pcr_box_d2(const float4 lo, const float4 hi, floa
     float dy = fmaxf(fmaxf(lo.y - qy, qy - hi.y), 0.0f);
     float dz = fmaxf(fmaxf(lo.z - qz, qz - hi.z), 0.0f);
     return pcr_d2(dx, dy, dz);
-}
-
-// mask of the children of (lvl, node) whose box is closer than `bound` (strict)
-__device__ static inline uint32_t pcr_child_mask(const float4 *__restrict__ boxes, const BvhMeta &m, int lvl, int node,
-                                                  float qx, float qy, float qz, float bound) {
-    const int cl = lvl - 1;
-    const int first = node * PCR_FANOUT;
-    const int cnt = m.cnt[cl];
-    const float4 *b = boxes + 2 * (size_t)(m.off[cl] + first);
-    uint32_t mask = 0;
-#pragma unroll
-    for (int c = 0; c < PCR_FANOUT; c++) {
-        if (first + c < cnt) {
-            float4 lo = b[2 * c], hi = b[2 * c + 1];
-            if (pcr_box_d2(lo, hi, qx, qy, qz) < bound) mask |= 1u << c;
-        }
-    }
-    return mask;
-}
-
-// Stack-free depth-first traversal: one pending-children byte per level packed in a 64-bit word.
-// Visitor: float bound() const;  void leaf(int leaf_index).
-template <class V>
-__device__ static inline void pcr_bvh_traverse(const float4 *__restrict__ boxes, const BvhMeta &m, float qx, float qy,
-                                               float qz, V &v) {
-    const int top = m.n_levels - 1;
-    int lvl = top + 1, node = 0;
-    uint64_t pending = 0;
-    uint32_t mask = pcr_child_mask(boxes, m, lvl, node, qx, qy, qz, v.bound());
-    for (;;) {
-        if (mask == 0) {
-            if (lvl > top) break;
-            lvl++; node >>= 3;
-            mask = (uint32_t)(pending >> (8 * lvl)) & 0xffu;
-            continue;
-        }
-        const int c = __builtin_ctz(mask);
-        mask &= mask - 1;
-        const int child = node * PCR_FANOUT + c;
-        if (lvl == 1) {
-            v.leaf(child);
-        } else {
-            v.on_node();
-            pending = (pending & ~(0xffull << (8 * lvl))) | ((uint64_t)mask << (8 * lvl));
-            lvl--; node = child;
-            mask = pcr_child_mask(boxes, m, lvl, node, qx, qy, qz, v.bound());
-        }
-    }
-}
-
-// greedy descent to the leaf whose ancestors are nearest at every level (cold-start seed for 1-NN)
-__device__ static inline int pcr_bvh_greedy_leaf(const float4 *__restrict__ boxes, const BvhMeta &m, float qx, float qy, float qz) {
-    int node = 0;
-    for (int lvl = m.n_levels; lvl >= 1; lvl--) {
-        const int cl = lvl - 1, first = node * PCR_FANOUT, cnt = m.cnt[cl];
-        const float4 *b = boxes + 2 * (size_t)(m.off[cl] + first);
-        float best = 3.4e38f; int bc = 0;
-#pragma unroll
-        for (int c = 0; c < PCR_FANOUT; c++) {
-            if (first + c < cnt) {
-                float d = pcr_box_d2(b[2 * c], b[2 * c + 1], qx, qy, qz);
-                if (d < best) { best = d; bc = c; }
-            }
-        }
-        node = first + bc;
-    }
-    return node;
 }
 
 // ------------------------------------------------------------------------------ 8-lane (octet) DPP ops

@@ -6,9 +6,6 @@
 #include <vector>
 #include "../../include/pcr_hip.h"
 
-#define PCR_LEAF 8          // points per BVH leaf
-#define PCR_FANOUT 8        // children per BVH node
-#define PCR_MAX_LEVELS 12
 
 struct pcr_context {
     int device = 0;
