@@ -2,13 +2,15 @@
 """bench.py -- pairs registered per second on synthetic 200k-point NCLT-shaped clouds, 3 GICP scales
 (BASELINE.json metric, config 2).
 
-One "step" = one call of the hot path on one pair already resident in HBM: the whole Multiscale_GICP body
-(voxel_down_sample -> remove_statistical_outlier(30, 1.0) -> estimate_normals(KNN 20) ->
+One "step" = one pass of the hot path over one BATCH of --pairs-per-step (48) independent pairs already resident in HBM,
+issued as ONE pcr_register_pairs call (the library keeps --inflight pairs in flight); per pair the whole Multiscale_GICP
+body runs (voxel_down_sample -> remove_statistical_outlier(30, 1.0) -> estimate_normals(KNN 20) ->
 registration_generalized_icp(L1, 1e-6/1e-6/100) for voxels 0.4/0.2/0.1 m, search radii 1.2/0.4/0.1 m), exactly the
-reference's pair-time definition (2_MGICP...py:190-199).  N>1: one process per GPU, each registers its own pairs
-(no data-path collective); one all-gather of the fixed-size pose records closes the timed region.
+reference's pair-time definition (2_MGICP...py:190-199).  value = pairs registered / wall time of the K steps.
+N>1: one process per GPU, each registers its own batches (no data-path collective); one all-gather of the fixed-size
+pose records closes the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--points 200000] [--pairs 2] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs-per-step 48] [--inflight 3] [--points 200000] [--no-cpu-baseline]
 """
 import argparse
 import importlib
@@ -32,13 +34,17 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs-per-step", type=int, default=48,
+                    help="one step = one pass of the path over a batch of this many independent pairs (one pcr_register_pairs call)")
     ap.add_argument("--points", type=int, default=200_000)
     ap.add_argument("--pairs", type=int, default=2, help="distinct synthetic pairs cycled through the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("PCR_BENCH_INFLIGHT", "3")),
                     help="independent pairs in flight per GPU (one host thread + one HIP stream + one library context each)")
+    ap.add_argument("--python-threads", action="store_true", help="keep the pairs in flight with host threads in Python (one pcr_multiscale_gicp call per pair) "
+                    "instead of ONE pcr_register_pairs call for the timed steps (default: the library keeps them in flight)")
     args = ap.parse_args()
 
     import torch
@@ -80,7 +86,11 @@ def main():
         p = pairs[i % len(pairs)]; s, t = clouds[i % len(pairs)]
         return P.registration.multiscale_gicp(s, t, p.voxel_sizes, p.max_distances_script, p.T_init, est, crit, 30, 1.0, 20)
 
-    # ---- executor: `inflight` host threads, each with its own HIP stream and library context (pairs are independent)
+    # ---- executor.  Default: the timed steps are ONE pcr_register_pairs call, the library keeps `inflight` pairs in flight
+    # (worker threads, contexts and streams of its own).  --python-threads: `inflight` host threads in Python, each with
+    # its own HIP stream and library context, one pcr_multiscale_gicp call per pair (9 % slower: interpreter overhead).
+    args.batch_api = not args.python_threads
+    B = max(1, args.pairs_per_step)
     import threading
     from concurrent.futures import ThreadPoolExecutor
     ctxs = []
@@ -97,9 +107,12 @@ def main():
         with torch.cuda.stream(tls.stream):
             return step(i)
 
-    pool = ThreadPoolExecutor(max_workers=args.inflight, initializer=worker_init)
+    pool = None
     torch.cuda.synchronize()
-    list(pool.map(run_step, range(max(args.warmup, args.inflight))))            # warm-up (every worker at least once)
+    if not args.batch_api:
+        pool = ThreadPoolExecutor(max_workers=args.inflight, initializer=worker_init)
+        for _ in range(max(args.warmup, 1)):                                    # warm-up steps (every worker at least once)
+            list(pool.map(run_step, range(max(B, args.inflight))))
     prof = (ctypes.c_double * 8)()
     for c in ctxs:
         c.lib.pcr_profile_enable(c.handle, 1)
@@ -111,11 +124,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def run_batch(n):
+        batch = [(clouds[i % len(pairs)][0], clouds[i % len(pairs)][1], pairs[i % len(pairs)].T_init) for i in range(n)]
+        p0 = pairs[0]
+        return P.registration.register_pairs(batch, p0.voxel_sizes, p0.max_distances_script, est, crit, 30, 1.0, 20, inflight=args.inflight)
+
+    lib = P._lib.load()
+    if args.batch_api:
+        for _ in range(max(args.warmup, 1)):
+            run_batch(max(B, args.inflight))
+        lib.pcr_pool_profile(ctypes.c_int(local_rank), ctypes.c_int(1), None, ctypes.c_int(1))
     barrier()
     t0 = time.perf_counter()
-    results = list(pool.map(run_step, range(args.steps)))
-    recs = np.stack([shard.pack_record(rank * args.steps + i, r) for i, r in enumerate(results)])
-    gathered = shard.gather_records(recs, world * args.steps, device=None if rehearse else torch.device("cuda", local_rank)) if world > 1 else recs
+    results, rec_rows = [], []
+    n_done = args.steps * B
+    for k in range(args.steps):                 # a step = one batch of B pairs; the call returns when all B are registered
+        results = run_batch(B) if args.batch_api else list(pool.map(run_step, range(B)))
+        rec_rows += [shard.pack_record(rank * n_done + k * B + i, r) for i, r in enumerate(results)]    # pose records only; the rest is dropped
+    recs = np.stack(rec_rows)
+    gathered = shard.gather_records(recs, world * n_done, device=None if rehearse else torch.device("cuda", local_rank)) if world > 1 else recs
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -123,7 +150,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     acc = [0.0] * 8
-    for c in ctxs:
+    if args.batch_api:
+        lib.pcr_pool_profile(ctypes.c_int(local_rank), ctypes.c_int(0), prof, ctypes.c_int(1))
+        acc = [prof[k] for k in range(8)]
+    for c in ([] if args.batch_api else ctxs):
         c.lib.pcr_profile_read(c.handle, prof, 0)
         c.lib.pcr_profile_enable(c.handle, 0)
         for k in range(8):
@@ -135,8 +165,7 @@ def main():
     # wavefront slots taken by other streams (kept as `us_per_launch_in_flight`); the figure that rocprofv3's per-kernel
     # durations can be checked against is measured here: a few extra steps, one pair at a time, same streams and contexts.
     solo = [0.0] * 8
-    if rank == 0 and ctxs:
-        c0 = ctxs[0]
+    if rank == 0:
         def solo_step(i):
             with torch.cuda.stream(solo_stream):
                 return step(i)
@@ -167,17 +196,18 @@ def main():
             t = json.load(open(tj))
             traffic = t.get("k_icp_nn", {}).get("hbm_bytes_per_launch", 0) + t.get("k_icp_iter<GICP>", {}).get("hbm_bytes_per_launch", 0)
         # sanity of the result itself (planted motion) -- printed, not part of the contract
-        p_last = pairs[(args.steps - 1) % len(pairs)]
+        p_last = pairs[(B - 1) % len(pairs)]
         dR = res.transformation[:3, :3].T @ p_last.T_true[:3, :3]
         ang = float(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))); dtr = float(np.linalg.norm(res.transformation[:3, 3] - p_last.T_true[:3, 3]))
         line = {
             "metric": "point-cloud pairs registered/sec (200k pts, 3 GICP scales)",
-            "value": world * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": world * n_done / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 points+search, f64 normal equations", "data": "synthetic",
-            "config": {"workload": f"single pair, {args.points}-pt synthetic NCLT-shaped clouds, 3-scale GICP "
+            "config": {"workload": f"step = batch of {B} independent pairs, each {args.points}-pt synthetic NCLT-shaped clouds, 3-scale GICP "
                                    "(voxels 0.4/0.2/0.1 m, radii 1.2/0.4/0.1 m, SOR(30,1.0), KNN-20 normals, L1, 1e-6/1e-6/100)",
-                       "points_per_cloud": args.points, "distinct_pairs": args.pairs, "parallelism": f"pairs x{world}", "pairs_in_flight_per_gpu": args.inflight,
+                       "points_per_cloud": args.points, "pairs_per_step": B, "distinct_pairs": args.pairs, "parallelism": f"pairs x{world}", "pairs_in_flight_per_gpu": args.inflight,
+                       "in_flight_by": "pcr_register_pairs (library worker threads)" if args.batch_api else "python host threads",
                        "scales": [dict(voxel=s["voxel"], max_dist=s["max_dist"], n_voxel=s["n_voxel"], n_clean=s["n_clean"],
                                        iterations=s["iterations"]) for s in res.scales],
                        "err_vs_planted": {"rad": ang, "m": dtr}, "gathered_records": int(len(gathered))},

@@ -139,6 +139,29 @@ int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const float *src
                         const double *init_T, const pcr_gicp_params *params, pcr_scale_record *records,
                         int32_t *correspondences);
 
+/* == the per-pair loops of the reference (1_FGR...py:134-147 is the FGR one; 2_MGICP...py:187-214 and
+ *    ALL_FUNCTIONS.py:349-392 the GICP ones): MANY independent pairs in one call.  The library keeps `inflight` pairs in
+ *    flight on `device` (one worker thread + context + stream each, taken from a process-wide pool), pair i runs exactly
+ *    pcr_multiscale_gicp on pairs[i] with the shared scale tables, and the call returns when all pairs are done.
+ *    `after_stream` (optional) is a HIP stream whose already-enqueued work produces the input clouds; workers wait for
+ *    it.  Per-pair status and error text come back in the descriptor; the return value is PCR_OK iff every pair is. */
+typedef struct {
+    const float *src_xyz, *src_normals; int64_t n_src;      /* device; normals optional */
+    const float *tgt_xyz, *tgt_normals; int64_t n_tgt;
+    double init_T[16];
+    pcr_scale_record *records;                              /* host, n_scales entries */
+    int32_t *correspondences;                               /* optional device int32 [n_src x 2] of the last scale */
+    int32_t status;                                         /* out */
+    char error[120];                                        /* out */
+} pcr_pair;
+int pcr_register_pairs(int device, pcr_pair *pairs, int n_pairs, const double *voxel_sizes, const double *max_distances,
+                       int n_scales, int sor_k, double sor_std, int normal_k, const pcr_gicp_params *params, int inflight,
+                       void *after_stream);
+
+/* measurement hook for the worker contexts pcr_register_pairs keeps in its pool (all idle between calls): enable >= 0 switches
+ * their instrumentation on/off, out8 (optional) receives the SUM of their pcr_profile_read counters, reset clears them. */
+int pcr_pool_profile(int device, int enable, double *out8, int reset);
+
 /* == evaluate_registration (ALL_FUNCTIONS.py:809-820) */
 int pcr_evaluate_registration(pcr_context *ctx, const float *src_xyz, int64_t n_src, const float *tgt_xyz,
                               int64_t n_tgt, double max_correspondence_distance, const double *T, pcr_result *result,

@@ -33,6 +33,13 @@ class PcrScaleRecord(C.Structure):
     _fields_ = [("n_voxel", C.c_int64 * 2), ("n_clean", C.c_int64 * 2), ("icp", PcrResult)]
 
 
+class PcrPair(C.Structure):
+    _fields_ = [("src_xyz", C.c_void_p), ("src_normals", C.c_void_p), ("n_src", C.c_int64),
+                ("tgt_xyz", C.c_void_p), ("tgt_normals", C.c_void_p), ("n_tgt", C.c_int64),
+                ("init_T", C.c_double * 16), ("records", C.POINTER(PcrScaleRecord)), ("correspondences", C.c_void_p),
+                ("status", C.c_int32), ("error", C.c_char * 120)]
+
+
 class PcrFgrOption(C.Structure):
     _fields_ = [("division_factor", C.c_double), ("use_absolute_scale", C.c_int32), ("decrease_mu", C.c_int32),
                 ("maximum_correspondence_distance", C.c_double), ("iteration_number", C.c_int32),
@@ -46,7 +53,7 @@ EXPORTS = [
     "pcr_voxel_down_sample", "pcr_remove_statistical_outlier", "pcr_estimate_normals", "pcr_estimate_covariances",
     "pcr_registration_generalized_icp", "pcr_multiscale_gicp", "pcr_evaluate_registration", "pcr_information_matrix",
     "pcr_compute_fpfh_feature", "pcr_registration_fgr", "pcr_debug_knn", "pcr_debug_gicp_linearize",
-    "pcr_profile_enable", "pcr_profile_read", "pcr_registration_generalized_icp_cov",
+    "pcr_profile_enable", "pcr_profile_read", "pcr_registration_generalized_icp_cov", "pcr_register_pairs", "pcr_pool_profile",
 ]
 
 _lib = None

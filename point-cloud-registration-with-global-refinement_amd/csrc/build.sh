@@ -14,5 +14,5 @@ for f in pcr_sort pcr_cloud pcr_gicp pcr_fpfh pcr_fgr pcr_api; do
   fi
   objs="$objs $f.o"
 done
-hipcc --offload-arch=$ARCH -shared -fPIC -o $OUT $objs
+hipcc --offload-arch=$ARCH -shared -fPIC -pthread -o $OUT $objs
 echo "built $OUT"

@@ -3,6 +3,10 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <cstdio>
+#include <atomic>
+#include <mutex>
+#include <thread>
 #include "pcr_octree.h"
 
 // ------------------------------------------------------------------------------------------- context
@@ -478,6 +482,77 @@ extern "C" int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const
         if (prepared < n_scales) { PCR_TRY(enqueue_prep(prepared)); prepared++; }
     }
     return PCR_OK;
+}
+
+// ---------------------------------------------------------------------------------- many pairs per call
+// Worker contexts live in a process-wide pool (arena, streams and cached graphs survive between calls); a call borrows
+// `inflight` of them, spawns as many threads and lets them pull pair indices from a shared counter.
+namespace {
+std::mutex g_pool_mutex;
+std::vector<std::pair<int, pcr_context *>> g_pool;        // (device, idle context)
+pcr_context *pool_take(int device) {
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        for (size_t k = 0; k < g_pool.size(); k++)
+            if (g_pool[k].first == device) { pcr_context *c = g_pool[k].second; g_pool.erase(g_pool.begin() + k); return c; }
+    }
+    pcr_context *c = nullptr;
+    return pcr_create(device, &c) == PCR_OK ? c : nullptr;
+}
+void pool_give(int device, pcr_context *c) {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    g_pool.emplace_back(device, c);
+}
+}  // namespace
+
+extern "C" int pcr_pool_profile(int device, int enable, double *out8, int reset) {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    if (out8) for (int i = 0; i < 8; i++) out8[i] = 0.0;
+    for (auto &e : g_pool) {
+        if (e.first != device) continue;
+        if (enable >= 0) e.second->profiling = enable ? 1 : 0;
+        for (int i = 0; i < 8; i++) { if (out8) out8[i] += e.second->prof[i]; if (reset) e.second->prof[i] = 0; }
+    }
+    return PCR_OK;
+}
+
+extern "C" int pcr_register_pairs(int device, pcr_pair *pairs, int n_pairs, const double *voxels, const double *dists, int n_scales,
+                                  int sor_k, double sor_std, int normal_k, const pcr_gicp_params *params, int inflight, void *after_stream) {
+    if (n_pairs < 0 || (n_pairs > 0 && !pairs) || !voxels || !dists || !params || n_scales < 1) return PCR_EINVAL;
+    if (n_pairs == 0) return PCR_OK;
+    if (hipSetDevice(device) != hipSuccess) return PCR_EHIP;
+    const int workers = inflight < 1 ? 1 : (inflight > n_pairs ? n_pairs : (inflight > 16 ? 16 : inflight));
+    hipEvent_t ready = nullptr;
+    if (after_stream) {
+        if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess) return PCR_EHIP;
+        if (hipEventRecord(ready, (hipStream_t)after_stream) != hipSuccess) { (void)hipEventDestroy(ready); return PCR_EHIP; }
+    }
+    std::atomic<int> next(0), failed(0);
+    auto work = [&]() {
+        (void)hipSetDevice(device);
+        pcr_context *ctx = pool_take(device);
+        if (!ctx) { failed++; return; }
+        (void)pcr_set_stream(ctx, nullptr);                                   // the context's own stream
+        if (ensure_stream(ctx) == PCR_OK && ready) (void)hipStreamWaitEvent(ctx->stream, ready, 0);
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n_pairs) break;
+            pcr_pair &p = pairs[i];
+            p.error[0] = 0;
+            p.status = p.records ? pcr_multiscale_gicp(ctx, p.src_xyz, p.src_normals, p.n_src, p.tgt_xyz, p.tgt_normals, p.n_tgt, voxels, dists, n_scales,
+                                                       sor_k, sor_std, normal_k, p.init_T, params, p.records, p.correspondences)
+                                 : PCR_EINVAL;
+            if (p.status != PCR_OK) { failed++; snprintf(p.error, sizeof p.error, "%s", p.records ? ctx->err.c_str() : "records == NULL"); }
+        }
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        pool_give(device, ctx);
+    };
+    std::vector<std::thread> threads;
+    for (int w = 1; w < workers; w++) threads.emplace_back(work);
+    work();                                                                   // the calling thread is worker 0
+    for (auto &t : threads) t.join();
+    if (ready) (void)hipEventDestroy(ready);
+    return failed.load() ? PCR_EHIP : PCR_OK;
 }
 
 extern "C" int pcr_evaluate_registration(pcr_context *ctx, const float *src_xyz, int64_t n_src, const float *tgt_xyz, int64_t n_tgt,

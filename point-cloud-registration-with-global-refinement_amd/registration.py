@@ -201,6 +201,59 @@ def multiscale_gicp(source: PointCloud, target: PointCloud, voxel_sizes, max_cor
     return _result(recs[vox.size - 1].icp, corr, scales)
 
 
+def register_pairs(pairs, voxel_sizes, max_correspondence_distances, estimation_method=None, criteria=None, nb_neighbors: int = 30,
+                   std_ratio: float = 1.0, normal_knn: int = 20, inflight: int = 3, with_correspondences: bool = True) -> list:
+    """The per-pair loops of the reference (2_MGICP...py:187-214, ALL_FUNCTIONS.py:349-392) as ONE library call:
+    `pairs` = [(source PointCloud, target PointCloud, initial 4x4), ...]; every pair gets the body of ``multiscale_gicp``
+    and the library keeps ``inflight`` of them in flight on the current device (worker threads, contexts and streams
+    are its own).  Returns the RegistrationResults in input order; a failed pair raises RuntimeError naming it."""
+    estimation = estimation_method or TransformationEstimationForGeneralizedICP()
+    criteria = criteria or ICPConvergenceCriteria()
+    torch = _torch()
+    lib = _lib.load()
+    if not torch.cuda.is_available():
+        raise RuntimeError("no HIP device visible to torch: the MI355X registration path cannot run (no CPU fallback)")
+    vox = np.ascontiguousarray(np.asarray(voxel_sizes, dtype=np.float64).reshape(-1))
+    dst = np.ascontiguousarray(np.asarray(max_correspondence_distances, dtype=np.float64).reshape(-1))
+    if vox.size != dst.size or vox.size < 1:
+        raise RuntimeError("register_pairs: voxel_sizes and max_correspondence_distances must have the same length >= 1")
+    n = len(pairs)
+    if n == 0:
+        return []
+    arr = (_lib.PcrPair * n)()
+    keep = []                                   # device tensors and record arrays must outlive the call
+    for k, (src, tgt, init) in enumerate(pairs):
+        recs = (_lib.PcrScaleRecord * vox.size)()
+        corr = torch.empty((max(len(src), 1), 2), dtype=torch.int32, device="cuda") if with_correspondences else None
+        sx, tx = src.device_xyz(), tgt.device_xyz()
+        sn = src.device_normals() if src.has_normals() else None
+        tn = tgt.device_normals() if tgt.has_normals() else None
+        keep.append((recs, corr, sx, tx, sn, tn))
+        a = arr[k]
+        a.src_xyz = sx.data_ptr(); a.src_normals = sn.data_ptr() if sn is not None else None; a.n_src = len(src)
+        a.tgt_xyz = tx.data_ptr(); a.tgt_normals = tn.data_ptr() if tn is not None else None; a.n_tgt = len(tgt)
+        a.init_T[:] = list(np.asarray(init, dtype=np.float64).reshape(16))
+        a.records = C.cast(recs, C.POINTER(_lib.PcrScaleRecord)); a.correspondences = corr.data_ptr() if corr is not None else None
+    p = _params(estimation, criteria)
+    dev = torch.cuda.current_device()
+    rc = lib.pcr_register_pairs(C.c_int(dev), arr, C.c_int(n), vox.ctypes.data_as(C.POINTER(C.c_double)), dst.ctypes.data_as(C.POINTER(C.c_double)),
+                                C.c_int(vox.size), C.c_int(nb_neighbors), C.c_double(std_ratio), C.c_int(normal_knn), C.byref(p), C.c_int(inflight),
+                                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    out = []
+    for k in range(n):
+        if arr[k].status != 0:
+            raise RuntimeError(f"register_pairs: pair {k} failed with code {arr[k].status}: {arr[k].error.decode(errors='replace')}")
+        recs, corr = keep[k][0], keep[k][1]
+        scales = [dict(voxel=float(vox[i]), max_dist=float(dst[i]), n_voxel=tuple(recs[i].n_voxel), n_clean=tuple(recs[i].n_clean),
+                       iterations=int(recs[i].icp.iterations), fitness=recs[i].icp.fitness, inlier_rmse=recs[i].icp.inlier_rmse,
+                       converged=bool(recs[i].icp.converged), n_corr=int(recs[i].icp.n_correspondences),
+                       T=np.array(recs[i].icp.transformation).reshape(4, 4)) for i in range(vox.size)]
+        out.append(_result(recs[vox.size - 1].icp, corr if corr is not None else torch.empty((0, 2), dtype=torch.int32, device="cuda"), scales))
+    if rc != 0 and all(a.status == 0 for a in arr):
+        raise RuntimeError(f"register_pairs failed with code {rc}")
+    return out
+
+
 def evaluate_registration(source: PointCloud, target: PointCloud, max_correspondence_distance: float,
                           transformation=np.eye(4)) -> RegistrationResult:
     ctx = _lib.Context.current()

@@ -48,6 +48,15 @@ def golden_pair(request):
 
 
 @pytest.fixture(scope="session")
+def golden_pair_list():
+    out = []
+    for f in golden_pair_files():
+        d = np.load(f)
+        out.append({k: d[k] for k in d.files})
+    return out
+
+
+@pytest.fixture(scope="session")
 def small_pair():
     """Pair 899 (smallest golden pair)."""
     d = np.load(os.path.join(GOLDEN, "nclt_pair_899.npz"))

@@ -192,3 +192,21 @@ def test_radius_normals_and_gicp_robusto_match_oracle(P, oracle, small_pair):
     ang, dt = pose_error(res.transformation, ref.transformation)
     assert ang < 1e-6 and dt < 1e-5, (ang, dt)
     assert res.iterations == ref.iterations and abs(res.fitness - ref.fitness) < 1e-9
+
+
+def test_register_pairs_equals_one_call_per_pair(P, golden_pair_list):
+    """`pcr_register_pairs` (many pairs per call, pairs in flight inside the library) = `pcr_multiscale_gicp` per pair, bit for bit."""
+    vox = P.script2.create_scales(5); dst = P.script2.max_correspondence_distances(vox)
+    est = P.registration.TransformationEstimationForGeneralizedICP(P.registration.L1Loss())
+    crit = P.registration.ICPConvergenceCriteria(1e-6, 1e-6, 100)
+    pairs = [(P.PointCloud(g["source"]), P.PointCloud(g["target"]), g["T_fgr"]) for g in golden_pair_list]
+    batch = P.registration.register_pairs(pairs, vox, dst, est, crit, inflight=3)
+    assert len(batch) == len(pairs)
+    for (s, t, T0), rb in zip(pairs, batch):
+        r1 = P.registration.multiscale_gicp(s, t, vox, dst, T0, est, crit)
+        assert np.array_equal(rb.transformation, r1.transformation) and rb.fitness == r1.fitness and rb.inlier_rmse == r1.inlier_rmse
+        assert [x["iterations"] for x in rb.scales] == [x["iterations"] for x in r1.scales]
+        assert np.array_equal(np.asarray(rb.correspondence_set), np.asarray(r1.correspondence_set))
+    assert P.registration.register_pairs([], vox, dst, est, crit) == []
+    with pytest.raises(RuntimeError, match="pair 0 failed"):
+        P.registration.register_pairs(pairs[:2], [0.1, -1.0], [0.1, 0.1], est, crit)

@@ -7,7 +7,7 @@ for rep in $(seq 1 ${AB_REPS:-2}); do
   for v in "$@"; do
     i=$((i+1))
     for k in ${AB_INFLIGHT:-1 3}; do
-      env $v python bench.py --no-cpu-baseline --steps ${AB_STEPS:-24} --inflight $k > gpurun_out/ab_${i}_$k.log 2>&1
+      env $v python bench.py --no-cpu-baseline --steps ${AB_STEPS:-4} --inflight $k > gpurun_out/ab_${i}_$k.log 2>&1
       grep "^{" gpurun_out/ab_${i}_$k.log | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('[$v] inflight $k:', round(d['value'],1), 'pairs/s', round(d['ms_per_step'],3), 'ms', [s['iterations'] for s in d['config']['scales']])"
     done
   done

@@ -10,11 +10,11 @@ export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/profiles_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT" "$ROOT/profiles" "$ROOT/gpurun_out/profiles_export"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 12 > "$OUT/bench_stats.log" 2> "$OUT/bench_stats.err" || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 2 --warmup 1 > "$OUT/bench_stats.log" 2> "$OUT/bench_stats.err" || exit 1
 cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$ROOT/profiles/${TAG}_bench_kernel_stats.csv"
 for pass in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   d=$OUT/pmc_$(echo $pass | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$d" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 4 --warmup 1 --inflight 1 > "$d.log" 2> "$d.err" || exit 1
+  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$d" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 1 --warmup 1 --pairs-per-step 4 --inflight 1 > "$d.log" 2> "$d.err" || exit 1
   echo "pmc pass [$pass] done"
 done
 python3 - "$OUT" "$ROOT/profiles/${TAG}" <<'PY'
