@@ -106,14 +106,22 @@ def stage2_mgicp(cloud_dir: str, init_dir: str, out_dir: str, n_clouds: int, n_s
     mine, rank = _shard(n_clouds)
     clouds = load_circuit(cloud_dir, n_clouds, pattern, _clouds_of(mine, n_clouds))
 
-    def job(i):
-        s, t = sharding.circuit_pair(i, n_clouds)
-        r = functions.script2.Multiscale_GICP(clouds[s], clouds[t], n_scales, iterations, initial_T[i])
-        if verbose:
+    # one library call for the rank's whole block of pairs: the library keeps `inflight` of them in flight
+    from . import registration as reg
+    vox = functions.script2.create_scales(n_scales)
+    dst = functions.script2.max_correspondence_distances(vox)
+    mine = list(mine)
+    batch = [(clouds[sharding.circuit_pair(i, n_clouds)[0]], clouds[sharding.circuit_pair(i, n_clouds)[1]], initial_T[i]) for i in mine]
+    t0 = time.perf_counter()
+    res = reg.register_pairs(batch, vox, dst, reg.TransformationEstimationForGeneralizedICP(reg.L1Loss()),
+                             reg.ICPConvergenceCriteria(relative_fitness=1e-6, relative_rmse=1e-6, max_iteration=iterations), inflight=inflight)
+    dt = time.perf_counter() - t0
+    if verbose:
+        for i, r in zip(mine, res):
+            s, t = sharding.circuit_pair(i, n_clouds)
             print(f"Pair {s}->{t} RMSE: {round(r.inlier_rmse, 3)} m")
-        return r
-
-    table = _gather(_run_pairs(mine, job, inflight), n_clouds)
+        print(f"{len(mine)} pairs in {dt:.3f} s")
+    table = _gather([(i, r, 0.0) for i, r in zip(mine, res)], n_clouds)
     rel = [r["transformation"] for r in table]
     ab = refinement.poses_relativas_para_absolutas(rel)
     if rank == 0 and out_dir:
