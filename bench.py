@@ -23,7 +23,7 @@ import numpy as np
 
 # Pairs in flight use 3 HIP streams each (GICP loop + two preprocessing lanes); the runtime maps streams onto
 # GPU_MAX_HW_QUEUES hardware queues (default 4) and streams sharing a queue serialise.  Must be set before HIP starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--points", type=int, default=200_000)
     ap.add_argument("--pairs", type=int, default=2, help="distinct synthetic pairs cycled through the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("PCR_BENCH_INFLIGHT", "3")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("PCR_BENCH_INFLIGHT", "4")),
                     help="independent pairs in flight per GPU (one host thread + one HIP stream + one library context each)")
     ap.add_argument("--python-threads", action="store_true", help="keep the pairs in flight with host threads in Python (one pcr_multiscale_gicp call per pair) "
                     "instead of ONE pcr_register_pairs call for the timed steps (default: the library keeps them in flight)")
