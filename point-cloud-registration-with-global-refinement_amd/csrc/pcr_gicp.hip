@@ -671,7 +671,8 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
 
     // Launch in chunks; the state of chunk c is copied back while chunk c+1 is already queued, so the GPU never
     // idles on the host.  Launches after 'done' return at their first instruction.
-    const int total = a.max_it + 1, CHUNK = 8;
+    static const int chunk_env = getenv("PCR_ICP_CHUNK") ? atoi(getenv("PCR_ICP_CHUNK")) : 8;
+    const int total = a.max_it + 1, CHUNK = chunk_env < 1 ? 1 : (chunk_env > 32 ? 32 : chunk_env);
     // One chunk = CHUNK x (k_icp_nn, k_icp_iter) replayed as ONE hipGraph launch: the loop is launch-bound (a 3000-point
     // pair still takes 5 ms), and a graph costs one runtime call instead of 16.  The arena hands out the same addresses
     // for the same problem sizes, so the instantiated graph is cached in the context under its argument bytes.
@@ -679,7 +680,7 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     hipGraphExec_t chunk_exec = nullptr;
     if (use_graph && !stamp_path) {
         std::string key((const char *)&a, sizeof a);
-        const int extra[3] = {nbnn, nbmax, use_cov ? 1 : 0};
+        const int extra[4] = {nbnn, nbmax, use_cov ? 1 : 0, CHUNK};
         key.append((const char *)extra, sizeof extra);
         for (auto &g : ctx->icp_graphs) if (g.first == key) { chunk_exec = g.second; break; }
         if (!chunk_exec) {
