@@ -349,33 +349,9 @@ __global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 
     }
 }
 
-// ---- kernel 2 of an iteration: one correspondence per lane in float64 -> wave/LDS reduction -> last workgroup
-// finishes the iteration (sum partials, convergence test, 6x6 solve, pose update).
+// ---- one correspondence in float64: accumulates its 30 sums into acc[]; `cand` = candidate target point (or < 0)
 template <int MODE>
-__global__ void __launch_bounds__(LIN_BS) k_icp_iter(IcpArgs a) {
-    IcpState *st = a.state;
-    if (st->done) return;
-    __shared__ double red[LIN_BS / 16][NVP];       // one row per 16-lane DPP row
-    __shared__ double fin[16][NVP];
-    __shared__ int is_last;
-    __shared__ double ldl_w[96];
-    __shared__ int ldl_perm[6];
-    const int ns = *a.ns_ptr;
-    int nb = (ns + LIN_BS - 1) / LIN_BS;
-    if (nb < 1) nb = 1;
-    if (nb > (int)gridDim.x) nb = gridDim.x;
-    if ((int)blockIdx.x >= nb) return;
-    const unsigned long long t_entry = wall_clock64();
-    const int launches = st->launches;
-    double T[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) T[k] = st->T[k];
-
-    double acc[NV];
-#pragma unroll
-    for (int k = 0; k < NV; k++) acc[k] = 0.0;
-
-    for (int i = blockIdx.x * LIN_BS + threadIdx.x; i < ns; i += nb * LIN_BS) {
+__device__ static inline void icp_point(const IcpArgs &a, const double *T, int i, int ns, int cand_in, double *acc) {
     double qx = 0, qy = 0, qz = 0;
     int cand = -1;
     {
@@ -384,7 +360,7 @@ __global__ void __launch_bounds__(LIN_BS) k_icp_iter(IcpArgs a) {
         qx = T[0] * px + T[1] * py + T[2] * pz + T[3];
         qy = T[4] * px + T[5] * py + T[6] * pz + T[7];
         qz = T[8] * px + T[9] * py + T[10] * pz + T[11];
-        cand = a.match[i];
+        cand = cand_in;
     }
     if (a.dbg_visits) cand = -1;
 
@@ -477,8 +453,17 @@ __global__ void __launch_bounds__(LIN_BS) k_icp_iter(IcpArgs a) {
         }
         if (best < 0) a.match[i] = -(cand + 2);      // beyond max_dist in float64: keep the candidate as next start hint
     }
-    }
+}
 
+// ---- workgroup reduction of acc[], write-through partial row + ticket, and -- in the last-arriving workgroup -- the end of
+// the iteration: gather the rows, fixed-order sums, convergence test, 6x6 solve, pose update.  BS = workgroup size.
+template <int MODE, int BS>
+__device__ static inline void icp_finish(const IcpArgs &a, IcpState *st, const double *T, double *acc, int nb, int ns, int launches, unsigned long long t_entry) {
+    __shared__ double red[BS / 16][NVP];           // one row per 16-lane DPP row
+    __shared__ double fin[16][NVP];
+    __shared__ int is_last;
+    __shared__ double ldl_w[96];
+    __shared__ int ldl_perm[6];
     const unsigned long long t_search = wall_clock64() - t_entry;
     // ---- workgroup reduction: DPP butterfly inside every 16-lane row (no LDS crossbar), then the 64 rows in order
     const int lane = threadIdx.x & 63;
@@ -489,7 +474,7 @@ __global__ void __launch_bounds__(LIN_BS) k_icp_iter(IcpArgs a) {
     if (threadIdx.x < NV) {
         double s = red[0][threadIdx.x];
 #pragma unroll 8
-        for (int w = 1; w < LIN_BS / 16; w++) s += red[w][threadIdx.x];
+        for (int w = 1; w < BS / 16; w++) s += red[w][threadIdx.x];
         // publish write-through (sc1): no per-workgroup release fence (a release = whole-L2 write-back; ~700 of
         // them per launch serialised to >100 us).  cdna_hip_programming.md Guideline 16, recipe R1.
         __hip_atomic_store(&a.partials[(size_t)blockIdx.x * NVP + threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -508,28 +493,30 @@ __global__ void __launch_bounds__(LIN_BS) k_icp_iter(IcpArgs a) {
     }
     __syncthreads();
     if (a.stamps_it && (threadIdx.x & 63) == 0 && launches < ICP_STAMP_LAUNCHES) {
-        unsigned long long *w = a.stamps_it + 12 * ((size_t)launches * gridDim.x * (LIN_BS / 64) + (size_t)blockIdx.x * (LIN_BS / 64) + (threadIdx.x >> 6));
+        unsigned long long *w = a.stamps_it + 12 * ((size_t)launches * gridDim.x * (BS / 64) + (size_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6));
         w[0] = t_entry; w[1] = t_entry + t_search; w[2] = wall_clock64(); w[3] = 0; w[4] = t_ws; w[5] = t_drain;
     }
-    unsigned long long *wl = (a.stamps_it && launches < ICP_STAMP_LAUNCHES) ? a.stamps_it + 12 * ((size_t)launches * gridDim.x * (LIN_BS / 64) + (size_t)blockIdx.x * (LIN_BS / 64)) : nullptr;
+    unsigned long long *wl = (a.stamps_it && launches < ICP_STAMP_LAUNCHES) ? a.stamps_it + 12 * ((size_t)launches * gridDim.x * (BS / 64) + (size_t)blockIdx.x * (BS / 64)) : nullptr;
     if (!is_last) return;
 
-    // ---- last workgroup: gather the <= 128 partial rows with sc1 loads (coherent at agent scope without invalidating
-    // this XCD's L2: the acquire fence that plain loads would need took ~10 us here), eight rows per lane, one wait
+    // ---- last workgroup: gather the partial rows with sc1 loads (coherent at agent scope without invalidating this XCD's
+    // L2: the acquire fence that plain loads would need took ~10 us here), eight rows per lane and wait, 128 rows per round
     {
         const int vcol = threadIdx.x & 31, chunk = threadIdx.x >> 5;      // 16 chunks x 32 columns; chunk c <- rows c, c+16, ...
-        const double *p[8]; double v[8];
-#pragma unroll
-        for (int r = 0; r < 8; r++) p[r] = a.partials + (size_t)(chunk + 16 * r < nb ? chunk + 16 * r : 0) * NVP + vcol;
-        asm volatile("global_load_dwordx2 %0, %8, off sc0 sc1\n\tglobal_load_dwordx2 %1, %9, off sc0 sc1\n\t"
-                     "global_load_dwordx2 %2, %10, off sc0 sc1\n\tglobal_load_dwordx2 %3, %11, off sc0 sc1\n\t"
-                     "global_load_dwordx2 %4, %12, off sc0 sc1\n\tglobal_load_dwordx2 %5, %13, off sc0 sc1\n\t"
-                     "global_load_dwordx2 %6, %14, off sc0 sc1\n\tglobal_load_dwordx2 %7, %15, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
-                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
-                     : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]) : "memory");
         double s = 0.0;
+        for (int b0 = 0; b0 < nb; b0 += 128) {
+            const double *p[8]; double v[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) { const double x = chunk + 16 * r < nb ? v[r] : 0.0; s = vcol < NV ? s + x : fmax(s, x); }
+            for (int r = 0; r < 8; r++) p[r] = a.partials + (size_t)(b0 + chunk + 16 * r < nb ? b0 + chunk + 16 * r : 0) * NVP + vcol;
+            asm volatile("global_load_dwordx2 %0, %8, off sc0 sc1\n\tglobal_load_dwordx2 %1, %9, off sc0 sc1\n\t"
+                         "global_load_dwordx2 %2, %10, off sc0 sc1\n\tglobal_load_dwordx2 %3, %11, off sc0 sc1\n\t"
+                         "global_load_dwordx2 %4, %12, off sc0 sc1\n\tglobal_load_dwordx2 %5, %13, off sc0 sc1\n\t"
+                         "global_load_dwordx2 %6, %14, off sc0 sc1\n\tglobal_load_dwordx2 %7, %15, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                         : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]) : "memory");
+#pragma unroll
+            for (int r = 0; r < 8; r++) { const double x = b0 + chunk + 16 * r < nb ? v[r] : 0.0; s = vcol < NV ? s + x : fmax(s, x); }
+        }
         fin[chunk][vcol] = s;
     }
     if (wl && threadIdx.x == 0) wl[6] = wall_clock64();
@@ -594,9 +581,129 @@ __global__ void __launch_bounds__(LIN_BS) k_icp_iter(IcpArgs a) {
         st->ns = ns;
         st->t_live += wall_clock64() - t0k;
         if (a.stamps_it && launches < ICP_STAMP_LAUNCHES)
-            a.stamps_it[12 * ((size_t)launches * gridDim.x * (LIN_BS / 64) + (size_t)blockIdx.x * (LIN_BS / 64)) + 3] = wall_clock64();
+            a.stamps_it[12 * ((size_t)launches * gridDim.x * (BS / 64) + (size_t)blockIdx.x * (BS / 64)) + 3] = wall_clock64();
         st->done = stop ? 1 : 0;          // visible to the next launch through the kernel boundary
     }
+}
+
+// ---- kernel 2 of an iteration: one correspondence per lane in float64 -> wave/LDS reduction -> last workgroup
+// finishes the iteration (sum partials, convergence test, 6x6 solve, pose update).
+template <int MODE>
+__global__ void __launch_bounds__(LIN_BS) k_icp_iter(IcpArgs a) {
+    IcpState *st = a.state;
+    if (st->done) return;
+    const int ns = *a.ns_ptr;
+    int nb = (ns + LIN_BS - 1) / LIN_BS;
+    if (nb < 1) nb = 1;
+    if (nb > (int)gridDim.x) nb = gridDim.x;
+    if ((int)blockIdx.x >= nb) return;
+    const unsigned long long t_entry = wall_clock64();
+    const int launches = st->launches;
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = st->T[k];
+    double acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) acc[k] = 0.0;
+    for (int i = blockIdx.x * LIN_BS + threadIdx.x; i < ns; i += nb * LIN_BS) icp_point<MODE>(a, T, i, ns, a.match[i], acc);
+    icp_finish<MODE, LIN_BS>(a, st, T, acc, nb, ns, launches, t_entry);
+}
+
+// ---- ONE kernel per iteration (launches after the first of a scale): workgroup b owns source points [512 b, 512 b + 512):
+// certificates per lane -> its pending queries compacted into LDS -> the workgroup's 64 octets search them -> barrier ->
+// one correspondence per lane in float64 -> reduction / ticket / last-workgroup finish as in k_icp_iter.  Halves the
+// launches of the loop (the in-flight throughput is bound by the dispatch rate of small dependent kernels, ~90k/s
+// system-wide) and removes the match[] round trip between the two kernels.
+#define FUSED_BS 512
+__global__ void __launch_bounds__(FUSED_BS) k_icp_fused(IcpArgs a) {
+    IcpState *st = a.state;
+    constexpr int OPB = FUSED_BS / OCT;
+    __shared__ OctMeta m;
+    __shared__ OctStack<OPB> stk;
+    __shared__ float4 rec_q[FUSED_BS];         // pending queries of the workgroup: position + hint
+    __shared__ short rec_l[FUSED_BS];          //   and their lane (local point index)
+    __shared__ int cand_l[FUSED_BS];           // candidate target point per local point after the search phase
+    __shared__ int n_rec;
+    const int done = st->done, launches = st->launches;
+    const int ns = *a.ns_ptr, nt = *a.nt_ptr;
+    const int tid = threadIdx.x, lane = tid & 63, oct = lane >> 3, ol = lane & 7, ob = tid >> 3;
+    const int i = blockIdx.x * FUSED_BS + tid;
+    const int ic = i < a.src_cap ? i : 0;
+    const float4 pf = a.src_pts[ic];
+    const int mraw = a.match[ic];
+    const float4 refv = a.ref[ic];
+    const int rb = a.rbest[ic];
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = st->T[k];
+    int mword = 0;
+    if (tid < (int)(sizeof(OctMeta) / 4)) mword = ((const int *)a.tgt.meta)[tid];
+    if (done) return;
+    const int nb = (ns + FUSED_BS - 1) / FUSED_BS > 0 ? (ns + FUSED_BS - 1) / FUSED_BS : 1;
+    if ((int)blockIdx.x >= nb) return;
+    const unsigned long long t_entry = wall_clock64();
+    if (blockIdx.x == 0 && tid == 0) st->t_start = t_entry;
+    if (tid < (int)(sizeof(OctMeta) / 4)) ((int *)&m)[tid] = mword;
+    if (tid == 0) n_rec = 0;
+    __syncthreads();
+    // ---- phase A: one lane per point -- certificate or a place in the pending list
+    bool need = false;
+    int cand = -1;
+    {
+        float qx = 0, qy = 0, qz = 0; int hint = -1;
+        if (i < ns) {
+            const double px = pf.x, py = pf.y, pz = pf.z;
+            qx = (float)(T[0] * px + T[1] * py + T[2] * pz + T[3]);
+            qy = (float)(T[4] * px + T[5] * py + T[6] * pz + T[7]);
+            qz = (float)(T[8] * px + T[9] * py + T[10] * pz + T[11]);
+            hint = mraw >= 0 ? mraw : (mraw <= -2 ? -(mraw + 2) : -1);
+            const float ex = qx - refv.x, ey = qy - refv.y, ez = qz - refv.z;
+            const bool certified = refv.w > 0.0f && pcr_d2(ex, ey, ez) < refv.w * refv.w;
+            need = nt > 0 && !certified;
+            cand = certified ? rb : -1;                 // rb < 0: certified unmatched
+        }
+        const unsigned long long nbm = __ballot(need);
+        int base = 0;
+        if (lane == 0 && nbm != 0ull) base = atomicAdd(&n_rec, __builtin_popcountll(nbm));
+        base = __shfl(base, 0, 64);
+        if (need) {
+            const int slot = base + __builtin_popcountll(nbm & ((1ull << lane) - 1ull));
+            rec_q[slot] = make_float4(qx, qy, qz, __int_as_float(hint)); rec_l[slot] = (short)tid;
+        }
+        cand_l[tid] = cand;
+    }
+    __syncthreads();
+    // ---- phase B: the 64 octets work through the pending list
+    const int npend = n_rec;
+    for (int e0 = 0; e0 < npend; e0 += OPB) {
+        const int e = e0 + ob;
+        const bool live = e < npend;
+        if (__ballot(live) == 0ull) continue;
+        float qx = 0, qy = 0, qz = 0; int hint = -1, l = 0;
+        if (live) { const float4 r = rec_q[e]; qx = r.x; qy = r.y; qz = r.z; hint = __float_as_int(r.w); l = rec_l[e]; }
+        int start_pt = 0; float d1 = 0, d2 = 0;
+        const int best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.r2s, hint, ol, oct, ob, &start_pt, nullptr, &d1, &d2);
+        if (ol == 0 && live) {
+            const int qi = blockIdx.x * FUSED_BS + l;
+            const float slack = 2e-5f + 1e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz));
+            const float margin = best >= 0 ? 0.5f * (sqrtf(d2) - sqrtf(d1)) - slack : a.rs_minus_r - slack;
+            a.ref[qi] = make_float4(qx, qy, qz, margin > 0.0f ? margin : 0.0f);
+            a.rbest[qi] = best;
+            if (best < 0) a.match[qi] = -(start_pt + 2);       // next launch's start hint
+            cand_l[l] = best;
+        }
+    }
+    __syncthreads();
+    // ---- phase C: one correspondence per lane (icp_point stores the match, or the hint when the radius test fails)
+    double acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) acc[k] = 0.0;
+    if (i < ns) {
+        const int c = cand_l[tid];
+        if (c >= 0 && c != mraw) a.match[i] = c;
+        icp_point<ICP_MODE_GICP>(a, T, i, ns, c, acc);
+    }
+    icp_finish<ICP_MODE_GICP, FUSED_BS>(a, st, T, acc, nb, ns, launches, t_entry);
 }
 
 static void fill_args(IcpArgs &a, const DevCloud *src, const DevCloud *tgt, double max_dist, const pcr_gicp_params *p,
@@ -643,8 +750,9 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     const int cap = src->cap > 0 ? src->cap : 1;
     const int nbmax = (cap + LIN_BS - 1) / LIN_BS < LIN_MAX_BLOCKS ? (cap + LIN_BS - 1) / LIN_BS : LIN_MAX_BLOCKS;
     const int nbnn = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT);
+    const int nbf = (cap + FUSED_BS - 1) / FUSED_BS;                 // workgroups of the fused kernel: one per 512 source points
     IcpState *st = arena<IcpState>(ctx, 1);
-    double *partials = arena<double>(ctx, (size_t)nbmax * NVP);
+    double *partials = arena<double>(ctx, (size_t)(nbmax > nbf ? nbmax : nbf) * NVP);
     int32_t *match = match_dev ? match_dev : arena<int32_t>(ctx, cap);
     if (!st || !partials || !match) return PCR_ENOMEM;
     IcpArgs a; memset(&a, 0, sizeof a); fill_args(a, src, tgt, max_dist, p, match, st, partials, 0);
@@ -677,25 +785,32 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     // pair still takes 5 ms), and a graph costs one runtime call instead of 16.  The arena hands out the same addresses
     // for the same problem sizes, so the instantiated graph is cached in the context under its argument bytes.
     static const bool use_graph = !(getenv("PCR_ICP_GRAPH") && atoi(getenv("PCR_ICP_GRAPH")) == 0);
-    hipGraphExec_t chunk_exec = nullptr;
+    static const bool use_fused = !(getenv("PCR_ICP_FUSED") && atoi(getenv("PCR_ICP_FUSED")) == 0);
+    // launch 0 of a scale searches every query (cold): two kernels at full occupancy; later launches: the fused kernel
+    const bool fused = use_fused && a.ref && !use_cov && !stamp_path && nbf <= 4096;
+    auto enqueue = [&](int launch_index) {
+        if (fused && launch_index > 0) { hipLaunchKernelGGL(k_icp_fused, dim3(nbf), dim3(FUSED_BS), 0, ctx->stream, a); return; }
+        hipLaunchKernelGGL(k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
+        if (use_cov) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP_COV>), dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP>), dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
+    };
+    hipGraphExec_t chunk_exec[2] = {nullptr, nullptr};          // [0]: the chunk that starts with launch 0, [1]: every later chunk
     if (use_graph && !stamp_path) {
-        std::string key((const char *)&a, sizeof a);
-        const int extra[4] = {nbnn, nbmax, use_cov ? 1 : 0, CHUNK};
-        key.append((const char *)extra, sizeof extra);
-        for (auto &g : ctx->icp_graphs) if (g.first == key) { chunk_exec = g.second; break; }
-        if (!chunk_exec) {
-            hipGraph_t graph = nullptr;
-            PCR_HIP_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-            for (int k = 0; k < CHUNK; k++) {
-                hipLaunchKernelGGL(k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
-                if (use_cov) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP_COV>), dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
-                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP>), dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
+        for (int which = 0; which < 2; which++) {
+            std::string key((const char *)&a, sizeof a);
+            const int extra[6] = {nbnn, nbmax, use_cov ? 1 : 0, CHUNK, fused ? nbf : 0, which};
+            key.append((const char *)extra, sizeof extra);
+            for (auto &g : ctx->icp_graphs) if (g.first == key) { chunk_exec[which] = g.second; break; }
+            if (!chunk_exec[which]) {
+                hipGraph_t graph = nullptr;
+                PCR_HIP_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+                for (int k = 0; k < CHUNK; k++) enqueue(which == 0 ? k : CHUNK + k);
+                PCR_HIP_CHECK(ctx, hipStreamEndCapture(ctx->stream, &graph));
+                PCR_HIP_CHECK(ctx, hipGraphInstantiate(&chunk_exec[which], graph, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(graph);
+                if (ctx->icp_graphs.size() >= 32) { (void)hipGraphExecDestroy(ctx->icp_graphs.front().second); ctx->icp_graphs.erase(ctx->icp_graphs.begin()); }
+                ctx->icp_graphs.emplace_back(std::move(key), chunk_exec[which]);
             }
-            PCR_HIP_CHECK(ctx, hipStreamEndCapture(ctx->stream, &graph));
-            PCR_HIP_CHECK(ctx, hipGraphInstantiate(&chunk_exec, graph, nullptr, nullptr, 0));
-            (void)hipGraphDestroy(graph);
-            if (ctx->icp_graphs.size() >= 16) { (void)hipGraphExecDestroy(ctx->icp_graphs.front().second); ctx->icp_graphs.erase(ctx->icp_graphs.begin()); }
-            ctx->icp_graphs.emplace_back(std::move(key), chunk_exec);
         }
     }
     IcpState *slots = (IcpState *)ctx->pinned;      // two read-back slots
@@ -709,12 +824,9 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
                 while ((int)ctx->prof_events.size() < 2 * (n_chunks + 1)) { hipEvent_t e; PCR_HIP_CHECK(ctx, hipEventCreate(&e)); ctx->prof_events.push_back(e); }
                 PCR_HIP_CHECK(ctx, hipEventRecord(ctx->prof_events[2 * n_chunks], ctx->stream));
             }
-            if (chunk_exec && c == CHUNK) PCR_HIP_CHECK(ctx, hipGraphLaunch(chunk_exec, ctx->stream));
-            else for (int k = 0; k < c; k++) {
-                hipLaunchKernelGGL(k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
-                if (use_cov) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP_COV>), dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
-                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP>), dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
-            }
+            hipGraphExec_t ge = chunk_exec[launched == 0 ? 0 : 1];
+            if (ge && c == CHUNK) PCR_HIP_CHECK(ctx, hipGraphLaunch(ge, ctx->stream));
+            else for (int k = 0; k < c; k++) enqueue(launched + k);
             if (ctx->profiling) PCR_HIP_CHECK(ctx, hipEventRecord(ctx->prof_events[2 * n_chunks + 1], ctx->stream));
             n_chunks++;
             launched += c;

@@ -1,0 +1,28 @@
+"""Diagnostic: launch period of the GICP loop when N loops (and nothing else) share the GPU."""
+import importlib, os, sys, threading, time
+import numpy as np
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+P = importlib.import_module("point-cloud-registration-with-global-refinement_amd")
+syn = importlib.import_module("point-cloud-registration-with-global-refinement_amd.synthetic")
+reg = P.registration
+p = syn.make_pair(200000)
+est = reg.TransformationEstimationForGeneralizedICP(reg.L1Loss())
+cl = []
+for c in (p.source, p.target):
+    pc = P.PointCloud(c).voxel_down_sample(0.2); pc, _ = pc.remove_statistical_outlier(30, 1.0); pc.estimate_normals(P.KDTreeSearchParamKNN(20)); cl.append(pc)
+crit = reg.ICPConvergenceCriteria(1e-12, 1e-12, 64)      # never converges early: 64 iterations + 1
+def loop(n, out, k):
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        reg.registration_generalized_icp(cl[0], cl[1], 0.4, p.T_init, est, crit)
+        s.synchronize(); t0 = time.perf_counter(); its = 0
+        for _ in range(n):
+            r = reg.registration_generalized_icp(cl[0], cl[1], 0.4, p.T_init, est, crit); its += r.iterations + 1
+        s.synchronize(); out[k] = (time.perf_counter() - t0) / its
+for N in (1, 2, 4, 8):
+    out = [0.0] * N
+    th = [threading.Thread(target=loop, args=(6, out, k)) for k in range(N)]
+    [t.start() for t in th]; [t.join() for t in th]
+    print(f"{N} concurrent GICP loops: {np.mean(out) * 1e6:.1f} us per launch pair (min {min(out) * 1e6:.1f}, max {max(out) * 1e6:.1f})")
