@@ -93,40 +93,38 @@ __global__ void __launch_bounds__(BS) k_scan_tile_count(const uint8_t *__restric
     int tot; (void)block_exclusive_scan(c, &tot);
     if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
 }
-__global__ void __launch_bounds__(BS) k_scan_tile_sums(int *__restrict__ tile_sums, int n_tiles, int *__restrict__ total_out) {
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int b = 0; b < n_tiles; b += BS) {
-        int i = b + threadIdx.x;
-        int v = i < n_tiles ? tile_sums[i] : 0, tot;
-        int ex = block_exclusive_scan(v, &tot);
-        int c = carry;
-        if (i < n_tiles) tile_sums[i] = c + ex;
-        __syncthreads();
-        if (threadIdx.x == 0) carry = c + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total_out = carry;
-}
-__global__ void __launch_bounds__(BS) k_scan_tile_apply(const uint8_t *__restrict__ flags, const int *__restrict__ n_ptr, int n_host, const int *__restrict__ tile_sums, int *__restrict__ pos) {
+// exclusive positions: every tile first adds up the counts of the tiles before it (a few hundred ints, one read per lane)
+// instead of waiting for a separate single-workgroup scan of the tile counts -- one launch less per scan, and launches
+// are what bounds the throughput with several pairs in flight
+__global__ void __launch_bounds__(BS) k_scan_tile_apply(const uint8_t *__restrict__ flags, const int *__restrict__ n_ptr, int n_host, const int *__restrict__ tile_cnt,
+                                                        int *__restrict__ pos, int *__restrict__ total_out) {
+    __shared__ int wsum[BS / 64];
     const int n = n_ptr ? *n_ptr : n_host;
+    int before = 0;
+    for (int t = threadIdx.x; t < (int)blockIdx.x; t += BS) before += tile_cnt[t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_down(before, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = before;
+    __syncthreads();
+    int offset = 0;
+#pragma unroll
+    for (int w = 0; w < BS / 64; w++) offset += wsum[w];
     const int base = blockIdx.x * TILE + threadIdx.x * 4;
     int f[4], c = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) { f[j] = (base + j < n && flags[base + j]) ? 1 : 0; c += f[j]; }
-    int tot; int ex = block_exclusive_scan(c, &tot) + tile_sums[blockIdx.x];
+    int tot; int ex = block_exclusive_scan(c, &tot) + offset;
 #pragma unroll
     for (int j = 0; j < 4; j++) { if (base + j < n) pos[base + j] = ex; ex += f[j]; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = offset + tot;
 }
 
 int pcr_dev_flag_scan(pcr_context *ctx, const uint8_t *flags, const int *n_ptr, int n_cap, int *pos, int *total_dev) {
     const int n_tiles = (n_cap + TILE - 1) / TILE;
-    int *tile_sums = arena<int>(ctx, (size_t)n_tiles + 1);
-    if (!tile_sums) return PCR_ENOMEM;
-    hipLaunchKernelGGL(k_scan_tile_count, dim3(n_tiles), dim3(BS), 0, ctx->stream, flags, n_ptr, n_cap, tile_sums);
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(BS), 0, ctx->stream, tile_sums, n_tiles, total_dev);
-    hipLaunchKernelGGL(k_scan_tile_apply, dim3(n_tiles), dim3(BS), 0, ctx->stream, flags, n_ptr, n_cap, tile_sums, pos);
+    int *tile_cnt = arena<int>(ctx, (size_t)n_tiles + 1);
+    if (!tile_cnt) return PCR_ENOMEM;
+    hipLaunchKernelGGL(k_scan_tile_count, dim3(n_tiles), dim3(BS), 0, ctx->stream, flags, n_ptr, n_cap, tile_cnt);
+    hipLaunchKernelGGL(k_scan_tile_apply, dim3(n_tiles), dim3(BS), 0, ctx->stream, flags, n_ptr, n_cap, tile_cnt, pos, total_dev);
     return PCR_OK;
 }
 
@@ -268,27 +266,45 @@ int pcr_dev_sort_cloud(pcr_context *ctx, const float *xyz, int64_t n, const doub
 
 // ====================================================================== linear octree build (K2, part 2)
 // A: level of the highest Morton bit in which consecutive keys differ (-1: identical keys) + histogram
-__global__ void __launch_bounds__(BS) k_oct_lstar(const uint64_t *__restrict__ keys, const int *__restrict__ n_ptr, signed char *__restrict__ ls, int *__restrict__ hist) {
+#define OCT_ROW 24      // ints per tile row: cumulative node-start counts of the 22 key levels (+ padding)
+__global__ void __launch_bounds__(BS) k_oct_lstar(const uint64_t *__restrict__ keys, const int *__restrict__ n_ptr, signed char *__restrict__ ls, int *__restrict__ rows) {
     __shared__ int h[OCT_KEY_LEVELS];
     if (threadIdx.x < OCT_KEY_LEVELS) h[threadIdx.x] = 0;
     __syncthreads();
-    const int n = *n_ptr, i = blockIdx.x * BS + threadIdx.x;
-    if (i < n) {
-        int v;
-        if (i == 0) v = OCT_KEY_LEVELS - 1;
-        else {
-            const uint64_t x = keys[i] ^ keys[i - 1];
-            v = x ? (63 - __builtin_clzll(x)) / 3 : -1;
+    const int n = *n_ptr;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = blockIdx.x * TILE + j * BS + threadIdx.x;
+        if (i < n) {
+            int v;
+            if (i == 0) v = OCT_KEY_LEVELS - 1;
+            else {
+                const uint64_t x = keys[i] ^ keys[i - 1];
+                v = x ? (63 - __builtin_clzll(x)) / 3 : -1;
+            }
+            ls[i] = (signed char)v;
+            if (v >= 0) atomicAdd(&h[v], 1);
         }
-        ls[i] = (signed char)v;
-        if (v >= 0) atomicAdd(&h[v], 1);
     }
     __syncthreads();
-    if (threadIdx.x < OCT_KEY_LEVELS && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+    // row[l] = number of elements of this tile that start a node of level l (= differ from their predecessor at level >= l):
+    // no global histogram, no memset, and the same rows are the per-tile counts the node numbering needs
+    if (threadIdx.x < OCT_ROW) {
+        int c = 0;
+        for (int l = threadIdx.x; l < OCT_KEY_LEVELS; l++) c += h[l];
+        rows[blockIdx.x * OCT_ROW + threadIdx.x] = threadIdx.x < OCT_KEY_LEVELS ? c : 0;
+    }
 }
 // B: choose the leaf level (first level with <= n/4 cells: ~8 points per leaf), the root level, offsets
 struct OctGeom { float org[3]; float unit[3]; int leaf_div; };
-__global__ void k_oct_meta(const int *__restrict__ n_ptr, const int *__restrict__ hist, int node_cap, OctMeta *__restrict__ meta, int *__restrict__ child, OctGeom g) {
+__global__ void __launch_bounds__(64) k_oct_meta(const int *__restrict__ n_ptr, const int *__restrict__ rows, int n_tiles, int node_cap, OctMeta *__restrict__ meta, int *__restrict__ child, OctGeom g) {
+    __shared__ int tot[OCT_ROW];
+    if (threadIdx.x < OCT_ROW) {
+        int c = 0;
+        for (int t = 0; t < n_tiles; t++) c += rows[t * OCT_ROW + threadIdx.x];
+        tot[threadIdx.x] = c;
+    }
+    __syncthreads();
     if (threadIdx.x != 0) return;
     const int n = *n_ptr;
     OctMeta m;
@@ -298,7 +314,7 @@ __global__ void k_oct_meta(const int *__restrict__ n_ptr, const int *__restrict_
     if (n > 0) {
         int cnt[OCT_KEY_LEVELS + 1];
         cnt[OCT_KEY_LEVELS] = 0;
-        for (int l = OCT_KEY_LEVELS - 1; l >= 0; l--) cnt[l] = cnt[l + 1] + hist[l];
+        for (int l = OCT_KEY_LEVELS - 1; l >= 0; l--) cnt[l] = tot[l];
         const int want = n / g.leaf_div > 1 ? n / g.leaf_div : 1;
         int l0 = 0;
         while (l0 < OCT_KEY_LEVELS - 1 && cnt[l0] > want) l0++;
@@ -319,49 +335,24 @@ __global__ void k_oct_meta(const int *__restrict__ n_ptr, const int *__restrict_
     }
     *meta = m;
 }
-// C: per tile, number of node starts per stored level
-__global__ void __launch_bounds__(BS) k_oct_tile_count(const signed char *__restrict__ ls, const OctMeta *__restrict__ meta, int *__restrict__ tile_cnt) {
-    __shared__ int h[OCT_KEY_LEVELS + 1];
-    if (threadIdx.x <= OCT_KEY_LEVELS) h[threadIdx.x] = 0;
-    __syncthreads();
-    const int n = meta->n, l0 = meta->l0, nl = meta->nl;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int e = blockIdx.x * TILE + j * BS + threadIdx.x;
-        if (e < n) { const int v = ls[e]; if (v >= 0) atomicAdd(&h[v], 1); }
-    }
-    __syncthreads();
-    if (threadIdx.x < OCT_MAXL) {
-        int c = 0;
-        if ((int)threadIdx.x < nl) for (int l = l0 + threadIdx.x; l < OCT_KEY_LEVELS; l++) c += h[l];
-        tile_cnt[blockIdx.x * OCT_MAXL + threadIdx.x] = c;
-    }
-}
-// D: exclusive scan over tiles for every level (one workgroup, block-wide scan per level)
-__global__ void __launch_bounds__(BS) k_oct_tile_scan(int *__restrict__ tile_cnt, int n_tiles) {
-    __shared__ int carry;
-    for (int li = 0; li < OCT_MAXL; li++) {
-        if (threadIdx.x == 0) carry = 0;
-        __syncthreads();
-        for (int b = 0; b < n_tiles; b += BS) {
-            const int t = b + threadIdx.x;
-            const int v = t < n_tiles ? tile_cnt[t * OCT_MAXL + li] : 0;
-            int tot;
-            const int ex = block_exclusive_scan(v, &tot);
-            const int c = carry;
-            if (t < n_tiles) tile_cnt[t * OCT_MAXL + li] = c + ex;
-            __syncthreads();
-            if (threadIdx.x == 0) carry = c + tot;
-            __syncthreads();
-        }
-    }
-}
 // E: node ids by ballot ranking; write child links and the leaf of every point
-__global__ void __launch_bounds__(BS) k_oct_apply(const signed char *__restrict__ ls, const OctMeta *__restrict__ meta, const int *__restrict__ tile_cnt,
+__global__ void __launch_bounds__(BS) k_oct_apply(const signed char *__restrict__ ls, const OctMeta *__restrict__ meta, const int *__restrict__ rows,
                                                   int *__restrict__ child, int *__restrict__ leaf_of) {
     __shared__ int wtot[4][BS / PCR_WAVE][OCT_MAXL];
+    __shared__ int part[BS / OCT_MAXL][OCT_MAXL];
+    __shared__ int pre_s[OCT_MAXL];
     const int n = meta->n, l0 = meta->l0, nl = meta->nl;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // exclusive prefix over the tiles before this one, per stored level (was a separate single-workgroup scan launch)
+    {
+        const int li = threadIdx.x & (OCT_MAXL - 1), tl = threadIdx.x / OCT_MAXL;
+        int c = 0;
+        if (li < nl) for (int t = tl; t < (int)blockIdx.x; t += BS / OCT_MAXL) c += rows[t * OCT_ROW + l0 + li];
+        part[tl][li] = c;
+        __syncthreads();
+        if (threadIdx.x < OCT_MAXL) { int sum = 0; for (int k = 0; k < BS / OCT_MAXL; k++) sum += part[k][threadIdx.x]; pre_s[threadIdx.x] = sum; }
+        __syncthreads();
+    }
     int v[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) { const int e = blockIdx.x * TILE + j * BS + threadIdx.x; v[j] = e < n ? (int)ls[e] : -2; }
@@ -380,7 +371,7 @@ __global__ void __launch_bounds__(BS) k_oct_apply(const signed char *__restrict_
         for (int li = 0; li < nl; li++) {
             const bool f = v[j] >= l0 + li;
             const unsigned long long b = __ballot(f);
-            int pre = tile_cnt[blockIdx.x * OCT_MAXL + li];
+            int pre = pre_s[li];
             for (int jj = 0; jj < 4; jj++)
                 for (int ww = 0; ww < BS / PCR_WAVE; ww++)
                     if (jj < j || (jj == j && ww < w)) pre += wtot[jj][ww][li];
@@ -450,18 +441,13 @@ int pcr_dev_build_bvh(pcr_context *ctx, DevCloud *c) {
     ArenaMark mark(ctx);
     const int cap = c->cap, n_tiles = (cap + TILE - 1) / TILE;
     signed char *ls = arena<signed char>(ctx, cap);
-    int *hist = arena<int>(ctx, 32);
-    int *tile_cnt = arena<int>(ctx, (size_t)n_tiles * OCT_MAXL);
-    if (!ls || !hist || !tile_cnt) return PCR_ENOMEM;
-    PCR_HIP_CHECK(ctx, hipMemsetAsync(hist, 0, 32 * sizeof(int), ctx->stream));
-    const int nb = (cap + BS - 1) / BS;
-    hipLaunchKernelGGL(k_oct_lstar, dim3(nb), dim3(BS), 0, ctx->stream, c->keys, c->n, ls, hist);
+    int *rows = arena<int>(ctx, (size_t)n_tiles * OCT_ROW);
+    if (!ls || !rows) return PCR_ENOMEM;
+    hipLaunchKernelGGL(k_oct_lstar, dim3(n_tiles), dim3(BS), 0, ctx->stream, c->keys, c->n, ls, rows);
     OctGeom g; for (int d = 0; d < 3; d++) { g.org[d] = c->key_org[d]; g.unit[d] = c->key_unit[d]; }
     { static const int div = getenv("PCR_OCT_DIV") ? atoi(getenv("PCR_OCT_DIV")) : 4; g.leaf_div = div; }
-    hipLaunchKernelGGL(k_oct_meta, dim3(1), dim3(64), 0, ctx->stream, c->n, hist, (int)oct_node_capacity(cap), c->oct_meta, c->oct_child, g);
-    hipLaunchKernelGGL(k_oct_tile_count, dim3(n_tiles), dim3(BS), 0, ctx->stream, ls, c->oct_meta, tile_cnt);
-    hipLaunchKernelGGL(k_oct_tile_scan, dim3(1), dim3(BS), 0, ctx->stream, tile_cnt, n_tiles);
-    hipLaunchKernelGGL(k_oct_apply, dim3(n_tiles), dim3(BS), 0, ctx->stream, ls, c->oct_meta, tile_cnt, c->oct_child, c->leaf_of);
+    hipLaunchKernelGGL(k_oct_meta, dim3(1), dim3(64), 0, ctx->stream, c->n, rows, n_tiles, (int)oct_node_capacity(cap), c->oct_meta, c->oct_child, g);
+    hipLaunchKernelGGL(k_oct_apply, dim3(n_tiles), dim3(BS), 0, ctx->stream, ls, c->oct_meta, rows, c->oct_child, c->leaf_of);
     const int nbl = (cap / 2 + 1 + BS - 1) / BS;       // <= n/2 leaves (or 1)
     hipLaunchKernelGGL(k_oct_leaf_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->pts, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, c->pinfo);
     hipLaunchKernelGGL(k_oct_level_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, 1, c->pinfo);
