@@ -371,7 +371,7 @@ extern "C" int pcr_debug_gicp_linearize(pcr_context *ctx, const float *src_xyz, 
 
 // one cloud of one scale: voxel -> BVH -> SOR -> BVH -> normals   (ALL_FUNCTIONS.py:293-302)
 static int prep_scale(pcr_context *ctx, const float *xyz, const float *nrm, int64_t n, const double *b6, double voxel, int sor_k,
-                      double sor_std, int normal_k, DevCloud *clean, int **n_voxel_dev) {
+                      double sor_std, int normal_k, DevCloud *clean, int *cnt_voxel_out, int *cnt_clean_out) {
     DevCloud v;
     PCR_TRY(pcr_alloc_cloud(ctx, clean, (int)n, true, true));        // survives the mark below (allocated first)
     float4 *prior = nrm ? arena<float4>(ctx, n > 0 ? n : 1) : nullptr;
@@ -386,14 +386,12 @@ static int prep_scale(pcr_context *ctx, const float *xyz, const float *nrm, int6
         DevCloud tmp = *clean;
         tmp.nrm = prior;                                         // compacted voxel-mean normals = orientation prior
         tmp.nrm_final = clean->nrm;                              // normals of the cleaned cloud, straight from the SOR lists
-        PCR_TRY(pcr_dev_sor(ctx, &v, sor_k, sor_std, &tmp, nullptr, nullptr, normal_k, prior, todo, nv_keep + 1));
+        PCR_TRY(pcr_dev_sor(ctx, &v, sor_k, sor_std, &tmp, nullptr, nullptr, normal_k, prior, todo, nv_keep + 1, cnt_voxel_out, cnt_clean_out));
         for (int d = 0; d < 3; d++) { clean->key_org[d] = tmp.key_org[d]; clean->key_unit[d] = tmp.key_unit[d]; }
-        PCR_HIP_CHECK(ctx, hipMemcpyAsync(nv_keep, v.n, sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
     }
     PCR_TRY(pcr_dev_build_bvh(ctx, clean));
     // the few points whose list could not be proven exact: full search over the cleaned tree
     PCR_TRY(pcr_dev_normals(ctx, clean, PCR_SEARCH_KNN, normal_k, 0.0, prior, clean->nrm, nullptr, todo));
-    *n_voxel_dev = nv_keep;
     return PCR_OK;
 }
 
@@ -441,17 +439,19 @@ extern "C" int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const
     PCR_HIP_CHECK(ctx, hipEventRecord(ctx->side_ev[0], ctx->stream));       // inputs are ready once the caller's stream gets here
     PCR_HIP_CHECK(ctx, hipStreamWaitEvent(lane_t, ctx->side_ev[0], 0));
     if (lane_s != lane_t) PCR_HIP_CHECK(ctx, hipStreamWaitEvent(lane_s, ctx->side_ev[0], 0));
-    DevCloud cs[MAX_RING], ct[MAX_RING]; int *nvs[MAX_RING] = {}, *nvt[MAX_RING] = {};
+    DevCloud cs[MAX_RING], ct[MAX_RING];
+    int *cnt4 = arena<int>(ctx, 4 * MAX_RING);        // per ring slot: voxel counts (source, target), clean counts (source, target)
+    if (!cnt4) return PCR_ENOMEM;
     auto enqueue_prep = [&](int s) -> int {
         const int r = s % ring;
         {
             SideLane lane(ctx, blocks[r][1], blk_t, lane_t);
-            PCR_TRY(prep_scale(ctx, tgt_xyz, tgt_normals, n_tgt, bt, voxels[s], sor_k, sor_std, normal_k, &ct[r], &nvt[r]));
+            PCR_TRY(prep_scale(ctx, tgt_xyz, tgt_normals, n_tgt, bt, voxels[s], sor_k, sor_std, normal_k, &ct[r], cnt4 + 4 * r + 1, cnt4 + 4 * r + 3));
             PCR_HIP_CHECK(ctx, hipEventRecord(ctx->lane_ev[2 * r + 1], ctx->stream));
         }
         {
             SideLane lane(ctx, blocks[r][0], blk_s, lane_s);
-            PCR_TRY(prep_scale(ctx, src_xyz, src_normals, n_src, bs, voxels[s], sor_k, sor_std, normal_k, &cs[r], &nvs[r]));
+            PCR_TRY(prep_scale(ctx, src_xyz, src_normals, n_src, bs, voxels[s], sor_k, sor_std, normal_k, &cs[r], cnt4 + 4 * r, cnt4 + 4 * r + 2));
             PCR_HIP_CHECK(ctx, hipEventRecord(ctx->lane_ev[2 * r], ctx->stream));
         }
         return PCR_OK;
@@ -467,10 +467,7 @@ extern "C" int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const
         if (!match) return PCR_ENOMEM;
         PCR_TRY(pcr_dev_gicp(ctx, &cs[r], &ct[r], dists[s], T, params, &records[s].icp, match));
         int h[4];
-        PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h[0], nvs[r], sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h[1], nvt[r], sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h[2], cs[r].n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h[3], ct[r].n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP_CHECK(ctx, hipMemcpyAsync(h, cnt4 + 4 * r, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         records[s].n_voxel[0] = h[0]; records[s].n_voxel[1] = h[1]; records[s].n_clean[0] = h[2]; records[s].n_clean[1] = h[3];
         memcpy(T, records[s].icp.transformation, sizeof T);

@@ -84,12 +84,24 @@ __device__ static inline int block_exclusive_scan(int v, int *total) {   // BS t
     return base + inc - v;
 }
 
-__global__ void __launch_bounds__(BS) k_scan_tile_count(const uint8_t *__restrict__ flags, const int *__restrict__ n_ptr, int n_host, int *__restrict__ tile_sums) {
+// Optional flag producers fused into the counting pass (each saved a launch of its own): head flags of sorted keys
+// (voxel grid), or the SOR keep test on the mean neighbour distances.  The flags are stored for the later kernels.
+struct FlagSrc { const uint64_t *keys; const double *avg; const double *stats3; };
+__global__ void __launch_bounds__(BS) k_scan_tile_count(uint8_t *__restrict__ flags, const int *__restrict__ n_ptr, int n_host, int *__restrict__ tile_sums, FlagSrc src) {
     const int n = n_ptr ? *n_ptr : n_host;
     const int base = blockIdx.x * TILE + threadIdx.x * 4;
     int c = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) if (base + j < n) c += flags[base + j] ? 1 : 0;
+    for (int j = 0; j < 4; j++) {
+        const int i = base + j;
+        if (i < n) {
+            int f;
+            if (src.keys) { f = (i == 0 || src.keys[i] != src.keys[i - 1]) ? 1 : 0; flags[i] = (uint8_t)f; }
+            else if (src.avg) { const double v = src.avg[i]; f = (v > 0 && v < src.stats3[2]) ? 1 : 0; flags[i] = (uint8_t)f; }
+            else f = flags[i] ? 1 : 0;
+            c += f;
+        }
+    }
     int tot; (void)block_exclusive_scan(c, &tot);
     if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
 }
@@ -119,13 +131,16 @@ __global__ void __launch_bounds__(BS) k_scan_tile_apply(const uint8_t *__restric
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = offset + tot;
 }
 
-int pcr_dev_flag_scan(pcr_context *ctx, const uint8_t *flags, const int *n_ptr, int n_cap, int *pos, int *total_dev) {
+static int flag_scan(pcr_context *ctx, uint8_t *flags, const int *n_ptr, int n_cap, int *pos, int *total_dev, FlagSrc src) {
     const int n_tiles = (n_cap + TILE - 1) / TILE;
     int *tile_cnt = arena<int>(ctx, (size_t)n_tiles + 1);
     if (!tile_cnt) return PCR_ENOMEM;
-    hipLaunchKernelGGL(k_scan_tile_count, dim3(n_tiles), dim3(BS), 0, ctx->stream, flags, n_ptr, n_cap, tile_cnt);
+    hipLaunchKernelGGL(k_scan_tile_count, dim3(n_tiles), dim3(BS), 0, ctx->stream, flags, n_ptr, n_cap, tile_cnt, src);
     hipLaunchKernelGGL(k_scan_tile_apply, dim3(n_tiles), dim3(BS), 0, ctx->stream, flags, n_ptr, n_cap, tile_cnt, pos, total_dev);
     return PCR_OK;
+}
+int pcr_dev_flag_scan(pcr_context *ctx, const uint8_t *flags, const int *n_ptr, int n_cap, int *pos, int *total_dev) {
+    return flag_scan(ctx, const_cast<uint8_t *>(flags), n_ptr, n_cap, pos, total_dev, FlagSrc{nullptr, nullptr, nullptr});
 }
 
 // ================================================================================== voxel (K1)
@@ -140,11 +155,6 @@ __global__ void __launch_bounds__(BS) k_voxel_keys(const float *__restrict__ xyz
     const uint32_t iz = (uint32_t)(int)floor((z - oz) / voxel);
     keys[i] = pcr_morton3(ix, iy, iz);
     vals[i] = (uint32_t)i;
-}
-__global__ void __launch_bounds__(BS) k_head_flags(const uint64_t *__restrict__ keys, int n, uint8_t *__restrict__ flags) {
-    const int i = blockIdx.x * BS + threadIdx.x;
-    if (i >= n) return;
-    flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
 }
 __global__ void __launch_bounds__(BS) k_voxel_mean(const float *__restrict__ xyz, const float *__restrict__ nrm_in, const uint64_t *__restrict__ keys,
                                                    const uint32_t *__restrict__ vals, const uint8_t *__restrict__ flags, const int *__restrict__ pos, int n,
@@ -195,8 +205,7 @@ int pcr_dev_voxel(pcr_context *ctx, const float *xyz, const float *nrm_in, int64
     const int nb = (ni + BS - 1) / BS;
     hipLaunchKernelGGL(k_voxel_keys, dim3(nb), dim3(BS), 0, ctx->stream, xyz, ni, ox, oy, oz, voxel, k0, v0);
     PCR_TRY(pcr_sort_pairs(ctx, temp, tb, k0, k1, v0, v1, n, end_bit));
-    hipLaunchKernelGGL(k_head_flags, dim3(nb), dim3(BS), 0, ctx->stream, k1, ni, flags);
-    PCR_TRY(pcr_dev_flag_scan(ctx, flags, nullptr, ni, pos, out->n));
+    PCR_TRY(flag_scan(ctx, flags, nullptr, ni, pos, out->n, FlagSrc{k1, nullptr, nullptr}));      // head flags produced inside the scan
     hipLaunchKernelGGL(k_voxel_mean, dim3(nb), dim3(BS), 0, ctx->stream, xyz, nrm_in, k1, v1, flags, pos, ni, out->pts, out->nrm, out->keys);
     return PCR_OK;
 }
@@ -601,6 +610,7 @@ struct KnnArgs {
     const uint8_t *todo;                                 // optional: only queries with todo[q] != 0 are processed
     unsigned long long *stamps;                          // diagnostics (PCR_KNN_STAMPS): 24 words per wavefront
     int seed_span;                                       // Morton-index half-width of the seed range (-1: k)
+    int *zero_a, *zero_b;                                // optional counters of LATER kernels, zeroed here (saves two memset launches)
 };
 
 __device__ static inline double octet_sum(double v) { return pcr_octet_sum(v); }
@@ -611,6 +621,7 @@ __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) {
     __shared__ OctMeta m;
     __shared__ OctGroupStack gstk[KNN_BS / 64];
     if (threadIdx.x == 0) m = *a.t.meta;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { if (a.zero_a) *a.zero_a = 0; if (a.zero_b) *a.zero_b = 0; }
     __syncthreads();
     const int n = m.n;
     const int lane = threadIdx.x & 63, oct = lane >> 3, ol = lane & 7, ob = threadIdx.x >> 3;
@@ -1010,16 +1021,12 @@ __global__ void __launch_bounds__(256) k_sor_stats(const double *__restrict__ av
         *ticket = 0u;
     }
 }
-__global__ void __launch_bounds__(BS) k_sor_flags(const double *__restrict__ avg, const int *__restrict__ n_ptr, const double *__restrict__ stats3, uint8_t *__restrict__ flags) {
-    const int i = blockIdx.x * BS + threadIdx.x;
-    if (i >= *n_ptr) return;
-    const double v = avg[i];
-    flags[i] = (v > 0 && v < stats3[2]) ? 1 : 0;
-}
 __global__ void __launch_bounds__(BS) k_compact_cloud(const float4 *__restrict__ pts, const float4 *__restrict__ nrm, const uint8_t *__restrict__ flags, const int *__restrict__ pos,
                                                       const int *__restrict__ n_ptr, float4 *__restrict__ out_pts, float4 *__restrict__ out_nrm,
-                                                      const uint64_t *__restrict__ keys, uint64_t *__restrict__ out_keys) {
+                                                      const uint64_t *__restrict__ keys, uint64_t *__restrict__ out_keys,
+                                                      int *__restrict__ cnt_in_out, int *__restrict__ cnt_kept_out, const int *__restrict__ kept_n) {
     const int i = blockIdx.x * BS + threadIdx.x;
+    if (i == 0) { if (cnt_in_out) *cnt_in_out = *n_ptr; if (cnt_kept_out) *cnt_kept_out = *kept_n; }    // counts for the host, one copy later
     if (i >= *n_ptr || !flags[i]) return;
     const int o = pos[i];
     out_pts[o] = pts[i];
@@ -1028,7 +1035,7 @@ __global__ void __launch_bounds__(BS) k_compact_cloud(const float4 *__restrict__
 }
 
 int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double std_ratio, DevCloud *out, uint8_t *keep_sorted, double *avg_sorted,
-                int normal_k, const float4 *prior_out, uint8_t *todo_out, int *todo_count) {
+                int normal_k, const float4 *prior_out, uint8_t *todo_out, int *todo_count, int *cnt_in_out, int *cnt_kept_out) {
     if (nb_neighbors < 1 || !(std_ratio > 0.0)) { ctx->err = "nb_neighbors < 1 or std_ratio <= 0"; return PCR_EINVAL; }
     for (int d = 0; d < 3; d++) { out->key_org[d] = in->key_org[d]; out->key_unit[d] = in->key_unit[d]; }
     if (in->cap <= 0) { PCR_HIP_CHECK(ctx, hipMemsetAsync(out->n, 0, sizeof(int), ctx->stream)); return PCR_OK; }
@@ -1040,7 +1047,6 @@ int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double s
     uint8_t *flags = keep_sorted ? keep_sorted : arena<uint8_t>(ctx, in->cap);
     int *pos = arena<int>(ctx, in->cap);
     if (!avg || !stats3 || !stat_partials || !stat_ticket || !flags || !pos) return PCR_ENOMEM;
-    PCR_HIP_CHECK(ctx, hipMemsetAsync(stat_ticket, 0, sizeof(unsigned int), ctx->stream));
     // normals of the cleaned cloud straight from this pass's lists when they can be exact (see k_normals_from_lists)
     const bool fuse = normal_k > 0 && todo_out && nb_neighbors <= 32 && normal_k <= nb_neighbors;
     int32_t *lidx = fuse ? arena<int32_t>(ctx, (size_t)in->cap * 32) : nullptr;
@@ -1048,16 +1054,15 @@ int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double s
     if (fuse && (!lidx || !ld2)) return PCR_ENOMEM;
     KnnArgs a = {};
     a.t = oct_view(in); a.n_ptr = in->n; a.k = nb_neighbors; a.avg = avg; a.list_idx = lidx; a.list_d2 = ld2;
+    a.zero_a = (int *)stat_ticket; a.zero_b = (fuse && todo_out) ? todo_count : nullptr;      // zeroed by the search kernel for the kernels after it
     knn_radius(a, PCR_SEARCH_KNN, 0);
     PCR_TRY(launch_knn<KNN_MODE_SOR>(ctx, in, a));
     hipLaunchKernelGGL(k_sor_stats, dim3(SOR_STAT_BLOCKS), dim3(256), 0, ctx->stream, avg, in->n, std_ratio, stats3, stat_partials, stat_ticket);
     const int nb = (in->cap + BS - 1) / BS;
-    hipLaunchKernelGGL(k_sor_flags, dim3(nb), dim3(BS), 0, ctx->stream, avg, in->n, stats3, flags);
-    PCR_TRY(pcr_dev_flag_scan(ctx, flags, in->n, in->cap, pos, out->n));
-    hipLaunchKernelGGL(k_compact_cloud, dim3(nb), dim3(BS), 0, ctx->stream, in->pts, in->nrm, flags, pos, in->n, out->pts, out->nrm, in->keys, out->keys);
+    PCR_TRY(flag_scan(ctx, flags, in->n, in->cap, pos, out->n, FlagSrc{nullptr, avg, stats3}));      // keep flags produced inside the scan
+    hipLaunchKernelGGL(k_compact_cloud, dim3(nb), dim3(BS), 0, ctx->stream, in->pts, in->nrm, flags, pos, in->n, out->pts, out->nrm, in->keys, out->keys, cnt_in_out, cnt_kept_out, out->n);
     if (todo_out) {
         if (fuse) {
-            PCR_HIP_CHECK(ctx, hipMemsetAsync(todo_count, 0, sizeof(int), ctx->stream));
             NflArgs f;
             f.pts = in->pts; f.n_ptr = in->n; f.lidx = lidx; f.ld2 = ld2; f.keep = flags; f.pos = pos; f.k_list = nb_neighbors; f.k_nrm = normal_k;
             f.prior = prior_out; f.normals = out->nrm_final; f.todo = todo_out; f.todo_count = todo_count;
