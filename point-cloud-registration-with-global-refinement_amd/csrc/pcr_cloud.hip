@@ -306,13 +306,17 @@ __global__ void __launch_bounds__(BS) k_oct_lstar(const uint64_t *__restrict__ k
 }
 // B: choose the leaf level (first level with <= n/4 cells: ~8 points per leaf), the root level, offsets
 struct OctGeom { float org[3]; float unit[3]; int leaf_div; };
-__global__ void __launch_bounds__(64) k_oct_meta(const int *__restrict__ n_ptr, const int *__restrict__ rows, int n_tiles, int node_cap, OctMeta *__restrict__ meta, int *__restrict__ child, OctGeom g) {
+__global__ void __launch_bounds__(256) k_oct_meta(const int *__restrict__ n_ptr, const int *__restrict__ rows, int n_tiles, int node_cap, OctMeta *__restrict__ meta, int *__restrict__ child, OctGeom g) {
+    __shared__ int part[8][32];
     __shared__ int tot[OCT_ROW];
-    if (threadIdx.x < OCT_ROW) {
+    {
+        const int l = threadIdx.x & 31, tl = threadIdx.x >> 5;          // 8 tile lanes x 32 columns
         int c = 0;
-        for (int t = 0; t < n_tiles; t++) c += rows[t * OCT_ROW + threadIdx.x];
-        tot[threadIdx.x] = c;
+        if (l < OCT_ROW) for (int t = tl; t < n_tiles; t += 8) c += rows[t * OCT_ROW + l];
+        part[tl][l] = c;
     }
+    __syncthreads();
+    if (threadIdx.x < OCT_ROW) { int c = 0; for (int k = 0; k < 8; k++) c += part[k][threadIdx.x]; tot[threadIdx.x] = c; }
     __syncthreads();
     if (threadIdx.x != 0) return;
     const int n = *n_ptr;
@@ -455,13 +459,13 @@ int pcr_dev_build_bvh(pcr_context *ctx, DevCloud *c) {
     hipLaunchKernelGGL(k_oct_lstar, dim3(n_tiles), dim3(BS), 0, ctx->stream, c->keys, c->n, ls, rows);
     OctGeom g; for (int d = 0; d < 3; d++) { g.org[d] = c->key_org[d]; g.unit[d] = c->key_unit[d]; }
     { static const int div = getenv("PCR_OCT_DIV") ? atoi(getenv("PCR_OCT_DIV")) : 4; g.leaf_div = div; }
-    hipLaunchKernelGGL(k_oct_meta, dim3(1), dim3(64), 0, ctx->stream, c->n, rows, n_tiles, (int)oct_node_capacity(cap), c->oct_meta, c->oct_child, g);
+    hipLaunchKernelGGL(k_oct_meta, dim3(1), dim3(256), 0, ctx->stream, c->n, rows, n_tiles, (int)oct_node_capacity(cap), c->oct_meta, c->oct_child, g);
     hipLaunchKernelGGL(k_oct_apply, dim3(n_tiles), dim3(BS), 0, ctx->stream, ls, c->oct_meta, rows, c->oct_child, c->leaf_of);
     const int nbl = (cap / 2 + 1 + BS - 1) / BS;       // <= n/2 leaves (or 1)
     hipLaunchKernelGGL(k_oct_leaf_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->pts, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, c->pinfo);
     hipLaunchKernelGGL(k_oct_level_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, 1, c->pinfo);
-    hipLaunchKernelGGL(k_oct_level_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, 2, c->pinfo);
-    hipLaunchKernelGGL(k_oct_upper_boxes, dim3(1), dim3(1024), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, 3);
+    // levels >= 2 (n/64 nodes and fewer) in ONE workgroup, level by level: a launch less than one grid per level
+    hipLaunchKernelGGL(k_oct_upper_boxes, dim3(1), dim3(1024), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, 2);
     return PCR_OK;
 }
 
