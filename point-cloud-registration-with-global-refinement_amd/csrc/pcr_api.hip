@@ -371,9 +371,9 @@ extern "C" int pcr_debug_gicp_linearize(pcr_context *ctx, const float *src_xyz, 
 
 // one cloud of one scale: voxel -> BVH -> SOR -> BVH -> normals   (ALL_FUNCTIONS.py:293-302)
 static int prep_scale(pcr_context *ctx, const float *xyz, const float *nrm, int64_t n, const double *b6, double voxel, int sor_k,
-                      double sor_std, int normal_k, DevCloud *clean, int *cnt_voxel_out, int *cnt_clean_out) {
+                      double sor_std, int normal_k, DevCloud *clean, int *cnt_voxel_out, int *cnt_clean_out, bool need_tree) {
     DevCloud v;
-    PCR_TRY(pcr_alloc_cloud(ctx, clean, (int)n, true, true));        // survives the mark below (allocated first)
+    PCR_TRY(pcr_alloc_cloud(ctx, clean, (int)n, true, need_tree));   // survives the mark below (allocated first)
     float4 *prior = nrm ? arena<float4>(ctx, n > 0 ? n : 1) : nullptr;
     int *nv_keep = arena<int>(ctx, 2);
     uint8_t *todo = arena<uint8_t>(ctx, n > 0 ? n : 1);
@@ -386,12 +386,13 @@ static int prep_scale(pcr_context *ctx, const float *xyz, const float *nrm, int6
         DevCloud tmp = *clean;
         tmp.nrm = prior;                                         // compacted voxel-mean normals = orientation prior
         tmp.nrm_final = clean->nrm;                              // normals of the cleaned cloud, straight from the SOR lists
-        PCR_TRY(pcr_dev_sor(ctx, &v, sor_k, sor_std, &tmp, nullptr, nullptr, normal_k, prior, todo, nv_keep + 1, cnt_voxel_out, cnt_clean_out));
+        PCR_TRY(pcr_dev_sor(ctx, &v, sor_k, sor_std, &tmp, nullptr, nullptr, normal_k, prior, todo, nv_keep + 1, cnt_voxel_out, cnt_clean_out, !need_tree));
         for (int d = 0; d < 3; d++) { clean->key_org[d] = tmp.key_org[d]; clean->key_unit[d] = tmp.key_unit[d]; }
     }
-    PCR_TRY(pcr_dev_build_bvh(ctx, clean));
-    // the few points whose list could not be proven exact: full search over the cleaned tree
-    PCR_TRY(pcr_dev_normals(ctx, clean, PCR_SEARCH_KNN, normal_k, 0.0, prior, clean->nrm, nullptr, todo));
+    if (need_tree) {     // a GICP target: its tree serves the correspondence search and the few incomplete normal lists
+        PCR_TRY(pcr_dev_build_bvh(ctx, clean));
+        PCR_TRY(pcr_dev_normals(ctx, clean, PCR_SEARCH_KNN, normal_k, 0.0, prior, clean->nrm, nullptr, todo));
+    }
     return PCR_OK;
 }
 
@@ -446,12 +447,12 @@ extern "C" int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const
         const int r = s % ring;
         {
             SideLane lane(ctx, blocks[r][1], blk_t, lane_t);
-            PCR_TRY(prep_scale(ctx, tgt_xyz, tgt_normals, n_tgt, bt, voxels[s], sor_k, sor_std, normal_k, &ct[r], cnt4 + 4 * r + 1, cnt4 + 4 * r + 3));
+            PCR_TRY(prep_scale(ctx, tgt_xyz, tgt_normals, n_tgt, bt, voxels[s], sor_k, sor_std, normal_k, &ct[r], cnt4 + 4 * r + 1, cnt4 + 4 * r + 3, true));
             PCR_HIP_CHECK(ctx, hipEventRecord(ctx->lane_ev[2 * r + 1], ctx->stream));
         }
         {
             SideLane lane(ctx, blocks[r][0], blk_s, lane_s);
-            PCR_TRY(prep_scale(ctx, src_xyz, src_normals, n_src, bs, voxels[s], sor_k, sor_std, normal_k, &cs[r], cnt4 + 4 * r, cnt4 + 4 * r + 2));
+            PCR_TRY(prep_scale(ctx, src_xyz, src_normals, n_src, bs, voxels[s], sor_k, sor_std, normal_k, &cs[r], cnt4 + 4 * r, cnt4 + 4 * r + 2, false));
             PCR_HIP_CHECK(ctx, hipEventRecord(ctx->lane_ev[2 * r], ctx->stream));
         }
         return PCR_OK;

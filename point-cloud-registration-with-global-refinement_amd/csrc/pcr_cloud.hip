@@ -615,6 +615,8 @@ struct KnnArgs {
     unsigned long long *stamps;                          // diagnostics (PCR_KNN_STAMPS): 24 words per wavefront
     int seed_span;                                       // Morton-index half-width of the seed range (-1: k)
     int *zero_a, *zero_b;                                // optional counters of LATER kernels, zeroed here (saves two memset launches)
+    const uint8_t *keep; const int *pos;                 // optional: search only among points with keep[i] != 0; results and `todo`
+                                                         //   are indexed by pos[i] (the compacted order) -- the cleaned cloud needs no tree of its own
 };
 
 __device__ static inline double octet_sum(double v) { return pcr_octet_sum(v); }
@@ -632,7 +634,8 @@ __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) {
     const unsigned long long t_begin = wall_clock64();
     const unsigned long long c_begin = a.stamps ? __builtin_readcyclecounter() : 0ull;
     const int qi = blockIdx.x * OPB + ob;
-    const bool live = qi < n && (!a.todo || a.todo[qi]);
+    const int oq = (a.keep && qi < n) ? a.pos[qi] : qi;                 // output / todo index of this query
+    const bool live = qi < n && (!a.keep || a.keep[qi]) && (!a.todo || a.todo[oq]);
     if (__ballot(live) == 0ull) return;                      // nothing to do for this wavefront
     const float4 q = a.t.pts[live ? qi : 0];
     OctetKnn<SLOTS> tk;
@@ -654,7 +657,7 @@ __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) {
         for (int base = first; base < first + count; base += OCT) {
             float d2 = 0.0f; bool pass = false;
             const int idx = base + ol;
-            if (live && idx < first + count && (seeding || idx < plo || idx > phi)) {
+            if (live && idx < first + count && (seeding || idx < plo || idx > phi) && (!a.keep || a.keep[idx])) {
                 const float4 p = a.t.pts[idx];
                 d2 = pcr_d2(p.x - q.x, p.y - q.y, p.z - q.z);
                 pass = d2 < tk.worst;
@@ -681,7 +684,7 @@ __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) {
 #pragma unroll
     for (int j = 0; j < SLOTS; j++) {
         const int idx = c0 + OCT * j + ol;
-        if (live && OCT * j + ol < filled && idx <= phi) {
+        if (live && OCT * j + ol < filled && idx <= phi && (!a.keep || a.keep[idx])) {
             const float4 p = a.t.pts[idx];
             const float d2 = pcr_d2(p.x - q.x, p.y - q.y, p.z - q.z);
             if (d2 < a.r2cap_f) { tk.sd[j] = d2; tk.si[j] = idx; }
@@ -758,16 +761,16 @@ __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) {
                 C6[0] = cu[3] - cu[0] * cu[0]; C6[1] = cu[4] - cu[0] * cu[1]; C6[2] = cu[5] - cu[0] * cu[2];
                 C6[3] = cu[6] - cu[1] * cu[1]; C6[4] = cu[7] - cu[1] * cu[2]; C6[5] = cu[8] - cu[2] * cu[2];
             } else { C6[0] = 1; C6[1] = 0; C6[2] = 0; C6[3] = 1; C6[4] = 0; C6[5] = 1; }
-            if (a.cov6) { for (int t = 0; t < 6; t++) a.cov6[(size_t)qi * 6 + t] = (float)C6[t]; }
+            if (a.cov6) { for (int t = 0; t < 6; t++) a.cov6[(size_t)oq * 6 + t] = (float)C6[t]; }
             if (a.normals) {
                 double nv[3];
                 d_fast_eigen3x3(C6, nv);
                 const double nn = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
                 double px = 0, py = 0, pz = 0;
-                if (a.prior) { const float4 pr = a.prior[qi]; px = pr.x; py = pr.y; pz = pr.z; }
+                if (a.prior) { const float4 pr = a.prior[oq]; px = pr.x; py = pr.y; pz = pr.z; }
                 if (nn == 0.0 || !(nn == nn)) { if (a.prior) { nv[0] = px; nv[1] = py; nv[2] = pz; } else { nv[0] = 0; nv[1] = 0; nv[2] = 1; } }
                 if (a.prior && nv[0] * px + nv[1] * py + nv[2] * pz < 0.0) { nv[0] = -nv[0]; nv[1] = -nv[1]; nv[2] = -nv[2]; }
-                a.normals[qi] = make_float4((float)nv[0], (float)nv[1], (float)nv[2], 0.0f);
+                a.normals[oq] = make_float4((float)nv[0], (float)nv[1], (float)nv[2], 0.0f);
             }
         }
     } else {
@@ -1039,7 +1042,7 @@ __global__ void __launch_bounds__(BS) k_compact_cloud(const float4 *__restrict__
 }
 
 int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double std_ratio, DevCloud *out, uint8_t *keep_sorted, double *avg_sorted,
-                int normal_k, const float4 *prior_out, uint8_t *todo_out, int *todo_count, int *cnt_in_out, int *cnt_kept_out) {
+                int normal_k, const float4 *prior_out, uint8_t *todo_out, int *todo_count, int *cnt_in_out, int *cnt_kept_out, bool fallback_here) {
     if (nb_neighbors < 1 || !(std_ratio > 0.0)) { ctx->err = "nb_neighbors < 1 or std_ratio <= 0"; return PCR_EINVAL; }
     for (int d = 0; d < 3; d++) { out->key_org[d] = in->key_org[d]; out->key_unit[d] = in->key_unit[d]; }
     if (in->cap <= 0) { PCR_HIP_CHECK(ctx, hipMemsetAsync(out->n, 0, sizeof(int), ctx->stream)); return PCR_OK; }
@@ -1073,6 +1076,15 @@ int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double s
             hipLaunchKernelGGL(k_normals_from_lists, dim3((unsigned)(((size_t)in->cap * OCT + KNN_BS - 1) / KNN_BS)), dim3(KNN_BS), 0, ctx->stream, f);
         } else {
             PCR_HIP_CHECK(ctx, hipMemsetAsync(todo_out, 1, (size_t)in->cap, ctx->stream));
+        }
+        if (fallback_here && normal_k > 0) {
+            // the incomplete lists are searched right here, over the INPUT cloud's tree restricted to the kept points: the
+            // cleaned cloud then needs no tree of its own (7 launches less; only a GICP target needs one)
+            KnnArgs b = {};
+            b.t = oct_view(in); b.n_ptr = in->n; b.k = normal_k; b.prior = prior_out; b.normals = out->nrm_final; b.todo = todo_out;
+            b.keep = flags; b.pos = pos;
+            knn_radius(b, PCR_SEARCH_KNN, 0);
+            PCR_TRY(launch_knn<KNN_MODE_NORMALS>(ctx, in, b));
         }
     }
     return PCR_OK;

@@ -99,7 +99,8 @@ int pcr_dev_build_bvh(pcr_context *ctx, DevCloud *c);
 int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double std_ratio, DevCloud *out,
                 uint8_t *keep_sorted /*optional device, in.cap*/, double *avg_sorted /*optional*/,
                 int normal_k = 0, const float4 *prior_out = nullptr, uint8_t *todo_out = nullptr, int *todo_count = nullptr,
-                int *cnt_in_out = nullptr, int *cnt_kept_out = nullptr /* optional device ints: input and kept counts */);
+                int *cnt_in_out = nullptr, int *cnt_kept_out = nullptr /* optional device ints: input and kept counts */,
+                bool fallback_here = false /* search the incomplete lists over `in`'s tree restricted to kept points */);
 // normals (and optionally covariances) by k-NN / hybrid / radius neighbourhoods over the BVH
 int pcr_dev_normals(pcr_context *ctx, DevCloud *c, int search_kind, int knn, double radius, const float4 *prior,
                     float4 *normals_out, float *cov6_out /*optional, sorted order, 6 per point*/, const uint8_t *todo = nullptr);
