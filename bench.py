@@ -194,7 +194,7 @@ def main():
         tj = os.path.join(ROOT, "profiles", "r01_traffic.json")                    # rocprofv3 --pmc passes (profiles/README.md)
         if os.path.exists(tj):
             t = json.load(open(tj))
-            traffic = t.get("k_icp_nn", {}).get("hbm_bytes_per_launch", 0) + t.get("k_icp_iter<GICP>", {}).get("hbm_bytes_per_launch", 0)
+            traffic = t.get("k_icp_fused", {}).get("hbm_bytes_per_launch") or None
         # sanity of the result itself (planted motion) -- printed, not part of the contract
         p_last = pairs[(B - 1) % len(pairs)]
         dR = res.transformation[:3, :3].T @ p_last.T_true[:3, :3]
@@ -212,7 +212,7 @@ def main():
                                        iterations=s["iterations"]) for s in res.scales],
                        "err_vs_planted": {"rad": ang, "m": dtr}, "gathered_records": int(len(gathered))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_icp_nn + k_icp_iter<GICP> (one GICP iteration)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_icp_fused (one GICP iteration; the first launch of a scale is k_icp_nn + k_icp_iter)",
                          "bytes_per_launch": bytes_per_launch, "us_per_launch_hip_events": us_event,
                          "us_per_launch_in_kernel_clock": us_kernel, "us_per_launch_in_flight": us_in_flight,
                          "measured_on": "4 extra single-pair steps after the timed region (same process, HIP events on the launch stream)",

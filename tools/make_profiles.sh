@@ -28,7 +28,7 @@ def load(pat):
         d[r["Kernel_Name"]][r["Counter_Name"]].append((float(r["Counter_Value"]), dur))
     return d
 fetch, write, tcc = load("pmc_FETCH_SIZE"), load("pmc_WRITE_SIZE"), load("pmc_TCC_HIT_sum_TCC_MISS_sum")
-short = {"k_icp_nn(IcpArgs)": "k_icp_nn", "void k_icp_iter<0>(IcpArgs)": "k_icp_iter<GICP>", "void k_knn<0, 4>(KnnArgs)": "k_knn<SOR,4>",
+short = {"k_icp_fused(IcpArgs)": "k_icp_fused", "k_icp_nn(IcpArgs)": "k_icp_nn", "void k_icp_iter<0>(IcpArgs)": "k_icp_iter<GICP>", "void k_knn<0, 4>(KnnArgs)": "k_knn<SOR,4>",
          "void k_knn<1, 4>(KnnArgs)": "k_knn<NORMALS,4>", "k_normals_from_lists(NflArgs)": "k_normals_from_lists"}
 rows, js = [], {}
 for full, name in short.items():
