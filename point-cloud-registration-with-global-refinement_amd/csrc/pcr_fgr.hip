@@ -483,6 +483,84 @@ __device__ static bool fgr_solve6(const double *S, const double *b, double *x) {
     return ok;
 }
 
+// one correspondence of the GNC objective: accumulates s J^T J (21) and s J^T r (6) into acc[]
+__device__ static inline void fgr_accumulate(const FgrOptArgs &a, const double *T, double par, int c, double *acc) {
+    const double *p = a.p0 + (size_t)a.corr[2 * c] * 3, *q0 = a.q0 + (size_t)a.corr[2 * c + 1] * 3;
+    const double qx = T[0] * q0[0] + T[1] * q0[1] + T[2] * q0[2] + T[3];
+    const double qy = T[4] * q0[0] + T[5] * q0[1] + T[6] * q0[2] + T[7];
+    const double qz = T[8] * q0[0] + T[9] * q0[1] + T[10] * q0[2] + T[11];
+    const double rx = p[0] - qx, ry = p[1] - qy, rz = p[2] - qz;
+    const double temp = par / (rx * rx + ry * ry + rz * rz + par), s = temp * temp;
+    const double J[3][6] = {{0, -qz, qy, -1, 0, 0}, {qz, 0, -qx, 0, -1, 0}, {-qy, qx, 0, 0, 0, -1}};
+    const double r[3] = {rx, ry, rz};
+#pragma unroll
+    for (int row = 0; row < 3; row++) {
+        int t = 0;
+#pragma unroll
+        for (int u = 0; u < 6; u++) {
+            const double wj = s * J[row][u];
+#pragma unroll
+            for (int v = u; v < 6; v++) acc[t++] += wj * J[row][v];
+            acc[21 + u] += wj * r[row];
+        }
+    }
+}
+// solve the 6x6 system of one iteration and left-multiply the pose (Open3D: SolveLinearSystemPSD(-JTJ, JTr) == JTJ x = -JTr)
+__device__ static inline void fgr_update(const double *S, double *trans /*16*/) {
+    double nb6[6], x[6];
+#pragma unroll
+    for (int p = 0; p < 6; p++) nb6[p] = -S[21 + p];
+    double U[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    if (fgr_solve6(S, nb6, x)) {
+        const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]), sg = sin(x[2]);
+        U[0] = cg * cb; U[1] = cg * sb * sa - sg * ca; U[2] = cg * sb * ca + sg * sa; U[3] = x[3];
+        U[4] = sg * cb; U[5] = sg * sb * sa + cg * ca; U[6] = sg * sb * ca - cg * sa; U[7] = x[4];
+        U[8] = -sb;     U[9] = cb * sa;                U[10] = cb * ca;               U[11] = x[5];
+    }
+    double Tn[16];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) { double s = 0; for (int k = 0; k < 4; k++) s += U[r * 4 + k] * trans[k * 4 + c]; Tn[r * 4 + c] = s; }
+    for (int k = 0; k < 16; k++) trans[k] = Tn[k];
+}
+
+// ---- small correspondence sets (NCLT-size clouds): ALL iterations in ONE launch of one 1024-thread workgroup -- the
+// multi-workgroup version costs a kernel launch per iteration (300 of them), and launches are what bounds the throughput
+#define FSB 1024
+__global__ void __launch_bounds__(FSB) k_fgr_opt_single(FgrOptArgs a, int iterations) {
+    __shared__ double red[FSB / 16][FNVP];
+    __shared__ double S[FNVP];
+    __shared__ double trans[16];
+    __shared__ double par_s;
+    FgrState *st = a.st;
+    if (threadIdx.x < 16) trans[threadIdx.x] = st->trans[threadIdx.x];
+    if (threadIdx.x == 0) par_s = st->par;
+    __syncthreads();
+    int itr = st->itr;
+    for (int it = 0; it < iterations; it++) {
+        double T[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) T[k] = trans[k];
+        const double par = par_s;
+        double acc[FNV];
+#pragma unroll
+        for (int k = 0; k < FNV; k++) acc[k] = 0.0;
+        for (int c = threadIdx.x; c < a.ncorr; c += FSB) fgr_accumulate(a, T, par, c, acc);
+#pragma unroll
+        for (int k = 0; k < FNV; k++) { const double s = pcr_row16_sum(acc[k]); if ((threadIdx.x & 15) == 0) red[threadIdx.x >> 4][k] = s; }
+        __syncthreads();
+        if (threadIdx.x < FNV) { double s = 0; for (int r = 0; r < FSB / 16; r++) s += red[r][threadIdx.x]; S[threadIdx.x] = s; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            fgr_update(S, trans);
+            if (a.decrease_mu && (itr % 4 == 0) && par_s > a.max_corr_dist) par_s = par_s / a.division_factor;
+        }
+        itr++;
+        __syncthreads();
+    }
+    if (threadIdx.x < 16) st->trans[threadIdx.x] = trans[threadIdx.x];
+    if (threadIdx.x == 0) { st->par = par_s; st->itr = itr; }
+}
+
 __global__ void __launch_bounds__(FB) k_fgr_iter(FgrOptArgs a) {
     __shared__ double red[FB / PCR_WAVE][FNVP];
     __shared__ double fin[8][FNVP];
@@ -495,27 +573,7 @@ __global__ void __launch_bounds__(FB) k_fgr_iter(FgrOptArgs a) {
     double acc[FNV];
 #pragma unroll
     for (int k = 0; k < FNV; k++) acc[k] = 0.0;
-    for (int c = blockIdx.x * FB + threadIdx.x; c < a.ncorr; c += gridDim.x * FB) {
-        const double *p = a.p0 + (size_t)a.corr[2 * c] * 3, *q0 = a.q0 + (size_t)a.corr[2 * c + 1] * 3;
-        const double qx = T[0] * q0[0] + T[1] * q0[1] + T[2] * q0[2] + T[3];
-        const double qy = T[4] * q0[0] + T[5] * q0[1] + T[6] * q0[2] + T[7];
-        const double qz = T[8] * q0[0] + T[9] * q0[1] + T[10] * q0[2] + T[11];
-        const double rx = p[0] - qx, ry = p[1] - qy, rz = p[2] - qz;
-        const double temp = par / (rx * rx + ry * ry + rz * rz + par), s = temp * temp;
-        const double J[3][6] = {{0, -qz, qy, -1, 0, 0}, {qz, 0, -qx, 0, -1, 0}, {-qy, qx, 0, 0, 0, -1}};
-        const double r[3] = {rx, ry, rz};
-#pragma unroll
-        for (int row = 0; row < 3; row++) {
-            int t = 0;
-#pragma unroll
-            for (int u = 0; u < 6; u++) {
-                const double wj = s * J[row][u];
-#pragma unroll
-                for (int v = u; v < 6; v++) acc[t++] += wj * J[row][v];
-                acc[21 + u] += wj * r[row];
-            }
-        }
-    }
+    for (int c = blockIdx.x * FB + threadIdx.x; c < a.ncorr; c += gridDim.x * FB) fgr_accumulate(a, T, par, c, acc);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < FNV; k++) { const double s = pcr_wave_sum(acc[k]); if (lane == 0) red[wv][k] = s; }
@@ -531,17 +589,27 @@ __global__ void __launch_bounds__(FB) k_fgr_iter(FgrOptArgs a) {
     if (threadIdx.x == 0) {
         const unsigned int t = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = (t == gridDim.x - 1);
-        if (last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         is_last = last;
     }
     __syncthreads();
     if (!is_last) return;
     {
-        const int vcol = threadIdx.x & 31, chunk = threadIdx.x >> 5;
-        const int nb = gridDim.x, per = (nb + 7) / 8;
-        const int b0 = chunk * per, b1 = min(nb, b0 + per);
+        const int vcol = threadIdx.x & 31, chunk = threadIdx.x >> 5;      // 8 chunks x 32 columns; chunk c <- rows c, c+8, ...
+        const int nb = gridDim.x;
         double s = 0;
-        if (vcol < FNV) for (int b = b0; b < b1; b++) s += a.partials[(size_t)b * FNVP + vcol];
+        for (int b0 = 0; b0 < nb; b0 += 64) {          // sc1 loads (coherent at agent scope without an acquire fence), 8 in flight
+            const double *p[8]; double v[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) p[r] = a.partials + (size_t)(b0 + chunk + 8 * r < nb ? b0 + chunk + 8 * r : 0) * FNVP + vcol;
+            asm volatile("global_load_dwordx2 %0, %8, off sc0 sc1\n\tglobal_load_dwordx2 %1, %9, off sc0 sc1\n\t"
+                         "global_load_dwordx2 %2, %10, off sc0 sc1\n\tglobal_load_dwordx2 %3, %11, off sc0 sc1\n\t"
+                         "global_load_dwordx2 %4, %12, off sc0 sc1\n\tglobal_load_dwordx2 %5, %13, off sc0 sc1\n\t"
+                         "global_load_dwordx2 %6, %14, off sc0 sc1\n\tglobal_load_dwordx2 %7, %15, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                         : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]) : "memory");
+#pragma unroll
+            for (int r = 0; r < 8; r++) if (vcol < FNV && b0 + chunk + 8 * r < nb) s += v[r];
+        }
         fin[chunk][vcol] = s;
     }
     __syncthreads();
@@ -553,22 +621,10 @@ __global__ void __launch_bounds__(FB) k_fgr_iter(FgrOptArgs a) {
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const double *S = fin[0];
-        // Open3D: SolveLinearSystemPSD(-JTJ, JTr)  ==  JTJ x = -JTr
-        double nb6[6], x[6];
-#pragma unroll
-        for (int p = 0; p < 6; p++) nb6[p] = -S[21 + p];
-        double U[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-        if (fgr_solve6(S, nb6, x)) {
-            const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]), sg = sin(x[2]);
-            U[0] = cg * cb; U[1] = cg * sb * sa - sg * ca; U[2] = cg * sb * ca + sg * sa; U[3] = x[3];
-            U[4] = sg * cb; U[5] = sg * sb * sa + cg * ca; U[6] = sg * sb * ca - cg * sa; U[7] = x[4];
-            U[8] = -sb;     U[9] = cb * sa;                U[10] = cb * ca;               U[11] = x[5];
-        }
-        double Tn[16];
-        for (int r = 0; r < 4; r++)
-            for (int c = 0; c < 4; c++) { double s = 0; for (int k = 0; k < 4; k++) s += U[r * 4 + k] * st->trans[k * 4 + c]; Tn[r * 4 + c] = s; }
-        for (int k = 0; k < 16; k++) st->trans[k] = Tn[k];
+        double tr[16];
+        for (int k = 0; k < 16; k++) tr[k] = st->trans[k];
+        fgr_update(fin[0], tr);
+        for (int k = 0; k < 16; k++) st->trans[k] = tr[k];
         if (a.decrease_mu && (st->itr % 4 == 0) && st->par > a.max_corr_dist) st->par = st->par / a.division_factor;
         st->itr = st->itr + 1;
         __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -676,7 +732,9 @@ extern "C" int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, cons
             oa.p0 = P[0]; oa.q0 = P[1]; oa.corr = corr; oa.ncorr = (int)ncorr; oa.st = st; oa.partials = partials;
             oa.decrease_mu = opt->decrease_mu; oa.max_corr_dist = opt->maximum_correspondence_distance; oa.division_factor = opt->division_factor;
             hipLaunchKernelGGL(k_fgr_init, dim3(1), dim3(64), 0, ctx->stream, st, scale_start);
-            for (int it = 0; it < opt->iteration_number; it++) hipLaunchKernelGGL(k_fgr_iter, dim3(nb), dim3(FB), 0, ctx->stream, oa);
+            static const int single_max = getenv("PCR_FGR_SINGLE_MAX") ? atoi(getenv("PCR_FGR_SINGLE_MAX")) : 16384;
+            if (ncorr <= single_max) hipLaunchKernelGGL(k_fgr_opt_single, dim3(1), dim3(FSB), 0, ctx->stream, oa, (int)opt->iteration_number);
+            else for (int it = 0; it < opt->iteration_number; it++) hipLaunchKernelGGL(k_fgr_iter, dim3(nb), dim3(FB), 0, ctx->stream, oa);
             FgrState h;
             PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
             PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
