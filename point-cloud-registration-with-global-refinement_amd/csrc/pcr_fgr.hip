@@ -732,7 +732,8 @@ extern "C" int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, cons
             oa.p0 = P[0]; oa.q0 = P[1]; oa.corr = corr; oa.ncorr = (int)ncorr; oa.st = st; oa.partials = partials;
             oa.decrease_mu = opt->decrease_mu; oa.max_corr_dist = opt->maximum_correspondence_distance; oa.division_factor = opt->division_factor;
             hipLaunchKernelGGL(k_fgr_init, dim3(1), dim3(64), 0, ctx->stream, st, scale_start);
-            static const int single_max = getenv("PCR_FGR_SINGLE_MAX") ? atoi(getenv("PCR_FGR_SINGLE_MAX")) : 16384;
+            static const int single_max = getenv("PCR_FGR_SINGLE_MAX") ? atoi(getenv("PCR_FGR_SINGLE_MAX")) : 8192;   // above this one CU's float64 rate makes the single workgroup slower than 300 launches (measured at 16.5k: 6 ms vs 4 ms)
+            if (getenv("PCR_DEBUG_FGR")) fprintf(stderr, "fgr: ncross %lld ncorr %lld iterations %d\n", (long long)ncross, (long long)ncorr, (int)opt->iteration_number);
             if (ncorr <= single_max) hipLaunchKernelGGL(k_fgr_opt_single, dim3(1), dim3(FSB), 0, ctx->stream, oa, (int)opt->iteration_number);
             else for (int it = 0; it < opt->iteration_number; it++) hipLaunchKernelGGL(k_fgr_iter, dim3(nb), dim3(FB), 0, ctx->stream, oa);
             FgrState h;
