@@ -525,6 +525,7 @@ extern "C" int pcr_register_pairs(int device, pcr_pair *pairs, int n_pairs, cons
         if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess) return PCR_EHIP;
         if (hipEventRecord(ready, (hipStream_t)after_stream) != hipSuccess) { (void)hipEventDestroy(ready); return PCR_EHIP; }
     }
+    for (int i = 0; i < n_pairs; i++) { pairs[i].status = PCR_EHIP; snprintf(pairs[i].error, sizeof pairs[i].error, "not processed (no worker context)"); }
     std::atomic<int> next(0), failed(0);
     auto work = [&]() {
         (void)hipSetDevice(device);
