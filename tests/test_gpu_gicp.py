@@ -210,3 +210,25 @@ def test_register_pairs_equals_one_call_per_pair(P, golden_pair_list):
     assert P.registration.register_pairs([], vox, dst, est, crit) == []
     with pytest.raises(RuntimeError, match="pair 0 failed"):
         P.registration.register_pairs(pairs[:2], [0.1, -1.0], [0.1, 0.1], est, crit)
+
+
+def test_register_pairs_ragged_sizes_stress(P, small_pair):
+    """Many pairs of very different sizes (so arenas grow, cached launch graphs miss and get evicted, pooled worker contexts are
+    reused) through the in-flight path must equal the one-pair-at-a-time results bit for bit."""
+    rng = np.random.default_rng(11)
+    src, tgt, T0 = small_pair["source"], small_pair["target"], small_pair["T_fgr"]
+    sizes = [300, 1500, 7000, len(src), 900, 12000, 40, 5000, len(src), 2500, 640, 9000, 3000, 15000, 100, 6000, 11000, 450, 8000, 2000]
+    pairs = []
+    for k, n in enumerate(sizes):
+        a = src[rng.permutation(len(src))[: min(n, len(src))]]; b = tgt[rng.permutation(len(tgt))[: min(max(n, 64), len(tgt))]]
+        pairs.append((P.PointCloud(a), P.PointCloud(b), T0))
+    vox = [0.4, 0.2]; dst = [1.2, 0.4]
+    est = P.registration.TransformationEstimationForGeneralizedICP(P.registration.L1Loss())
+    crit = P.registration.ICPConvergenceCriteria(1e-6, 1e-6, 30)
+    ref = [P.registration.multiscale_gicp(s, t, vox, dst, T, est, crit) for s, t, T in pairs]
+    for inflight in (4, 2, 7):
+        got = P.registration.register_pairs(pairs, vox, dst, est, crit, inflight=inflight)
+        for k, (a, b) in enumerate(zip(got, ref)):
+            assert np.array_equal(a.transformation, b.transformation), (inflight, k, sizes[k])
+            assert a.fitness == b.fitness and [x["iterations"] for x in a.scales] == [x["iterations"] for x in b.scales]
+            assert [x["n_clean"] for x in a.scales] == [x["n_clean"] for x in b.scales]
