@@ -25,8 +25,10 @@ def pkg(sub=None):
 def pose_error(A, B):
     """(rotation angle [rad], translation distance [m]) between two 4x4 poses."""
     A = np.asarray(A, float); B = np.asarray(B, float)
-    dR = A[:3, :3].T @ B[:3, :3]
-    ang = float(np.arccos(np.clip((np.trace(dR) - 1.0) / 2.0, -1.0, 1.0)))
+    # chord form of the rotation angle, ||Ra - Rb||_F = 2*sqrt(2)*sin(angle/2): the same angle as arccos((tr-1)/2) for
+    # rotations, but exactly 0 for A == B even when the poses come from 10-decimal text files and are orthonormal only
+    # to 1e-10 (arccos then reads 1e-5 rad out of nothing: the shipped Facade poses do that)
+    ang = float(2.0 * np.arcsin(min(1.0, np.linalg.norm(A[:3, :3] - B[:3, :3]) / (2.0 * np.sqrt(2.0)))))
     return ang, float(np.linalg.norm(A[:3, 3] - B[:3, 3]))
 
 

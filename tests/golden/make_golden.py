@@ -31,6 +31,14 @@ def main(ref):
         np.savez_compressed(os.path.join(HERE, f"nclt_pair_{i:03d}.npz"), source=src, target=tgt, T_fgr=T_fgr,
                             T_gicp=T_gicp, pair=np.int64(i))
         print(f"pair {i}: source {src.shape[0]} pts, target {tgt.shape[0]} pts")
+    # one pair of the Facade loop (terrestrial scanner, 84k / 45k points: BASELINE config 4's data).  The shipped Facade
+    # GICP poses were NOT made with script-2 parameters (the oracle lands 1e-3 rad / 2 cm away, all 7 pairs), so this pair
+    # pins nothing by itself: it is a HIP-vs-oracle parity case on a second sensor and point density.
+    fac = os.path.join(ref, "nuvens/nuvens_pre_processadas/Facade")
+    np.savez_compressed(os.path.join(HERE, "facade_pair_1_0.npz"), source=pio.read_pcd_xyz(os.path.join(fac, "s1.pcd")),
+                        target=pio.read_pcd_xyz(os.path.join(fac, "s0.pcd")),
+                        T_fgr=pio.read_pose(os.path.join(ref, "relative_poses_FGR/Facade/pose_1_0.txt")),
+                        T_gicp=pio.read_pose(os.path.join(ref, "relative_poses_FGR_GICP/Facade/pose_1_0.txt")))
     # pose chains for the host-side pose-algebra tests (tiny)
     for name, n in (("Facade", 7), ("Courtyard", 8)):
         rel = [pio.read_pose(os.path.join(ref, f"relative_poses_FGR_GICP/{name}/{f}"))

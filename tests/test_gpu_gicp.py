@@ -149,6 +149,26 @@ def test_multiscale_gicp_reproduces_shipped_pose(P, golden_pair):
     assert ang <= (3e-3 if noisy else TOL_RAD) and dt <= (3e-2 if noisy else TOL_M), (int(g["pair"]), ang, dt)
 
 
+def test_facade_pair_matches_oracle(P, oracle):
+    """BASELINE config 4's data: one pair of the shipped Facade loop (terrestrial scanner, 84k / 45k points, denser and
+    more anisotropic than NCLT).  Stage counts bit-exact at all 5 script-2 scales, L2 pose on the oracle's to f32-search
+    accuracy, L1 pose inside the north-star tolerance of the oracle's."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "facade_pair_1_0.npz"))
+    src, tgt, T0 = g["source"], g["target"], g["T_fgr"]
+    vox = P.script2.create_scales(5); dst = P.script2.max_correspondence_distances(vox)
+    crit = P.registration.ICPConvergenceCriteria(1e-6, 1e-6, 100)
+    for loss, oloss, tol in ((P.registration.L2Loss(), oracle.LOSS_L2, (1e-5, 1e-4)), (P.registration.L1Loss(), oracle.LOSS_L1, (TOL_RAD, TOL_M))):
+        est = P.registration.TransformationEstimationForGeneralizedICP(loss)
+        res = P.registration.multiscale_gicp(P.PointCloud(src), P.PointCloud(tgt), vox, dst, T0, est, crit)
+        ref = oracle.multiscale_gicp(src, tgt, vox, dst, T0, loss=oloss)
+        for a, b in zip(res.scales, ref.extra["scales"]):
+            assert a["n_voxel"] == tuple(b["n_voxel"]) and a["n_clean"] == tuple(b["n_clean"])
+        ang, dt = pose_error(res.transformation, ref.transformation)
+        assert ang <= tol[0] and dt <= tol[1], (type(loss).__name__, ang, dt)
+
+
 def test_stepwise_call_sequence_equals_fused_call(P, small_pair):
     """The reference's call-by-call sequence through the stand-ins and the single fused C call agree (L2: smooth)."""
     import copy
