@@ -38,7 +38,7 @@ __device__ static inline float pcr_box_d2(const float4 lo, const float4 hi, floa
 // compiles to ds_bpermute.  quad_perm covers xor 1 / xor 2, row_half_mirror (lane i <-> 7-i of each 8) joins the
 // two quads of an octet; after the first two steps a quad is uniform, so the mirror acts as xor 4.
 template <int CTRL>
-__device__ static inline int pcr_dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+__device__ static inline int pcr_dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
 template <int CTRL>
 __device__ static inline float pcr_dpp_f(float v) { return __int_as_float(pcr_dpp_i<CTRL>(__float_as_int(v))); }
 #define PCR_DPP_XOR1 0xB1      // quad_perm [1,0,3,2]
