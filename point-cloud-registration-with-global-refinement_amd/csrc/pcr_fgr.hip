@@ -426,17 +426,29 @@ struct FgrState {
     double par;
     unsigned int ticket;
     int itr;
+    unsigned long long t_dbg[4];     // diagnostics (PCR_DEBUG_FGR), 100 MHz ticks summed over the iterations of the single-workgroup kernel
 };
 struct FgrOptArgs {
-    const double *p0, *q0;           // normalised cloud 0 (source) and cloud 1 (target)
-    const int32_t *corr; int ncorr;
+    const double *pq; int stride;    // the correspondences' points gathered ONCE, structure of arrays: pq[k * stride + c], k = 0..2 the
+                                     //   cloud-0 (source) point, k = 3..5 the cloud-1 (target) point of correspondence c -- the 300
+                                     //   iterations then stream coalesced float64 columns instead of chasing corr[] -> point twice each
+    int ncorr;
     FgrState *st; double *partials;
     int decrease_mu; double max_corr_dist, division_factor;
 };
+__global__ void __launch_bounds__(FB) k_fgr_gather_pairs(const double *__restrict__ p0, const double *__restrict__ q0, const int32_t *__restrict__ corr, int ncorr, int stride,
+                                                         double *__restrict__ pq) {
+    const int c = blockIdx.x * FB + threadIdx.x;
+    if (c >= ncorr) return;
+    const double *p = p0 + (size_t)corr[2 * c] * 3, *q = q0 + (size_t)corr[2 * c + 1] * 3;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { pq[(size_t)k * stride + c] = p[k]; pq[(size_t)(3 + k) * stride + c] = q[k]; }
+}
 __global__ void k_fgr_init(FgrState *st, double par) {
     if (threadIdx.x == 0) {
         for (int k = 0; k < 16; k++) st->trans[k] = (k % 5 == 0) ? 1.0 : 0.0;
         st->par = par; st->ticket = 0; st->itr = 0;
+        for (int k = 0; k < 4; k++) st->t_dbg[k] = 0;
     }
 }
 // 6x6 LDL^T without pivoting in registers (as in pcr_gicp.hip); the system here is -JTJ x = JTr
@@ -483,27 +495,51 @@ __device__ static bool fgr_solve6(const double *S, const double *b, double *x) {
     return ok;
 }
 
-// one correspondence of the GNC objective: accumulates s J^T J (21) and s J^T r (6) into acc[]
-__device__ static inline void fgr_accumulate(const FgrOptArgs &a, const double *T, double par, int c, double *acc) {
-    const double *p = a.p0 + (size_t)a.corr[2 * c] * 3, *q0 = a.q0 + (size_t)a.corr[2 * c + 1] * 3;
-    const double qx = T[0] * q0[0] + T[1] * q0[1] + T[2] * q0[2] + T[3];
-    const double qy = T[4] * q0[0] + T[5] * q0[1] + T[6] * q0[2] + T[7];
-    const double qz = T[8] * q0[0] + T[9] * q0[1] + T[10] * q0[2] + T[11];
-    const double rx = p[0] - qx, ry = p[1] - qy, rz = p[2] - qz;
+// one correspondence of the GNC objective.  The three Jacobian rows are [-[q]x | -I] (q = moved target point), so
+// s J^T J and s J^T r have only FC = 16 distinct sums: s q q^T (6), s q (3), s (1) and the six entries of s J^T r.  Accumulating
+// those instead of the 27 generic products is 3x fewer float64 operations per correspondence (the generic form multiplies
+// the structural zeros: 0 * x cannot be folded without fast-math); fgr_expand() lays them out as the 21 + 6 sums the
+// solver takes.
+#define FC 16
+__device__ static inline void fgr_load(const FgrOptArgs &a, int c, double *v /*6*/) {
+    const double *col = a.pq + c;
+#pragma unroll
+    for (int k = 0; k < 6; k++) v[k] = col[(size_t)k * a.stride];
+}
+__device__ static inline void fgr_math(const double *T, double par, const double *v /*p, q0*/, double *acc /*FC*/) {
+    const double qx = T[0] * v[3] + T[1] * v[4] + T[2] * v[5] + T[3];
+    const double qy = T[4] * v[3] + T[5] * v[4] + T[6] * v[5] + T[7];
+    const double qz = T[8] * v[3] + T[9] * v[4] + T[10] * v[5] + T[11];
+    const double rx = v[0] - qx, ry = v[1] - qy, rz = v[2] - qz;
     const double temp = par / (rx * rx + ry * ry + rz * rz + par), s = temp * temp;
-    const double J[3][6] = {{0, -qz, qy, -1, 0, 0}, {qz, 0, -qx, 0, -1, 0}, {-qy, qx, 0, 0, 0, -1}};
-    const double r[3] = {rx, ry, rz};
+    const double sx = s * qx, sy = s * qy, sz = s * qz;
+    acc[0] += sx * qx; acc[1] += sy * qy; acc[2] += sz * qz;
+    acc[3] += sx * qy; acc[4] += sx * qz; acc[5] += sy * qz;
+    acc[6] += sx; acc[7] += sy; acc[8] += sz; acc[9] += s;
+    acc[10] += sz * ry - sy * rz;          // s (q x r) with the sign of J^T r: rows [0,-qz,qy], [qz,0,-qx], [-qy,qx,0]
+    acc[11] += sx * rz - sz * rx;
+    acc[12] += sy * rx - sx * ry;
+    acc[13] -= s * rx; acc[14] -= s * ry; acc[15] -= s * rz;
+}
+// correspondences first, first + step, ... < ncorr: four of them in flight per lane (24 independent coalesced loads, then the math)
+__device__ static inline void fgr_accumulate_all(const FgrOptArgs &a, const double *T, double par, int first, int step, double *acc /*FC*/) {
+    for (int c0 = first; c0 < a.ncorr; c0 += 4 * step) {
+        double v[4][6];
 #pragma unroll
-    for (int row = 0; row < 3; row++) {
-        int t = 0;
+        for (int u = 0; u < 4; u++) { const int c = c0 + u * step; fgr_load(a, c < a.ncorr ? c : c0, v[u]); }
 #pragma unroll
-        for (int u = 0; u < 6; u++) {
-            const double wj = s * J[row][u];
-#pragma unroll
-            for (int v = u; v < 6; v++) acc[t++] += wj * J[row][v];
-            acc[21 + u] += wj * r[row];
-        }
+        for (int u = 0; u < 4; u++) if (c0 + u * step < a.ncorr) fgr_math(T, par, v[u], acc);
     }
+}
+// FC sums -> upper triangle of J^T J (21, row-major) followed by J^T r (6)
+__device__ static inline void fgr_expand(const double *c, double *S /*27*/) {
+    const double A = c[0], B = c[1], C = c[2], D = c[3], E = c[4], F = c[5], G = c[6], H = c[7], I = c[8], W = c[9];
+    S[0] = B + C; S[1] = -D; S[2] = -E; S[3] = 0; S[4] = -I; S[5] = H;
+    S[6] = A + C; S[7] = -F; S[8] = I; S[9] = 0; S[10] = -G;
+    S[11] = A + B; S[12] = -H; S[13] = G; S[14] = 0;
+    S[15] = W; S[16] = 0; S[17] = 0; S[18] = W; S[19] = 0; S[20] = W;
+#pragma unroll
+    for (int k = 0; k < 6; k++) S[21 + k] = c[10 + k];
 }
 // solve the 6x6 system of one iteration and left-multiply the pose (Open3D: SolveLinearSystemPSD(-JTJ, JTr) == JTJ x = -JTr)
 __device__ static inline void fgr_update(const double *S, double *trans /*16*/) {
@@ -512,7 +548,8 @@ __device__ static inline void fgr_update(const double *S, double *trans /*16*/) 
     for (int p = 0; p < 6; p++) nb6[p] = -S[21 + p];
     double U[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     if (fgr_solve6(S, nb6, x)) {
-        const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]), sg = sin(x[2]);
+        double ca, sa, cb, sb, cg, sg;
+        sincos(x[0], &sa, &ca); sincos(x[1], &sb, &cb); sincos(x[2], &sg, &cg);
         U[0] = cg * cb; U[1] = cg * sb * sa - sg * ca; U[2] = cg * sb * ca + sg * sa; U[3] = x[3];
         U[4] = sg * cb; U[5] = sg * sb * sa + cg * ca; U[6] = sg * sb * ca - cg * sa; U[7] = x[4];
         U[8] = -sb;     U[9] = cb * sa;                U[10] = cb * ca;               U[11] = x[5];
@@ -536,29 +573,37 @@ __global__ void __launch_bounds__(FSB) k_fgr_opt_single(FgrOptArgs a, int iterat
     if (threadIdx.x == 0) par_s = st->par;
     __syncthreads();
     int itr = st->itr;
+    unsigned long long tA = 0, tB = 0, tC = 0;
     for (int it = 0; it < iterations; it++) {
+        const unsigned long long t0 = wall_clock64();
         double T[12];
 #pragma unroll
         for (int k = 0; k < 12; k++) T[k] = trans[k];
         const double par = par_s;
-        double acc[FNV];
+        double acc[FC];
 #pragma unroll
-        for (int k = 0; k < FNV; k++) acc[k] = 0.0;
-        for (int c = threadIdx.x; c < a.ncorr; c += FSB) fgr_accumulate(a, T, par, c, acc);
+        for (int k = 0; k < FC; k++) acc[k] = 0.0;
+        fgr_accumulate_all(a, T, par, threadIdx.x, FSB, acc);
+        const unsigned long long t1 = wall_clock64();
 #pragma unroll
-        for (int k = 0; k < FNV; k++) { const double s = pcr_row16_sum(acc[k]); if ((threadIdx.x & 15) == 0) red[threadIdx.x >> 4][k] = s; }
+        for (int k = 0; k < FC; k++) { const double s = pcr_row16_sum(acc[k]); if ((threadIdx.x & 15) == 0) red[threadIdx.x >> 4][k] = s; }
         __syncthreads();
-        if (threadIdx.x < FNV) { double s = 0; for (int r = 0; r < FSB / 16; r++) s += red[r][threadIdx.x]; S[threadIdx.x] = s; }
+        if (threadIdx.x < FC) { double s = 0; for (int r = 0; r < FSB / 16; r++) s += red[r][threadIdx.x]; S[threadIdx.x] = s; }
         __syncthreads();
+        const unsigned long long t2 = wall_clock64();
+        tA += t1 - t0; tB += t2 - t1;
         if (threadIdx.x == 0) {
-            fgr_update(S, trans);
+            double S27[FNV];
+            fgr_expand(S, S27);
+            fgr_update(S27, trans);
             if (a.decrease_mu && (itr % 4 == 0) && par_s > a.max_corr_dist) par_s = par_s / a.division_factor;
         }
         itr++;
         __syncthreads();
+        tC += wall_clock64() - t2;
     }
     if (threadIdx.x < 16) st->trans[threadIdx.x] = trans[threadIdx.x];
-    if (threadIdx.x == 0) { st->par = par_s; st->itr = itr; }
+    if (threadIdx.x == 0) { st->par = par_s; st->itr = itr; st->t_dbg[0] = tA; st->t_dbg[1] = tB; st->t_dbg[2] = tC; }
 }
 
 __global__ void __launch_bounds__(FB) k_fgr_iter(FgrOptArgs a) {
@@ -570,15 +615,15 @@ __global__ void __launch_bounds__(FB) k_fgr_iter(FgrOptArgs a) {
 #pragma unroll
     for (int k = 0; k < 12; k++) T[k] = st->trans[k];
     const double par = st->par;
-    double acc[FNV];
+    double acc[FC];
 #pragma unroll
-    for (int k = 0; k < FNV; k++) acc[k] = 0.0;
-    for (int c = blockIdx.x * FB + threadIdx.x; c < a.ncorr; c += gridDim.x * FB) fgr_accumulate(a, T, par, c, acc);
+    for (int k = 0; k < FC; k++) acc[k] = 0.0;
+    fgr_accumulate_all(a, T, par, blockIdx.x * FB + threadIdx.x, gridDim.x * FB, acc);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < FNV; k++) { const double s = pcr_wave_sum(acc[k]); if (lane == 0) red[wv][k] = s; }
+    for (int k = 0; k < FC; k++) { const double s = pcr_wave_sum(acc[k]); if (lane == 0) red[wv][k] = s; }
     __syncthreads();
-    if (threadIdx.x < FNV) {
+    if (threadIdx.x < FC) {
         double s = red[0][threadIdx.x];
 #pragma unroll
         for (int w = 1; w < FB / PCR_WAVE; w++) s += red[w][threadIdx.x];
@@ -608,7 +653,7 @@ __global__ void __launch_bounds__(FB) k_fgr_iter(FgrOptArgs a) {
                          : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
                          : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]) : "memory");
 #pragma unroll
-            for (int r = 0; r < 8; r++) if (vcol < FNV && b0 + chunk + 8 * r < nb) s += v[r];
+            for (int r = 0; r < 8; r++) if (vcol < FC && b0 + chunk + 8 * r < nb) s += v[r];
         }
         fin[chunk][vcol] = s;
     }
@@ -621,9 +666,10 @@ __global__ void __launch_bounds__(FB) k_fgr_iter(FgrOptArgs a) {
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double tr[16];
+        double tr[16], S27[FNV];
         for (int k = 0; k < 16; k++) tr[k] = st->trans[k];
-        fgr_update(fin[0], tr);
+        fgr_expand(fin[0], S27);
+        fgr_update(S27, tr);
         for (int k = 0; k < 16; k++) st->trans[k] = tr[k];
         if (a.decrease_mu && (st->itr % 4 == 0) && st->par > a.max_corr_dist) st->par = st->par / a.division_factor;
         st->itr = st->itr + 1;
@@ -727,12 +773,15 @@ extern "C" int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, cons
             if (nb > 256) nb = 256;
             FgrState *st = arena<FgrState>(ctx, 1);
             double *partials = arena<double>(ctx, (size_t)nb * FNVP);
-            if (!st || !partials) return PCR_ENOMEM;
+            const int stride = (int)((ncorr + 63) / 64 * 64);
+            double *pq = arena<double>(ctx, (size_t)stride * 6);
+            if (!st || !partials || !pq) return PCR_ENOMEM;
+            hipLaunchKernelGGL(k_fgr_gather_pairs, dim3((unsigned)((ncorr + FB - 1) / FB)), dim3(FB), 0, ctx->stream, P[0], P[1], corr, (int)ncorr, stride, pq);
             FgrOptArgs oa;
-            oa.p0 = P[0]; oa.q0 = P[1]; oa.corr = corr; oa.ncorr = (int)ncorr; oa.st = st; oa.partials = partials;
+            oa.pq = pq; oa.stride = stride; oa.ncorr = (int)ncorr; oa.st = st; oa.partials = partials;
             oa.decrease_mu = opt->decrease_mu; oa.max_corr_dist = opt->maximum_correspondence_distance; oa.division_factor = opt->division_factor;
             hipLaunchKernelGGL(k_fgr_init, dim3(1), dim3(64), 0, ctx->stream, st, scale_start);
-            static const int single_max = getenv("PCR_FGR_SINGLE_MAX") ? atoi(getenv("PCR_FGR_SINGLE_MAX")) : 8192;   // above this one CU's float64 rate makes the single workgroup slower than 300 launches (measured at 16.5k: 6 ms vs 4 ms)
+            static const int single_max = getenv("PCR_FGR_SINGLE_MAX") ? atoi(getenv("PCR_FGR_SINGLE_MAX")) : 11000;   // one CU needs 0.8 us of float64 work per 1000 correspondences and iteration (+1.4 us solve); a launch per iteration costs 11 us
             if (getenv("PCR_DEBUG_FGR")) fprintf(stderr, "fgr: ncross %lld ncorr %lld iterations %d\n", (long long)ncross, (long long)ncorr, (int)opt->iteration_number);
             if (ncorr <= single_max) hipLaunchKernelGGL(k_fgr_opt_single, dim3(1), dim3(FSB), 0, ctx->stream, oa, (int)opt->iteration_number);
             else for (int it = 0; it < opt->iteration_number; it++) hipLaunchKernelGGL(k_fgr_iter, dim3(nb), dim3(FB), 0, ctx->stream, oa);
@@ -740,6 +789,8 @@ extern "C" int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, cons
             PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
             PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             memcpy(trans, h.trans, sizeof trans);
+            if (getenv("PCR_DEBUG_FGR") && h.t_dbg[0]) fprintf(stderr, "fgr single-workgroup optimiser, us per iteration: accumulate %.2f reduce %.2f solve+update %.2f\n",
+                                                            h.t_dbg[0] * 0.01 / h.itr, h.t_dbg[1] * 0.01 / h.itr, h.t_dbg[2] * 0.01 / h.itr);
         }
         // ---- GetTransformationOriginalScale, then invert: source -> target
         double To[16] = {0};
