@@ -427,6 +427,8 @@ struct FgrState {
     unsigned int ticket;
     int itr;
     unsigned long long t_dbg[4];     // diagnostics (PCR_DEBUG_FGR), 100 MHz ticks summed over the iterations of the single-workgroup kernel
+    unsigned int arrive;             // k_fgr_opt_multi: workgroups arrived, summed over the iterations (monotonic barrier counter)
+    int failed;                      // k_fgr_opt_multi: a workgroup gave up waiting (co-residency not granted): the host reruns with one launch per iteration
 };
 struct FgrOptArgs {
     const double *pq; int stride;    // the correspondences' points gathered ONCE, structure of arrays: pq[k * stride + c], k = 0..2 the
@@ -449,6 +451,7 @@ __global__ void k_fgr_init(FgrState *st, double par) {
         for (int k = 0; k < 16; k++) st->trans[k] = (k % 5 == 0) ? 1.0 : 0.0;
         st->par = par; st->ticket = 0; st->itr = 0;
         for (int k = 0; k < 4; k++) st->t_dbg[k] = 0;
+        st->arrive = 0; st->failed = 0;
     }
 }
 // 6x6 LDL^T without pivoting in registers (as in pcr_gicp.hip); the system here is -JTJ x = JTr
@@ -604,6 +607,88 @@ __global__ void __launch_bounds__(FSB) k_fgr_opt_single(FgrOptArgs a, int iterat
     }
     if (threadIdx.x < 16) st->trans[threadIdx.x] = trans[threadIdx.x];
     if (threadIdx.x == 0) { st->par = par_s; st->itr = itr; st->t_dbg[0] = tA; st->t_dbg[1] = tB; st->t_dbg[2] = tC; }
+}
+
+// ---- mid-size correspondence sets: ALL iterations in ONE launch of FMG co-resident workgroups.  Per iteration every
+// workgroup publishes its row of FC sums (write-through), arrives at a monotonic counter, waits until all FMG have arrived,
+// then gathers the FMG rows in fixed order and solves the 6x6 system ITSELF (1.4 us, redundantly: bit-identical poses in every
+// workgroup, and one synchronisation per iteration instead of two).  Rows are double-buffered by iteration parity (a
+// workgroup can be at most one barrier ahead).  FMG = 8 workgroups of 512 threads always fit next to anything else; should
+// they nevertheless not become co-resident, every waiter gives up after `timeout_ticks` (50 ms), sets `failed`, and the host falls
+// back to one launch per iteration -- every wave reaches an exit.
+#define FMG 8
+#define FMB 512
+__global__ void __launch_bounds__(FMB) k_fgr_opt_multi(FgrOptArgs a, int iterations, double *rows /* 2 x FMG x FNVP */, unsigned long long timeout_ticks) {
+    __shared__ double red[FMB / 16][FC];
+    __shared__ double S[FC];
+    __shared__ double trans[16];
+    __shared__ double par_s;
+    __shared__ int bail;
+    FgrState *st = a.st;
+    const int G = gridDim.x;
+    if (threadIdx.x < 16) trans[threadIdx.x] = st->trans[threadIdx.x];
+    if (threadIdx.x == 0) { par_s = st->par; bail = 0; }
+    __syncthreads();
+    int itr = st->itr;
+    for (int it = 0; it < iterations; it++) {
+        double T[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) T[k] = trans[k];
+        const double par = par_s;
+        double acc[FC];
+#pragma unroll
+        for (int k = 0; k < FC; k++) acc[k] = 0.0;
+        fgr_accumulate_all(a, T, par, blockIdx.x * FMB + threadIdx.x, G * FMB, acc);
+#pragma unroll
+        for (int k = 0; k < FC; k++) { const double s = pcr_row16_sum(acc[k]); if ((threadIdx.x & 15) == 0) red[threadIdx.x >> 4][k] = s; }
+        __syncthreads();
+        double *buf = rows + (size_t)(it & 1) * FMG * FNVP;
+        if (threadIdx.x < FC) {
+            double s = 0;
+            for (int r = 0; r < FMB / 16; r++) s += red[r][threadIdx.x];
+            __hip_atomic_store(&buf[(size_t)blockIdx.x * FNVP + threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the row is out before the workgroup arrives
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(&st->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int want = (unsigned int)(it + 1) * (unsigned int)G;
+            const unsigned long long t0 = wall_clock64();
+            while (__hip_atomic_load(&st->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                if (wall_clock64() - t0 > timeout_ticks || __hip_atomic_load(&st->failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { bail = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+        if (bail) {
+            if (threadIdx.x == 0) __hip_atomic_store(&st->failed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        // one coherent load per lane (the compiler issues relaxed-atomic loads one at a time: a loop of FMG of them is FMG round trips)
+        if (threadIdx.x < FMG * FC) {
+            const int b = threadIdx.x / FC, col = threadIdx.x % FC;
+            red[b][col] = b < G ? __hip_atomic_load(&buf[(size_t)b * FNVP + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+        __syncthreads();
+        if (threadIdx.x < FC) {
+            double s = 0;
+            for (int b = 0; b < FMG; b++) s += red[b][threadIdx.x];
+            S[threadIdx.x] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double S27[FNV];
+            fgr_expand(S, S27);
+            fgr_update(S27, trans);
+            if (a.decrease_mu && (itr % 4 == 0) && par_s > a.max_corr_dist) par_s = par_s / a.division_factor;
+        }
+        itr++;
+        __syncthreads();
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < 16) st->trans[threadIdx.x] = trans[threadIdx.x];
+        if (threadIdx.x == 0) { st->par = par_s; st->itr = itr; }
+    }
 }
 
 __global__ void __launch_bounds__(FB) k_fgr_iter(FgrOptArgs a) {
@@ -783,11 +868,27 @@ extern "C" int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, cons
             hipLaunchKernelGGL(k_fgr_init, dim3(1), dim3(64), 0, ctx->stream, st, scale_start);
             static const int single_max = getenv("PCR_FGR_SINGLE_MAX") ? atoi(getenv("PCR_FGR_SINGLE_MAX")) : 11000;   // one CU needs 0.8 us of float64 work per 1000 correspondences and iteration (+1.4 us solve); a launch per iteration costs 11 us
             if (getenv("PCR_DEBUG_FGR")) fprintf(stderr, "fgr: ncross %lld ncorr %lld iterations %d\n", (long long)ncross, (long long)ncorr, (int)opt->iteration_number);
-            if (ncorr <= single_max) hipLaunchKernelGGL(k_fgr_opt_single, dim3(1), dim3(FSB), 0, ctx->stream, oa, (int)opt->iteration_number);
-            else for (int it = 0; it < opt->iteration_number; it++) hipLaunchKernelGGL(k_fgr_iter, dim3(nb), dim3(FB), 0, ctx->stream, oa);
+            static const int multi_min = getenv("PCR_FGR_MULTI_MIN") ? atoi(getenv("PCR_FGR_MULTI_MIN")) : 6000;       // from here on FMG co-resident workgroups in one launch
+            static const int multi_max = getenv("PCR_FGR_MULTI_MAX") ? atoi(getenv("PCR_FGR_MULTI_MAX")) : 400000;
+            double *rows = arena<double>(ctx, (size_t)2 * FMG * FNVP);
+            if (!rows) return PCR_ENOMEM;
+            const bool multi = ncorr >= multi_min && ncorr <= multi_max;
             FgrState h;
+            auto per_iteration = [&]() { for (int it = 0; it < opt->iteration_number; it++) hipLaunchKernelGGL(k_fgr_iter, dim3(nb), dim3(FB), 0, ctx->stream, oa); };
+            // PCR_FGR_MULTI_TIMEOUT: ticks of the 100 MHz wall clock a workgroup waits at the barrier (tests set 0 to force the fallback)
+            static const unsigned long long fm_timeout = getenv("PCR_FGR_MULTI_TIMEOUT") ? strtoull(getenv("PCR_FGR_MULTI_TIMEOUT"), nullptr, 10) : 5000000ull;
+            if (multi) hipLaunchKernelGGL(k_fgr_opt_multi, dim3(FMG), dim3(FMB), 0, ctx->stream, oa, (int)opt->iteration_number, rows, fm_timeout);
+            else if (ncorr <= single_max) hipLaunchKernelGGL(k_fgr_opt_single, dim3(1), dim3(FSB), 0, ctx->stream, oa, (int)opt->iteration_number);
+            else per_iteration();
             PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
             PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            if (multi && h.failed) {                 // the workgroups were not co-resident in time: same result, one launch per iteration
+                if (getenv("PCR_DEBUG_FGR")) fprintf(stderr, "fgr: multi-workgroup optimiser gave up waiting, falling back to one launch per iteration\n");
+                hipLaunchKernelGGL(k_fgr_init, dim3(1), dim3(64), 0, ctx->stream, st, scale_start);
+                per_iteration();
+                PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+                PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            }
             memcpy(trans, h.trans, sizeof trans);
             if (getenv("PCR_DEBUG_FGR") && h.t_dbg[0]) fprintf(stderr, "fgr single-workgroup optimiser, us per iteration: accumulate %.2f reduce %.2f solve+update %.2f\n",
                                                             h.t_dbg[0] * 0.01 / h.itr, h.t_dbg[1] * 0.01 / h.itr, h.t_dbg[2] * 0.01 / h.itr);

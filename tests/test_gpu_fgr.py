@@ -114,3 +114,25 @@ def test_mfma_feature_matching_vs_float32_bruteforce(P, fgr_inputs, monkeypatch)
     ang, dt = pose_error(a.transformation, b.transformation)
     assert ang < 2e-3 and dt < 2e-2, (ang, dt)
     assert abs(a.fitness - b.fitness) < 0.01
+
+
+def test_fgr_optimiser_variants_agree():
+    """The three optimiser variants (one workgroup / 8 co-resident workgroups with an in-kernel barrier / one launch per
+    iteration) and the forced fallback of the barrier variant (timeout 0) give the same pose up to summation order."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variants = {"single": {"PCR_FGR_SINGLE_MAX": "1000000000", "PCR_FGR_MULTI_MIN": "1000000000"},
+                "multi": {"PCR_FGR_MULTI_MIN": "0"},
+                "per-iteration": {"PCR_FGR_SINGLE_MAX": "0", "PCR_FGR_MULTI_MIN": "1000000000"},
+                "fallback": {"PCR_FGR_MULTI_MIN": "0", "PCR_FGR_MULTI_TIMEOUT": "0", "PCR_DEBUG_FGR": "1"}}
+    poses = {}
+    for name, env in variants.items():
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "fgr_pose.py")], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (name, out.stderr[-2000:])
+        line = [l for l in out.stdout.splitlines() if l.startswith("POSE ")][-1]
+        poses[name] = np.array([float(v) for v in line.split()[1:]]).reshape(4, 4)
+        if name == "fallback":
+            assert "falling back" in out.stderr
+    for name in ("multi", "per-iteration", "fallback"):
+        a, d = pose_error(poses[name], poses["single"])
+        assert a < 1e-9 and d < 1e-9, (name, a, d)
