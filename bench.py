@@ -39,6 +39,10 @@ def main():
     ap.add_argument("--pairs-per-step", type=int, default=48,
                     help="one step = one pass of the path over a batch of this many independent pairs (one pcr_register_pairs call)")
     ap.add_argument("--points", type=int, default=200_000)
+    ap.add_argument("--fixed-iterations", type=int, default=0, help="diagnostics only: run exactly this many GICP iterations per scale (criteria 0/0/N) so that "
+                    "A/B runs of kernel variants do the same work whatever their summation order")
+    ap.add_argument("--loss", choices=["l1", "l2"], default="l1", help="diagnostics only: l2 makes the iteration counts independent of the summation order "
+                    "(the reference's L1-IRLS trajectory is chaotic: 41-89 iterations for the same pair), for A/B runs of kernel variants; the metric is quoted on l1")
     ap.add_argument("--pairs", type=int, default=2, help="distinct synthetic pairs cycled through the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("PCR_BENCH_INFLIGHT", "4")),
@@ -79,8 +83,10 @@ def main():
     else:
         pairs = [syn.make_pair(args.points, index=i) for i in range(args.pairs)]
     clouds = [(P.PointCloud(p.source), P.PointCloud(p.target)) for p in pairs]       # resident in HBM before timing
-    est = P.registration.TransformationEstimationForGeneralizedICP(P.registration.L1Loss())
+    est = P.registration.TransformationEstimationForGeneralizedICP(P.registration.L1Loss() if args.loss == "l1" else P.registration.L2Loss())
     crit = P.registration.ICPConvergenceCriteria(relative_fitness=1e-6, relative_rmse=1e-6, max_iteration=100)
+    if args.fixed_iterations > 0:
+        crit = P.registration.ICPConvergenceCriteria(relative_fitness=0.0, relative_rmse=0.0, max_iteration=args.fixed_iterations)
 
     def step(i):
         p = pairs[i % len(pairs)]; s, t = clouds[i % len(pairs)]
@@ -205,7 +211,7 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 points+search, f64 normal equations", "data": "synthetic",
             "config": {"workload": f"step = batch of {B} independent pairs, each {args.points}-pt synthetic NCLT-shaped clouds, 3-scale GICP "
-                                   "(voxels 0.4/0.2/0.1 m, radii 1.2/0.4/0.1 m, SOR(30,1.0), KNN-20 normals, L1, 1e-6/1e-6/100)",
+                                   f"(voxels 0.4/0.2/0.1 m, radii 1.2/0.4/0.1 m, SOR(30,1.0), KNN-20 normals, {args.loss.upper()}, 1e-6/1e-6/100)",
                        "points_per_cloud": args.points, "pairs_per_step": B, "distinct_pairs": args.pairs, "parallelism": f"pairs x{world}", "pairs_in_flight_per_gpu": args.inflight,
                        "in_flight_by": "pcr_register_pairs (library worker threads)" if args.batch_api else "python host threads",
                        "scales": [dict(voxel=s["voxel"], max_dist=s["max_dist"], n_voxel=s["n_voxel"], n_clean=s["n_clean"],
