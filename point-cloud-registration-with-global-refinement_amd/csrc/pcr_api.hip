@@ -371,7 +371,8 @@ extern "C" int pcr_debug_gicp_linearize(pcr_context *ctx, const float *src_xyz, 
 
 // one cloud of one scale: voxel -> BVH -> SOR -> BVH -> normals   (ALL_FUNCTIONS.py:293-302)
 static int prep_scale(pcr_context *ctx, const float *xyz, const float *nrm, int64_t n, const double *b6, double voxel, int sor_k,
-                      double sor_std, int normal_k, DevCloud *clean, int *cnt_voxel_out, int *cnt_clean_out, bool need_tree) {
+                      double sor_std, int normal_k, DevCloud *clean, int *cnt_voxel_out, int *cnt_clean_out, bool need_tree,
+                      const DevCloud *voxel_done = nullptr /* the voxel cloud of this scale when the merged pass has made it */) {
     DevCloud v;
     PCR_TRY(pcr_alloc_cloud(ctx, clean, (int)n, true, need_tree));   // survives the mark below (allocated first)
     float4 *prior = nrm ? arena<float4>(ctx, n > 0 ? n : 1) : nullptr;
@@ -381,7 +382,12 @@ static int prep_scale(pcr_context *ctx, const float *xyz, const float *nrm, int6
     {
         ArenaMark mark(ctx);
         PCR_TRY(pcr_alloc_cloud(ctx, &v, (int)n, nrm != nullptr, true));
-        PCR_TRY(pcr_dev_voxel(ctx, xyz, nrm, n, b6, voxel, &v));
+        if (voxel_done) {
+            v.pts = voxel_done->pts; v.nrm = voxel_done->nrm; v.keys = voxel_done->keys; v.n = voxel_done->n;
+            for (int d = 0; d < 3; d++) { v.key_org[d] = voxel_done->key_org[d]; v.key_unit[d] = voxel_done->key_unit[d]; }
+        } else {
+            PCR_TRY(pcr_dev_voxel(ctx, xyz, nrm, n, b6, voxel, &v));
+        }
         PCR_TRY(pcr_dev_build_bvh(ctx, &v));
         DevCloud tmp = *clean;
         tmp.nrm = prior;                                         // compacted voxel-mean normals = orientation prior
@@ -414,7 +420,11 @@ extern "C" int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const
     static const int ahead_env = getenv("PCR_PIPELINE") ? atoi(getenv("PCR_PIPELINE")) : 3;
     constexpr int MAX_RING = 4;
     const int ring = ahead_env < 1 ? 1 : (ahead_env > MAX_RING ? MAX_RING : ahead_env);      // scales prepared ahead (+ the one in use)
-    PCR_TRY(pcr_arena_reserve(ctx, (size_t)ring * (blk_s + blk_t) + pcr_scratch_bytes_for(n_src)));
+    // the voxel stage of all scales in one pass per cloud (13 launches instead of 13 per scale); PCR_VOXEL_MERGED=0: one by one
+    static const bool merged_env = !(getenv("PCR_VOXEL_MERGED") && atoi(getenv("PCR_VOXEL_MERGED")) == 0);
+    const bool try_merged = merged_env && n_scales >= 2 && n_scales <= 4;
+    const size_t vox_bytes = try_merged ? (size_t)n_scales * ((size_t)(n_src > 0 ? n_src : 1) + (size_t)(n_tgt > 0 ? n_tgt : 1)) * 48 + (1u << 16) : 0;
+    PCR_TRY(pcr_arena_reserve(ctx, (size_t)ring * (blk_s + blk_t) + pcr_scratch_bytes_for(n_src) + vox_bytes));
     double bs[6], bt[6];
     PCR_TRY(pcr_dev_bounds(ctx, src_xyz, n_src, bs));
     PCR_TRY(pcr_dev_bounds(ctx, tgt_xyz, n_tgt, bt));
@@ -443,16 +453,32 @@ extern "C" int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const
     DevCloud cs[MAX_RING], ct[MAX_RING];
     int *cnt4 = arena<int>(ctx, 4 * MAX_RING);        // per ring slot: voxel counts (source, target), clean counts (source, target)
     if (!cnt4) return PCR_ENOMEM;
+    DevCloud vs[4], vt[4];                            // voxel clouds of all scales (points, keys, count; no tree) when the merged pass runs
+    bool merged_s = false, merged_t = false;
+    if (try_merged) {
+        for (int s = 0; s < n_scales; s++) {
+            PCR_TRY(pcr_alloc_cloud(ctx, &vt[s], (int)n_tgt, tgt_normals != nullptr, false));
+            PCR_TRY(pcr_alloc_cloud(ctx, &vs[s], (int)n_src, src_normals != nullptr, false));
+        }
+        {   // scratch of the pass = the lane's first ring block, which the same lane reuses afterwards (stream order)
+            SideLane lane(ctx, blocks[0][1], blk_t, lane_t);
+            PCR_TRY(pcr_dev_voxel_multi(ctx, tgt_xyz, tgt_normals, n_tgt, bt, voxels, n_scales, vt, &merged_t));
+        }
+        {
+            SideLane lane(ctx, blocks[0][0], blk_s, lane_s);
+            PCR_TRY(pcr_dev_voxel_multi(ctx, src_xyz, src_normals, n_src, bs, voxels, n_scales, vs, &merged_s));
+        }
+    }
     auto enqueue_prep = [&](int s) -> int {
         const int r = s % ring;
         {
             SideLane lane(ctx, blocks[r][1], blk_t, lane_t);
-            PCR_TRY(prep_scale(ctx, tgt_xyz, tgt_normals, n_tgt, bt, voxels[s], sor_k, sor_std, normal_k, &ct[r], cnt4 + 4 * r + 1, cnt4 + 4 * r + 3, true));
+            PCR_TRY(prep_scale(ctx, tgt_xyz, tgt_normals, n_tgt, bt, voxels[s], sor_k, sor_std, normal_k, &ct[r], cnt4 + 4 * r + 1, cnt4 + 4 * r + 3, true, merged_t ? &vt[s] : nullptr));
             PCR_HIP_CHECK(ctx, hipEventRecord(ctx->lane_ev[2 * r + 1], ctx->stream));
         }
         {
             SideLane lane(ctx, blocks[r][0], blk_s, lane_s);
-            PCR_TRY(prep_scale(ctx, src_xyz, src_normals, n_src, bs, voxels[s], sor_k, sor_std, normal_k, &cs[r], cnt4 + 4 * r, cnt4 + 4 * r + 2, false));
+            PCR_TRY(prep_scale(ctx, src_xyz, src_normals, n_src, bs, voxels[s], sor_k, sor_std, normal_k, &cs[r], cnt4 + 4 * r, cnt4 + 4 * r + 2, false, merged_s ? &vs[s] : nullptr));
             PCR_HIP_CHECK(ctx, hipEventRecord(ctx->lane_ev[2 * r], ctx->stream));
         }
         return PCR_OK;

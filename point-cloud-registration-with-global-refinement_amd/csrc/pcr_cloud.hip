@@ -6,6 +6,7 @@
 // (SURVEY.md A.1-A.4).  All kernels are count-driven by a DEVICE-side int so that no host round trip is
 // needed between stages.
 #include <cstdlib>
+#include <cstring>
 #include <cstdio>
 #include "pcr_octree.h"
 
@@ -207,6 +208,100 @@ int pcr_dev_voxel(pcr_context *ctx, const float *xyz, const float *nrm_in, int64
     PCR_TRY(pcr_sort_pairs(ctx, temp, tb, k0, k1, v0, v1, n, end_bit));
     PCR_TRY(flag_scan(ctx, flags, nullptr, ni, pos, out->n, FlagSrc{k1, nullptr, nullptr}));      // head flags produced inside the scan
     hipLaunchKernelGGL(k_voxel_mean, dim3(nb), dim3(BS), 0, ctx->stream, xyz, nrm_in, k1, v1, flags, pos, ni, out->pts, out->nrm, out->keys);
+    return PCR_OK;
+}
+
+// ---- the voxel stage of ALL scales of a multiscale registration in ONE keys / sort / scan / mean pass: element e = s * n + i is
+// point i on the grid of scale s, the scale index sits above the Morton bits of the key.  Every scale owns exactly n consecutive
+// elements of the sorted order, so its first voxel is pos[s * n] and no count has to come back to the host.  Same member order
+// inside a voxel as the one-scale pass (stable sort, original index order) => bit-identical means; 13 launches instead of 13 S.
+#define VOX_MAX_SCALES 4
+struct VoxelGrids { double ox[VOX_MAX_SCALES], oy[VOX_MAX_SCALES], oz[VOX_MAX_SCALES], voxel[VOX_MAX_SCALES]; };
+struct VoxelOuts { float4 *pts[VOX_MAX_SCALES]; float4 *nrm[VOX_MAX_SCALES]; uint64_t *keys[VOX_MAX_SCALES]; int *n[VOX_MAX_SCALES]; };
+__global__ void __launch_bounds__(BS) k_voxel_keys_multi(const float *__restrict__ xyz, int n, int n_scales, VoxelGrids g, int shift,
+                                                         uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const int e = blockIdx.x * BS + threadIdx.x;
+    if (e >= n * n_scales) return;
+    const int s = e / n, i = e - s * n;
+    const double x = (double)xyz[i * 3], y = (double)xyz[i * 3 + 1], z = (double)xyz[i * 3 + 2];
+    double ox = g.ox[0], oy = g.oy[0], oz = g.oz[0], voxel = g.voxel[0];
+#pragma unroll
+    for (int k = 1; k < VOX_MAX_SCALES; k++) if (s == k) { ox = g.ox[k]; oy = g.oy[k]; oz = g.oz[k]; voxel = g.voxel[k]; }
+    const uint32_t ix = (uint32_t)(int)floor((x - ox) / voxel);        // identical float64 expression to the one-scale kernel
+    const uint32_t iy = (uint32_t)(int)floor((y - oy) / voxel);
+    const uint32_t iz = (uint32_t)(int)floor((z - oz) / voxel);
+    keys[e] = ((uint64_t)s << shift) | pcr_morton3(ix, iy, iz);
+    vals[e] = (uint32_t)i;
+}
+__global__ void __launch_bounds__(BS) k_voxel_mean_multi(const float *__restrict__ xyz, const float *__restrict__ nrm_in, const uint64_t *__restrict__ keys,
+                                                         const uint32_t *__restrict__ vals, const uint8_t *__restrict__ flags, const int *__restrict__ pos,
+                                                         const int *__restrict__ total, int n, int n_scales, int shift, VoxelOuts o) {
+    const int p = blockIdx.x * BS + threadIdx.x;
+    const int ne = n * n_scales;
+    if (p >= ne) return;
+    const int s = p / n;
+    const int base = pos[s * n];                       // element s * n starts scale s: always a voxel head
+    float4 *out_pts = o.pts[0], *out_nrm = o.nrm[0]; uint64_t *out_keys = o.keys[0]; int *out_n = o.n[0];
+#pragma unroll
+    for (int k = 1; k < VOX_MAX_SCALES; k++) if (s == k) { out_pts = o.pts[k]; out_nrm = o.nrm[k]; out_keys = o.keys[k]; out_n = o.n[k]; }
+    if (p == s * n) *out_n = (s + 1 < n_scales ? pos[(s + 1) * n] : *total) - base;
+    if (!flags[p]) return;
+    const uint64_t key = keys[p];
+    double sx = 0, sy = 0, sz = 0, nx = 0, ny = 0, nz = 0;
+    int j = p;
+    do {   // members in input order (stable sort) => same float64 sum as the oracle
+        const uint32_t v = vals[j];
+        sx += (double)xyz[v * 3]; sy += (double)xyz[v * 3 + 1]; sz += (double)xyz[v * 3 + 2];
+        if (nrm_in) { nx += (double)nrm_in[v * 3]; ny += (double)nrm_in[v * 3 + 1]; nz += (double)nrm_in[v * 3 + 2]; }
+        j++;
+    } while (j < ne && keys[j] == key);
+    const double c = (double)(j - p);
+    const int idx = pos[p] - base;
+    out_pts[idx] = make_float4((float)(sx / c), (float)(sy / c), (float)(sz / c), 0.0f);
+    out_keys[idx] = key & ((1ull << shift) - 1ull);
+    if (nrm_in && out_nrm) out_nrm[idx] = make_float4((float)(nx / c), (float)(ny / c), (float)(nz / c), 0.0f);
+}
+
+// returns PCR_EINVAL with ctx->err == "" (and does nothing) when the scales cannot share one key: the caller then runs them one by one
+int pcr_dev_voxel_multi(pcr_context *ctx, const float *xyz, const float *nrm_in, int64_t n, const double *b6, const double *voxels, int n_scales, DevCloud *outs, bool *done) {
+    *done = false;
+    if (n_scales < 2 || n_scales > VOX_MAX_SCALES || n <= 0 || n * n_scales > 0x7fffffff / 4) return PCR_OK;
+    VoxelGrids g; VoxelOuts o;
+    std::memset(&g, 0, sizeof g); std::memset(&o, 0, sizeof o);
+    int shift = 0;
+    for (int s = 0; s < n_scales; s++) {
+        const double voxel = voxels[s];
+        if (!(voxel > 0.0)) { ctx->err = "voxel_size <= 0"; return PCR_EINVAL; }
+        g.ox[s] = b6[0] - voxel * 0.5; g.oy[s] = b6[1] - voxel * 0.5; g.oz[s] = b6[2] - voxel * 0.5; g.voxel[s] = voxel;
+        uint32_t mx = 0;
+        for (int d = 0; d < 3; d++) {
+            double e = floor((b6[3 + d] - (b6[d] - voxel * 0.5)) / voxel);
+            if (!(e < 2097152.0)) { ctx->err = "voxel_size is too small"; return PCR_EINVAL; }
+            if ((uint32_t)e > mx) mx = (uint32_t)e;
+        }
+        if (3 * bits_for(mx) > shift) shift = 3 * bits_for(mx);
+        outs[s].key_org[0] = (float)g.ox[s]; outs[s].key_org[1] = (float)g.oy[s]; outs[s].key_org[2] = (float)g.oz[s];
+        outs[s].key_unit[0] = outs[s].key_unit[1] = outs[s].key_unit[2] = (float)voxel;
+        o.pts[s] = outs[s].pts; o.nrm[s] = outs[s].nrm; o.keys[s] = outs[s].keys; o.n[s] = outs[s].n;
+    }
+    if (shift < 1) shift = 1;
+    const int end_bit = shift + bits_for((uint32_t)(n_scales - 1));
+    if (end_bit > 64) return PCR_OK;                    // the scale index does not fit above the Morton bits
+    ArenaMark mark(ctx);
+    const size_t ne = (size_t)n * n_scales;
+    uint64_t *k0 = arena<uint64_t>(ctx, ne), *k1 = arena<uint64_t>(ctx, ne);
+    uint32_t *v0 = arena<uint32_t>(ctx, ne), *v1 = arena<uint32_t>(ctx, ne);
+    uint8_t *flags = arena<uint8_t>(ctx, ne);
+    int *pos = arena<int>(ctx, ne), *total = arena<int>(ctx, 1);
+    const size_t tb = pcr_sort_temp_bytes(ne);
+    void *temp = pcr_arena_alloc(ctx, tb);
+    if (!k0 || !k1 || !v0 || !v1 || !flags || !pos || !total || !temp) return PCR_OK;      // not enough scratch in this block: one by one
+    const int nb = (int)((ne + BS - 1) / BS);
+    hipLaunchKernelGGL(k_voxel_keys_multi, dim3(nb), dim3(BS), 0, ctx->stream, xyz, (int)n, n_scales, g, shift, k0, v0);
+    PCR_TRY(pcr_sort_pairs(ctx, temp, tb, k0, k1, v0, v1, ne, end_bit));
+    PCR_TRY(flag_scan(ctx, flags, nullptr, (int)ne, pos, total, FlagSrc{k1, nullptr, nullptr}));
+    hipLaunchKernelGGL(k_voxel_mean_multi, dim3(nb), dim3(BS), 0, ctx->stream, xyz, nrm_in, k1, v1, flags, pos, total, (int)n, n_scales, shift, o);
+    *done = true;
     return PCR_OK;
 }
 
