@@ -422,7 +422,7 @@ extern "C" int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const
     const int ring = ahead_env < 1 ? 1 : (ahead_env > MAX_RING ? MAX_RING : ahead_env);      // scales prepared ahead (+ the one in use)
     // the voxel stage of all scales in one pass per cloud (13 launches instead of 13 per scale); PCR_VOXEL_MERGED=0: one by one
     static const bool merged_env = !(getenv("PCR_VOXEL_MERGED") && atoi(getenv("PCR_VOXEL_MERGED")) == 0);
-    const bool try_merged = merged_env && n_scales >= 2 && n_scales <= 4;
+    const bool try_merged = merged_env && n_scales >= 2 && n_scales <= 8;
     const size_t vox_bytes = try_merged ? (size_t)n_scales * ((size_t)(n_src > 0 ? n_src : 1) + (size_t)(n_tgt > 0 ? n_tgt : 1)) * 48 + (1u << 16) : 0;
     PCR_TRY(pcr_arena_reserve(ctx, (size_t)ring * (blk_s + blk_t) + pcr_scratch_bytes_for(n_src) + vox_bytes));
     double bs[6], bt[6];
@@ -453,7 +453,7 @@ extern "C" int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const
     DevCloud cs[MAX_RING], ct[MAX_RING];
     int *cnt4 = arena<int>(ctx, 4 * MAX_RING);        // per ring slot: voxel counts (source, target), clean counts (source, target)
     if (!cnt4) return PCR_ENOMEM;
-    DevCloud vs[4], vt[4];                            // voxel clouds of all scales (points, keys, count; no tree) when the merged pass runs
+    DevCloud vs[8], vt[8];                            // voxel clouds of all scales (points, keys, count; no tree) when the merged pass runs
     bool merged_s = false, merged_t = false;
     if (try_merged) {
         for (int s = 0; s < n_scales; s++) {

@@ -215,7 +215,7 @@ int pcr_dev_voxel(pcr_context *ctx, const float *xyz, const float *nrm_in, int64
 // point i on the grid of scale s, the scale index sits above the Morton bits of the key.  Every scale owns exactly n consecutive
 // elements of the sorted order, so its first voxel is pos[s * n] and no count has to come back to the host.  Same member order
 // inside a voxel as the one-scale pass (stable sort, original index order) => bit-identical means; 13 launches instead of 13 S.
-#define VOX_MAX_SCALES 4
+#define VOX_MAX_SCALES 8
 struct VoxelGrids { double ox[VOX_MAX_SCALES], oy[VOX_MAX_SCALES], oz[VOX_MAX_SCALES], voxel[VOX_MAX_SCALES]; };
 struct VoxelOuts { float4 *pts[VOX_MAX_SCALES]; float4 *nrm[VOX_MAX_SCALES]; uint64_t *keys[VOX_MAX_SCALES]; int *n[VOX_MAX_SCALES]; };
 __global__ void __launch_bounds__(BS) k_voxel_keys_multi(const float *__restrict__ xyz, int n, int n_scales, VoxelGrids g, int shift,

@@ -91,7 +91,7 @@ int pcr_dev_bounds(pcr_context *ctx, const float *xyz, int64_t n, double *bounds
 // voxel grid mean in Morton order of the voxel index; out.cap must be >= n
 int pcr_dev_voxel(pcr_context *ctx, const float *xyz, const float *nrm_in, int64_t n, const double *bounds6,
                   double voxel, DevCloud *out);
-// voxel stage of up to 4 scales in one pass (outs[s]: pts / keys / n / optional nrm allocated by the caller, cap >= n); *done = false
+// voxel stage of up to 8 scales in one pass (outs[s]: pts / keys / n / optional nrm allocated by the caller, cap >= n); *done = false
 // (and nothing enqueued) when the scales cannot share one sort key or the scratch does not fit: run them one by one then
 int pcr_dev_voxel_multi(pcr_context *ctx, const float *xyz, const float *nrm_in, int64_t n, const double *bounds6, const double *voxels,
                         int n_scales, DevCloud *outs, bool *done);
