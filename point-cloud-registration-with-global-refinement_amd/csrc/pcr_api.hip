@@ -381,14 +381,13 @@ static int prep_scale(pcr_context *ctx, const float *xyz, const float *nrm, int6
     if (!nv_keep || !todo || (nrm && !prior)) return PCR_ENOMEM;
     {
         ArenaMark mark(ctx);
-        PCR_TRY(pcr_alloc_cloud(ctx, &v, (int)n, nrm != nullptr, true));
         if (voxel_done) {
-            v.pts = voxel_done->pts; v.nrm = voxel_done->nrm; v.keys = voxel_done->keys; v.n = voxel_done->n;
-            for (int d = 0; d < 3; d++) { v.key_org[d] = voxel_done->key_org[d]; v.key_unit[d] = voxel_done->key_unit[d]; }
+            v = *voxel_done;                                         // voxel cloud and its tree made by the merged passes
         } else {
+            PCR_TRY(pcr_alloc_cloud(ctx, &v, (int)n, nrm != nullptr, true));
             PCR_TRY(pcr_dev_voxel(ctx, xyz, nrm, n, b6, voxel, &v));
+            PCR_TRY(pcr_dev_build_bvh(ctx, &v));
         }
-        PCR_TRY(pcr_dev_build_bvh(ctx, &v));
         DevCloud tmp = *clean;
         tmp.nrm = prior;                                         // compacted voxel-mean normals = orientation prior
         tmp.nrm_final = clean->nrm;                              // normals of the cleaned cloud, straight from the SOR lists
@@ -423,7 +422,7 @@ extern "C" int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const
     // the voxel stage of all scales in one pass per cloud (13 launches instead of 13 per scale); PCR_VOXEL_MERGED=0: one by one
     static const bool merged_env = !(getenv("PCR_VOXEL_MERGED") && atoi(getenv("PCR_VOXEL_MERGED")) == 0);
     const bool try_merged = merged_env && n_scales >= 2 && n_scales <= 8;
-    const size_t vox_bytes = try_merged ? (size_t)n_scales * ((size_t)(n_src > 0 ? n_src : 1) + (size_t)(n_tgt > 0 ? n_tgt : 1)) * 48 + (1u << 16) : 0;
+    const size_t vox_bytes = try_merged ? (size_t)n_scales * ((size_t)(n_src > 0 ? n_src : 1) + (size_t)(n_tgt > 0 ? n_tgt : 1) + 512) * 136 + (1u << 16) : 0;   // points, keys, normals, tree
     PCR_TRY(pcr_arena_reserve(ctx, (size_t)ring * (blk_s + blk_t) + pcr_scratch_bytes_for(n_src) + vox_bytes));
     double bs[6], bt[6];
     PCR_TRY(pcr_dev_bounds(ctx, src_xyz, n_src, bs));
@@ -457,16 +456,20 @@ extern "C" int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const
     bool merged_s = false, merged_t = false;
     if (try_merged) {
         for (int s = 0; s < n_scales; s++) {
-            PCR_TRY(pcr_alloc_cloud(ctx, &vt[s], (int)n_tgt, tgt_normals != nullptr, false));
-            PCR_TRY(pcr_alloc_cloud(ctx, &vs[s], (int)n_src, src_normals != nullptr, false));
+            PCR_TRY(pcr_alloc_cloud(ctx, &vt[s], (int)n_tgt, tgt_normals != nullptr, true));
+            PCR_TRY(pcr_alloc_cloud(ctx, &vs[s], (int)n_src, src_normals != nullptr, true));
         }
-        {   // scratch of the pass = the lane's first ring block, which the same lane reuses afterwards (stream order)
+        DevCloud *pt[8], *ps[8];
+        for (int s = 0; s < n_scales; s++) { pt[s] = &vt[s]; ps[s] = &vs[s]; }
+        {   // scratch of the passes = the lane's first ring block, which the same lane reuses afterwards (stream order)
             SideLane lane(ctx, blocks[0][1], blk_t, lane_t);
             PCR_TRY(pcr_dev_voxel_multi(ctx, tgt_xyz, tgt_normals, n_tgt, bt, voxels, n_scales, vt, &merged_t));
+            if (merged_t) PCR_TRY(pcr_dev_build_bvh_batch(ctx, pt, n_scales));      // the trees of all scales: 6 launches
         }
         {
             SideLane lane(ctx, blocks[0][0], blk_s, lane_s);
             PCR_TRY(pcr_dev_voxel_multi(ctx, src_xyz, src_normals, n_src, bs, voxels, n_scales, vs, &merged_s));
+            if (merged_s) PCR_TRY(pcr_dev_build_bvh_batch(ctx, ps, n_scales));
         }
     }
     auto enqueue_prep = [&](int s) -> int {

@@ -371,7 +371,7 @@ int pcr_dev_sort_cloud(pcr_context *ctx, const float *xyz, int64_t n, const doub
 // ====================================================================== linear octree build (K2, part 2)
 // A: level of the highest Morton bit in which consecutive keys differ (-1: identical keys) + histogram
 #define OCT_ROW 24      // ints per tile row: cumulative node-start counts of the 22 key levels (+ padding)
-__global__ void __launch_bounds__(BS) k_oct_lstar(const uint64_t *__restrict__ keys, const int *__restrict__ n_ptr, signed char *__restrict__ ls, int *__restrict__ rows) {
+__device__ static inline void d_oct_lstar(const uint64_t *__restrict__ keys, const int *__restrict__ n_ptr, signed char *__restrict__ ls, int *__restrict__ rows) {
     __shared__ int h[OCT_KEY_LEVELS];
     if (threadIdx.x < OCT_KEY_LEVELS) h[threadIdx.x] = 0;
     __syncthreads();
@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(BS) k_oct_lstar(const uint64_t *__restrict__ k
 }
 // B: choose the leaf level (first level with <= n/4 cells: ~8 points per leaf), the root level, offsets
 struct OctGeom { float org[3]; float unit[3]; int leaf_div; };
-__global__ void __launch_bounds__(256) k_oct_meta(const int *__restrict__ n_ptr, const int *__restrict__ rows, int n_tiles, int node_cap, OctMeta *__restrict__ meta, int *__restrict__ child, OctGeom g) {
+__device__ static inline void d_oct_meta(const int *__restrict__ n_ptr, const int *__restrict__ rows, int n_tiles, int node_cap, OctMeta *__restrict__ meta, int *__restrict__ child, OctGeom g) {
     __shared__ int part[8][32];
     __shared__ int tot[OCT_ROW];
     {
@@ -444,7 +444,7 @@ __global__ void __launch_bounds__(256) k_oct_meta(const int *__restrict__ n_ptr,
     *meta = m;
 }
 // E: node ids by ballot ranking; write child links and the leaf of every point
-__global__ void __launch_bounds__(BS) k_oct_apply(const signed char *__restrict__ ls, const OctMeta *__restrict__ meta, const int *__restrict__ rows,
+__device__ static inline void d_oct_apply(const signed char *__restrict__ ls, const OctMeta *__restrict__ meta, const int *__restrict__ rows,
                                                   int *__restrict__ child, int *__restrict__ leaf_of) {
     __shared__ int wtot[4][BS / PCR_WAVE][OCT_MAXL];
     __shared__ int part[BS / OCT_MAXL][OCT_MAXL];
@@ -491,7 +491,7 @@ __global__ void __launch_bounds__(BS) k_oct_apply(const signed char *__restrict_
     }
 }
 // F/G: tight boxes, bottom-up
-__global__ void __launch_bounds__(BS) k_oct_leaf_boxes(const float4 *__restrict__ pts, const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up,
+__device__ static inline void d_oct_leaf_boxes(const float4 *__restrict__ pts, const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up,
                                                        int4 *__restrict__ pinfo) {
     const int j = blockIdx.x * BS + threadIdx.x;
     if (meta->nl < 1 || j >= meta->cnt[0]) return;
@@ -526,14 +526,14 @@ __device__ static inline void oct_node_box(const OctMeta &m, const int *__restri
     lo.w = __int_as_float(a); hi.w = __int_as_float(b - a);
     boxes[2 * (size_t)(m.off[li] + j)] = lo; boxes[2 * (size_t)(m.off[li] + j) + 1] = hi;
 }
-__global__ void __launch_bounds__(BS) k_oct_level_boxes(const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up, int li,
+__device__ static inline void d_oct_level_boxes(const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up, int li,
                                                         int4 *__restrict__ pinfo) {
     const int j = blockIdx.x * BS + threadIdx.x;
     if (li >= meta->nl || j >= meta->cnt[li]) return;
     oct_node_box(*meta, child, boxes, up, li, j, pinfo);
 }
 // remaining (small) levels in ONE workgroup, level by level
-__global__ void __launch_bounds__(1024) k_oct_upper_boxes(const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up, int first_li) {
+__device__ static inline void d_oct_upper_boxes(const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up, int first_li) {
     __shared__ OctMeta m;
     if (threadIdx.x == 0) m = *meta;
     __syncthreads();
@@ -544,25 +544,74 @@ __global__ void __launch_bounds__(1024) k_oct_upper_boxes(const OctMeta *__restr
     }
 }
 
-int pcr_dev_build_bvh(pcr_context *ctx, DevCloud *c) {
-    if (c->cap <= 0) return PCR_OK;
+// ---- the six build kernels serve up to OCT_BATCH trees per launch: blockIdx.y picks the tree (the voxel clouds of all scales
+// of a registration are built together: 6 launches instead of 6 per scale)
+#define OCT_BATCH 8
+struct OctBuildDesc {
+    const uint64_t *keys; const int *n; signed char *ls; int *rows; OctMeta *meta; int *child; int *leaf_of;
+    const float4 *pts; float4 *nodes; int4 *up; int4 *pinfo; OctGeom g; int n_tiles, node_cap;
+};
+struct OctBuildBatch { OctBuildDesc d[OCT_BATCH]; };
+__global__ void __launch_bounds__(BS) k_oct_lstar(OctBuildBatch b) {
+    const OctBuildDesc &d = b.d[blockIdx.y];
+    if ((int)blockIdx.x >= d.n_tiles) return;
+    d_oct_lstar(d.keys, d.n, d.ls, d.rows);
+}
+__global__ void __launch_bounds__(256) k_oct_meta(OctBuildBatch b) {
+    const OctBuildDesc &d = b.d[blockIdx.y];
+    d_oct_meta(d.n, d.rows, d.n_tiles, d.node_cap, d.meta, d.child, d.g);
+}
+__global__ void __launch_bounds__(BS) k_oct_apply(OctBuildBatch b) {
+    const OctBuildDesc &d = b.d[blockIdx.y];
+    if ((int)blockIdx.x >= d.n_tiles) return;
+    d_oct_apply(d.ls, d.meta, d.rows, d.child, d.leaf_of);
+}
+__global__ void __launch_bounds__(BS) k_oct_leaf_boxes(OctBuildBatch b) {
+    const OctBuildDesc &d = b.d[blockIdx.y];
+    d_oct_leaf_boxes(d.pts, d.meta, d.child, d.nodes, d.up, d.pinfo);
+}
+__global__ void __launch_bounds__(BS) k_oct_level_boxes(OctBuildBatch b, int li) {
+    const OctBuildDesc &d = b.d[blockIdx.y];
+    d_oct_level_boxes(d.meta, d.child, d.nodes, d.up, li, d.pinfo);
+}
+__global__ void __launch_bounds__(1024) k_oct_upper_boxes(OctBuildBatch b, int first_li) {
+    const OctBuildDesc &d = b.d[blockIdx.y];
+    d_oct_upper_boxes(d.meta, d.child, d.nodes, d.up, first_li);
+}
+
+int pcr_dev_build_bvh_batch(pcr_context *ctx, DevCloud *const *cs, int count) {
+    if (count < 1) return PCR_OK;
+    if (count > OCT_BATCH) { ctx->err = "too many trees in one batch"; return PCR_EINVAL; }
     ArenaMark mark(ctx);
-    const int cap = c->cap, n_tiles = (cap + TILE - 1) / TILE;
-    signed char *ls = arena<signed char>(ctx, cap);
-    int *rows = arena<int>(ctx, (size_t)n_tiles * OCT_ROW);
-    if (!ls || !rows) return PCR_ENOMEM;
-    hipLaunchKernelGGL(k_oct_lstar, dim3(n_tiles), dim3(BS), 0, ctx->stream, c->keys, c->n, ls, rows);
-    OctGeom g; for (int d = 0; d < 3; d++) { g.org[d] = c->key_org[d]; g.unit[d] = c->key_unit[d]; }
-    { static const int div = getenv("PCR_OCT_DIV") ? atoi(getenv("PCR_OCT_DIV")) : 4; g.leaf_div = div; }
-    hipLaunchKernelGGL(k_oct_meta, dim3(1), dim3(256), 0, ctx->stream, c->n, rows, n_tiles, (int)oct_node_capacity(cap), c->oct_meta, c->oct_child, g);
-    hipLaunchKernelGGL(k_oct_apply, dim3(n_tiles), dim3(BS), 0, ctx->stream, ls, c->oct_meta, rows, c->oct_child, c->leaf_of);
-    const int nbl = (cap / 2 + 1 + BS - 1) / BS;       // <= n/2 leaves (or 1)
-    hipLaunchKernelGGL(k_oct_leaf_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->pts, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, c->pinfo);
-    hipLaunchKernelGGL(k_oct_level_boxes, dim3(nbl), dim3(BS), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, 1, c->pinfo);
-    // levels >= 2 (n/64 nodes and fewer) in ONE workgroup, level by level: a launch less than one grid per level
-    hipLaunchKernelGGL(k_oct_upper_boxes, dim3(1), dim3(1024), 0, ctx->stream, c->oct_meta, c->oct_child, c->oct_nodes, c->oct_up, 2);
+    OctBuildBatch b; std::memset(&b, 0, sizeof b);
+    static const int div = getenv("PCR_OCT_DIV") ? atoi(getenv("PCR_OCT_DIV")) : 4;
+    int m = 0, max_tiles = 0, max_nbl = 0;
+    for (int k = 0; k < count; k++) {
+        DevCloud *c = cs[k];
+        if (c->cap <= 0) continue;
+        OctBuildDesc &d = b.d[m++];
+        d.n_tiles = (c->cap + TILE - 1) / TILE; d.node_cap = (int)oct_node_capacity(c->cap);
+        d.ls = arena<signed char>(ctx, c->cap); d.rows = arena<int>(ctx, (size_t)d.n_tiles * OCT_ROW);
+        if (!d.ls || !d.rows) return PCR_ENOMEM;
+        d.keys = c->keys; d.n = c->n; d.meta = c->oct_meta; d.child = c->oct_child; d.leaf_of = c->leaf_of;
+        d.pts = c->pts; d.nodes = c->oct_nodes; d.up = c->oct_up; d.pinfo = c->pinfo;
+        for (int a = 0; a < 3; a++) { d.g.org[a] = c->key_org[a]; d.g.unit[a] = c->key_unit[a]; }
+        d.g.leaf_div = div;
+        const int nbl = (c->cap / 2 + 1 + BS - 1) / BS;       // <= n/2 leaves (or 1)
+        if (d.n_tiles > max_tiles) max_tiles = d.n_tiles;
+        if (nbl > max_nbl) max_nbl = nbl;
+    }
+    if (m == 0) return PCR_OK;
+    hipLaunchKernelGGL(k_oct_lstar, dim3(max_tiles, m), dim3(BS), 0, ctx->stream, b);
+    hipLaunchKernelGGL(k_oct_meta, dim3(1, m), dim3(256), 0, ctx->stream, b);
+    hipLaunchKernelGGL(k_oct_apply, dim3(max_tiles, m), dim3(BS), 0, ctx->stream, b);
+    hipLaunchKernelGGL(k_oct_leaf_boxes, dim3(max_nbl, m), dim3(BS), 0, ctx->stream, b);
+    hipLaunchKernelGGL(k_oct_level_boxes, dim3(max_nbl, m), dim3(BS), 0, ctx->stream, b, 1);
+    // levels >= 2 (n/64 nodes and fewer) in ONE workgroup per tree, level by level: a launch less than one grid per level
+    hipLaunchKernelGGL(k_oct_upper_boxes, dim3(1, m), dim3(1024), 0, ctx->stream, b, 2);
     return PCR_OK;
 }
+int pcr_dev_build_bvh(pcr_context *ctx, DevCloud *c) { return pcr_dev_build_bvh_batch(ctx, &c, 1); }
 
 static inline OctView oct_view(const DevCloud *c) {
     OctView v; v.pts = c->pts; v.nodes = c->oct_nodes; v.up = c->oct_up; v.meta = c->oct_meta; v.leaf_of = c->leaf_of; v.keys = c->keys; v.pinfo = c->pinfo;

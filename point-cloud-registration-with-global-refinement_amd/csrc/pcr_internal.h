@@ -99,6 +99,7 @@ int pcr_dev_voxel_multi(pcr_context *ctx, const float *xyz, const float *nrm_in,
 int pcr_dev_sort_cloud(pcr_context *ctx, const float *xyz, int64_t n, const double *bounds6, DevCloud *out,
                        uint32_t *perm);
 int pcr_dev_build_bvh(pcr_context *ctx, DevCloud *c);
+int pcr_dev_build_bvh_batch(pcr_context *ctx, DevCloud *const *cs, int count);     // up to 8 trees per launch (blockIdx.y)
 // SOR: keep flags + compaction into `out` (out.cap >= in.cap); returns nothing to the host
 int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double std_ratio, DevCloud *out,
                 uint8_t *keep_sorted /*optional device, in.cap*/, double *avg_sorted /*optional*/,
