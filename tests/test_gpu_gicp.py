@@ -252,3 +252,19 @@ def test_register_pairs_ragged_sizes_stress(P, small_pair):
             assert np.array_equal(a.transformation, b.transformation), (inflight, k, sizes[k])
             assert a.fitness == b.fitness and [x["iterations"] for x in a.scales] == [x["iterations"] for x in b.scales]
             assert [x["n_clean"] for x in a.scales] == [x["n_clean"] for x in b.scales]
+
+
+def test_switches_do_not_change_the_result():
+    """Every execution switch (merged voxel pass, fused iteration kernel, skip certificates, hipGraph replay, ring depth, lanes)
+    only changes HOW the same arithmetic is scheduled: pose bits, iteration counts and cloud counts are identical."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variants = [{}, {"PCR_VOXEL_MERGED": "0"}, {"PCR_ICP_FUSED": "0"}, {"PCR_ICP_SKIP": "0"}, {"PCR_ICP_GRAPH": "0"},
+                {"PCR_PIPELINE": "1", "PCR_LANES": "1"}, {"PCR_VOXEL_MERGED": "0", "PCR_ICP_FUSED": "0", "PCR_ICP_GRAPH": "0", "PCR_PIPELINE": "2"}]
+    lines = []
+    for env in variants:
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "gicp_pose.py")], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (env, out.stderr[-2000:])
+        lines.append([l for l in out.stdout.splitlines() if l.startswith("GICP ")][-1])
+    for env, line in zip(variants[1:], lines[1:]):
+        assert line == lines[0], (env, line[:80], lines[0][:80])
