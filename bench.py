@@ -190,11 +190,11 @@ def main():
         res = results[-1]
         # ---- roofline of the hot loop: ONE GICP iteration = k_icp_nn + k_icp_iter (SURVEY K10+K11), 48 B per source point
         ev_ms_f, ev_launches_f, ik_us_f, live_f, _, issued = (prof[i] for i in range(6))
-        us_in_flight = 1e3 * ev_ms_f / ev_launches_f if ev_launches_f else float("nan")
+        us_in_flight = 1e3 * ev_ms_f / ev_launches_f if ev_launches_f else None     # None: the pairs in flight share their launches (IcpEngine)
         ev_ms, ev_launches, ik_us, live, alg_bytes, _ = (solo[i] for i in range(6))
         bytes_per_launch = alg_bytes / live if live else 0.0
-        us_event = 1e3 * ev_ms / ev_launches if ev_launches else float("nan")     # HIP events over fully-live chunks
-        us_kernel = ik_us / live if live else float("nan")                         # kernels' own s_memrealtime stamps
+        us_event = 1e3 * ev_ms / ev_launches if ev_launches else None              # HIP events over fully-live chunks
+        us_kernel = ik_us / live if live else None                                 # kernels' own s_memrealtime stamps
         achieved = bytes_per_launch / (us_event * 1e-6) / 1e9 if ev_launches else 0.0
         traffic = None
         tj = os.path.join(ROOT, "profiles", "r01_traffic.json")                    # rocprofv3 --pmc passes (profiles/README.md)
