@@ -399,7 +399,7 @@ __device__ static inline void d_oct_lstar(const uint64_t *__restrict__ keys, con
         rows[blockIdx.x * OCT_ROW + threadIdx.x] = threadIdx.x < OCT_KEY_LEVELS ? c : 0;
     }
 }
-// B: choose the leaf level (first level with <= n/4 cells: ~8 points per leaf), the root level, offsets
+// B: choose the leaf level (first level with <= n/leaf_div cells; levels are 8x apart, so 6 means 6-48 points per leaf), the root level, offsets
 struct OctGeom { float org[3]; float unit[3]; int leaf_div; };
 __device__ static inline void d_oct_meta(const int *__restrict__ n_ptr, const int *__restrict__ rows, int n_tiles, int node_cap, OctMeta *__restrict__ meta, int *__restrict__ child, OctGeom g) {
     __shared__ int part[8][32];
@@ -584,7 +584,7 @@ int pcr_dev_build_bvh_batch(pcr_context *ctx, DevCloud *const *cs, int count) {
     if (count > OCT_BATCH) { ctx->err = "too many trees in one batch"; return PCR_EINVAL; }
     ArenaMark mark(ctx);
     OctBuildBatch b; std::memset(&b, 0, sizeof b);
-    static const int div = getenv("PCR_OCT_DIV") ? atoi(getenv("PCR_OCT_DIV")) : 4;
+    static const int div = getenv("PCR_OCT_DIV") ? atoi(getenv("PCR_OCT_DIV")) : 6;
     int m = 0, max_tiles = 0, max_nbl = 0;
     for (int k = 0; k < count; k++) {
         DevCloud *c = cs[k];
