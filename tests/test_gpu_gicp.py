@@ -268,3 +268,10 @@ def test_switches_do_not_change_the_result():
         lines.append([l for l in out.stdout.splitlines() if l.startswith("GICP ")][-1])
     for env, line in zip(variants[1:], lines[1:]):
         assert line == lines[0], (env, line[:80], lines[0][:80])
+    # clouds that carry normals (averaged per voxel, orientation prior of the estimated ones): merged and per-scale voxel passes agree
+    with_n = []
+    for env in ({"GICP_POSE_WITH_NORMALS": "1"}, {"GICP_POSE_WITH_NORMALS": "1", "PCR_VOXEL_MERGED": "0"}):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "gicp_pose.py")], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (env, out.stderr[-2000:])
+        with_n.append([l for l in out.stdout.splitlines() if l.startswith("GICP ")][-1])
+    assert with_n[0] == with_n[1]
