@@ -66,3 +66,19 @@ def test_config5_two_million_points_recovers_planted_motion(P, pair200k):
     assert ang < 2e-3 and dt < 2e-2, (ang, dt)
     assert len(res.scales) == 5 and all(s["n_clean"][0] <= s["n_voxel"][0] <= 2_000_000 for s in res.scales)
     assert res.scales[-1]["n_voxel"][0] > 1_000_000 and res.fitness > 0.5
+
+
+def test_config2_fgr_variant_global_then_multiscale(P, pair200k):
+    """Config 2's FGR variant: `registro_FGR` (voxel 0.1, script-1 parameters) from NO initial guess on the
+    200 000-point pair, then the multiscale GICP from its pose: FGR lands inside its statistical band around the planted
+    motion, the refinement inside the config-2 bound."""
+    p = pair200k
+    src, tgt = P.PointCloud(p.source), P.PointCloud(p.target)
+    fgr = P.script1.registro_FGR(src, tgt, 0.1, seed=11)
+    ang, dt = pose_error(fgr.transformation, p.T_true)
+    assert ang < 3e-2 and dt < 0.5, (ang, dt)
+    est = P.registration.TransformationEstimationForGeneralizedICP(P.registration.L1Loss())
+    crit = P.registration.ICPConvergenceCriteria(1e-6, 1e-6, 100)
+    res = P.registration.multiscale_gicp(P.PointCloud(p.source), P.PointCloud(p.target), p.voxel_sizes, p.max_distances_script, fgr.transformation, est, crit)
+    ang, dt = pose_error(res.transformation, p.T_true)
+    assert ang < 2e-3 and dt < 2e-2, (ang, dt)
