@@ -262,7 +262,8 @@ __global__ void __launch_bounds__(BS) k_voxel_mean_multi(const float *__restrict
     if (nrm_in && out_nrm) out_nrm[idx] = make_float4((float)(nx / c), (float)(ny / c), (float)(nz / c), 0.0f);
 }
 
-// returns PCR_EINVAL with ctx->err == "" (and does nothing) when the scales cannot share one key: the caller then runs them one by one
+// *done = false (nothing enqueued) when the scales cannot share one sort key or the scratch block is too small: the caller then runs
+// them one by one; PCR_EINVAL only for the argument errors the one-scale pass reports too
 int pcr_dev_voxel_multi(pcr_context *ctx, const float *xyz, const float *nrm_in, int64_t n, const double *b6, const double *voxels, int n_scales, DevCloud *outs, bool *done) {
     *done = false;
     if (n_scales < 2 || n_scales > VOX_MAX_SCALES || n <= 0 || n * n_scales > 0x7fffffff / 4) return PCR_OK;
