@@ -1,0 +1,28 @@
+"""Diagnostic: many batches through pcr_register_pairs; free device memory before / after and throughput per block of batches
+(leaks or a growing arena would show as shrinking free memory or falling throughput)."""
+import importlib, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+import torch
+P = importlib.import_module("point-cloud-registration-with-global-refinement_amd")
+syn = importlib.import_module("point-cloud-registration-with-global-refinement_amd.synthetic")
+pairs = [syn.make_pair(200000, index=i) for i in range(2)]
+clouds = [(P.PointCloud(p.source), P.PointCloud(p.target), p.T_init) for p in pairs]
+est = P.registration.TransformationEstimationForGeneralizedICP(P.registration.L1Loss())
+crit = P.registration.ICPConvergenceCriteria(1e-6, 1e-6, 100)
+batch = [clouds[i % 2] for i in range(48)]
+n_blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+P.registration.register_pairs(batch, pairs[0].voxel_sizes, pairs[0].max_distances_script, est, crit, inflight=4)
+torch.cuda.synchronize()
+free0 = torch.cuda.mem_get_info()[0]
+ref = None
+for b in range(n_blocks):
+    t0 = time.perf_counter()
+    for _ in range(5):
+        res = P.registration.register_pairs(batch, pairs[0].voxel_sizes, pairs[0].max_distances_script, est, crit, inflight=4, with_correspondences=False)
+    dt = time.perf_counter() - t0
+    bits = [np.asarray(r.transformation).tobytes() for r in res[:2]]
+    if ref is None: ref = bits
+    assert bits == ref, "results changed between batches"
+    print(f"block {b}: {240 / dt:.1f} pairs/s, free device memory {torch.cuda.mem_get_info()[0] / 2**20:.0f} MiB (start {free0 / 2**20:.0f})", flush=True)
