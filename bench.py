@@ -2,24 +2,32 @@
 """bench.py -- pairs registered per second on synthetic 200k-point NCLT-shaped clouds, 3 GICP scales
 (BASELINE.json metric, config 2).
 
-One "step" = one pass of the hot path over one BATCH of --pairs-per-step (48) independent pairs already resident in HBM,
-issued as ONE pcr_register_pairs call (the library keeps --inflight pairs in flight); per pair the whole Multiscale_GICP
-body runs (voxel_down_sample -> remove_statistical_outlier(30, 1.0) -> estimate_normals(KNN 20) ->
-registration_generalized_icp(L1, 1e-6/1e-6/100) for voxels 0.4/0.2/0.1 m, search radii 1.2/0.4/0.1 m), exactly the
-reference's pair-time definition (2_MGICP...py:190-199).  value = pairs registered / wall time of the K steps.
-N>1: one process per GPU, each registers its own batches (no data-path collective); one all-gather of the fixed-size
-pose records closes the timed region.
+One "step" = one pass of the hot path over one BATCH of --pairs-per-step (48) independent, DISTINCT pairs already resident in
+HBM, issued as ONE pcr_register_pairs_plan call (the library keeps --inflight pairs in flight); per pair the whole
+Multiscale_GICP body runs (voxel_down_sample -> remove_statistical_outlier(30, 1.0) -> estimate_normals(KNN 20) ->
+registration_generalized_icp(L1, 1e-6/1e-6/100) for voxels 0.4/0.2/0.1 m), exactly the reference's pair-time definition
+(2_MGICP...py:190-199).  value = pairs registered / wall time of the K steps.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs-per-step 48] [--inflight 3] [--points 200000] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--variant gicp|fgr] [--radius-rule script|af] [--config5]
+                    [--pairs-per-step 48] [--inflight 4] [--points 200000] [--no-cpu-baseline] [--no-extras]
+
+--gpus N > 1: when no launcher has set RANK, this process starts N ranks itself (python -m torch.distributed.run, one fresh
+process per GPU) BEFORE anything touches HIP, forwards rank 0's JSON line and exits with the launcher's code.  Every rank
+registers its own batches (weak scaling, no data-path collective); one all-gather of the fixed-size pose records closes the
+timed region (RCCL; gloo under PCR_BENCH_REHEARSE=1 / PCR_BENCH_DRYRUN=1).
+
+The default line is the GICP path with the script-2 radii (1.2/0.4/0.1 m).  `extras` in the same line holds short measurements
+of the other forms SURVEY §8(d) names: the ALL_FUNCTIONS radius rule (radius_from_cloud_pair * 2^-i), the FGR variant of config 2
+(registro_FGR voxel 0.1 + the same 3-scale GICP, both inside the pair time) and config 5 (2M points, 5 scales, 64-NN normals).
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 # Pairs in flight use 3 HIP streams each (GICP loop + two preprocessing lanes); the runtime maps streams onto
 # GPU_MAX_HW_QUEUES hardware queues (default 4) and streams sharing a queue serialise.  Must be set before HIP starts.
@@ -29,32 +37,116 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "point-cloud-registration-with-global-refinement_amd"
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+F64_MFMA_PEAK_TFLOPS = 78.6      # MI355X spec, float64 matrix (v_mfma_f64_16x16x4)
+F16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: ~2.5 PF dense bf16/f16
+METRIC = "point-cloud pairs registered/sec (200k pts, 3 GICP scales)"
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs-per-step", type=int, default=48,
-                    help="one step = one pass of the path over a batch of this many independent pairs (one pcr_register_pairs call)")
+                    help="one step = one pass of the path over a batch of this many independent pairs (one pcr_register_pairs_plan call)")
     ap.add_argument("--points", type=int, default=200_000)
+    ap.add_argument("--variant", choices=["gicp", "fgr"], default="gicp",
+                    help="gicp: Multiscale_GICP from the perturbed start (the metric); fgr: config 2's FGR variant, registro_FGR (voxel 0.1) + "
+                         "Multiscale_GICP from its pose, both inside the pair time (ALL_FUNCTIONS.py:317-326)")
+    ap.add_argument("--radius-rule", choices=["script", "af"], default="script",
+                    help="script: 3*0.4, 2*0.2, 0.1 m (2_MGICP...py:115); af: radius_from_cloud_pair * 2^-i per pair (ALL_FUNCTIONS.py:277-278)")
+    ap.add_argument("--config5", action="store_true", help="BASELINE config 5 instead: 2M-point clouds (10 tiles of the 200k scene), 5 scales, 64-NN normals")
     ap.add_argument("--fixed-iterations", type=int, default=0, help="diagnostics only: run exactly this many GICP iterations per scale (criteria 0/0/N) so that "
                     "A/B runs of kernel variants do the same work whatever their summation order")
     ap.add_argument("--loss", choices=["l1", "l2"], default="l1", help="diagnostics only: l2 makes the iteration counts independent of the summation order "
                     "(the reference's L1-IRLS trajectory is chaotic: 41-89 iterations for the same pair), for A/B runs of kernel variants; the metric is quoted on l1")
-    ap.add_argument("--pairs", type=int, default=2, help="distinct synthetic pairs cycled through the steps")
+    ap.add_argument("--pairs", type=int, default=0, help="distinct pairs cycled through a step (default: --pairs-per-step, i.e. every pair of a batch is a "
+                    "different pair in different buffers)")
+    ap.add_argument("--base-pairs", type=int, default=2, help="independently generated scenes samples (20 s each unless cached); the distinct pairs are these, "
+                    "re-posed by a rigid motion of both clouds and re-ordered")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("PCR_BENCH_INFLIGHT", "4")),
-                    help="independent pairs in flight per GPU (one host thread + one HIP stream + one library context each)")
-    ap.add_argument("--python-threads", action="store_true", help="keep the pairs in flight with host threads in Python (one pcr_multiscale_gicp call per pair) "
-                    "instead of ONE pcr_register_pairs call for the timed steps (default: the library keeps them in flight)")
-    args = ap.parse_args()
+                    help="independent pairs in flight per GPU (one library worker thread + context + streams each)")
+    return ap.parse_args(argv)
 
+
+# ------------------------------------------------------------------------------------------------ N ranks from one command
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start N fresh rank processes through torch.distributed.run and
+    forward their output.  Nothing in THIS process has imported torch or touched HIP, and it does not exec: it waits for the
+    launcher and exits with its code."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    env["PCR_BENCH_LAUNCHED_BY"] = "bench.py"
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
+    saw_line = False
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        saw_line = saw_line or line.lstrip().startswith('{"metric"')
+    rc = proc.wait()
+    if rc == 0 and not saw_line:
+        print("bench.py: the ranks exited without printing the result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ dry run (launcher / gather plumbing on CPU)
+def dry_run(args, rank, world) -> int:
+    """PCR_BENCH_DRYRUN=1: no GPU work at all; every rank fabricates its pose records, the gloo all-gather, barrier and MAX-reduce
+    run exactly as in a real run and rank 0 prints a line flagged `dry_run` (tests/test_sharding.py checks n_gpus / n_ranks_seen)."""
+    import numpy as np
     import torch
     import torch.distributed as dist
+    shard = importlib.import_module(PKG + ".sharding")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    n_done = args.steps * args.pairs_per_step
+    t0 = time.perf_counter()
+    recs = np.zeros((n_done, shard.RECORD_DOUBLES)); recs[:, 0] = recs[:, 5] = recs[:, 10] = recs[:, 15] = 1.0
+    recs[:, 21] = rank * n_done + np.arange(n_done)
+    gathered = shard.gather_records(recs, world * n_done) if world > 1 else recs
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    seen = dist.get_world_size() if world > 1 else 1
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "pairs/s", "n_gpus": world, "n_ranks_seen": seen, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
+                          "data": "dry run: no registration was computed", "dry_run": True,
+                          "config": {"workload": "launcher / gather plumbing only", "gathered_records": int(len(gathered))}}))
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ the measured run of one rank
+def main(argv=None) -> int:
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args)
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if os.environ.get("PCR_BENCH_DRYRUN") == "1":
+        return dry_run(args, rank, world)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     # rehearsal of the N > 1 path on a one-GPU box: PCR_BENCH_REHEARSE=1 maps every rank onto device 0 and gathers over gloo
@@ -68,61 +160,49 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    n_ranks_seen = dist.get_world_size() if world > 1 else 1
 
     P = importlib.import_module(PKG)
     syn = importlib.import_module(PKG + ".synthetic")
     shard = importlib.import_module(PKG + ".sharding")
+    reg = P.registration
     ctypes = __import__("ctypes")
+    lib = P._lib.load()
+
+    B = max(1, args.pairs_per_step)
+    n_distinct = args.pairs if args.pairs > 0 else B
+    n_scales = 5 if args.config5 else 3
+    normal_k = 64 if args.config5 else 20
 
     # ---- synthetic workload (same seeds on every rank; every rank registers its own copy: weak scaling)
-    if args.points < 200_000:       # diagnostic sizes: a random subset of the 200k pair (the generator needs a full-size scene)
-        import dataclasses
-        base = [syn.make_pair(200_000, index=i) for i in range(args.pairs)]
-        sub = np.random.default_rng(7).permutation(200_000)[: args.points]
-        pairs = [dataclasses.replace(b, source=b.source[sub], target=b.target[sub]) for b in base]
-    else:
-        pairs = [syn.make_pair(args.points, index=i) for i in range(args.pairs)]
-    clouds = [(P.PointCloud(p.source), P.PointCloud(p.target)) for p in pairs]       # resident in HBM before timing
-    est = P.registration.TransformationEstimationForGeneralizedICP(P.registration.L1Loss() if args.loss == "l1" else P.registration.L2Loss())
-    crit = P.registration.ICPConvergenceCriteria(relative_fitness=1e-6, relative_rmse=1e-6, max_iteration=100)
+    def base_pair(i):
+        if args.points < 200_000:       # diagnostic sizes: a random subset of the 200k pair (the generator needs a full-size scene)
+            import dataclasses
+            b = syn.make_pair(200_000, index=i)
+            sub = np.random.default_rng(7).permutation(200_000)[: args.points]
+            return dataclasses.replace(b, source=b.source[sub], target=b.target[sub])
+        return syn.make_pair(args.points, index=i)
+
+    def workload(n_pairs, config5=False):
+        bases = [base_pair(i) for i in range(max(1, min(args.base_pairs, n_pairs)))]
+        if config5:
+            bases = [syn.tile_pair(b, 10, n_scales=5) for b in bases]
+        pairs = [syn.derive_pair(bases[k % len(bases)], k // len(bases)) for k in range(n_pairs)]
+        clouds = [(P.PointCloud(p.source), P.PointCloud(p.target)) for p in pairs]       # resident in HBM before timing
+        return pairs, clouds
+
+    pairs, clouds = workload(n_distinct, args.config5)
+    est = reg.TransformationEstimationForGeneralizedICP(reg.L1Loss() if args.loss == "l1" else reg.L2Loss())
+    crit = reg.ICPConvergenceCriteria(relative_fitness=1e-6, relative_rmse=1e-6, max_iteration=100)
     if args.fixed_iterations > 0:
-        crit = P.registration.ICPConvergenceCriteria(relative_fitness=0.0, relative_rmse=0.0, max_iteration=args.fixed_iterations)
+        crit = reg.ICPConvergenceCriteria(relative_fitness=0.0, relative_rmse=0.0, max_iteration=args.fixed_iterations)
 
-    def step(i):
-        p = pairs[i % len(pairs)]; s, t = clouds[i % len(pairs)]
-        return P.registration.multiscale_gicp(s, t, p.voxel_sizes, p.max_distances_script, p.T_init, est, crit, 30, 1.0, 20)
-
-    # ---- executor.  Default: the timed steps are ONE pcr_register_pairs call, the library keeps `inflight` pairs in flight
-    # (worker threads, contexts and streams of its own).  --python-threads: `inflight` host threads in Python, each with
-    # its own HIP stream and library context, one pcr_multiscale_gicp call per pair (9 % slower: interpreter overhead).
-    args.batch_api = not args.python_threads
-    B = max(1, args.pairs_per_step)
-    import threading
-    from concurrent.futures import ThreadPoolExecutor
-    ctxs = []
-    tls = threading.local()
-
-    def worker_init():
-        torch.cuda.set_device(local_rank)
-        tls.stream = torch.cuda.Stream(priority=int(os.environ.get("PCR_BENCH_STREAM_PRIO", "0")))
-        with torch.cuda.stream(tls.stream):
-            c = P._lib.Context.current()
-        ctxs.append(c)
-
-    def run_step(i):
-        with torch.cuda.stream(tls.stream):
-            return step(i)
-
-    pool = None
-    torch.cuda.synchronize()
-    if not args.batch_api:
-        pool = ThreadPoolExecutor(max_workers=args.inflight, initializer=worker_init)
-        for _ in range(max(args.warmup, 1)):                                    # warm-up steps (every worker at least once)
-            list(pool.map(run_step, range(max(B, args.inflight))))
-    prof = (ctypes.c_double * 8)()
-    for c in ctxs:
-        c.lib.pcr_profile_enable(c.handle, 1)
-        c.lib.pcr_profile_read(c.handle, prof, 1)
+    def run_batch(n, pairs=pairs, clouds=clouds, variant=args.variant, rule=args.radius_rule, inflight=args.inflight, knn=normal_k):
+        batch = [(clouds[i % len(pairs)][0], clouds[i % len(pairs)][1], pairs[i % len(pairs)].T_init) for i in range(n)]
+        p0 = pairs[0]
+        return reg.register_pairs_plan(batch, "fgr+gicp" if variant == "fgr" else "gicp", p0.voxel_sizes, p0.max_distances_script, est, crit, 30, 1.0, knn,
+                                       inflight=inflight, with_correspondences=False, fgr_voxel_size=0.1, fgr_use_absolute_scale=True, fgr_seed=20241008,
+                                       radius_rule="af" if rule == "af" else "given", prior_from_fgr=(variant == "fgr"))
 
     def barrier():
         torch.cuda.synchronize()
@@ -130,22 +210,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_batch(n):
-        batch = [(clouds[i % len(pairs)][0], clouds[i % len(pairs)][1], pairs[i % len(pairs)].T_init) for i in range(n)]
-        p0 = pairs[0]
-        return P.registration.register_pairs(batch, p0.voxel_sizes, p0.max_distances_script, est, crit, 30, 1.0, 20, inflight=args.inflight)
+    def pool_prof(enable=None, reset=False):
+        out = (ctypes.c_double * 16)()
+        lib.pcr_pool_profile(ctypes.c_int(local_rank), ctypes.c_int(-1 if enable is None else int(enable)), out, ctypes.c_int(int(reset)))
+        return [out[k] for k in range(16)]
 
-    lib = P._lib.load()
-    if args.batch_api:
-        for _ in range(max(args.warmup, 1)):
-            run_batch(max(B, args.inflight))
-        lib.pcr_pool_profile(ctypes.c_int(local_rank), ctypes.c_int(1), None, ctypes.c_int(1))
+    torch.cuda.synchronize()
+    for _ in range(max(args.warmup, 1)):                                        # W untimed warm-up steps (every worker context at least once)
+        run_batch(max(B, args.inflight))
+    pool_prof(enable=1, reset=True)
     barrier()
     t0 = time.perf_counter()
     results, rec_rows = [], []
     n_done = args.steps * B
     for k in range(args.steps):                 # a step = one batch of B pairs; the call returns when all B are registered
-        results = run_batch(B) if args.batch_api else list(pool.map(run_step, range(B)))
+        results = run_batch(B)
         rec_rows += [shard.pack_record(rank * n_done + k * B + i, r) for i, r in enumerate(results)]    # pose records only; the rest is dropped
     recs = np.stack(rec_rows)
     gathered = shard.gather_records(recs, world * n_done, device=None if rehearse else torch.device("cuda", local_rank)) if world > 1 else recs
@@ -155,85 +234,153 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    acc = [0.0] * 8
-    if args.batch_api:
-        lib.pcr_pool_profile(ctypes.c_int(local_rank), ctypes.c_int(0), prof, ctypes.c_int(1))
-        acc = [prof[k] for k in range(8)]
-    for c in ([] if args.batch_api else ctxs):
-        c.lib.pcr_profile_read(c.handle, prof, 0)
-        c.lib.pcr_profile_enable(c.handle, 0)
-        for k in range(8):
-            acc[k] += prof[k]
-    prof = acc
+    prof = pool_prof(enable=0, reset=True)
 
-    # ---- roofline pass: the hot loop's launch period WITHOUT the other pairs' kernels in the way.  In the timed region
-    # three pairs share the GPU, so HIP events around a chunk of launches also count the time its kernels wait for
-    # wavefront slots taken by other streams (kept as `us_per_launch_in_flight`); the figure that rocprofv3's per-kernel
-    # durations can be checked against is measured here: a few extra steps, one pair at a time, same streams and contexts.
-    solo = [0.0] * 8
+    def pose_err(res, p):
+        dR = res.transformation[:3, :3].T @ p.T_true[:3, :3]
+        return {"rad": float(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))), "m": float(np.linalg.norm(res.transformation[:3, 3] - p.T_true[:3, 3]))}
+
+    line = None
     if rank == 0:
-        def solo_step(i):
-            with torch.cuda.stream(solo_stream):
-                return step(i)
-        solo_stream = torch.cuda.Stream()
-        with torch.cuda.stream(solo_stream):
-            cs = P._lib.Context.current()
-        solo_step(0)
-        cs.lib.pcr_profile_enable(cs.handle, 1); cs.lib.pcr_profile_read(cs.handle, prof_buf := (ctypes.c_double * 8)(), 1)
-        for i in range(4):
-            solo_step(i)
+        # ---- roofline pass: the hot loop's launch period WITHOUT the other pairs' kernels in the way.  In the timed region the
+        # pairs in flight share the GPU, so HIP events around a chunk of launches also count the time its kernels wait for
+        # wavefront slots taken by other streams (kept as `us_per_launch_in_flight`); the figure that rocprofv3's per-kernel
+        # durations can be checked against is measured here: a few extra steps, one pair at a time, same library path.
+        run_batch(1, inflight=1)
+        pool_prof(enable=1, reset=True)
+        run_batch(min(4, n_distinct), inflight=1)
         torch.cuda.synchronize()
-        cs.lib.pcr_profile_read(cs.handle, prof_buf, 0); cs.lib.pcr_profile_enable(cs.handle, 0)
-        solo = [prof_buf[k] for k in range(8)]
-
-    if rank == 0:
+        solo = pool_prof(enable=0, reset=True)
         res = results[-1]
-        # ---- roofline of the hot loop: ONE GICP iteration = k_icp_nn + k_icp_iter (SURVEY K10+K11), 48 B per source point
         ev_ms_f, ev_launches_f, ik_us_f, live_f, _, issued = (prof[i] for i in range(6))
-        us_in_flight = 1e3 * ev_ms_f / ev_launches_f if ev_launches_f else None     # None: the pairs in flight share their launches (IcpEngine)
+        us_in_flight = 1e3 * ev_ms_f / ev_launches_f if ev_launches_f else None
         ev_ms, ev_launches, ik_us, live, alg_bytes, _ = (solo[i] for i in range(6))
         bytes_per_launch = alg_bytes / live if live else 0.0
         us_event = 1e3 * ev_ms / ev_launches if ev_launches else None              # HIP events over fully-live chunks
         us_kernel = ik_us / live if live else None                                 # kernels' own s_memrealtime stamps
         achieved = bytes_per_launch / (us_event * 1e-6) / 1e9 if ev_launches else 0.0
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")                    # rocprofv3 --pmc passes (profiles/README.md)
-        if os.path.exists(tj):
-            t = json.load(open(tj))
-            traffic = t.get("k_icp_fused", {}).get("hbm_bytes_per_launch") or None
-        # sanity of the result itself (planted motion) -- printed, not part of the contract
-        p_last = pairs[(B - 1) % len(pairs)]
-        dR = res.transformation[:3, :3].T @ p_last.T_true[:3, :3]
-        ang = float(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))); dtr = float(np.linalg.norm(res.transformation[:3, 3] - p_last.T_true[:3, 3]))
+        traffic_file = None
+        for name in ("r02_traffic.json", "r01_traffic.json"):                      # rocprofv3 --pmc passes (profiles/README.md); NOT measured in this run
+            tj = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(tj):
+                t = json.load(open(tj))
+                traffic_file = {"file": "profiles/" + name, "hbm_bytes_per_launch": t.get("k_icp_fused", {}).get("hbm_bytes_per_launch"),
+                                "note": "tracked rocprofv3 --pmc result (FETCH_SIZE x2 + WRITE_SIZE), a previous run of the same kernel, not this run"}
+                break
+        rule_txt = "radius_from_cloud_pair * 2^-i per pair (ALL_FUNCTIONS.py:277-278)" if args.radius_rule == "af" else "radii " + "/".join(f"{d:g}" for d in pairs[0].max_distances_script) + " m"
+        workload_txt = (f"step = batch of {B} independent pairs ({n_distinct} distinct), each {len(pairs[0].source)}-pt synthetic NCLT-shaped clouds, "
+                        + ("registro_FGR (voxel 0.1) + " if args.variant == "fgr" else "") + f"{n_scales}-scale GICP (voxels " + "/".join(f"{v:g}" for v in pairs[0].voxel_sizes)
+                        + f" m, {rule_txt}, SOR(30,1.0), KNN-{normal_k} normals, {args.loss.upper()}, 1e-6/1e-6/100)")
         line = {
-            "metric": "point-cloud pairs registered/sec (200k pts, 3 GICP scales)",
-            "value": world * n_done / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": METRIC,
+            "value": world * n_done / dt, "unit": "pairs/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 points+search, f64 normal equations", "data": "synthetic",
-            "config": {"workload": f"step = batch of {B} independent pairs, each {args.points}-pt synthetic NCLT-shaped clouds, 3-scale GICP "
-                                   f"(voxels 0.4/0.2/0.1 m, radii 1.2/0.4/0.1 m, SOR(30,1.0), KNN-20 normals, {args.loss.upper()}, 1e-6/1e-6/100)",
-                       "points_per_cloud": args.points, "pairs_per_step": B, "distinct_pairs": args.pairs, "parallelism": f"pairs x{world}", "pairs_in_flight_per_gpu": args.inflight,
-                       "in_flight_by": "pcr_register_pairs (library worker threads)" if args.batch_api else "python host threads",
+            "config": {"workload": workload_txt, "variant": args.variant, "radius_rule": args.radius_rule,
+                       "points_per_cloud": int(len(pairs[0].source)), "pairs_per_step": B, "distinct_pairs": n_distinct,
+                       "distinct_how": f"{min(args.base_pairs, n_distinct)} independently sampled scene pairs, each re-posed by a rigid motion of both clouds and re-ordered (synthetic.derive_pair); every pair has its own buffers",
+                       "parallelism": f"pairs x{world}", "pairs_in_flight_per_gpu": args.inflight,
+                       "in_flight_by": "pcr_register_pairs_plan (library worker threads)",
                        "scales": [dict(voxel=s["voxel"], max_dist=s["max_dist"], n_voxel=s["n_voxel"], n_clean=s["n_clean"],
                                        iterations=s["iterations"]) for s in res.scales],
-                       "err_vs_planted": {"rad": ang, "m": dtr}, "gathered_records": int(len(gathered))},
+                       "iterations_per_pair_mean": float(np.mean([sum(s["iterations"] for s in r.scales) for r in results])),
+                       "err_vs_planted": pose_err(res, pairs[(B - 1) % len(pairs)]),
+                       "err_vs_planted_max_over_last_step": {k: float(max(pose_err(r, pairs[i % len(pairs)])[k] for i, r in enumerate(results))) for k in ("rad", "m")},
+                       "gathered_records": int(len(gathered))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_icp_fused (one GICP iteration; the first launch of a scale is k_icp_nn + k_icp_iter)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_from_profiles": traffic_file,
+                         "kernel": "k_icp_fused (one GICP iteration; the first launch of a scale is k_icp_nn + k_icp_iter)",
                          "bytes_per_launch": bytes_per_launch, "us_per_launch_hip_events": us_event,
                          "us_per_launch_in_kernel_clock": us_kernel, "us_per_launch_in_flight": us_in_flight,
-                         "measured_on": "4 extra single-pair steps after the timed region (same process, HIP events on the launch stream)",
+                         "measured_on": "up to 4 extra single-pair steps after the timed region (same process, HIP events on the launch stream)",
                          "live_launches": live, "launches_issued_timed_region": issued},
         }
+        if args.variant == "fgr" and solo[10] > 0:
+            line["roofline_fgr"] = fgr_roofline(solo)
+        if not args.no_extras and world == 1 and not args.config5 and args.variant == "gicp" and args.radius_rule == "script":
+            line["extras"] = extras(args, P, syn, reg, est, crit, pairs, clouds, run_batch, pool_prof, pose_err, workload)
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(pairs[0], args.points)
+            line["cpu_baseline"] = cpu_baseline(pairs[0], len(pairs[0].source), args.variant, args.radius_rule, normal_k)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+    return 0
 
 
-def cpu_baseline(pair, npts):
+def fgr_roofline(prof):
+    """Feature matching of registro_FGR (pcr_fgr.hip): HIP-event time over the nearest-neighbour kernels of both directions;
+    algorithmic flops = 2 * 33 * Ns * Nt per direction."""
+    ms, flops, launches = prof[8], prof[9], prof[10]
+    tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    return {"bound": "mfma", "achieved": tf, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F16_MFMA_PEAK_TFLOPS, "traffic": None,
+            "kernel": "k_feature_nn_screen (33-D nearest feature, f16 hi/lo split MFMA screen; survivors re-checked in float64)",
+            "flops_per_launch": flops / launches if launches else 0.0, "ms_per_launch_hip_events": ms / launches if launches else None,
+            "peak_note": "dense f16 MFMA peak; the screen spends 3 f16 products per float32-accurate product (128 of K per 33 dimensions), so 33/128 of the "
+                         "MFMA work is algorithmic; the float64 MFMA path it replaces peaks at 78.6 TFLOP/s"}
+
+
+def extras(args, P, syn, reg, est, crit, pairs, clouds, run_batch, pool_prof, pose_err, workload):
+    """Short measurements of the other forms of config 2 and of config 5, after the timed region, bounded to a few
+    seconds each.  Same library path, same pairs in flight; warm-up of one batch each."""
+    import numpy as np
+    import torch
+    out = {}
+    n = min(len(pairs), 16)
+
+    def timed(label, reps=2, **kw):
+        run_batch(n, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = run_batch(n, **kw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return res, reps * n / dt
+
+    res, pps = timed("af", rule="af")
+    out["gicp_af_radius_rule"] = {"pairs_per_s": pps, "pairs_timed": 2 * n, "max_distances_m": [s["max_dist"] for s in res[0].scales],
+                                  "iterations": [s["iterations"] for s in res[0].scales], "err_vs_planted": pose_err(res[0], pairs[0]),
+                                  "what": "same pairs, search radii radius_from_cloud_pair * 2^-i (ALL_FUNCTIONS.py:277-278): an effectively unbounded 1-NN"}
+    pool_prof(enable=1, reset=True)
+    res, pps = timed("fgr", variant="fgr")
+    fp = pool_prof(enable=0, reset=True)
+    out["fgr_plus_gicp"] = {"pairs_per_s": pps, "pairs_timed": 2 * n, "fgr_fitness": res[0].fgr.fitness, "fgr_inlier_rmse": res[0].fgr.inlier_rmse,
+                            "err_vs_planted_fgr": pose_err(res[0].fgr, pairs[0]), "err_vs_planted": pose_err(res[0], pairs[0]),
+                            "what": "config 2's FGR variant: registro_FGR (voxel 0.1, ALL_FUNCTIONS.py:178-203) + the same 3-scale GICP started from its pose; "
+                                    "both inside the pair time"}
+    if fp[10] > 0:
+        out["fgr_plus_gicp"]["roofline"] = fgr_roofline(fp)
+    try:
+        p5, c5 = workload(2, config5=True)
+        n5 = 4
+
+        def run5(m, inflight):
+            batch = [(c5[i % 2][0], c5[i % 2][1], p5[i % 2].T_init) for i in range(m)]
+            return reg.register_pairs_plan(batch, "gicp", p5[0].voxel_sizes, p5[0].max_distances_script, est, crit, 30, 1.0, 64, inflight=inflight, with_correspondences=False)
+        run5(2, 2)
+        pool_prof(enable=1, reset=True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        r5 = run5(n5, 2)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        f5 = pool_prof(enable=0, reset=True)
+        us = 1e3 * f5[0] / f5[1] if f5[1] else None
+        bpl = f5[4] / f5[3] if f5[3] else 0.0
+        out["config5_2M_points_5_scales_64nn"] = {
+            "pairs_per_s": n5 / dt, "pairs_timed": n5, "points_per_cloud": int(len(p5[0].source)), "pairs_in_flight": 2,
+            "scales": [dict(voxel=s["voxel"], n_clean=s["n_clean"], iterations=s["iterations"]) for s in r5[0].scales],
+            "err_vs_planted": pose_err(r5[0], p5[0]),
+            "roofline": {"bound": "hbm", "kernel": "k_icp_fused", "bytes_per_launch": bpl, "us_per_launch_hip_events_in_flight": us,
+                         "achieved": (bpl / (us * 1e-6) / 1e9) if us else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (bpl / (us * 1e-6) / 1e9 / HBM_PEAK_GBS) if us else 0.0},
+            "what": "BASELINE config 5: 2M-point clouds (10 tiles of the 200k scene, synthetic.tile_pair), script-2 5-scale table, 64-NN normals"}
+    except Exception as e:      # noqa: BLE001 -- an extra must never cost the main line
+        out["config5_2M_points_5_scales_64nn"] = {"error": repr(e)}
+    return out
+
+
+def cpu_baseline(pair, npts, variant, rule, normal_k):
     """The oracle ("port": float64 C/OpenMP restatement of the Open3D CPU path) on the SAME workload, timed on
-    this host's cores.  Bounded sample: as many repetitions of pair 0 as fit in ~20 s (at least one)."""
+    this host's cores.  Bounded sample: as many repetitions of pair 0 as fit in ~20 s (at least one, at most five)."""
     from oracle import oracle as orc
     orc.build()
     # a 1-GPU box grants this job a 16-core CPU share although os.cpu_count() reports the whole host
@@ -245,14 +392,21 @@ def cpu_baseline(pair, npts):
     orc.set_num_threads(cores)
     t0 = time.perf_counter(); n = 0
     while True:
-        orc.multiscale_gicp(pair.source, pair.target, pair.voxel_sizes, pair.max_distances_script, pair.T_init)
+        dists = pair.max_distances_script
+        T0 = pair.T_init
+        if variant == "fgr":
+            T0 = orc.registro_fgr(pair.source, pair.target, 0.1, True, seed=20241008).transformation
+        if rule == "af":
+            r = orc.radius_from_cloud_pair(pair.source, pair.target)
+            dists = [r * 2.0 ** -i for i in range(len(pair.voxel_sizes))]
+        orc.multiscale_gicp(pair.source, pair.target, pair.voxel_sizes, dists, T0, normal_k=normal_k)
         n += 1
         if time.perf_counter() - t0 > 20.0 or n >= 5:
             break
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{n} x pair 0 of the same {npts}-pt workload (identical parameters), OpenMP threads = {cores}"}
+            "sample": f"{n} x pair 0 of the same {npts}-pt workload (identical parameters, variant {variant}, radius rule {rule}), OpenMP threads = {cores}"}
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -14,8 +14,14 @@
  *   - caller owns every buffer; the library owns a per-context scratch arena;
  *   - return 0 on success, negative pcr_status otherwise; degenerate-but-valid results
  *     (no correspondences: fitness 0, rmse 0, T = init) are NOT errors (Open3D behaviour);
- *   - calls are ordered on the context's stream and return after their scalar outputs are
- *     on the host.
+ *   - calls are ordered on the context's stream (pcr_set_stream).  Entry points with host outputs (counts, poses, results)
+ *     return after those are on the host; entry points whose outputs are all device buffers (pcr_estimate_normals,
+ *     pcr_estimate_covariances, pcr_compute_fpfh_feature, pcr_debug_knn) only enqueue and return;
+ *   - stream NULL = the legacy default stream: the library works on a stream of its own and fences every call against the
+ *     default stream on both sides (the call sees everything enqueued there before it; work enqueued there after the call
+ *     sees its results);
+ *   - every kernel launch is followed by hipGetLastError(); a failed launch turns the call into PCR_EHIP with file:line
+ *     in pcr_last_error().
  */
 #ifndef PCR_HIP_H
 #define PCR_HIP_H
@@ -85,7 +91,7 @@ typedef struct {
 /* ---- context ---------------------------------------------------------------------- */
 int pcr_create(int device, pcr_context **out);
 int pcr_destroy(pcr_context *ctx);
-int pcr_set_stream(pcr_context *ctx, void *hip_stream);       /* NULL = context-owned stream */
+int pcr_set_stream(pcr_context *ctx, void *hip_stream);       /* NULL = the legacy default stream (fenced, see above) */
 const char *pcr_last_error(const pcr_context *ctx);
 int pcr_version(void);
 
@@ -143,8 +149,8 @@ int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const float *src
  *    ALL_FUNCTIONS.py:349-392 the GICP ones): MANY independent pairs in one call.  The library keeps `inflight` pairs in
  *    flight on `device` (one worker thread + context + stream each, taken from a process-wide pool), pair i runs exactly
  *    pcr_multiscale_gicp on pairs[i] with the shared scale tables, and the call returns when all pairs are done.
- *    `after_stream` (optional) is a HIP stream whose already-enqueued work produces the input clouds; workers wait for
- *    it.  Per-pair status and error text come back in the descriptor; the return value is PCR_OK iff every pair is. */
+ *    `after_stream` is the HIP stream whose already-enqueued work produces the input clouds (NULL = the legacy default
+ *    stream); the workers always wait for it.  Per-pair status and error text come back in the descriptor; the return value is PCR_OK iff every pair is. */
 typedef struct {
     const float *src_xyz, *src_normals; int64_t n_src;      /* device; normals optional */
     const float *tgt_xyz, *tgt_normals; int64_t n_tgt;
@@ -158,9 +164,54 @@ int pcr_register_pairs(int device, pcr_pair *pairs, int n_pairs, const double *v
                        int n_scales, int sor_k, double sor_std, int normal_k, const pcr_gicp_params *params, int inflight,
                        void *after_stream);
 
+/* == registro_FGR as ONE call (ALL_FUNCTIONS.py:178-203 / 1_FGR...py:41-66): estimate_normals(Hybrid(normal_radius, normal_max_nn))
+ *    on both clouds -> compute_fpfh_feature(Hybrid(feature_radius, feature_max_nn)) on both -> FGR with `option` ->
+ *    evaluate_registration.  Each cloud is Morton-sorted and indexed ONCE for all four uses.  The reference's side effect (both
+ *    inputs gain normals) is returned through src/tgt_normals_out (optional, device, caller order); src/tgt_prior are the
+ *    normals the clouds already carry, if any (Open3D flips the new normal to agree with them).                                */
+typedef struct {
+    double normal_radius;  int32_t normal_max_nn;      /* 2 * voxel_size, 20    (ALL_FUNCTIONS.py:181) */
+    double feature_radius; int32_t feature_max_nn;     /* 10 * voxel_size, 200  (ALL_FUNCTIONS.py:185) */
+    pcr_fgr_option option;                             /* ALL_FUNCTIONS.py:189-196 */
+} pcr_fgr_params;
+int pcr_registro_fgr(pcr_context *ctx, const float *src_xyz, const float *src_prior, int64_t n_src, const float *tgt_xyz,
+                     const float *tgt_prior, int64_t n_tgt, const pcr_fgr_params *params, float *src_normals_out,
+                     float *tgt_normals_out, pcr_result *result, int32_t *correspondences);
+
+/* == the reference's per-pair loops with a choice of what runs per pair:
+ *    PCR_STAGE_FGR       script 1 (1_FGR...py:134-147):                 registro_FGR                      -> pairs[i].fgr
+ *    PCR_STAGE_GICP      script 2 (2_MGICP...py:187-214):               Multiscale_GICP from init_T       -> pairs[i].records
+ *    PCR_STAGE_FGR_GICP  Coarse_to_fine_FGR_M_GICP (ALL_FUNCTIONS.py:317-332, full_registration :349-392): registro_FGR, then
+ *                        Multiscale_GICP from its pose (init_T ignored)                                   -> both
+ *    radius_rule 0: max_distances as given (script 2 table); 1: ALL_FUNCTIONS.py:277-278, radius_from_cloud_pair(source, target)
+ *    * 2^-scale computed per pair from the two AABBs (max_distances ignored).  gicp_prior_from_fgr: the normals registro_FGR
+ *    left on the clouds are the orientation prior of every scale (the ALL_FUNCTIONS flow; the scripts reload the clouds).
+ *    info_max_dist > 0: pairs[i].info36 <- get_information_matrix_from_point_clouds(source, target, info_max_dist, final pose)
+ *    (ALL_FUNCTIONS.py:327-331).  The library keeps `inflight` pairs in flight exactly as pcr_register_pairs does.              */
+typedef enum { PCR_STAGE_GICP = 1, PCR_STAGE_FGR = 2, PCR_STAGE_FGR_GICP = 3 } pcr_stage;
+typedef struct {
+    int32_t stage;
+    const pcr_fgr_params *fgr;                          /* stages with FGR; option.seed + pair index seeds pair i */
+    const double *voxel_sizes, *max_distances; int32_t n_scales;
+    int32_t radius_rule;
+    int32_t sor_k; double sor_std; int32_t normal_k;
+    const pcr_gicp_params *gicp;
+    int32_t gicp_prior_from_fgr;
+    double info_max_dist;
+    int32_t inflight;
+} pcr_pairs_plan;
+typedef struct {
+    pcr_pair base;                                      /* inputs, records (stages with GICP), correspondences of the LAST stage run, status */
+    pcr_result fgr;                                     /* out, stages with FGR */
+    float *src_normals_out, *tgt_normals_out;           /* optional device buffers (n x 3): the normals registro_FGR leaves on the clouds */
+    double max_distances[8];                            /* out: the per-scale search radii actually used (radius_rule 1) */
+    double info36[36];                                  /* out when info_max_dist > 0 */
+} pcr_pair_ex;
+int pcr_register_pairs_plan(int device, pcr_pair_ex *pairs, int n_pairs, const pcr_pairs_plan *plan, void *after_stream);
+
 /* measurement hook for the worker contexts pcr_register_pairs keeps in its pool (all idle between calls): enable >= 0 switches
- * their instrumentation on/off, out8 (optional) receives the SUM of their pcr_profile_read counters, reset clears them. */
-int pcr_pool_profile(int device, int enable, double *out8, int reset);
+ * their instrumentation on/off, out16 (optional) receives the SUM of their pcr_profile_read counters, reset clears them. */
+int pcr_pool_profile(int device, int enable, double *out16, int reset);
 
 /* == evaluate_registration (ALL_FUNCTIONS.py:809-820) */
 int pcr_evaluate_registration(pcr_context *ctx, const float *src_xyz, int64_t n_src, const float *tgt_xyz,
@@ -183,11 +234,13 @@ int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, const float *sr
 /* ---- measurement hooks (bench.py): no reference counterpart -------------------------- */
 /* While enabled, pcr_multiscale_gicp / pcr_registration_generalized_icp bracket every chunk of GICP-iteration
  * launches with HIP events on the context stream and the kernel stamps itself with s_memrealtime.
- * out8 = { [0] ms of HIP-event time over chunks whose launches were all live, [1] launches in those chunks,
- *          [2] us of in-kernel time summed over live launches, [3] live launches,
- *          [4] algorithmic bytes of the live launches (48 B x source points), [5] launches issued, 0, 0 } */
+ * out16 = { [0] ms of HIP-event time over chunks whose launches were all live, [1] launches in those chunks,
+ *           [2] us of in-kernel time summed over live launches, [3] live launches,
+ *           [4] algorithmic bytes of the live launches (48 B x source points), [5] launches issued, [6], [7] diagnostics,
+ *           [8] ms of HIP-event time over the feature-matching kernels of registro_FGR, [9] their algorithmic flops
+ *           (2 * 33 * Ns * Nt per direction), [10] launches, rest 0 } */
 int pcr_profile_enable(pcr_context *ctx, int on);
-int pcr_profile_read(pcr_context *ctx, double *out8, int reset);
+int pcr_profile_read(pcr_context *ctx, double *out16, int reset);
 
 /* ---- test hooks (exercised by tests/ only) ----------------------------------------- */
 /* exact k nearest neighbours of every point of a cloud (self included), through the same index the

@@ -270,3 +270,24 @@ def registration_fgr(src_xyz, src_feat, tgt_xyz, tgt_feat, division_factor=1.4, 
     out = _res(r)
     out.extra.update(n_cross=ncross.value, n_tuple_corr=ntup.value)
     return out
+
+
+def radius_from_cloud_pair(src_xyz, tgt_xyz) -> float:
+    """ALL_FUNCTIONS.py:1092-1101: mean over the two clouds of the cube root of the AABB volume."""
+    s = _f64(src_xyz, 3); t = _f64(tgt_xyz, 3)
+    d1 = s.max(0) - s.min(0); d2 = t.max(0) - t.min(0)
+    return float(((d1[0] * d1[1] * d1[2]) ** (1 / 3) + (d2[0] * d2[1] * d2[2]) ** (1 / 3)) / 2)
+
+
+def registro_fgr(src_xyz, tgt_xyz, voxel_size, use_absolute_scale=True, seed=0, src_prior=None, tgt_prior=None):
+    """``registro_FGR`` (ALL_FUNCTIONS.py:178-203; script 1:41-66 with use_absolute_scale=False) composed from the oracle's
+    restatements of the five Open3D calls.  ``extra`` carries the normals the reference leaves on the clouds and the features."""
+    s = _f64(src_xyz, 3); t = _f64(tgt_xyz, 3)
+    n_pontos = int((len(s) + len(t)) / 2)
+    sn = estimate_normals(s, SEARCH_HYBRID, 20, 2 * voxel_size, prior=src_prior)
+    tn = estimate_normals(t, SEARCH_HYBRID, 20, 2 * voxel_size, prior=tgt_prior)
+    fs = compute_fpfh(s, sn, SEARCH_HYBRID, 200, 10 * voxel_size)
+    ft = compute_fpfh(t, tn, SEARCH_HYBRID, 200, 10 * voxel_size)
+    out = registration_fgr(s, fs, t, ft, 1.4, use_absolute_scale, True, 2 * voxel_size, 300, 0.95, int(n_pontos * 0.2), True, seed)
+    out.extra.update(src_normals=sn, tgt_normals=tn, src_feat=fs, tgt_feat=ft)
+    return out

@@ -47,6 +47,25 @@ class PcrFgrOption(C.Structure):
                 ("seed", C.c_uint64)]
 
 
+class PcrFgrParams(C.Structure):
+    _fields_ = [("normal_radius", C.c_double), ("normal_max_nn", C.c_int32), ("feature_radius", C.c_double),
+                ("feature_max_nn", C.c_int32), ("option", PcrFgrOption)]
+
+
+class PcrPairsPlan(C.Structure):
+    _fields_ = [("stage", C.c_int32), ("fgr", C.POINTER(PcrFgrParams)), ("voxel_sizes", C.POINTER(C.c_double)),
+                ("max_distances", C.POINTER(C.c_double)), ("n_scales", C.c_int32), ("radius_rule", C.c_int32),
+                ("sor_k", C.c_int32), ("sor_std", C.c_double), ("normal_k", C.c_int32), ("gicp", C.POINTER(PcrGicpParams)),
+                ("gicp_prior_from_fgr", C.c_int32), ("info_max_dist", C.c_double), ("inflight", C.c_int32)]
+
+
+class PcrPairEx(C.Structure):
+    _fields_ = [("base", PcrPair), ("fgr", PcrResult), ("src_normals_out", C.c_void_p), ("tgt_normals_out", C.c_void_p),
+                ("max_distances", C.c_double * 8), ("info36", C.c_double * 36)]
+
+
+STAGE_GICP, STAGE_FGR, STAGE_FGR_GICP = 1, 2, 3
+
 # every symbol include/pcr_hip.h declares (tests check the export table against this list)
 EXPORTS = [
     "pcr_create", "pcr_destroy", "pcr_set_stream", "pcr_last_error", "pcr_version", "pcr_bounds",
@@ -54,6 +73,7 @@ EXPORTS = [
     "pcr_registration_generalized_icp", "pcr_multiscale_gicp", "pcr_evaluate_registration", "pcr_information_matrix",
     "pcr_compute_fpfh_feature", "pcr_registration_fgr", "pcr_debug_knn", "pcr_debug_gicp_linearize",
     "pcr_profile_enable", "pcr_profile_read", "pcr_registration_generalized_icp_cov", "pcr_register_pairs", "pcr_pool_profile",
+    "pcr_registro_fgr", "pcr_register_pairs_plan",
 ]
 
 _lib = None
@@ -95,9 +115,16 @@ def load():
 
 
 class Context:
-    """One libpcr_hip context (scratch arena + stream) per (device, torch stream)."""
+    """One libpcr_hip context (scratch arena + stream) per (device, torch stream, thread).
 
-    _cache: dict = {}
+    The cache is bounded (least recently used contexts are destroyed: each holds a device arena of hundreds of MB) and guarded
+    by a lock; ``close()`` destroys a context explicitly.  ``stream_ptr == 0`` is torch's default stream = the legacy default
+    stream: the library then runs on a stream of its own and fences every call against the default stream on both sides
+    (``pcr_set_stream(ctx, NULL)``, include/pcr_hip.h)."""
+
+    _cache: "dict" = {}
+    _cache_lock = threading.Lock()
+    MAX_CACHED = 16
 
     def __init__(self, device: int, stream_ptr: int):
         lib = load()
@@ -111,6 +138,12 @@ class Context:
         self.lib = lib
         lib.pcr_set_stream(h, C.c_void_p(stream_ptr))
 
+    def close(self):
+        """Destroy the library context (waits for its stream, frees the arena)."""
+        h, self.handle = self.handle, None
+        if h is not None and h.value:
+            self.lib.pcr_destroy(h)
+
     @classmethod
     def current(cls) -> "Context":
         import torch
@@ -119,11 +152,24 @@ class Context:
         dev = torch.cuda.current_device()
         sp = int(torch.cuda.current_stream(dev).cuda_stream)
         key = (dev, sp, threading.get_ident())
-        ctx = cls._cache.get(key)
-        if ctx is None:
-            ctx = cls(dev, sp)
-            cls._cache[key] = ctx
+        stale = []
+        with cls._cache_lock:
+            ctx = cls._cache.pop(key, None)
+            if ctx is None or ctx.handle is None:
+                ctx = cls(dev, sp)
+            cls._cache[key] = ctx                       # most recently used last
+            while len(cls._cache) > cls.MAX_CACHED:
+                stale.append(cls._cache.pop(next(iter(cls._cache))))
+        for c in stale:
+            c.close()
         return ctx
+
+    @classmethod
+    def close_all(cls):
+        with cls._cache_lock:
+            ctxs = list(cls._cache.values()); cls._cache.clear()
+        for c in ctxs:
+            c.close()
 
     def check(self, rc: int, what: str):
         if rc == PCR_OK:

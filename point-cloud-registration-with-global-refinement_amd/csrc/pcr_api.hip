@@ -10,7 +10,7 @@
 #include "pcr_octree.h"
 
 // ------------------------------------------------------------------------------------------- context
-extern "C" int pcr_version(void) { return 100; }
+extern "C" int pcr_version(void) { return 200; }
 
 extern "C" int pcr_create(int device, pcr_context **out) {
     if (!out) return PCR_EINVAL;
@@ -33,6 +33,9 @@ extern "C" int pcr_create(int device, pcr_context **out) {
     if (hipHostMalloc((void **)&ctx->pinned, ctx->pinned_cap, hipHostMallocDefault) != hipSuccess) { delete ctx; return PCR_EHIP; }
     for (int i = 0; i < 2; i++)
         if (hipEventCreateWithFlags(&ctx->ev[i], hipEventDisableTiming) != hipSuccess) { delete ctx; return PCR_EHIP; }
+    for (int i = 0; i < 2; i++)
+        if (hipEventCreateWithFlags(&ctx->fence_ev[i], hipEventDisableTiming) != hipSuccess) { delete ctx; return PCR_EHIP; }
+    ctx->fence_default = true;          // until pcr_set_stream says otherwise the caller is assumed to work on the default stream
     *out = ctx;
     return PCR_OK;
 }
@@ -42,8 +45,10 @@ extern "C" int pcr_destroy(pcr_context *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->aux) (void)hipFree(ctx->aux);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (int i = 0; i < 2; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < 2; i++) if (ctx->fence_ev[i]) (void)hipEventDestroy(ctx->fence_ev[i]);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     for (auto &g : ctx->icp_graphs) (void)hipGraphExecDestroy(g.second);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -58,8 +63,17 @@ extern "C" int pcr_destroy(pcr_context *ctx) {
 extern "C" int pcr_set_stream(pcr_context *ctx, void *s) {
     if (!ctx) return PCR_EINVAL;
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;      // null: the context's own stream, created on first use
+    // NULL = the legacy default stream (what torch.cuda.current_stream().cuda_stream is for torch's default stream): the work runs
+    // on the context's own stream, created on first use, fenced against the default stream on both sides of every call
+    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    ctx->fence_default = (s == nullptr);
     return PCR_OK;
+}
+// worker contexts of pcr_register_pairs: own stream, no fences (the call orders its workers against `after_stream` itself)
+static void use_private_stream(pcr_context *ctx) {
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->stream = ctx->own_stream;
+    ctx->fence_default = false;
 }
 
 extern "C" int pcr_profile_enable(pcr_context *ctx, int on) {
@@ -67,9 +81,9 @@ extern "C" int pcr_profile_enable(pcr_context *ctx, int on) {
     ctx->profiling = on ? 1 : 0;
     return PCR_OK;
 }
-extern "C" int pcr_profile_read(pcr_context *ctx, double *out8, int reset) {
-    if (!ctx || !out8) return PCR_EINVAL;
-    for (int i = 0; i < 8; i++) { out8[i] = ctx->prof[i]; if (reset) ctx->prof[i] = 0; }
+extern "C" int pcr_profile_read(pcr_context *ctx, double *out16, int reset) {
+    if (!ctx || !out16) return PCR_EINVAL;
+    for (int i = 0; i < 16; i++) { out16[i] = ctx->prof[i]; if (reset) ctx->prof[i] = 0; }
     return PCR_OK;
 }
 
@@ -105,11 +119,31 @@ static int ensure_lanes(pcr_context *ctx, int lanes) {
     if (lanes > 1 && !ctx->side_stream2 && hipStreamCreateWithFlags(&ctx->side_stream2, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return PCR_EHIP; }
     return PCR_OK;
 }
-#define ENTER(ctx)                                                               \
-    if (!(ctx)) return PCR_EINVAL;                                               \
-    if (hipSetDevice((ctx)->device) != hipSuccess) return PCR_EHIP;              \
-    (ctx)->err.clear();                                                          \
+int pcr_enter(pcr_context *ctx) {
+    if (!ctx) return PCR_EINVAL;
+    if (hipSetDevice(ctx->device) != hipSuccess) return PCR_EHIP;
+    ctx->err.clear();
+    ctx->launch_err = hipSuccess;
+    (void)hipGetLastError();                                  // errors of earlier, unrelated calls on this thread are not ours
     if (ensure_stream(ctx) != PCR_OK) return PCR_EHIP;
+    if (ctx->fence_default) {                                 // ordered after everything the caller has enqueued on the default stream
+        PCR_HIP_CHECK(ctx, hipEventRecord(ctx->fence_ev[0], (hipStream_t)0));
+        PCR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->fence_ev[0], 0));
+    }
+    return PCR_OK;
+}
+int pcr_leave(pcr_context *ctx, int rc) {
+    if (ctx->launch_err != hipSuccess && rc == PCR_OK) {
+        ctx->err = std::string("kernel launch failed at ") + (ctx->launch_file ? ctx->launch_file : "?") + ":" + std::to_string(ctx->launch_line) + ": " + hipGetErrorString(ctx->launch_err);
+        rc = PCR_EHIP;
+    }
+    if (ctx->fence_default && ctx->stream) {                  // what the caller enqueues on the default stream next sees the results
+        if (hipEventRecord(ctx->fence_ev[1], ctx->stream) != hipSuccess || hipStreamWaitEvent((hipStream_t)0, ctx->fence_ev[1], 0) != hipSuccess) {
+            if (rc == PCR_OK) { ctx->err = "default-stream fence failed"; rc = PCR_EHIP; }
+        }
+    }
+    return rc;
+}
 
 int pcr_alloc_cloud(pcr_context *ctx, DevCloud *c, int cap, bool with_nrm, bool with_tree) {
     const int cc = cap > 0 ? cap : 1;
@@ -149,15 +183,16 @@ int pcr_import_cloud(pcr_context *ctx, const float *xyz, const float *nrm, int64
 
 // -------------------------------------------------------------------------------------- geometry API
 extern "C" int pcr_bounds(pcr_context *ctx, const float *xyz, int64_t n, double *b6) {
-    ENTER(ctx);
+    return pcr_api_call(ctx, [&]() -> int {
     if (n < 0 || !b6 || (n > 0 && !xyz)) return PCR_EINVAL;
     PCR_TRY(pcr_arena_reserve(ctx, 1 << 20));
     return pcr_dev_bounds(ctx, xyz, n, b6);
+    });
 }
 
 extern "C" int pcr_voxel_down_sample(pcr_context *ctx, const float *xyz, const float *normals_in, int64_t n, double voxel,
                                      float *out_xyz, float *out_normals, int64_t *out_n) {
-    ENTER(ctx);
+    return pcr_api_call(ctx, [&]() -> int {
     if (n < 0 || !out_n || (n > 0 && (!xyz || !out_xyz))) return PCR_EINVAL;
     if (!(voxel > 0.0)) { ctx->err = "voxel_size <= 0"; return PCR_EINVAL; }
     *out_n = 0;
@@ -171,6 +206,7 @@ extern "C" int pcr_voxel_down_sample(pcr_context *ctx, const float *xyz, const f
     PCR_TRY(pcr_dev_pack_f4_to_f3(ctx, v.pts, v.n, v.cap, out_xyz));
     if (normals_in && out_normals) PCR_TRY(pcr_dev_pack_f4_to_f3(ctx, v.nrm, v.n, v.cap, out_normals));
     return pcr_read_count(ctx, v.n, out_n);
+    });
 }
 
 __global__ void k_keep_to_caller(const uint8_t *__restrict__ keep_sorted, const uint32_t *__restrict__ perm, int n, uint8_t *__restrict__ keep_caller) {
@@ -187,7 +223,7 @@ __global__ void k_emit_kept(const float *__restrict__ xyz, const uint8_t *__rest
 
 extern "C" int pcr_remove_statistical_outlier(pcr_context *ctx, const float *xyz, int64_t n, int nb_neighbors, double std_ratio,
                                               uint8_t *keep_mask, float *out_xyz, int64_t *out_index, int64_t *out_n) {
-    ENTER(ctx);
+    return pcr_api_call(ctx, [&]() -> int {
     if (n < 0 || (n > 0 && !xyz)) return PCR_EINVAL;
     if (nb_neighbors < 1 || !(std_ratio > 0.0)) { ctx->err = "nb_neighbors < 1 or std_ratio <= 0"; return PCR_EINVAL; }
     if (out_n) *out_n = 0;
@@ -203,19 +239,20 @@ extern "C" int pcr_remove_statistical_outlier(pcr_context *ctx, const float *xyz
     if (!keep_sorted || !keep_caller || !pos || !total) return PCR_ENOMEM;
     PCR_TRY(pcr_dev_sor(ctx, &c, nb_neighbors, std_ratio, &kept, keep_sorted, nullptr));
     const int nb = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(k_keep_to_caller, dim3(nb), dim3(256), 0, ctx->stream, keep_sorted, perm, (int)n, keep_caller);
+    PCR_LAUNCH(ctx, k_keep_to_caller, dim3(nb), dim3(256), 0, ctx->stream, keep_sorted, perm, (int)n, keep_caller);
     // emit the kept points in CALLER order (select_by_index semantics)
     PCR_TRY(pcr_dev_flag_scan(ctx, keep_caller, nullptr, (int)n, pos, total));
-    if (out_xyz || out_index) hipLaunchKernelGGL(k_emit_kept, dim3(nb), dim3(256), 0, ctx->stream, xyz, keep_caller, pos, (int)n, out_xyz, out_index);
+    if (out_xyz || out_index) PCR_LAUNCH(ctx, k_emit_kept, dim3(nb), dim3(256), 0, ctx->stream, xyz, keep_caller, pos, (int)n, out_xyz, out_index);
     int64_t m = 0;
     PCR_TRY(pcr_read_count(ctx, total, &m));
     if (out_n) *out_n = m;
     return PCR_OK;
+    });
 }
 
 extern "C" int pcr_estimate_normals(pcr_context *ctx, const float *xyz, int64_t n, int search_kind, int knn, double radius,
                                     const float *prior_normals, float *normals) {
-    ENTER(ctx);
+    return pcr_api_call(ctx, [&]() -> int {
     if (n < 0 || (n > 0 && (!xyz || !normals))) return PCR_EINVAL;
     if (n == 0) return PCR_OK;
     PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n) + (size_t)n * 64));
@@ -225,8 +262,8 @@ extern "C" int pcr_estimate_normals(pcr_context *ctx, const float *xyz, int64_t 
     if (!nout) return PCR_ENOMEM;
     PCR_TRY(pcr_dev_normals(ctx, &c, search_kind, knn, radius, c.nrm, nout, nullptr));
     PCR_TRY(pcr_dev_scatter_rows_f4_to_f3(ctx, nout, perm, c.n, c.cap, normals));
-    PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    return PCR_OK;
+    return PCR_OK;                      // no scalar output: asynchronous on the context's stream
+    });
 }
 
 __global__ void k_scatter_cov6(const float *__restrict__ src, const uint32_t *__restrict__ perm, int n, float *__restrict__ dst) {
@@ -237,7 +274,7 @@ __global__ void k_scatter_cov6(const float *__restrict__ src, const uint32_t *__
 }
 
 extern "C" int pcr_estimate_covariances(pcr_context *ctx, const float *xyz, int64_t n, int search_kind, int knn, double radius, float *cov6) {
-    ENTER(ctx);
+    return pcr_api_call(ctx, [&]() -> int {
     if (n < 0 || (n > 0 && (!xyz || !cov6))) return PCR_EINVAL;
     if (n == 0) return PCR_OK;
     PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n) + (size_t)n * 64));
@@ -246,9 +283,9 @@ extern "C" int pcr_estimate_covariances(pcr_context *ctx, const float *xyz, int6
     float *cs = arena<float>(ctx, (size_t)n * 6);
     if (!cs) return PCR_ENOMEM;
     PCR_TRY(pcr_dev_normals(ctx, &c, search_kind, knn, radius, nullptr, nullptr, cs));
-    hipLaunchKernelGGL(k_scatter_cov6, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, cs, perm, (int)n, cov6);
-    PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    return PCR_OK;
+    PCR_LAUNCH(ctx, k_scatter_cov6, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, cs, perm, (int)n, cov6);
+    return PCR_OK;                      // asynchronous on the context's stream
+    });
 }
 
 __global__ void k_knn_unpermute(const int32_t *si, const float *sd, const int32_t *sc, const uint32_t *perm, int n, int k, int32_t *idx, float *d2, int32_t *counts) {
@@ -268,7 +305,7 @@ __global__ void k_match_unpermute(const int32_t *m, const uint32_t *sp, const ui
 }
 
 extern "C" int pcr_debug_knn(pcr_context *ctx, const float *xyz, int64_t n, int k, double radius, int32_t *idx, float *d2, int32_t *counts) {
-    ENTER(ctx);
+    return pcr_api_call(ctx, [&]() -> int {
     if (n <= 0 || !xyz || !idx || !d2) return PCR_EINVAL;
     // sort, search over the BVH, then report rows and indices in the CALLER's point order
     PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n) + (size_t)n * (size_t)k * 16 + (size_t)n * 64));
@@ -279,9 +316,9 @@ extern "C" int pcr_debug_knn(pcr_context *ctx, const float *xyz, int64_t n, int 
     int32_t *sc = arena<int32_t>(ctx, n);
     if (!si || !sd || !sc) return PCR_ENOMEM;
     PCR_TRY(pcr_dev_knn_debug(ctx, &c, k, radius, si, sd, sc));
-    hipLaunchKernelGGL(k_knn_unpermute, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, si, sd, sc, perm, (int)n, k, idx, d2, counts);
-    PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    PCR_LAUNCH(ctx, k_knn_unpermute, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, si, sd, sc, perm, (int)n, k, idx, d2, counts);
     return PCR_OK;
+    });
 }
 
 // ---------------------------------------------------------------------------------- registration API
@@ -295,7 +332,7 @@ extern "C" int pcr_registration_generalized_icp(pcr_context *ctx, const float *s
                                                 const float *tgt_xyz, const float *tgt_normals, int64_t n_tgt, double max_dist,
                                                 const double *init_T, const pcr_gicp_params *params, pcr_result *result,
                                                 int32_t *correspondences) {
-    ENTER(ctx);
+    return pcr_api_call(ctx, [&]() -> int {
     if (!params || !result || n_src < 0 || n_tgt < 0) return PCR_EINVAL;
     if (!(max_dist > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
     if ((n_src > 0 && (!src_xyz || !src_normals)) || (n_tgt > 0 && (!tgt_xyz || !tgt_normals))) { ctx->err = "missing cloud or normals"; return PCR_EINVAL; }
@@ -312,6 +349,7 @@ extern "C" int pcr_registration_generalized_icp(pcr_context *ctx, const float *s
         PCR_TRY(pcr_dev_compact_matches(ctx, match, s.n, s.cap, sperm, tperm, correspondences, &nc));
     }
     return PCR_OK;
+    });
 }
 
 __global__ void k_gather_cov6(const float *__restrict__ src, const uint32_t *__restrict__ perm, int n, float *__restrict__ dst) {
@@ -325,7 +363,7 @@ extern "C" int pcr_registration_generalized_icp_cov(pcr_context *ctx, const floa
                                                     const float *tgt_xyz, const float *tgt_cov6, int64_t n_tgt, double max_dist,
                                                     const double *init_T, const pcr_gicp_params *params, pcr_result *result,
                                                     int32_t *correspondences) {
-    ENTER(ctx);
+    return pcr_api_call(ctx, [&]() -> int {
     if (!params || !result || n_src < 0 || n_tgt < 0) return PCR_EINVAL;
     if (!(max_dist > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
     if ((n_src > 0 && (!src_xyz || !src_cov6)) || (n_tgt > 0 && (!tgt_xyz || !tgt_cov6))) { ctx->err = "missing cloud or covariances"; return PCR_EINVAL; }
@@ -338,21 +376,22 @@ extern "C" int pcr_registration_generalized_icp_cov(pcr_context *ctx, const floa
     t.cov6 = arena<float>(ctx, (size_t)(n_tgt > 0 ? n_tgt : 1) * 6);
     int32_t *match = arena<int32_t>(ctx, n_src > 0 ? n_src : 1);
     if (!s.cov6 || !t.cov6 || !match) return PCR_ENOMEM;
-    if (n_src > 0) hipLaunchKernelGGL(k_gather_cov6, dim3((unsigned)((n_src + 255) / 256)), dim3(256), 0, ctx->stream, src_cov6, sperm, (int)n_src, s.cov6);
-    if (n_tgt > 0) hipLaunchKernelGGL(k_gather_cov6, dim3((unsigned)((n_tgt + 255) / 256)), dim3(256), 0, ctx->stream, tgt_cov6, tperm, (int)n_tgt, t.cov6);
+    if (n_src > 0) PCR_LAUNCH(ctx, k_gather_cov6, dim3((unsigned)((n_src + 255) / 256)), dim3(256), 0, ctx->stream, src_cov6, sperm, (int)n_src, s.cov6);
+    if (n_tgt > 0) PCR_LAUNCH(ctx, k_gather_cov6, dim3((unsigned)((n_tgt + 255) / 256)), dim3(256), 0, ctx->stream, tgt_cov6, tperm, (int)n_tgt, t.cov6);
     PCR_TRY(pcr_dev_gicp(ctx, &s, &t, max_dist, init_T, params, result, match));
     if (correspondences) {
         int64_t nc = 0;
         PCR_TRY(pcr_dev_compact_matches(ctx, match, s.n, s.cap, sperm, tperm, correspondences, &nc));
     }
     return PCR_OK;
+    });
 }
 
 extern "C" int pcr_debug_gicp_linearize(pcr_context *ctx, const float *src_xyz, const float *src_normals, int64_t n_src,
                                         const float *tgt_xyz, const float *tgt_normals, int64_t n_tgt, double max_dist,
                                         const double *T, const pcr_gicp_params *params, double *JTJ36, double *JTr6,
                                         double *stats3, int32_t *match_out) {
-    ENTER(ctx);
+    return pcr_api_call(ctx, [&]() -> int {
     if (!params || !JTJ36 || !JTr6 || !stats3 || n_src <= 0 || n_tgt <= 0) return PCR_EINVAL;
     PCR_TRY(check_T(ctx, T));
     PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n_src) + pcr_scratch_bytes_for(n_tgt)));
@@ -363,10 +402,11 @@ extern "C" int pcr_debug_gicp_linearize(pcr_context *ctx, const float *src_xyz, 
     if (!match) return PCR_ENOMEM;
     PCR_TRY(pcr_dev_linearize_once(ctx, &s, &t, max_dist, T, params, JTJ36, JTr6, stats3, match));
     if (match_out) {
-        hipLaunchKernelGGL(k_match_unpermute, dim3((unsigned)((n_src + 255) / 256)), dim3(256), 0, ctx->stream, match, sperm, tperm, (int)n_src, match_out, getenv("PCR_DEBUG_VISITS") ? 1 : 0);
+        PCR_LAUNCH(ctx, k_match_unpermute, dim3((unsigned)((n_src + 255) / 256)), dim3(256), 0, ctx->stream, match, sperm, tperm, (int)n_src, match_out, getenv("PCR_DEBUG_VISITS") ? 1 : 0);
         PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     }
     return PCR_OK;
+    });
 }
 
 // one cloud of one scale: voxel -> BVH -> SOR -> BVH -> normals   (ALL_FUNCTIONS.py:293-302)
@@ -401,12 +441,11 @@ static int prep_scale(pcr_context *ctx, const float *xyz, const float *nrm, int6
     return PCR_OK;
 }
 
-extern "C" int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const float *src_normals, int64_t n_src,
-                                   const float *tgt_xyz, const float *tgt_normals, int64_t n_tgt, const double *voxels,
-                                   const double *dists, int n_scales, int sor_k, double sor_std, int normal_k,
-                                   const double *init_T, const pcr_gicp_params *params, pcr_scale_record *records,
-                                   int32_t *correspondences) {
-    ENTER(ctx);
+static int multiscale_gicp_impl(pcr_context *ctx, const float *src_xyz, const float *src_normals, int64_t n_src,
+                                const float *tgt_xyz, const float *tgt_normals, int64_t n_tgt, const double *voxels,
+                                const double *dists, int n_scales, int sor_k, double sor_std, int normal_k,
+                                const double *init_T, const pcr_gicp_params *params, pcr_scale_record *records,
+                                int32_t *correspondences) {
     if (!params || !records || !voxels || !dists || n_scales < 1 || n_src < 0 || n_tgt < 0) return PCR_EINVAL;
     if ((n_src > 0 && !src_xyz) || (n_tgt > 0 && !tgt_xyz)) return PCR_EINVAL;
     PCR_TRY(check_T(ctx, init_T));
@@ -510,6 +549,16 @@ extern "C" int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const
     }
     return PCR_OK;
 }
+extern "C" int pcr_multiscale_gicp(pcr_context *ctx, const float *src_xyz, const float *src_normals, int64_t n_src,
+                                   const float *tgt_xyz, const float *tgt_normals, int64_t n_tgt, const double *voxels,
+                                   const double *dists, int n_scales, int sor_k, double sor_std, int normal_k,
+                                   const double *init_T, const pcr_gicp_params *params, pcr_scale_record *records,
+                                   int32_t *correspondences) {
+    return pcr_api_call(ctx, [&]() -> int {
+        return multiscale_gicp_impl(ctx, src_xyz, src_normals, n_src, tgt_xyz, tgt_normals, n_tgt, voxels, dists, n_scales, sor_k, sor_std, normal_k,
+                                    init_T, params, records, correspondences);
+    });
+}
 
 // ---------------------------------------------------------------------------------- many pairs per call
 // Worker contexts live in a process-wide pool (arena, streams and cached graphs survive between calls); a call borrows
@@ -532,45 +581,101 @@ void pool_give(int device, pcr_context *c) {
 }
 }  // namespace
 
-extern "C" int pcr_pool_profile(int device, int enable, double *out8, int reset) {
+extern "C" int pcr_pool_profile(int device, int enable, double *out16, int reset) {
     std::lock_guard<std::mutex> lock(g_pool_mutex);
-    if (out8) for (int i = 0; i < 8; i++) out8[i] = 0.0;
+    if (out16) for (int i = 0; i < 16; i++) out16[i] = 0.0;
     for (auto &e : g_pool) {
         if (e.first != device) continue;
         if (enable >= 0) e.second->profiling = enable ? 1 : 0;
-        for (int i = 0; i < 8; i++) { if (out8) out8[i] += e.second->prof[i]; if (reset) e.second->prof[i] = 0; }
+        for (int i = 0; i < 16; i++) { if (out16) out16[i] += e.second->prof[i]; if (reset) e.second->prof[i] = 0; }
     }
     return PCR_OK;
 }
 
-extern "C" int pcr_register_pairs(int device, pcr_pair *pairs, int n_pairs, const double *voxels, const double *dists, int n_scales,
-                                  int sor_k, double sor_std, int normal_k, const pcr_gicp_params *params, int inflight, void *after_stream) {
-    if (n_pairs < 0 || (n_pairs > 0 && !pairs) || !voxels || !dists || !params || n_scales < 1) return PCR_EINVAL;
+static int information_matrix_impl(pcr_context *ctx, const float *src_xyz, int64_t n_src, const float *tgt_xyz, int64_t n_tgt,
+                                   double max_dist, const double *T, double *info36);
+// one pair of a plan on a worker context (one pcr_enter / pcr_leave around everything: launch errors are the pair's)
+static int run_pair(pcr_context *ctx, pcr_pair_ex &px, int index, const pcr_pairs_plan &plan) {
+    return pcr_api_call(ctx, [&]() -> int {
+        pcr_pair &p = px.base;
+        const bool do_fgr = plan.stage == PCR_STAGE_FGR || plan.stage == PCR_STAGE_FGR_GICP, do_gicp = plan.stage == PCR_STAGE_GICP || plan.stage == PCR_STAGE_FGR_GICP;
+        if (!do_fgr && !do_gicp) { ctx->err = "unknown stage"; return PCR_EINVAL; }
+        if (do_fgr && !plan.fgr) { ctx->err = "plan.fgr == NULL"; return PCR_EINVAL; }
+        if (do_gicp && (!plan.voxel_sizes || !plan.gicp || plan.n_scales < 1 || plan.n_scales > 8 || !p.records || (plan.radius_rule == 0 && !plan.max_distances))) {
+            ctx->err = "plan: missing scale tables / parameters / records (1..8 scales)"; return PCR_EINVAL;
+        }
+        const float *sn = p.src_normals, *tn = p.tgt_normals;
+        double T0[16];
+        memcpy(T0, p.init_T, sizeof T0);
+        if (do_fgr) {
+            float *sno = px.src_normals_out, *tno = px.tgt_normals_out;
+            if (do_gicp && plan.gicp_prior_from_fgr && (!sno || !tno)) {
+                // the normals registro_FGR leaves on the clouds outlive its arena: context-owned side buffer
+                const size_t need = (size_t)(p.n_src + p.n_tgt + 2) * 3 * sizeof(float);
+                if (need > ctx->aux_cap) {
+                    PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                    if (ctx->aux) { PCR_HIP_CHECK(ctx, hipFree(ctx->aux)); ctx->aux = nullptr; ctx->aux_cap = 0; }
+                    if (hipMalloc((void **)&ctx->aux, need + need / 4) != hipSuccess) { ctx->err = "hipMalloc(aux)"; return PCR_ENOMEM; }
+                    ctx->aux_cap = need + need / 4;
+                }
+                if (!sno) sno = (float *)ctx->aux;
+                if (!tno) tno = (float *)ctx->aux + (size_t)(p.n_src + 1) * 3;
+            }
+            pcr_fgr_params fp = *plan.fgr;
+            fp.option.seed = plan.fgr->option.seed + (uint64_t)index;
+            PCR_TRY(pcr_registro_fgr_impl(ctx, p.src_xyz, p.src_normals, p.n_src, p.tgt_xyz, p.tgt_normals, p.n_tgt, &fp, sno, tno, &px.fgr,
+                                          do_gicp ? nullptr : p.correspondences));
+            memcpy(T0, px.fgr.transformation, sizeof T0);
+            if (do_gicp && plan.gicp_prior_from_fgr) { sn = sno; tn = tno; }
+        }
+        const double *Tfinal = T0;
+        if (do_gicp) {
+            double dists[8];
+            if (plan.radius_rule == 1) {              // ALL_FUNCTIONS.py:277-278 + 1092-1101
+                double bs[6], bt[6];
+                PCR_TRY(pcr_arena_reserve(ctx, 1 << 20));
+                PCR_TRY(pcr_dev_bounds(ctx, p.src_xyz, p.n_src, bs));
+                PCR_TRY(pcr_dev_bounds(ctx, p.tgt_xyz, p.n_tgt, bt));
+                const double r1 = std::pow((bs[3] - bs[0]) * (bs[4] - bs[1]) * (bs[5] - bs[2]), 1.0 / 3.0), r2 = std::pow((bt[3] - bt[0]) * (bt[4] - bt[1]) * (bt[5] - bt[2]), 1.0 / 3.0);
+                const double r = (r1 + r2) / 2;
+                for (int i = 0; i < plan.n_scales; i++) dists[i] = r * std::pow(2.0, -(double)i);
+            } else for (int i = 0; i < plan.n_scales; i++) dists[i] = plan.max_distances[i];
+            for (int i = 0; i < 8; i++) px.max_distances[i] = i < plan.n_scales ? dists[i] : 0.0;
+            PCR_TRY(multiscale_gicp_impl(ctx, p.src_xyz, sn, p.n_src, p.tgt_xyz, tn, p.n_tgt, plan.voxel_sizes, dists, plan.n_scales, plan.sor_k, plan.sor_std,
+                                         plan.normal_k, T0, plan.gicp, p.records, p.correspondences));
+            Tfinal = p.records[plan.n_scales - 1].icp.transformation;
+        }
+        if (plan.info_max_dist > 0.0) PCR_TRY(information_matrix_impl(ctx, p.src_xyz, p.n_src, p.tgt_xyz, p.n_tgt, plan.info_max_dist, Tfinal, px.info36));
+        return PCR_OK;
+    });
+}
+
+extern "C" int pcr_register_pairs_plan(int device, pcr_pair_ex *pairs, int n_pairs, const pcr_pairs_plan *plan, void *after_stream) {
+    if (n_pairs < 0 || (n_pairs > 0 && !pairs) || !plan) return PCR_EINVAL;
     if (n_pairs == 0) return PCR_OK;
     if (hipSetDevice(device) != hipSuccess) return PCR_EHIP;
+    const int inflight = plan->inflight;
     const int workers = inflight < 1 ? 1 : (inflight > n_pairs ? n_pairs : (inflight > 16 ? 16 : inflight));
+    // the workers wait for everything already enqueued on `after_stream` (NULL = the legacy default stream, which is what torch's
+    // default stream is): the producers of the clouds, normals and initial poses
     hipEvent_t ready = nullptr;
-    if (after_stream) {
-        if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess) return PCR_EHIP;
-        if (hipEventRecord(ready, (hipStream_t)after_stream) != hipSuccess) { (void)hipEventDestroy(ready); return PCR_EHIP; }
-    }
-    for (int i = 0; i < n_pairs; i++) { pairs[i].status = PCR_EHIP; snprintf(pairs[i].error, sizeof pairs[i].error, "not processed (no worker context)"); }
+    if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess) return PCR_EHIP;
+    if (hipEventRecord(ready, (hipStream_t)after_stream) != hipSuccess) { (void)hipEventDestroy(ready); return PCR_EHIP; }
+    for (int i = 0; i < n_pairs; i++) { pairs[i].base.status = PCR_EHIP; snprintf(pairs[i].base.error, sizeof pairs[i].base.error, "not processed (no worker context)"); }
     std::atomic<int> next(0), failed(0);
     auto work = [&]() {
         (void)hipSetDevice(device);
         pcr_context *ctx = pool_take(device);
         if (!ctx) { failed++; return; }
-        (void)pcr_set_stream(ctx, nullptr);                                   // the context's own stream
-        if (ensure_stream(ctx) == PCR_OK && ready) (void)hipStreamWaitEvent(ctx->stream, ready, 0);
+        use_private_stream(ctx);
+        if (ensure_stream(ctx) == PCR_OK) (void)hipStreamWaitEvent(ctx->stream, ready, 0);
         for (;;) {
             const int i = next.fetch_add(1);
             if (i >= n_pairs) break;
-            pcr_pair &p = pairs[i];
+            pcr_pair &p = pairs[i].base;
             p.error[0] = 0;
-            p.status = p.records ? pcr_multiscale_gicp(ctx, p.src_xyz, p.src_normals, p.n_src, p.tgt_xyz, p.tgt_normals, p.n_tgt, voxels, dists, n_scales,
-                                                       sor_k, sor_std, normal_k, p.init_T, params, p.records, p.correspondences)
-                                 : PCR_EINVAL;
-            if (p.status != PCR_OK) { failed++; snprintf(p.error, sizeof p.error, "%s", p.records ? ctx->err.c_str() : "records == NULL"); }
+            p.status = run_pair(ctx, pairs[i], i, *plan);
+            if (p.status != PCR_OK) { failed++; snprintf(p.error, sizeof p.error, "%s", ctx->err.c_str()); }
         }
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
         pool_give(device, ctx);
@@ -579,13 +684,27 @@ extern "C" int pcr_register_pairs(int device, pcr_pair *pairs, int n_pairs, cons
     for (int w = 1; w < workers; w++) threads.emplace_back(work);
     work();                                                                   // the calling thread is worker 0
     for (auto &t : threads) t.join();
-    if (ready) (void)hipEventDestroy(ready);
+    (void)hipEventDestroy(ready);
     return failed.load() ? PCR_EHIP : PCR_OK;
 }
 
-extern "C" int pcr_evaluate_registration(pcr_context *ctx, const float *src_xyz, int64_t n_src, const float *tgt_xyz, int64_t n_tgt,
-                                         double max_dist, const double *T, pcr_result *result, int32_t *correspondences) {
-    ENTER(ctx);
+// the GICP-only form (2_MGICP...py:187-214): pcr_register_pairs_plan with stage PCR_STAGE_GICP and the given radii
+extern "C" int pcr_register_pairs(int device, pcr_pair *pairs, int n_pairs, const double *voxels, const double *dists, int n_scales,
+                                  int sor_k, double sor_std, int normal_k, const pcr_gicp_params *params, int inflight, void *after_stream) {
+    if (n_pairs < 0 || (n_pairs > 0 && !pairs) || !voxels || !dists || !params || n_scales < 1) return PCR_EINVAL;
+    if (n_pairs == 0) return PCR_OK;
+    std::vector<pcr_pair_ex> ex((size_t)n_pairs);
+    for (int i = 0; i < n_pairs; i++) { memset(&ex[i], 0, sizeof(pcr_pair_ex)); ex[i].base = pairs[i]; }
+    pcr_pairs_plan plan; memset(&plan, 0, sizeof plan);
+    plan.stage = PCR_STAGE_GICP; plan.voxel_sizes = voxels; plan.max_distances = dists; plan.n_scales = n_scales; plan.sor_k = sor_k; plan.sor_std = sor_std;
+    plan.normal_k = normal_k; plan.gicp = params; plan.inflight = inflight;
+    const int rc = pcr_register_pairs_plan(device, ex.data(), n_pairs, &plan, after_stream);
+    for (int i = 0; i < n_pairs; i++) pairs[i] = ex[i].base;
+    return rc;
+}
+
+int pcr_evaluate_registration_impl(pcr_context *ctx, const float *src_xyz, int64_t n_src, const float *tgt_xyz, int64_t n_tgt,
+                                   double max_dist, const double *T, pcr_result *result, int32_t *correspondences) {
     if (!result || n_src < 0 || n_tgt < 0) return PCR_EINVAL;
     if (!(max_dist > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
     PCR_TRY(check_T(ctx, T));
@@ -603,10 +722,13 @@ extern "C" int pcr_evaluate_registration(pcr_context *ctx, const float *src_xyz,
     }
     return PCR_OK;
 }
+extern "C" int pcr_evaluate_registration(pcr_context *ctx, const float *src_xyz, int64_t n_src, const float *tgt_xyz, int64_t n_tgt,
+                                         double max_dist, const double *T, pcr_result *result, int32_t *correspondences) {
+    return pcr_api_call(ctx, [&]() -> int { return pcr_evaluate_registration_impl(ctx, src_xyz, n_src, tgt_xyz, n_tgt, max_dist, T, result, correspondences); });
+}
 
-extern "C" int pcr_information_matrix(pcr_context *ctx, const float *src_xyz, int64_t n_src, const float *tgt_xyz, int64_t n_tgt,
-                                      double max_dist, const double *T, double *info36) {
-    ENTER(ctx);
+static int information_matrix_impl(pcr_context *ctx, const float *src_xyz, int64_t n_src, const float *tgt_xyz, int64_t n_tgt,
+                                   double max_dist, const double *T, double *info36) {
     if (!info36 || n_src < 0 || n_tgt < 0) return PCR_EINVAL;
     if (!(max_dist > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
     PCR_TRY(check_T(ctx, T));
@@ -616,4 +738,8 @@ extern "C" int pcr_information_matrix(pcr_context *ctx, const float *src_xyz, in
     PCR_TRY(pcr_import_cloud(ctx, tgt_xyz, nullptr, n_tgt, &t, nullptr, false));
     pcr_result r;
     return pcr_dev_evaluate(ctx, &s, &t, max_dist, T, &r, nullptr, info36);
+}
+extern "C" int pcr_information_matrix(pcr_context *ctx, const float *src_xyz, int64_t n_src, const float *tgt_xyz, int64_t n_tgt,
+                                      double max_dist, const double *T, double *info36) {
+    return pcr_api_call(ctx, [&]() -> int { return information_matrix_impl(ctx, src_xyz, n_src, tgt_xyz, n_tgt, max_dist, T, info36); });
 }

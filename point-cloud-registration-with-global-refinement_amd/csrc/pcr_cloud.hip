@@ -47,8 +47,8 @@ int pcr_dev_bounds(pcr_context *ctx, const float *xyz, int64_t n, double *b6) {
     float *part = arena<float>(ctx, (size_t)nb * 6 + 6);
     if (!part) return PCR_ENOMEM;
     float *out6 = part + (size_t)nb * 6;
-    hipLaunchKernelGGL(k_bounds_partial, dim3(nb), dim3(BS), 0, ctx->stream, xyz, n, part);
-    hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(64), 0, ctx->stream, part, nb, out6);
+    PCR_LAUNCH(ctx, k_bounds_partial, dim3(nb), dim3(BS), 0, ctx->stream, xyz, n, part);
+    PCR_LAUNCH(ctx, k_bounds_final, dim3(1), dim3(64), 0, ctx->stream, part, nb, out6);
     float h[6];
     PCR_HIP_CHECK(ctx, hipMemcpyAsync(h, out6, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -136,8 +136,8 @@ static int flag_scan(pcr_context *ctx, uint8_t *flags, const int *n_ptr, int n_c
     const int n_tiles = (n_cap + TILE - 1) / TILE;
     int *tile_cnt = arena<int>(ctx, (size_t)n_tiles + 1);
     if (!tile_cnt) return PCR_ENOMEM;
-    hipLaunchKernelGGL(k_scan_tile_count, dim3(n_tiles), dim3(BS), 0, ctx->stream, flags, n_ptr, n_cap, tile_cnt, src);
-    hipLaunchKernelGGL(k_scan_tile_apply, dim3(n_tiles), dim3(BS), 0, ctx->stream, flags, n_ptr, n_cap, tile_cnt, pos, total_dev);
+    PCR_LAUNCH(ctx, k_scan_tile_count, dim3(n_tiles), dim3(BS), 0, ctx->stream, flags, n_ptr, n_cap, tile_cnt, src);
+    PCR_LAUNCH(ctx, k_scan_tile_apply, dim3(n_tiles), dim3(BS), 0, ctx->stream, flags, n_ptr, n_cap, tile_cnt, pos, total_dev);
     return PCR_OK;
 }
 int pcr_dev_flag_scan(pcr_context *ctx, const uint8_t *flags, const int *n_ptr, int n_cap, int *pos, int *total_dev) {
@@ -204,10 +204,10 @@ int pcr_dev_voxel(pcr_context *ctx, const float *xyz, const float *nrm_in, int64
     void *temp = pcr_arena_alloc(ctx, tb);
     if (!k0 || !k1 || !v0 || !v1 || !flags || !pos || !temp) return PCR_ENOMEM;
     const int nb = (ni + BS - 1) / BS;
-    hipLaunchKernelGGL(k_voxel_keys, dim3(nb), dim3(BS), 0, ctx->stream, xyz, ni, ox, oy, oz, voxel, k0, v0);
+    PCR_LAUNCH(ctx, k_voxel_keys, dim3(nb), dim3(BS), 0, ctx->stream, xyz, ni, ox, oy, oz, voxel, k0, v0);
     PCR_TRY(pcr_sort_pairs(ctx, temp, tb, k0, k1, v0, v1, n, end_bit));
     PCR_TRY(flag_scan(ctx, flags, nullptr, ni, pos, out->n, FlagSrc{k1, nullptr, nullptr}));      // head flags produced inside the scan
-    hipLaunchKernelGGL(k_voxel_mean, dim3(nb), dim3(BS), 0, ctx->stream, xyz, nrm_in, k1, v1, flags, pos, ni, out->pts, out->nrm, out->keys);
+    PCR_LAUNCH(ctx, k_voxel_mean, dim3(nb), dim3(BS), 0, ctx->stream, xyz, nrm_in, k1, v1, flags, pos, ni, out->pts, out->nrm, out->keys);
     return PCR_OK;
 }
 
@@ -298,10 +298,10 @@ int pcr_dev_voxel_multi(pcr_context *ctx, const float *xyz, const float *nrm_in,
     void *temp = pcr_arena_alloc(ctx, tb);
     if (!k0 || !k1 || !v0 || !v1 || !flags || !pos || !total || !temp) return PCR_OK;      // not enough scratch in this block: one by one
     const int nb = (int)((ne + BS - 1) / BS);
-    hipLaunchKernelGGL(k_voxel_keys_multi, dim3(nb), dim3(BS), 0, ctx->stream, xyz, (int)n, n_scales, g, shift, k0, v0);
+    PCR_LAUNCH(ctx, k_voxel_keys_multi, dim3(nb), dim3(BS), 0, ctx->stream, xyz, (int)n, n_scales, g, shift, k0, v0);
     PCR_TRY(pcr_sort_pairs(ctx, temp, tb, k0, k1, v0, v1, ne, end_bit));
     PCR_TRY(flag_scan(ctx, flags, nullptr, (int)ne, pos, total, FlagSrc{k1, nullptr, nullptr}));
-    hipLaunchKernelGGL(k_voxel_mean_multi, dim3(nb), dim3(BS), 0, ctx->stream, xyz, nrm_in, k1, v1, flags, pos, total, (int)n, n_scales, shift, o);
+    PCR_LAUNCH(ctx, k_voxel_mean_multi, dim3(nb), dim3(BS), 0, ctx->stream, xyz, nrm_in, k1, v1, flags, pos, total, (int)n, n_scales, shift, o);
     *done = true;
     return PCR_OK;
 }
@@ -336,20 +336,20 @@ __global__ void k_set_int(int *p, int v) { *p = v; }
 
 int pcr_dev_gather_f3_to_f4(pcr_context *ctx, const float *src, const uint32_t *perm, int64_t n, float4 *dst) {
     if (n <= 0) return PCR_OK;
-    hipLaunchKernelGGL(k_gather_f3_to_f4, dim3((unsigned)((n + BS - 1) / BS)), dim3(BS), 0, ctx->stream, src, perm, (int)n, dst);
+    PCR_LAUNCH(ctx, k_gather_f3_to_f4, dim3((unsigned)((n + BS - 1) / BS)), dim3(BS), 0, ctx->stream, src, perm, (int)n, dst);
     return PCR_OK;
 }
 int pcr_dev_unpack_f3_to_f4(pcr_context *ctx, const float *src, int64_t n, float4 *dst) { return pcr_dev_gather_f3_to_f4(ctx, src, nullptr, n, dst); }
 int pcr_dev_scatter_rows_f4_to_f3(pcr_context *ctx, const float4 *src, const uint32_t *perm, const int *n, int cap, float *dst) {
     if (cap <= 0) return PCR_OK;
-    hipLaunchKernelGGL(k_scatter_f4_to_f3, dim3((cap + BS - 1) / BS), dim3(BS), 0, ctx->stream, src, perm, n, cap, dst);
+    PCR_LAUNCH(ctx, k_scatter_f4_to_f3, dim3((cap + BS - 1) / BS), dim3(BS), 0, ctx->stream, src, perm, n, cap, dst);
     return PCR_OK;
 }
 int pcr_dev_pack_f4_to_f3(pcr_context *ctx, const float4 *src, const int *n, int cap, float *dst) { return pcr_dev_scatter_rows_f4_to_f3(ctx, src, nullptr, n, cap, dst); }
 
 int pcr_dev_sort_cloud(pcr_context *ctx, const float *xyz, int64_t n, const double *b6, DevCloud *out, uint32_t *perm) {
     if (n > 0x7fffffff / 4) { ctx->err = "cloud too large"; return PCR_EINVAL; }
-    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, ctx->stream, out->n, (int)n);
+    PCR_LAUNCH(ctx, k_set_int, dim3(1), dim3(1), 0, ctx->stream, out->n, (int)n);
     if (n == 0) return PCR_OK;
     ArenaMark mark(ctx);
     uint64_t *k0 = arena<uint64_t>(ctx, n), *k1 = out->keys;
@@ -363,9 +363,9 @@ int pcr_dev_sort_cloud(pcr_context *ctx, const float *xyz, int64_t n, const doub
         out->key_org[d] = (float)b6[d]; out->key_unit[d] = e > 0 ? (float)(e / 65535.0) : 1.0f;
     }
     const int nb = (int)((n + BS - 1) / BS);
-    hipLaunchKernelGGL(k_raw_keys, dim3(nb), dim3(BS), 0, ctx->stream, xyz, (int)n, (float)b6[0], (float)b6[1], (float)b6[2], s[0], s[1], s[2], k0, v0);
+    PCR_LAUNCH(ctx, k_raw_keys, dim3(nb), dim3(BS), 0, ctx->stream, xyz, (int)n, (float)b6[0], (float)b6[1], (float)b6[2], s[0], s[1], s[2], k0, v0);
     PCR_TRY(pcr_sort_pairs(ctx, temp, tb, k0, k1, v0, perm, n, 48));
-    hipLaunchKernelGGL(k_gather_f3_to_f4, dim3(nb), dim3(BS), 0, ctx->stream, xyz, perm, (int)n, out->pts);
+    PCR_LAUNCH(ctx, k_gather_f3_to_f4, dim3(nb), dim3(BS), 0, ctx->stream, xyz, perm, (int)n, out->pts);
     return PCR_OK;
 }
 
@@ -603,13 +603,13 @@ int pcr_dev_build_bvh_batch(pcr_context *ctx, DevCloud *const *cs, int count) {
         if (nbl > max_nbl) max_nbl = nbl;
     }
     if (m == 0) return PCR_OK;
-    hipLaunchKernelGGL(k_oct_lstar, dim3(max_tiles, m), dim3(BS), 0, ctx->stream, b);
-    hipLaunchKernelGGL(k_oct_meta, dim3(1, m), dim3(256), 0, ctx->stream, b);
-    hipLaunchKernelGGL(k_oct_apply, dim3(max_tiles, m), dim3(BS), 0, ctx->stream, b);
-    hipLaunchKernelGGL(k_oct_leaf_boxes, dim3(max_nbl, m), dim3(BS), 0, ctx->stream, b);
-    hipLaunchKernelGGL(k_oct_level_boxes, dim3(max_nbl, m), dim3(BS), 0, ctx->stream, b, 1);
+    PCR_LAUNCH(ctx, k_oct_lstar, dim3(max_tiles, m), dim3(BS), 0, ctx->stream, b);
+    PCR_LAUNCH(ctx, k_oct_meta, dim3(1, m), dim3(256), 0, ctx->stream, b);
+    PCR_LAUNCH(ctx, k_oct_apply, dim3(max_tiles, m), dim3(BS), 0, ctx->stream, b);
+    PCR_LAUNCH(ctx, k_oct_leaf_boxes, dim3(max_nbl, m), dim3(BS), 0, ctx->stream, b);
+    PCR_LAUNCH(ctx, k_oct_level_boxes, dim3(max_nbl, m), dim3(BS), 0, ctx->stream, b, 1);
     // levels >= 2 (n/64 nodes and fewer) in ONE workgroup per tree, level by level: a launch less than one grid per level
-    hipLaunchKernelGGL(k_oct_upper_boxes, dim3(1, m), dim3(1024), 0, ctx->stream, b, 2);
+    PCR_LAUNCH(ctx, k_oct_upper_boxes, dim3(1, m), dim3(1024), 0, ctx->stream, b, 2);
     return PCR_OK;
 }
 int pcr_dev_build_bvh(pcr_context *ctx, DevCloud *c) { return pcr_dev_build_bvh_batch(ctx, &c, 1); }
@@ -961,9 +961,9 @@ static int launch_knn(pcr_context *ctx, const DevCloud *c, KnnArgs a) {
         }
     } dump{ctx, stamp_path, a.stamps, stamp_words, MODE, a.k};
     { static const int ss = getenv("PCR_KNN_SEED") ? atoi(getenv("PCR_KNN_SEED")) : -1; a.seed_span = ss; }
-    if (a.k <= 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn<MODE, 4>), grid, block, 0, ctx->stream, a);
-    else if (a.k <= 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn<MODE, 8>), grid, block, 0, ctx->stream, a);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_knn<MODE, 25>), grid, block, 0, ctx->stream, a);
+    if (a.k <= 32) PCR_LAUNCH(ctx, k_knn<MODE, 4>, grid, block, 0, ctx->stream, a);
+    else if (a.k <= 64) PCR_LAUNCH(ctx, k_knn<MODE, 8>, grid, block, 0, ctx->stream, a);
+    else PCR_LAUNCH(ctx, k_knn<MODE, 25>, grid, block, 0, ctx->stream, a);
     return PCR_OK;
 }
 
@@ -1209,16 +1209,16 @@ int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double s
     a.zero_a = (int *)stat_ticket; a.zero_b = (fuse && todo_out) ? todo_count : nullptr;      // zeroed by the search kernel for the kernels after it
     knn_radius(a, PCR_SEARCH_KNN, 0);
     PCR_TRY(launch_knn<KNN_MODE_SOR>(ctx, in, a));
-    hipLaunchKernelGGL(k_sor_stats, dim3(SOR_STAT_BLOCKS), dim3(256), 0, ctx->stream, avg, in->n, std_ratio, stats3, stat_partials, stat_ticket);
+    PCR_LAUNCH(ctx, k_sor_stats, dim3(SOR_STAT_BLOCKS), dim3(256), 0, ctx->stream, avg, in->n, std_ratio, stats3, stat_partials, stat_ticket);
     const int nb = (in->cap + BS - 1) / BS;
     PCR_TRY(flag_scan(ctx, flags, in->n, in->cap, pos, out->n, FlagSrc{nullptr, avg, stats3}));      // keep flags produced inside the scan
-    hipLaunchKernelGGL(k_compact_cloud, dim3(nb), dim3(BS), 0, ctx->stream, in->pts, in->nrm, flags, pos, in->n, out->pts, out->nrm, in->keys, out->keys, cnt_in_out, cnt_kept_out, out->n);
+    PCR_LAUNCH(ctx, k_compact_cloud, dim3(nb), dim3(BS), 0, ctx->stream, in->pts, in->nrm, flags, pos, in->n, out->pts, out->nrm, in->keys, out->keys, cnt_in_out, cnt_kept_out, out->n);
     if (todo_out) {
         if (fuse) {
             NflArgs f;
             f.pts = in->pts; f.n_ptr = in->n; f.lidx = lidx; f.ld2 = ld2; f.keep = flags; f.pos = pos; f.k_list = nb_neighbors; f.k_nrm = normal_k;
             f.prior = prior_out; f.normals = out->nrm_final; f.todo = todo_out; f.todo_count = todo_count;
-            hipLaunchKernelGGL(k_normals_from_lists, dim3((unsigned)(((size_t)in->cap * OCT + KNN_BS - 1) / KNN_BS)), dim3(KNN_BS), 0, ctx->stream, f);
+            PCR_LAUNCH(ctx, k_normals_from_lists, dim3((unsigned)(((size_t)in->cap * OCT + KNN_BS - 1) / KNN_BS)), dim3(KNN_BS), 0, ctx->stream, f);
         } else {
             PCR_HIP_CHECK(ctx, hipMemsetAsync(todo_out, 1, (size_t)in->cap, ctx->stream));
         }
@@ -1244,7 +1244,7 @@ int pcr_dev_normals(pcr_context *ctx, DevCloud *c, int search_kind, int knn, dou
         RadArgs r;
         r.t = oct_view(c); r.n_ptr = c->n; r.r2 = radius * radius; r.r2f = (float)(r.r2 * (1.0 + 1e-6));
         r.prior = prior; r.normals = normals_out; r.cov6 = cov6_out;
-        hipLaunchKernelGGL(k_radius_moments, dim3((unsigned)(((size_t)c->cap * OCT + KNN_BS - 1) / KNN_BS)), dim3(KNN_BS), 0, ctx->stream, r);
+        PCR_LAUNCH(ctx, k_radius_moments, dim3((unsigned)(((size_t)c->cap * OCT + KNN_BS - 1) / KNN_BS)), dim3(KNN_BS), 0, ctx->stream, r);
         return PCR_OK;
     }
     if (knn < 1) { ctx->err = "knn < 1"; return PCR_EINVAL; }

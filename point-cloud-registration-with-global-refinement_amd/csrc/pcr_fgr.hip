@@ -137,19 +137,14 @@ __global__ void __launch_bounds__(FB) k_fpfh(FpfhArgs a) {
     }
 }
 
-extern "C" int pcr_compute_fpfh_feature(pcr_context *ctx, const float *xyz, const float *normals, int64_t n, int search_kind, int knn,
-                                        double radius, float *feat33) {
-    if (!ctx) return PCR_EINVAL;
-    if (hipSetDevice(ctx->device) != hipSuccess) return PCR_EHIP;
-    ctx->err.clear();
-    if (n < 0 || (n > 0 && (!xyz || !normals || !feat33))) return PCR_EINVAL;
+// FPFH of an imported cloud (Morton-sorted points + normals + octree); rows of feat33 in CALLER order (perm: sorted -> caller)
+static size_t fpfh_scratch_bytes(int64_t n, int knn) { return (size_t)(n > 0 ? n : 1) * ((size_t)knn * 8 + 33 * 8 + 64) + (1u << 16); }
+static int fpfh_of_cloud(pcr_context *ctx, const DevCloud &c, const uint32_t *perm, int64_t n, int search_kind, int knn, double radius, float *feat33) {
     if (search_kind == PCR_SEARCH_RADIUS) { ctx->err = "compute_fpfh_feature: pure radius search not implemented (use Hybrid or KNN)"; return PCR_EINVAL; }
     if (knn < 1 || knn > 200) { ctx->err = "compute_fpfh_feature: max_nn must be in 1..200"; return PCR_EINVAL; }
     if (search_kind == PCR_SEARCH_HYBRID && !(radius > 0)) { ctx->err = "radius <= 0"; return PCR_EINVAL; }
     if (n == 0) return PCR_OK;
-    PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n) + (size_t)n * ((size_t)knn * 8 + 33 * 8 + 64)));
-    DevCloud c; uint32_t *perm = nullptr;
-    PCR_TRY(pcr_import_cloud(ctx, xyz, normals, n, &c, &perm, false));
+    ArenaMark mark(ctx);
     int32_t *nbr = arena<int32_t>(ctx, (size_t)n * knn);
     float *nd2 = arena<float>(ctx, (size_t)n * knn);
     double *spfh = arena<double>(ctx, (size_t)n * 33);
@@ -160,10 +155,21 @@ extern "C" int pcr_compute_fpfh_feature(pcr_context *ctx, const float *xyz, cons
     a.r2 = search_kind == PCR_SEARCH_HYBRID ? radius * radius : 1e300;
     a.spfh = spfh; a.perm = perm; a.feat = feat33;
     const dim3 grid((unsigned)(((size_t)n * OCT + FB - 1) / FB));
-    hipLaunchKernelGGL(k_spfh, grid, dim3(FB), 0, ctx->stream, a);
-    hipLaunchKernelGGL(k_fpfh, grid, dim3(FB), 0, ctx->stream, a);
-    PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    PCR_LAUNCH(ctx, k_spfh, grid, dim3(FB), 0, ctx->stream, a);
+    PCR_LAUNCH(ctx, k_fpfh, grid, dim3(FB), 0, ctx->stream, a);
     return PCR_OK;
+}
+
+extern "C" int pcr_compute_fpfh_feature(pcr_context *ctx, const float *xyz, const float *normals, int64_t n, int search_kind, int knn,
+                                        double radius, float *feat33) {
+    return pcr_api_call(ctx, [&]() -> int {
+    if (n < 0 || (n > 0 && (!xyz || !normals || !feat33))) return PCR_EINVAL;
+    if (n == 0) return PCR_OK;
+    PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(n) + fpfh_scratch_bytes(n, knn > 0 && knn <= 200 ? knn : 1)));
+    DevCloud c; uint32_t *perm = nullptr;
+    PCR_TRY(pcr_import_cloud(ctx, xyz, normals, n, &c, &perm, false));
+    return fpfh_of_cloud(ctx, c, perm, n, search_kind, knn, radius, feat33);      // no scalar output: asynchronous on the context's stream
+    });
 }
 
 // ======================================================================== feature matching (K7)
@@ -298,7 +304,7 @@ __global__ void __launch_bounds__(FB) k_feature_nn_pick(const double *__restrict
 // nearest database row for every query row (exact, float64 contraction on the matrix cores)
 static int feature_nn(pcr_context *ctx, const float *db, int n_db, const float *q, int n_q, int32_t *out) {
     if (n_db < 64 || n_q < 64 || getenv("PCR_FEATURE_NN_BRUTE")) {
-        hipLaunchKernelGGL(k_feature_nn, dim3((n_q + FB - 1) / FB), dim3(FB), 0, ctx->stream, db, n_db, q, n_q, out);
+        PCR_LAUNCH(ctx, k_feature_nn, dim3((n_q + FB - 1) / FB), dim3(FB), 0, ctx->stream, db, n_db, q, n_q, out);
         return PCR_OK;
     }
     ArenaMark mark(ctx);
@@ -313,10 +319,10 @@ static int feature_nn(pcr_context *ctx, const float *db, int n_db, const float *
     double *qT = arena<double>(ctx, (size_t)FK * nqp), *qn = arena<double>(ctx, nqp);
     double *cd = arena<double>(ctx, (size_t)nqp * splits); int *ci = arena<int>(ctx, (size_t)nqp * splits);
     if (!dbT || !dbn || !qT || !qn || !cd || !ci) return PCR_ENOMEM;
-    hipLaunchKernelGGL(k_feat_transpose, dim3((ndp + FB - 1) / FB), dim3(FB), 0, ctx->stream, db, n_db, ndp, dbT, dbn);
-    hipLaunchKernelGGL(k_feat_transpose, dim3((nqp + FB - 1) / FB), dim3(FB), 0, ctx->stream, q, n_q, nqp, qT, qn);
-    hipLaunchKernelGGL(k_feature_nn_mfma, dim3(nqp / 256, splits), dim3(FB), 0, ctx->stream, dbT, dbn, ndp, qT, qn, nqp, tps, cd, ci);
-    hipLaunchKernelGGL(k_feature_nn_pick, dim3((n_q + FB - 1) / FB), dim3(FB), 0, ctx->stream, cd, ci, n_q, splits, out);
+    PCR_LAUNCH(ctx, k_feat_transpose, dim3((ndp + FB - 1) / FB), dim3(FB), 0, ctx->stream, db, n_db, ndp, dbT, dbn);
+    PCR_LAUNCH(ctx, k_feat_transpose, dim3((nqp + FB - 1) / FB), dim3(FB), 0, ctx->stream, q, n_q, nqp, qT, qn);
+    PCR_LAUNCH(ctx, k_feature_nn_mfma, dim3(nqp / 256, splits), dim3(FB), 0, ctx->stream, dbT, dbn, ndp, qT, qn, nqp, tps, cd, ci);
+    PCR_LAUNCH(ctx, k_feature_nn_pick, dim3((n_q + FB - 1) / FB), dim3(FB), 0, ctx->stream, cd, ci, n_q, splits, out);
     return PCR_OK;
 }
 
@@ -768,9 +774,9 @@ static int normalise(pcr_context *ctx, const float *xyz, int64_t n, double *out6
     double *part = arena<double>(ctx, (size_t)nb * 3 + 3 + nb);
     if (!part) return PCR_ENOMEM;
     double *mean3 = part + (size_t)nb * 3, *pmax = mean3 + 3;
-    hipLaunchKernelGGL(k_sum3, dim3(nb), dim3(FB), 0, ctx->stream, xyz, (int)n, part);
-    hipLaunchKernelGGL(k_sum3_final, dim3(1), dim3(64), 0, ctx->stream, part, nb, (int)n, mean3);
-    hipLaunchKernelGGL(k_center, dim3(nb), dim3(FB), 0, ctx->stream, xyz, (int)n, mean3, out64, pmax);
+    PCR_LAUNCH(ctx, k_sum3, dim3(nb), dim3(FB), 0, ctx->stream, xyz, (int)n, part);
+    PCR_LAUNCH(ctx, k_sum3_final, dim3(1), dim3(64), 0, ctx->stream, part, nb, (int)n, mean3);
+    PCR_LAUNCH(ctx, k_center, dim3(nb), dim3(FB), 0, ctx->stream, xyz, (int)n, mean3, out64, pmax);
     std::vector<double> h((size_t)3 + nb);
     PCR_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), mean3, sizeof(double) * (3 + (size_t)nb), hipMemcpyDeviceToHost, ctx->stream));
     PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -780,22 +786,22 @@ static int normalise(pcr_context *ctx, const float *xyz, int64_t n, double *out6
     return PCR_OK;
 }
 
-extern "C" int pcr_evaluate_registration(pcr_context *ctx, const float *src_xyz, int64_t n_src, const float *tgt_xyz, int64_t n_tgt,
-                                         double max_dist, const double *T, pcr_result *result, int32_t *correspondences);
 
-extern "C" int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, const float *src_feat, int64_t ns, const float *tgt_xyz,
-                                    const float *tgt_feat, int64_t nt, const pcr_fgr_option *opt, pcr_result *result, int32_t *correspondences) {
-    if (!ctx) return PCR_EINVAL;
-    if (hipSetDevice(ctx->device) != hipSuccess) return PCR_EHIP;
-    ctx->err.clear();
-    if (!opt || !result || ns < 0 || nt < 0) return PCR_EINVAL;
-    if ((ns > 0 && (!src_xyz || !src_feat)) || (nt > 0 && (!tgt_xyz || !tgt_feat))) return PCR_EINVAL;
-    if (ns > 0x7fffffff / 8 || nt > 0x7fffffff / 8) { ctx->err = "cloud too large"; return PCR_EINVAL; }
-    double Tsrc2tgt[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+static size_t fgr_scratch_bytes(int64_t ns, int64_t nt, const pcr_fgr_option *opt) {
+    const int64_t nmax = ns > nt ? ns : nt;
+    const long long trial_cap = opt->tuple_test ? 100ll * nmax : 0;
+    return (size_t)(ns + nt) * (24 + 8 + 16) + (size_t)nmax * 32 + (size_t)trial_cap * 5 + (size_t)nmax * 64 + (size_t)nmax * (FK * 16 + 32 * 12 + 64) + (64u << 20);
+}
+
+// AdvancedMatching + OptimizePairwiseRegistration: the source -> target pose from the two clouds and their features (caller-order
+// device arrays).  Scratch comes from the arena above the current mark (the caller has reserved fgr_scratch_bytes).
+static int fgr_pose(pcr_context *ctx, const float *src_xyz, const float *src_feat, int64_t ns, const float *tgt_xyz, const float *tgt_feat, int64_t nt,
+                    const pcr_fgr_option *opt, double *Tsrc2tgt) {
+    { const double I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}; memcpy(Tsrc2tgt, I, sizeof I); }
     if (ns > 0 && nt > 0) {
         const int64_t nmax = ns > nt ? ns : nt;
         const long long trial_cap = opt->tuple_test ? 100ll * nmax : 0;
-        PCR_TRY(pcr_arena_reserve(ctx, (size_t)(ns + nt) * (24 + 8 + 16) + (size_t)nmax * 32 + (size_t)trial_cap * 5 + (size_t)nmax * 64 + (size_t)nmax * (FK * 16 + 32 * 12 + 64) + (64u << 20)));
+        ArenaMark mark(ctx);
         // ---- NormalizePointCloud
         double *P[2] = {arena<double>(ctx, (size_t)ns * 3), arena<double>(ctx, (size_t)nt * 3)};
         if (!P[0] || !P[1]) return PCR_ENOMEM;
@@ -805,8 +811,8 @@ extern "C" int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, cons
         const double scale = mx[0] > mx[1] ? mx[0] : mx[1];
         const double scale_global = opt->use_absolute_scale ? 1.0 : scale, scale_start = opt->use_absolute_scale ? scale : 1.0;
         if (scale_global != 1.0) {
-            hipLaunchKernelGGL(k_scale, dim3((unsigned)((ns * 3 + FB - 1) / FB)), dim3(FB), 0, ctx->stream, P[0], (long long)ns * 3, scale_global);
-            hipLaunchKernelGGL(k_scale, dim3((unsigned)((nt * 3 + FB - 1) / FB)), dim3(FB), 0, ctx->stream, P[1], (long long)nt * 3, scale_global);
+            PCR_LAUNCH(ctx, k_scale, dim3((unsigned)((ns * 3 + FB - 1) / FB)), dim3(FB), 0, ctx->stream, P[0], (long long)ns * 3, scale_global);
+            PCR_LAUNCH(ctx, k_scale, dim3((unsigned)((nt * 3 + FB - 1) / FB)), dim3(FB), 0, ctx->stream, P[1], (long long)nt * 3, scale_global);
         }
         // ---- AdvancedMatching: mutual nearest neighbours in feature space; i = the larger cloud
         const int swapped = nt > ns ? 1 : 0;
@@ -817,11 +823,20 @@ extern "C" int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, cons
         int *cpos = arena<int>(ctx, nPti), *ncross_dev = arena<int>(ctx, 1);
         int32_t *cross = arena<int32_t>(ctx, (size_t)nPti * 2);
         if (!j_to_i || !i_to_j || !cflags || !cpos || !ncross_dev || !cross) return PCR_ENOMEM;
+        hipEvent_t pe[2] = {nullptr, nullptr};
+        if (ctx->profiling) { PCR_HIP_CHECK(ctx, hipEventCreate(&pe[0])); PCR_HIP_CHECK(ctx, hipEventCreate(&pe[1])); PCR_HIP_CHECK(ctx, hipEventRecord(pe[0], ctx->stream)); }
         PCR_TRY(feature_nn(ctx, fi, nPti, fj, nPtj, j_to_i));
         PCR_TRY(feature_nn(ctx, fj, nPtj, fi, nPti, i_to_j));
-        hipLaunchKernelGGL(k_cross_flags, dim3((nPti + FB - 1) / FB), dim3(FB), 0, ctx->stream, i_to_j, j_to_i, nPti, cflags);
+        if (ctx->profiling) {             // bench instrumentation: HIP-event time over the two matching passes (pcr_hip.h, out16[8..10])
+            PCR_HIP_CHECK(ctx, hipEventRecord(pe[1], ctx->stream));
+            PCR_HIP_CHECK(ctx, hipEventSynchronize(pe[1]));
+            float ms = 0; PCR_HIP_CHECK(ctx, hipEventElapsedTime(&ms, pe[0], pe[1]));
+            ctx->prof[8] += ms; ctx->prof[9] += 2.0 * (2.0 * 33.0 * (double)nPti * (double)nPtj); ctx->prof[10] += 2.0;
+            (void)hipEventDestroy(pe[0]); (void)hipEventDestroy(pe[1]);
+        }
+        PCR_LAUNCH(ctx, k_cross_flags, dim3((nPti + FB - 1) / FB), dim3(FB), 0, ctx->stream, i_to_j, j_to_i, nPti, cflags);
         PCR_TRY(pcr_dev_flag_scan(ctx, cflags, nullptr, nPti, cpos, ncross_dev));
-        hipLaunchKernelGGL(k_cross_emit, dim3((nPti + FB - 1) / FB), dim3(FB), 0, ctx->stream, i_to_j, cflags, cpos, nPti, cross);
+        PCR_LAUNCH(ctx, k_cross_emit, dim3((nPti + FB - 1) / FB), dim3(FB), 0, ctx->stream, i_to_j, cflags, cpos, nPti, cross);
         int64_t ncross = 0;
         PCR_TRY(pcr_read_count(ctx, ncross_dev, &ncross));
         // ---- tuple test
@@ -836,9 +851,9 @@ extern "C" int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, cons
             ta.pi = swapped ? P[1] : P[0]; ta.pj = swapped ? P[0] : P[1]; ta.cross = cross; ta.ncross = (int)ncross;
             ta.seed = opt->seed; ta.tuple_scale = opt->tuple_scale; ta.trials = trials;
             const unsigned gb = (unsigned)((trials + FB - 1) / FB);
-            hipLaunchKernelGGL(k_tuple_flags, dim3(gb), dim3(FB), 0, ctx->stream, ta, tflags);
+            PCR_LAUNCH(ctx, k_tuple_flags, dim3(gb), dim3(FB), 0, ctx->stream, ta, tflags);
             PCR_TRY(pcr_dev_flag_scan(ctx, tflags, nullptr, (int)trials, tpos, ntup_dev));
-            hipLaunchKernelGGL(k_tuple_emit, dim3(gb), dim3(FB), 0, ctx->stream, ta, tflags, tpos, opt->maximum_tuple_count, swapped, corr);
+            PCR_LAUNCH(ctx, k_tuple_emit, dim3(gb), dim3(FB), 0, ctx->stream, ta, tflags, tpos, opt->maximum_tuple_count, swapped, corr);
             int64_t nacc = 0;
             PCR_TRY(pcr_read_count(ctx, ntup_dev, &nacc));
             if (nacc > opt->maximum_tuple_count) nacc = opt->maximum_tuple_count;
@@ -861,11 +876,11 @@ extern "C" int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, cons
             const int stride = (int)((ncorr + 63) / 64 * 64);
             double *pq = arena<double>(ctx, (size_t)stride * 6);
             if (!st || !partials || !pq) return PCR_ENOMEM;
-            hipLaunchKernelGGL(k_fgr_gather_pairs, dim3((unsigned)((ncorr + FB - 1) / FB)), dim3(FB), 0, ctx->stream, P[0], P[1], corr, (int)ncorr, stride, pq);
+            PCR_LAUNCH(ctx, k_fgr_gather_pairs, dim3((unsigned)((ncorr + FB - 1) / FB)), dim3(FB), 0, ctx->stream, P[0], P[1], corr, (int)ncorr, stride, pq);
             FgrOptArgs oa;
             oa.pq = pq; oa.stride = stride; oa.ncorr = (int)ncorr; oa.st = st; oa.partials = partials;
             oa.decrease_mu = opt->decrease_mu; oa.max_corr_dist = opt->maximum_correspondence_distance; oa.division_factor = opt->division_factor;
-            hipLaunchKernelGGL(k_fgr_init, dim3(1), dim3(64), 0, ctx->stream, st, scale_start);
+            PCR_LAUNCH(ctx, k_fgr_init, dim3(1), dim3(64), 0, ctx->stream, st, scale_start);
             static const int single_max = getenv("PCR_FGR_SINGLE_MAX") ? atoi(getenv("PCR_FGR_SINGLE_MAX")) : 11000;   // one CU needs 0.8 us of float64 work per 1000 correspondences and iteration (+1.4 us solve); a launch per iteration costs 11 us
             if (getenv("PCR_DEBUG_FGR")) fprintf(stderr, "fgr: ncross %lld ncorr %lld iterations %d\n", (long long)ncross, (long long)ncorr, (int)opt->iteration_number);
             static const int multi_min = getenv("PCR_FGR_MULTI_MIN") ? atoi(getenv("PCR_FGR_MULTI_MIN")) : 6000;       // from here on FMG co-resident workgroups in one launch
@@ -874,17 +889,17 @@ extern "C" int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, cons
             if (!rows) return PCR_ENOMEM;
             const bool multi = ncorr >= multi_min && ncorr <= multi_max;
             FgrState h;
-            auto per_iteration = [&]() { for (int it = 0; it < opt->iteration_number; it++) hipLaunchKernelGGL(k_fgr_iter, dim3(nb), dim3(FB), 0, ctx->stream, oa); };
+            auto per_iteration = [&]() { for (int it = 0; it < opt->iteration_number; it++) PCR_LAUNCH(ctx, k_fgr_iter, dim3(nb), dim3(FB), 0, ctx->stream, oa); };
             // PCR_FGR_MULTI_TIMEOUT: ticks of the 100 MHz wall clock a workgroup waits at the barrier (tests set 0 to force the fallback)
             static const unsigned long long fm_timeout = getenv("PCR_FGR_MULTI_TIMEOUT") ? strtoull(getenv("PCR_FGR_MULTI_TIMEOUT"), nullptr, 10) : 5000000ull;
-            if (multi) hipLaunchKernelGGL(k_fgr_opt_multi, dim3(FMG), dim3(FMB), 0, ctx->stream, oa, (int)opt->iteration_number, rows, fm_timeout);
-            else if (ncorr <= single_max) hipLaunchKernelGGL(k_fgr_opt_single, dim3(1), dim3(FSB), 0, ctx->stream, oa, (int)opt->iteration_number);
+            if (multi) PCR_LAUNCH(ctx, k_fgr_opt_multi, dim3(FMG), dim3(FMB), 0, ctx->stream, oa, (int)opt->iteration_number, rows, fm_timeout);
+            else if (ncorr <= single_max) PCR_LAUNCH(ctx, k_fgr_opt_single, dim3(1), dim3(FSB), 0, ctx->stream, oa, (int)opt->iteration_number);
             else per_iteration();
             PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
             PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             if (multi && h.failed) {                 // the workgroups were not co-resident in time: same result, one launch per iteration
                 if (getenv("PCR_DEBUG_FGR")) fprintf(stderr, "fgr: multi-workgroup optimiser gave up waiting, falling back to one launch per iteration\n");
-                hipLaunchKernelGGL(k_fgr_init, dim3(1), dim3(64), 0, ctx->stream, st, scale_start);
+                PCR_LAUNCH(ctx, k_fgr_init, dim3(1), dim3(64), 0, ctx->stream, st, scale_start);
                 per_iteration();
                 PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
                 PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -906,7 +921,70 @@ extern "C" int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, cons
         }
         for (int k = 0; k < 16; k++) if (!std::isfinite(Tsrc2tgt[k])) { ctx->err = "non-finite FGR pose"; return PCR_ENUMERIC; }
     }
-    // ---- EvaluateRegistration(source, target, maximum_correspondence_distance, T)
+    return PCR_OK;
+}
+
+static int fgr_check_args(pcr_context *ctx, const pcr_fgr_option *opt, int64_t ns, int64_t nt) {
+    if (!opt || ns < 0 || nt < 0) return PCR_EINVAL;
+    if (ns > 0x7fffffff / 8 || nt > 0x7fffffff / 8) { ctx->err = "cloud too large"; return PCR_EINVAL; }
     if (!(opt->maximum_correspondence_distance > 0.0)) { ctx->err = "maximum_correspondence_distance <= 0"; return PCR_EINVAL; }
-    return pcr_evaluate_registration(ctx, src_xyz, ns, tgt_xyz, nt, opt->maximum_correspondence_distance, Tsrc2tgt, result, correspondences);
+    return PCR_OK;
+}
+
+extern "C" int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, const float *src_feat, int64_t ns, const float *tgt_xyz,
+                                    const float *tgt_feat, int64_t nt, const pcr_fgr_option *opt, pcr_result *result, int32_t *correspondences) {
+    return pcr_api_call(ctx, [&]() -> int {
+    if (!result) return PCR_EINVAL;
+    PCR_TRY(fgr_check_args(ctx, opt, ns, nt));
+    if ((ns > 0 && (!src_xyz || !src_feat)) || (nt > 0 && (!tgt_xyz || !tgt_feat))) return PCR_EINVAL;
+    double Tsrc2tgt[16];
+    PCR_TRY(pcr_arena_reserve(ctx, fgr_scratch_bytes(ns, nt, opt)));
+    PCR_TRY(fgr_pose(ctx, src_xyz, src_feat, ns, tgt_xyz, tgt_feat, nt, opt, Tsrc2tgt));
+    // ---- EvaluateRegistration(source, target, maximum_correspondence_distance, T)
+    return pcr_evaluate_registration_impl(ctx, src_xyz, ns, tgt_xyz, nt, opt->maximum_correspondence_distance, Tsrc2tgt, result, correspondences);
+    });
+}
+
+// ---- registro_FGR in one call (ALL_FUNCTIONS.py:178-203): every cloud is sorted and indexed once; its tree serves the hybrid
+// normals, the FPFH neighbour lists and (target) the final evaluate_registration
+int pcr_registro_fgr_impl(pcr_context *ctx, const float *src_xyz, const float *src_prior, int64_t ns, const float *tgt_xyz, const float *tgt_prior, int64_t nt,
+                          const pcr_fgr_params *p, float *src_normals_out, float *tgt_normals_out, pcr_result *result, int32_t *correspondences) {
+    if (!p || !result) return PCR_EINVAL;
+    PCR_TRY(fgr_check_args(ctx, &p->option, ns, nt));
+    if ((ns > 0 && !src_xyz) || (nt > 0 && !tgt_xyz)) return PCR_EINVAL;
+    if (p->normal_max_nn < 1 || !(p->normal_radius > 0.0)) { ctx->err = "estimate_normals: radius <= 0 or max_nn < 1"; return PCR_EINVAL; }
+    const int fk = p->feature_max_nn > 0 && p->feature_max_nn <= 200 ? p->feature_max_nn : 1;
+    const size_t per_cloud = fpfh_scratch_bytes(ns > nt ? ns : nt, fk);
+    const size_t fgr_b = fgr_scratch_bytes(ns, nt, &p->option);
+    PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(ns) + pcr_scratch_bytes_for(nt) + (size_t)(ns + nt + 2) * (33 * 4 + 16 + 8) + (per_cloud > fgr_b ? per_cloud : fgr_b)));
+    DevCloud c[2]; uint32_t *perm[2] = {nullptr, nullptr}; float *feat[2];
+    const float *xyz[2] = {src_xyz, tgt_xyz}, *prior[2] = {src_prior, tgt_prior}; float *nout[2] = {src_normals_out, tgt_normals_out};
+    const int64_t n[2] = {ns, nt};
+    for (int k = 0; k < 2; k++) {
+        PCR_TRY(pcr_import_cloud(ctx, xyz[k], prior[k], n[k], &c[k], &perm[k], true));
+        float4 *nrm_new = arena<float4>(ctx, n[k] > 0 ? n[k] : 1);
+        feat[k] = arena<float>(ctx, (size_t)(n[k] > 0 ? n[k] : 1) * 33);
+        if (!nrm_new || !feat[k]) return PCR_ENOMEM;
+        if (n[k] == 0) continue;
+        PCR_TRY(pcr_dev_normals(ctx, &c[k], PCR_SEARCH_HYBRID, p->normal_max_nn, p->normal_radius, prior[k] ? c[k].nrm : nullptr, nrm_new, nullptr));
+        c[k].nrm = nrm_new;
+        if (nout[k]) PCR_TRY(pcr_dev_scatter_rows_f4_to_f3(ctx, nrm_new, perm[k], c[k].n, c[k].cap, nout[k]));
+        PCR_TRY(fpfh_of_cloud(ctx, c[k], perm[k], n[k], PCR_SEARCH_HYBRID, p->feature_max_nn, p->feature_radius, feat[k]));
+    }
+    double T[16];
+    PCR_TRY(fgr_pose(ctx, src_xyz, feat[0], ns, tgt_xyz, feat[1], nt, &p->option, T));
+    int32_t *match = arena<int32_t>(ctx, ns > 0 ? ns : 1);
+    if (!match) return PCR_ENOMEM;
+    PCR_TRY(pcr_dev_evaluate(ctx, &c[0], &c[1], p->option.maximum_correspondence_distance, T, result, match, nullptr));
+    for (int k = 0; k < 16; k++) result->transformation[k] = T[k];
+    if (correspondences) {
+        int64_t nc = 0;
+        PCR_TRY(pcr_dev_compact_matches(ctx, match, c[0].n, c[0].cap, perm[0], perm[1], correspondences, &nc));
+    }
+    return PCR_OK;
+}
+
+extern "C" int pcr_registro_fgr(pcr_context *ctx, const float *src_xyz, const float *src_prior, int64_t ns, const float *tgt_xyz, const float *tgt_prior, int64_t nt,
+                                const pcr_fgr_params *p, float *src_normals_out, float *tgt_normals_out, pcr_result *result, int32_t *correspondences) {
+    return pcr_api_call(ctx, [&]() -> int { return pcr_registro_fgr_impl(ctx, src_xyz, src_prior, ns, tgt_xyz, tgt_prior, nt, p, src_normals_out, tgt_normals_out, result, correspondences); });
 }

@@ -769,7 +769,7 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
         a.verify = getenv("PCR_ICP_VERIFY") ? 1 : 0;
     }
     IcpInit in; memcpy(in.T, T0, sizeof in.T);
-    hipLaunchKernelGGL(k_icp_init, dim3(1), dim3(64), 0, ctx->stream, st, in);
+    PCR_LAUNCH(ctx, k_icp_init, dim3(1), dim3(64), 0, ctx->stream, st, in);
     const char *stamp_path = getenv("PCR_ICP_STAMPS");          // diagnostics only
     const size_t sw_nn = (size_t)ICP_STAMP_LAUNCHES * nbnn * (ICP_BS / 64) * 2, sw_it = (size_t)ICP_STAMP_LAUNCHES * nbmax * (LIN_BS / 64) * 12;
     if (stamp_path) {
@@ -789,10 +789,10 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     // launch 0 of a scale searches every query (cold): two kernels at full occupancy; later launches: the fused kernel
     const bool fused = use_fused && a.ref && !use_cov && !stamp_path && nbf <= 4096;
     auto enqueue = [&](int launch_index) {
-        if (fused && launch_index > 0) { hipLaunchKernelGGL(k_icp_fused, dim3(nbf), dim3(FUSED_BS), 0, ctx->stream, a); return; }
-        hipLaunchKernelGGL(k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
-        if (use_cov) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP_COV>), dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP>), dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
+        if (fused && launch_index > 0) { PCR_LAUNCH(ctx, k_icp_fused, dim3(nbf), dim3(FUSED_BS), 0, ctx->stream, a); return; }
+        PCR_LAUNCH(ctx, k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
+        if (use_cov) PCR_LAUNCH(ctx, k_icp_iter<ICP_MODE_GICP_COV>, dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
+        else PCR_LAUNCH(ctx, k_icp_iter<ICP_MODE_GICP>, dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
     };
     hipGraphExec_t chunk_exec[2] = {nullptr, nullptr};          // [0]: the chunk that starts with launch 0, [1]: every later chunk
     if (use_graph && !stamp_path) {
@@ -808,7 +808,11 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
                 PCR_HIP_CHECK(ctx, hipStreamEndCapture(ctx->stream, &graph));
                 PCR_HIP_CHECK(ctx, hipGraphInstantiate(&chunk_exec[which], graph, nullptr, nullptr, 0));
                 (void)hipGraphDestroy(graph);
-                if (ctx->icp_graphs.size() >= 32) { (void)hipGraphExecDestroy(ctx->icp_graphs.front().second); ctx->icp_graphs.erase(ctx->icp_graphs.begin()); }
+                if (ctx->icp_graphs.size() >= 32) {           // evict the oldest entry this call does not use itself
+                    size_t victim = 0;
+                    while (victim < ctx->icp_graphs.size() && ctx->icp_graphs[victim].second == chunk_exec[0]) victim++;
+                    if (victim < ctx->icp_graphs.size()) { (void)hipGraphExecDestroy(ctx->icp_graphs[victim].second); ctx->icp_graphs.erase(ctx->icp_graphs.begin() + victim); }
+                }
                 ctx->icp_graphs.emplace_back(std::move(key), chunk_exec[which]);
             }
         }
@@ -887,9 +891,9 @@ int pcr_dev_linearize_once(pcr_context *ctx, const DevCloud *src, const DevCloud
     if (!st || !partials || !match) return PCR_ENOMEM;
     IcpArgs a; memset(&a, 0, sizeof a); fill_args(a, src, tgt, max_dist, p, match, st, partials, 1);
     IcpInit in; memcpy(in.T, T, sizeof in.T);
-    hipLaunchKernelGGL(k_icp_init, dim3(1), dim3(64), 0, ctx->stream, st, in);
-    hipLaunchKernelGGL(k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_GICP>), dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
+    PCR_LAUNCH(ctx, k_icp_init, dim3(1), dim3(64), 0, ctx->stream, st, in);
+    PCR_LAUNCH(ctx, k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
+    PCR_LAUNCH(ctx, k_icp_iter<ICP_MODE_GICP>, dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
     IcpState h;
     PCR_TRY(read_state(ctx, st, &h));
     int t = 0;
@@ -912,9 +916,9 @@ int pcr_dev_evaluate(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt,
     if (!st || !partials || !match) return PCR_ENOMEM;
     IcpArgs a; memset(&a, 0, sizeof a); fill_args(a, src, tgt, max_dist, nullptr, match, st, partials, 1);
     IcpInit in; memcpy(in.T, T, sizeof in.T);
-    hipLaunchKernelGGL(k_icp_init, dim3(1), dim3(64), 0, ctx->stream, st, in);
-    hipLaunchKernelGGL(k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_icp_iter<ICP_MODE_EVAL>), dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
+    PCR_LAUNCH(ctx, k_icp_init, dim3(1), dim3(64), 0, ctx->stream, st, in);
+    PCR_LAUNCH(ctx, k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
+    PCR_LAUNCH(ctx, k_icp_iter<ICP_MODE_EVAL>, dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
     IcpState h;
     PCR_TRY(read_state(ctx, st, &h));
     if (out) { state_to_result(h, out); out->iterations = 0; out->converged = 0; }
@@ -948,9 +952,9 @@ int pcr_dev_compact_matches(pcr_context *ctx, const int32_t *match, const int *n
     int *total = arena<int>(ctx, 1);
     if (!flags || !pos || !total) return PCR_ENOMEM;
     const int nb = (cap + 255) / 256;
-    hipLaunchKernelGGL(k_match_flags, dim3(nb), dim3(256), 0, ctx->stream, match, n, flags);
+    PCR_LAUNCH(ctx, k_match_flags, dim3(nb), dim3(256), 0, ctx->stream, match, n, flags);
     PCR_TRY(pcr_dev_flag_scan(ctx, flags, n, cap, pos, total));
-    hipLaunchKernelGGL(k_match_emit, dim3(nb), dim3(256), 0, ctx->stream, match, n, flags, pos, src_perm, tgt_perm, corr_out);
+    PCR_LAUNCH(ctx, k_match_emit, dim3(nb), dim3(256), 0, ctx->stream, match, n, flags, pos, src_perm, tgt_perm, corr_out);
     if (n_corr) PCR_TRY(pcr_read_count(ctx, total, n_corr));
     return PCR_OK;
 }

@@ -17,15 +17,45 @@ struct pcr_context {
     hipEvent_t lane_ev[8] = {};   // [ring slot][cloud]: prepared cloud ready
     char *arena = nullptr;
     size_t arena_cap = 0, arena_off = 0;
+    char *aux = nullptr;           // side buffer that outlives the arena within one pair of a plan (normals left by registro_FGR)
+    size_t aux_cap = 0;
     char *pinned = nullptr;        // host-pinned read-back window
     size_t pinned_cap = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
     int profiling = 0;             // bench instrumentation (pcr_profile_*)
-    double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [0..7] GICP loop (pcr_hip.h), [8..10] feature matching: ms, flops, launches
     std::vector<hipEvent_t> prof_events;
     std::vector<std::pair<std::string, hipGraphExec_t>> icp_graphs;   // captured launch chunks of the GICP loop, keyed by their arguments
     std::string err;
+    // The caller's stream is the legacy default stream (pcr_set_stream(ctx, NULL), torch's default stream): the work runs on the
+    // context's own stream (graph capture is not allowed on the legacy stream) and every call is fenced against the
+    // default stream on both sides: own stream waits for what the caller has enqueued, the default stream waits for the call.
+    bool fence_default = false;
+    hipEvent_t fence_ev[2] = {nullptr, nullptr};
+    // first failed kernel launch of the current call (hipGetLastError after every launch); reported by pcr_leave
+    hipError_t launch_err = hipSuccess;
+    const char *launch_file = nullptr; int launch_line = 0;
 };
+
+// every extern "C" entry point runs its body between these two (pcr_api.hip): device, stream, fences, launch errors
+int pcr_enter(pcr_context *ctx);
+int pcr_leave(pcr_context *ctx, int rc);
+template <class F> static inline int pcr_api_call(pcr_context *ctx, F &&body) {
+    const int rc = pcr_enter(ctx);
+    if (rc != PCR_OK) return rc;
+    return pcr_leave(ctx, body());
+}
+
+// kernel launch + hipGetLastError: a failed launch (bad grid, missing code object, out of resources) is remembered in the
+// context and turns the call's status into PCR_EHIP instead of surfacing later as a wrong result or a timeout
+template <class... KArgs, class... Args>
+static inline void pcr_launch(pcr_context *ctx, const char *file, int line, void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem,
+                              hipStream_t stream, Args &&...args) {
+    hipLaunchKernelGGL(kernel, grid, block, shmem, stream, static_cast<KArgs>(args)...);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess && ctx->launch_err == hipSuccess) { ctx->launch_err = e; ctx->launch_file = file; ctx->launch_line = line; }
+}
+#define PCR_LAUNCH(ctx, ...) pcr_launch(ctx, __FILE__, __LINE__, __VA_ARGS__)
 
 #define PCR_HIP_CHECK(ctx, expr)                                                                   \
     do {                                                                                           \
@@ -123,6 +153,11 @@ int pcr_dev_gather_f3_to_f4(pcr_context *ctx, const float *src_packed, const uin
 int pcr_alloc_cloud(pcr_context *ctx, DevCloud *c, int cap, bool with_nrm, bool with_tree);
 // Morton-sorted copy of a caller cloud (+ optional normals) with its octree; perm maps sorted -> caller index
 int pcr_import_cloud(pcr_context *ctx, const float *xyz, const float *nrm, int64_t n, DevCloud *c, uint32_t **perm_out, bool force_nrm);
+
+int pcr_registro_fgr_impl(pcr_context *ctx, const float *src_xyz, const float *src_prior, int64_t ns, const float *tgt_xyz, const float *tgt_prior, int64_t nt,
+                          const pcr_fgr_params *p, float *src_normals_out, float *tgt_normals_out, pcr_result *result, int32_t *correspondences);
+int pcr_evaluate_registration_impl(pcr_context *ctx, const float *src_xyz, int64_t n_src, const float *tgt_xyz, int64_t n_tgt,
+                                   double max_dist, const double *T, pcr_result *result, int32_t *correspondences);
 
 // ---- gicp (pcr_gicp.hip) --------------------------------------------------------------------------
 struct IcpOutputs { pcr_result res; };

@@ -10,15 +10,13 @@ module-level code with hard-wired constants, as functions with the same data flo
 
 Pair i registers cloud i+1 onto cloud i; the last pair closes the loop (cloud 0 onto cloud n-1).  Pairs are independent:
 under `torch.distributed` every rank takes a contiguous block of them (`sharding.partition`), keeps `inflight` pairs in
-flight on its GPU (host threads, one HIP stream each) and ONE all-gather leaves the ordered pose table on every rank.
+flight on its GPU (library worker threads: `pcr_register_pairs_plan`) and ONE all-gather leaves the ordered pose table on every rank.
 Nothing here is on the measured hot path; it only feeds it.
 """
 from __future__ import annotations
 
 import os
-import threading
 import time
-from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -30,27 +28,6 @@ def load_circuit(cloud_dir: str, n_clouds: int, pattern: str = "s{i}.pcd", indic
     """`{i: PointCloud}` for the requested cloud indices (all by default): `o3d.io.read_point_cloud(f".../s{i}.pcd")`."""
     want = range(n_clouds) if indices is None else sorted(set(indices))
     return {i: PointCloud(io.read_pcd_xyz(os.path.join(cloud_dir, pattern.format(i=i)))) for i in want}
-
-
-def _run_pairs(pair_indices, job, inflight: int):
-    """Run job(i) for every pair index with `inflight` host threads, each on its own stream."""
-    import torch
-    tls = threading.local()
-    dev = torch.cuda.current_device()
-
-    def init():
-        torch.cuda.set_device(dev)
-        tls.stream = torch.cuda.Stream()
-
-    def run(i):
-        with torch.cuda.stream(tls.stream):
-            t0 = time.perf_counter()
-            r = job(i)
-            torch.cuda.current_stream().synchronize()
-            return i, r, time.perf_counter() - t0
-
-    with ThreadPoolExecutor(max_workers=max(1, inflight), initializer=init) as pool:
-        return list(pool.map(run, list(pair_indices)))
 
 
 def _shard(n_pairs: int):
@@ -83,13 +60,17 @@ def stage1_fgr(cloud_dir: str, out_dir: str, n_clouds: int, voxel_size: float = 
     mine, rank = _shard(n_clouds)
     clouds = load_circuit(cloud_dir, n_clouds, pattern, _clouds_of(mine, n_clouds))
 
-    def job(i):
-        s, t = sharding.circuit_pair(i, n_clouds)
-        if verbose:
+    # one library call for the rank's whole block of pairs (stage FGR): the library keeps `inflight` of them in flight
+    from . import registration as reg
+    mine = list(mine)
+    batch = [(clouds[sharding.circuit_pair(i, n_clouds)[0]], clouds[sharding.circuit_pair(i, n_clouds)[1]], None) for i in mine]
+    if verbose:
+        for i in mine:
+            s, t = sharding.circuit_pair(i, n_clouds)
             print(f"Registering cloud {s} in cloud {t}")
-        return functions.script1.registro_FGR(clouds[s], clouds[t], voxel_size, seed=None if seed is None else seed + i)
-
-    table = _gather(_run_pairs(mine, job, inflight), n_clouds)
+    res = reg.register_pairs_plan(batch, "fgr", inflight=inflight, fgr_voxel_size=voxel_size, fgr_use_absolute_scale=False,
+                                  fgr_seed=None if seed is None else seed + (mine[0] if mine else 0))
+    table = _gather([(i, r, 0.0) for i, r in zip(mine, res)], n_clouds)
     poses = [r["transformation"] for r in table]
     if rank == 0 and out_dir:
         os.makedirs(out_dir, exist_ok=True)

@@ -22,8 +22,12 @@ KNN_NORMAIS = 20         # ALL_FUNCTIONS.py:301, 2_MGICP...py:152
 
 
 # ------------------------------------------------------------------------------- ALL_FUNCTIONS.py variants
-def registro_FGR(source, target, voxel_size, _use_absolute_scale=True, seed=None):
-    """ALL_FUNCTIONS.py:178-203.  Mutates ``source``/``target`` (adds normals), like the reference."""
+def registro_FGR(source, target, voxel_size, _use_absolute_scale=True, seed=None, stepwise=False):
+    """ALL_FUNCTIONS.py:178-203.  Mutates ``source``/``target`` (adds normals), like the reference.  One library call
+    (``pcr_registro_fgr``: each cloud is sorted and indexed once); ``stepwise=True`` replays the reference's five Open3D
+    calls through the stand-ins instead (tests compare the two)."""
+    if not stepwise:
+        return _r.registro_fgr(source, target, voxel_size, _use_absolute_scale, seed)
     n_pontos = int((len(source.points) + len(target.points)) / 2)
     kd_tree_normais = _g.KDTreeSearchParamHybrid(radius=2 * voxel_size, max_nn=20)
     source.estimate_normals(kd_tree_normais)
@@ -142,9 +146,9 @@ class script1:
     """Private copies in 1_FGR_pairwise_registration_in_NCLT_dataset.py."""
 
     @staticmethod
-    def registro_FGR(source, target, voxel_size, seed=None):
+    def registro_FGR(source, target, voxel_size, seed=None, stepwise=False):
         """Script 1:41-66: identical to the library version except ``use_absolute_scale=False`` (:54)."""
-        return registro_FGR(source, target, voxel_size, _use_absolute_scale=False, seed=seed)
+        return registro_FGR(source, target, voxel_size, _use_absolute_scale=False, seed=seed, stepwise=stepwise)
 
 
 class script2:

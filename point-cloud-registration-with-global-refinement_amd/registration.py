@@ -194,64 +194,159 @@ def multiscale_gicp(source: PointCloud, target: PointCloud, voxel_sizes, max_cor
         vox.ctypes.data_as(C.POINTER(C.c_double)), dst.ctypes.data_as(C.POINTER(C.c_double)), C.c_int(vox.size),
         C.c_int(nb_neighbors), C.c_double(std_ratio), C.c_int(normal_knn), Tp, C.byref(p), recs, _ptr(corr)),
         "multiscale_gicp")
-    scales = [dict(voxel=float(vox[i]), max_dist=float(dst[i]), n_voxel=tuple(recs[i].n_voxel), n_clean=tuple(recs[i].n_clean),
-                   iterations=int(recs[i].icp.iterations), fitness=recs[i].icp.fitness, inlier_rmse=recs[i].icp.inlier_rmse,
-                   converged=bool(recs[i].icp.converged), n_corr=int(recs[i].icp.n_correspondences),
-                   T=np.array(recs[i].icp.transformation).reshape(4, 4)) for i in range(vox.size)]
+    scales = _scale_dicts(recs, vox, dst)
     return _result(recs[vox.size - 1].icp, corr, scales)
 
 
-def register_pairs(pairs, voxel_sizes, max_correspondence_distances, estimation_method=None, criteria=None, nb_neighbors: int = 30,
-                   std_ratio: float = 1.0, normal_knn: int = 20, inflight: int = 3, with_correspondences: bool = True) -> list:
-    """The per-pair loops of the reference (2_MGICP...py:187-214, ALL_FUNCTIONS.py:349-392) as ONE library call:
-    `pairs` = [(source PointCloud, target PointCloud, initial 4x4), ...]; every pair gets the body of ``multiscale_gicp``
-    and the library keeps ``inflight`` of them in flight on the current device (worker threads, contexts and streams
-    are its own).  Returns the RegistrationResults in input order; a failed pair raises RuntimeError naming it."""
+_fgr_seed_counter = [0x9E3779B97F4A7C15]
+
+
+def _scale_dicts(recs, vox, dst):
+    return [dict(voxel=float(vox[i]), max_dist=float(dst[i]), n_voxel=tuple(recs[i].n_voxel), n_clean=tuple(recs[i].n_clean),
+                 iterations=int(recs[i].icp.iterations), fitness=recs[i].icp.fitness, inlier_rmse=recs[i].icp.inlier_rmse,
+                 converged=bool(recs[i].icp.converged), n_corr=int(recs[i].icp.n_correspondences),
+                 T=np.array(recs[i].icp.transformation).reshape(4, 4)) for i in range(len(vox))]
+
+
+def _fgr_params(voxel_size: float, use_absolute_scale: bool, n_pontos: int, seed) -> _lib.PcrFgrParams:
+    """The constants of ``registro_FGR`` (ALL_FUNCTIONS.py:181-196 / 1_FGR...py:44-59) for one voxel size."""
+    if seed is None:                       # Open3D draws from std::random_device; here a process-local counter
+        _fgr_seed_counter[0] = (_fgr_seed_counter[0] * 6364136223846793005 + 1442695040888963407) & (2 ** 64 - 1)
+        seed = _fgr_seed_counter[0]
+    opt = _lib.PcrFgrOption(1.4, int(bool(use_absolute_scale)), 1, 2 * voxel_size, 300, 0.95, int(n_pontos * 0.2), 1, int(seed) & (2 ** 64 - 1))
+    return _lib.PcrFgrParams(2 * voxel_size, 20, 10 * voxel_size, 200, opt)
+
+
+def registro_fgr(source: PointCloud, target: PointCloud, voxel_size: float, use_absolute_scale: bool = True, seed=None) -> RegistrationResult:
+    """``registro_FGR`` (ALL_FUNCTIONS.py:178-203; script 1:41-66 with ``use_absolute_scale=False``) as ONE library call:
+    hybrid normals, FPFH, feature matching, tuple test, GNC optimisation and the final evaluation, every cloud sorted and
+    indexed once.  Like the reference it leaves normals on ``source`` and ``target``."""
+    ctx = _lib.Context.current()
+    torch = _torch()
+    ns, nt = len(source), len(target)
+    fp = _fgr_params(voxel_size, use_absolute_scale, int((ns + nt) / 2), seed)
+    corr = torch.empty((max(ns, 1), 2), dtype=torch.int32, device="cuda")
+    sno = torch.empty((max(ns, 1), 3), dtype=torch.float32, device="cuda")
+    tno = torch.empty((max(nt, 1), 3), dtype=torch.float32, device="cuda")
+    res = _lib.PcrResult()
+    ctx.check(ctx.lib.pcr_registro_fgr(ctx.handle, _ptr(source.device_xyz()), _ptr(source.device_normals() if source.has_normals() else None), C.c_int64(ns),
+                                       _ptr(target.device_xyz()), _ptr(target.device_normals() if target.has_normals() else None), C.c_int64(nt),
+                                       C.byref(fp), _ptr(sno), _ptr(tno), C.byref(res), _ptr(corr)), "registro_FGR")
+    if ns:
+        source._nrm = sno[:ns]
+    if nt:
+        target._nrm = tno[:nt]
+    return _result(res, corr)
+
+
+def register_pairs_plan(pairs, stage: str = "gicp", voxel_sizes=None, max_correspondence_distances=None, estimation_method=None, criteria=None,
+                        nb_neighbors: int = 30, std_ratio: float = 1.0, normal_knn: int = 20, inflight: int = 3, with_correspondences: bool = True,
+                        fgr_voxel_size: float = 0.1, fgr_use_absolute_scale: bool = True, fgr_seed=None, radius_rule: str = "given",
+                        prior_from_fgr: bool = False, info_max_dist: float = 0.0, keep_fgr_normals: bool = False) -> list:
+    """The per-pair loops of the reference as ONE library call (``pcr_register_pairs_plan``): `pairs` = [(source PointCloud,
+    target PointCloud, initial 4x4 or None), ...].
+
+    stage "fgr"       = script 1 (1_FGR...py:134-147): ``registro_FGR`` per pair;
+    stage "gicp"      = script 2 (2_MGICP...py:187-214): ``Multiscale_GICP`` from the given initial pose;
+    stage "fgr+gicp"  = ``Coarse_to_fine_FGR_M_GICP`` / ``full_registration`` (ALL_FUNCTIONS.py:317-332, 349-392).
+    radius_rule "af"  = search radii ``radius_from_cloud_pair * 2**-i`` per pair (ALL_FUNCTIONS.py:277-278) instead of the given list.
+    The library keeps ``inflight`` pairs in flight on the current device.  Returns RegistrationResults in input order (for
+    stages with FGR the FGR result is attached as ``.fgr``; ``.information`` when ``info_max_dist > 0``)."""
     estimation = estimation_method or TransformationEstimationForGeneralizedICP()
     criteria = criteria or ICPConvergenceCriteria()
     torch = _torch()
     lib = _lib.load()
     if not torch.cuda.is_available():
         raise RuntimeError("no HIP device visible to torch: the MI355X registration path cannot run (no CPU fallback)")
-    vox = np.ascontiguousarray(np.asarray(voxel_sizes, dtype=np.float64).reshape(-1))
-    dst = np.ascontiguousarray(np.asarray(max_correspondence_distances, dtype=np.float64).reshape(-1))
-    if vox.size != dst.size or vox.size < 1:
-        raise RuntimeError("register_pairs: voxel_sizes and max_correspondence_distances must have the same length >= 1")
+    stage_id = {"gicp": _lib.STAGE_GICP, "fgr": _lib.STAGE_FGR, "fgr+gicp": _lib.STAGE_FGR_GICP}[stage]
+    do_fgr, do_gicp = stage_id != _lib.STAGE_GICP, stage_id != _lib.STAGE_FGR
+    vox = np.ascontiguousarray(np.asarray(voxel_sizes if voxel_sizes is not None else [], dtype=np.float64).reshape(-1))
+    rule = {"given": 0, "af": 1}[radius_rule]
+    dst = np.ascontiguousarray(np.asarray(max_correspondence_distances if max_correspondence_distances is not None else np.zeros(vox.size), dtype=np.float64).reshape(-1))
+    if do_gicp and (vox.size < 1 or vox.size > 8 or dst.size != vox.size):
+        raise RuntimeError("register_pairs: voxel_sizes and max_correspondence_distances must have the same length (1..8)")
     n = len(pairs)
     if n == 0:
         return []
-    arr = (_lib.PcrPair * n)()
+    arr = (_lib.PcrPairEx * n)()
     keep = []                                   # device tensors and record arrays must outlive the call
     for k, (src, tgt, init) in enumerate(pairs):
-        recs = (_lib.PcrScaleRecord * vox.size)()
+        recs = (_lib.PcrScaleRecord * max(vox.size, 1))()
         corr = torch.empty((max(len(src), 1), 2), dtype=torch.int32, device="cuda") if with_correspondences else None
         sx, tx = src.device_xyz(), tgt.device_xyz()
         sn = src.device_normals() if src.has_normals() else None
         tn = tgt.device_normals() if tgt.has_normals() else None
-        keep.append((recs, corr, sx, tx, sn, tn))
-        a = arr[k]
+        sno = torch.empty((max(len(src), 1), 3), dtype=torch.float32, device="cuda") if (do_fgr and keep_fgr_normals) else None
+        tno = torch.empty((max(len(tgt), 1), 3), dtype=torch.float32, device="cuda") if (do_fgr and keep_fgr_normals) else None
+        keep.append((recs, corr, sx, tx, sn, tn, sno, tno))
+        a = arr[k].base
         a.src_xyz = sx.data_ptr(); a.src_normals = sn.data_ptr() if sn is not None else None; a.n_src = len(src)
         a.tgt_xyz = tx.data_ptr(); a.tgt_normals = tn.data_ptr() if tn is not None else None; a.n_tgt = len(tgt)
-        a.init_T[:] = list(np.asarray(init, dtype=np.float64).reshape(16))
+        a.init_T[:] = list(np.asarray(np.eye(4) if init is None else init, dtype=np.float64).reshape(16))
         a.records = C.cast(recs, C.POINTER(_lib.PcrScaleRecord)); a.correspondences = corr.data_ptr() if corr is not None else None
+        arr[k].src_normals_out = sno.data_ptr() if sno is not None else None
+        arr[k].tgt_normals_out = tno.data_ptr() if tno is not None else None
     p = _params(estimation, criteria)
+    plan = _lib.PcrPairsPlan()
+    plan.stage = stage_id
+    fp = None
+    if do_fgr:
+        n_pontos = int((len(pairs[0][0]) + len(pairs[0][1])) / 2)
+        if any(int((len(s) + len(t)) / 2) != n_pontos for s, t, _ in pairs):
+            # maximum_tuple_count depends on the pair's sizes (ALL_FUNCTIONS.py:179,196): one plan per distinct size
+            out = [None] * n
+            groups = {}
+            for k, (s, t, _) in enumerate(pairs):
+                groups.setdefault(int((len(s) + len(t)) / 2), []).append(k)
+            for ks in groups.values():
+                sub = register_pairs_plan([pairs[k] for k in ks], stage, voxel_sizes, max_correspondence_distances, estimation, criteria, nb_neighbors,
+                                          std_ratio, normal_knn, inflight, with_correspondences, fgr_voxel_size, fgr_use_absolute_scale,
+                                          None if fgr_seed is None else fgr_seed + ks[0], radius_rule, prior_from_fgr, info_max_dist, keep_fgr_normals)
+                for k, r in zip(ks, sub):
+                    out[k] = r
+            return out
+        fp = _fgr_params(fgr_voxel_size, fgr_use_absolute_scale, n_pontos, fgr_seed)
+        plan.fgr = C.pointer(fp)
+    plan.voxel_sizes = vox.ctypes.data_as(C.POINTER(C.c_double)); plan.max_distances = dst.ctypes.data_as(C.POINTER(C.c_double))
+    plan.n_scales = int(vox.size); plan.radius_rule = rule
+    plan.sor_k = int(nb_neighbors); plan.sor_std = float(std_ratio); plan.normal_k = int(normal_knn)
+    plan.gicp = C.pointer(p); plan.gicp_prior_from_fgr = int(bool(prior_from_fgr)); plan.info_max_dist = float(info_max_dist); plan.inflight = int(inflight)
     dev = torch.cuda.current_device()
-    rc = lib.pcr_register_pairs(C.c_int(dev), arr, C.c_int(n), vox.ctypes.data_as(C.POINTER(C.c_double)), dst.ctypes.data_as(C.POINTER(C.c_double)),
-                                C.c_int(vox.size), C.c_int(nb_neighbors), C.c_double(std_ratio), C.c_int(normal_knn), C.byref(p), C.c_int(inflight),
-                                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    rc = lib.pcr_register_pairs_plan(C.c_int(dev), arr, C.c_int(n), C.byref(plan), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     out = []
     for k in range(n):
-        if arr[k].status != 0:
-            raise RuntimeError(f"register_pairs: pair {k} failed with code {arr[k].status}: {arr[k].error.decode(errors='replace')}")
-        recs, corr = keep[k][0], keep[k][1]
-        scales = [dict(voxel=float(vox[i]), max_dist=float(dst[i]), n_voxel=tuple(recs[i].n_voxel), n_clean=tuple(recs[i].n_clean),
-                       iterations=int(recs[i].icp.iterations), fitness=recs[i].icp.fitness, inlier_rmse=recs[i].icp.inlier_rmse,
-                       converged=bool(recs[i].icp.converged), n_corr=int(recs[i].icp.n_correspondences),
-                       T=np.array(recs[i].icp.transformation).reshape(4, 4)) for i in range(vox.size)]
-        out.append(_result(recs[vox.size - 1].icp, corr if corr is not None else torch.empty((0, 2), dtype=torch.int32, device="cuda"), scales))
-    if rc != 0 and all(a.status == 0 for a in arr):
+        b = arr[k].base
+        if b.status != 0:
+            raise RuntimeError(f"register_pairs: pair {k} failed with code {b.status}: {b.error.decode(errors='replace')}")
+        recs, corr, sno, tno = keep[k][0], keep[k][1], keep[k][6], keep[k][7]
+        empty = torch.empty((0, 2), dtype=torch.int32, device="cuda")
+        if do_gicp:
+            used = np.array(arr[k].max_distances[: vox.size]) if rule == 1 else dst
+            r = _result(recs[vox.size - 1].icp, corr if corr is not None else empty, _scale_dicts(recs, vox, used))
+        else:
+            r = _result(arr[k].fgr, corr if corr is not None else empty)
+        if do_fgr:
+            r.fgr = _result(arr[k].fgr, None)
+            if keep_fgr_normals:              # the reference's side effect: both inputs gain normals
+                src, tgt, _ = pairs[k]
+                if len(src):
+                    src._nrm = sno[: len(src)]
+                if len(tgt):
+                    tgt._nrm = tno[: len(tgt)]
+        if info_max_dist > 0:
+            r.information = np.array(arr[k].info36, dtype=np.float64).reshape(6, 6)
+        out.append(r)
+    if rc != 0:
         raise RuntimeError(f"register_pairs failed with code {rc}")
     return out
+
+
+def register_pairs(pairs, voxel_sizes, max_correspondence_distances, estimation_method=None, criteria=None, nb_neighbors: int = 30,
+                   std_ratio: float = 1.0, normal_knn: int = 20, inflight: int = 3, with_correspondences: bool = True) -> list:
+    """The per-pair loop of script 2 (2_MGICP...py:187-214) as ONE library call: every pair gets the body of ``multiscale_gicp``
+    from its initial pose; see ``register_pairs_plan``."""
+    return register_pairs_plan(pairs, "gicp", voxel_sizes, max_correspondence_distances, estimation_method, criteria, nb_neighbors, std_ratio,
+                               normal_knn, inflight, with_correspondences)
 
 
 def evaluate_registration(source: PointCloud, target: PointCloud, max_correspondence_distance: float,
@@ -293,9 +388,6 @@ def compute_fpfh_feature(cloud: PointCloud, search_param) -> Feature:
     ctx.check(ctx.lib.pcr_compute_fpfh_feature(ctx.handle, _ptr(cloud.device_xyz()), _ptr(cloud.device_normals()), C.c_int64(n),
                                                C.c_int(kind), C.c_int(knn), C.c_double(radius), _ptr(feat)), "compute_fpfh_feature")
     return Feature(feat[:n].contiguous())
-
-
-_fgr_seed_counter = [0x9E3779B97F4A7C15]
 
 
 def registration_fgr_based_on_feature_matching(source: PointCloud, target: PointCloud, source_feature: Feature,

@@ -246,3 +246,22 @@ def tile_pair(p: SyntheticPair, copies: int, pitch: float = 260.0, n_scales: int
     src = mov @ Ti[:3, :3].T + Ti[:3, 3]
     vox, dst = (p.voxel_sizes, p.max_distances_script) if n_scales is None else _scales(n_scales)
     return SyntheticPair(src.astype(np.float32), tgt.astype(np.float32), p.T_true, p.T_init, vox, dst)
+
+
+def derive_pair(p: SyntheticPair, k: int, seed: int = SEED) -> SyntheticPair:
+    """Distinct pair number k from a generated pair in milliseconds (the generator needs ~20 s per pair): BOTH clouds are moved by
+    the same rigid motion G_k (yaw about the sensor axis and a shift in the ground plane), so the scene is seen at another
+    heading and lands differently on every voxel grid, and the points are re-ordered.  The planted motion and the start become
+    G T G^-1.  k = 0 is the pair itself."""
+    if k == 0:
+        return p
+    rng = np.random.default_rng([seed, 77, k])
+    G = np.eye(4)
+    G[:3, :3] = _rot([0, 0, 1], rng.uniform(0, 2 * np.pi))
+    G[:2, 3] = rng.uniform(-15.0, 15.0, 2)
+    Gi = np.linalg.inv(G)
+
+    def move(x):
+        x = x.astype(np.float64) @ G[:3, :3].T + G[:3, 3]
+        return x[rng.permutation(len(x))].astype(np.float32)
+    return SyntheticPair(move(p.source), move(p.target), G @ p.T_true @ Gi, G @ p.T_init @ Gi, p.voxel_sizes, p.max_distances_script)

@@ -21,6 +21,12 @@ def _run(args, env=None):
 
 def test_bench_json_contract():
     d = _run(["--steps", "1", "--warmup", "1", "--pairs-per-step", "8"])
+    assert d["n_ranks_seen"] == 1 and d["config"]["distinct_pairs"] == 8 and d["roofline"]["traffic"] is None
+    ex = d["extras"]
+    for k in ("gicp_af_radius_rule", "fgr_plus_gicp", "config5_2M_points_5_scales_64nn"):
+        assert k in ex and "error" not in ex[k], (k, ex.get(k))
+        assert ex[k]["pairs_per_s"] > 0 and ex[k]["err_vs_planted"]["rad"] < 2e-3 and ex[k]["err_vs_planted"]["m"] < 2e-2, (k, ex[k])
+    assert ex["fgr_plus_gicp"]["roofline"]["bound"] == "mfma" and ex["fgr_plus_gicp"]["roofline"]["achieved"] > 0
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline"):
         assert k in d, k
@@ -48,3 +54,9 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["gathered_records"] == 12 and "cpu_baseline" not in d
+
+
+def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
+    """`python bench.py --gpus 2` (no torchrun around it): bench.py starts the ranks itself; both share device 0 here."""
+    d = _run(["--gpus", "2", "--steps", "1", "--warmup", "1", "--pairs-per-step", "4", "--no-cpu-baseline"], env={"PCR_BENCH_REHEARSE": "1"})
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["config"]["gathered_records"] == 8

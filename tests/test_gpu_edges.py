@@ -122,3 +122,57 @@ def test_calls_that_must_fail_loudly(P, small_pair):
     # an empty cloud in a batch reports an error for that pair only
     res = P.registration.register_pairs([(src, tgt, np.eye(4))], [0.4], [1.2], est, crit)
     assert np.isfinite(res[0].transformation).all()
+
+
+def test_calls_are_ordered_after_torch_work_on_the_default_stream(P, oracle, small_pair):
+    """torch's default stream is the legacy NULL stream while the library works on a stream of its own: every call must wait
+    for the torch kernels that produce its inputs (deepcopy = clone, transform = matmul, float conversions), and torch work
+    enqueued after an asynchronous call (estimate_normals returns without a host sync) must see its outputs.  A missing fence
+    shows up as a voxel grid / normals of half-written buffers."""
+    import copy
+    import torch
+    rng = np.random.default_rng(11)
+    base = np.concatenate([small_pair["source"] + rng.normal(0, 3.0, 3).astype(np.float32) for _ in range(40)])   # ~600k points
+    T = np.eye(4); T[:3, :3] = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]]); T[:3, 3] = [5.0, -3.0, 1.0]
+    pc = P.PointCloud(base)
+    torch.cuda.synchronize()
+    for rep in range(4):
+        q = copy.deepcopy(pc)
+        q.transform(T)                                 # asynchronous torch kernels on the default stream ...
+        v = q.voxel_down_sample(0.7)                   # ... and a library call right behind them
+        ref = oracle.voxel_down_sample(q.points.astype(np.float32), 0.7)
+        assert len(v) == len(ref)
+        assert np.array_equal(_sorted_rows(v.points), _sorted_rows(ref.astype(np.float32))), rep
+    # asynchronous call followed by torch work on its output
+    small = P.PointCloud(base[:50000])
+    small.estimate_normals(P.KDTreeSearchParamKNN(knn=20))
+    doubled = (small._nrm * 2.0).cpu().numpy()         # default-stream kernel reading the normals just enqueued
+    torch.cuda.synchronize()
+    assert np.array_equal(doubled, small.normals.astype(np.float32) * 2.0)
+    assert np.allclose(np.linalg.norm(small.normals, axis=1), 1.0, atol=1e-5)
+
+
+def test_register_pairs_waits_for_the_producers_of_its_inputs(P, small_pair):
+    """pcr_register_pairs: the workers wait for the stream the inputs were produced on, also when that is the default (NULL)
+    stream.  Inputs made by torch kernels right before the call give the same poses as inputs that were synchronised first."""
+    import copy
+    import torch
+    est = P.registration.TransformationEstimationForGeneralizedICP(P.registration.L2Loss())
+    crit = P.registration.ICPConvergenceCriteria(1e-6, 1e-6, 20)
+    vox, dst = [0.4, 0.2], [1.2, 0.4]
+    T = np.eye(4); T[:3, 3] = [0.3, -0.2, 0.05]
+    src0, tgt0 = P.PointCloud(small_pair["source"]), P.PointCloud(small_pair["target"])
+
+    def inputs():
+        out = []
+        for k in range(6):
+            s = copy.deepcopy(src0); s.transform(T)
+            out.append((s, copy.deepcopy(tgt0), small_pair["T_fgr"] @ np.linalg.inv(T)))
+        return out
+    a = inputs()
+    torch.cuda.synchronize()
+    ref = P.registration.register_pairs(a, vox, dst, est, crit, inflight=3)
+    got = P.registration.register_pairs(inputs(), vox, dst, est, crit, inflight=3)       # no synchronisation in between
+    for r, g in zip(ref, got):
+        assert np.array_equal(r.transformation, g.transformation)
+        assert [s["n_clean"] for s in r.scales] == [s["n_clean"] for s in g.scales]

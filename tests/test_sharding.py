@@ -74,3 +74,25 @@ def test_gather_records_single_process_identity():
     assert list(out[:, 21]) == [0, 1, 2]
     with pytest.raises(RuntimeError):
         sh.gather_records(recs[:2], 3)
+
+
+def test_bench_gpus_2_launches_two_ranks_itself():
+    """`python bench.py --gpus 2` with NO launcher around it must start two ranks itself (round-1 finding: --gpus was parsed and
+    dropped, so the driver's N = 8 run would have been one rank).  PCR_BENCH_DRYRUN=1 keeps the GPU out of it: the launcher, the
+    rank environment, the gloo all-gather of the pose records, the barrier and the MAX-reduce run as in a real run."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PCR_BENCH_DRYRUN"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs-per-step", "5"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["dry_run"] is True
+    assert d["config"]["gathered_records"] == 2 * 2 * 5          # ranks x steps x pairs per step
+    # a launcher that started a different number of ranks than --gpus says is an error, not a silently smaller job
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], cwd=ROOT, env=env2, capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
