@@ -31,6 +31,9 @@ int orc_covariances_from_normals(const double *normals, int64_t n, double eps, d
     return ORC_OK;
 }
 
+static int64_t g_sum_chunk = 256;
+int orc_set_sum_chunk(int chunk) { int old = (int)g_sum_chunk; if (chunk >= 1) g_sum_chunk = chunk; return old; }
+
 static inline double loss_weight(int loss, double k, double r) {
     switch (loss) {
         case ORC_LOSS_L1: return 1.0 / fabs(r);
@@ -43,8 +46,10 @@ static inline double loss_weight(int loss, double k, double r) {
  * fixed chunks so that the sums are identical for every thread count.           */
 int orc_gicp_linearize(const double *src_xyz, const double *src_cov9, const double *tgt_xyz, const double *tgt_cov9,
                        const int32_t *corr, int64_t n_corr, int loss, double loss_k, double *JTJ, double *JTr, double *r2) {
-    /* fixed-size chunks summed in chunk order: the result does not depend on the thread count */
-    enum { CHUNK = 256 };
+    /* fixed-size chunks summed in chunk order: the result does not depend on the thread count.  The chunk size is a knob
+     * (orc_set_sum_chunk, default 256) ONLY so that tests can measure how far the L1-IRLS end pose moves when nothing but the
+     * float64 summation tree changes: that spread is the noise floor every device-vs-oracle L1 bound is derived from. */
+    const int64_t CHUNK = g_sum_chunk;
     int64_t n_chunks = (n_corr + CHUNK - 1) / CHUNK;
     double *part = (double *)calloc((size_t)(n_chunks > 0 ? n_chunks : 1) * 43, sizeof(double));
 #pragma omp parallel for schedule(static)

@@ -94,6 +94,30 @@ def set_num_threads(n: int) -> int:
     return lib().orc_set_num_threads(int(n))
 
 
+def set_sum_chunk(chunk: int) -> int:
+    """Size of the fixed summation chunks of the GICP normal equations (default 256); returns the previous value.  Changing it
+    changes NOTHING but the float64 summation tree -- tests use it to measure the L1-IRLS noise floor of the algorithm itself."""
+    return lib().orc_set_sum_chunk(int(chunk))
+
+
+def l1_spread(run, chunks=(64, 1024, 4096)):
+    """Poses of `run()` under the default and the given summation chunkings -> (default result, max rotation [rad] and translation
+    [m] distance of any variant from the default).  The reference's L1 weights 1/|r| make the end pose chaotic in the last bits
+    of the sums, so this spread -- not a hand-picked constant -- is what bounds a device-vs-oracle comparison on L1."""
+    base = run()
+    ang = dt = 0.0
+    for c in chunks:
+        old = set_sum_chunk(c)
+        try:
+            r = run()
+        finally:
+            set_sum_chunk(old)
+        A, B = base.transformation, r.transformation
+        ang = max(ang, float(2.0 * np.arcsin(min(1.0, np.linalg.norm(A[:3, :3] - B[:3, :3]) / (2.0 * np.sqrt(2.0))))))
+        dt = max(dt, float(np.linalg.norm(A[:3, 3] - B[:3, 3])))
+    return base, ang, dt
+
+
 def get_num_threads() -> int:
     return lib().orc_get_num_threads()
 
@@ -229,7 +253,7 @@ def multiscale_gicp(src_xyz, tgt_xyz, voxels, dists, T0, src_normals=None, tgt_n
     last = stats[vox.size - 1].icp
     out = _res(last, corr[: last.n_corr].copy())
     out.extra["scales"] = [dict(n_voxel=tuple(st.n_voxel), n_clean=tuple(st.n_clean), iterations=int(st.icp.iterations),
-                                fitness=st.icp.fitness, inlier_rmse=st.icp.inlier_rmse, converged=bool(st.icp.converged),
+                                fitness=st.icp.fitness, inlier_rmse=st.icp.inlier_rmse, converged=bool(st.icp.converged), n_corr=int(st.icp.n_corr),
                                 T=np.array(st.icp.T).reshape(4, 4)) for st in stats]
     return out
 

@@ -95,6 +95,8 @@ int orc_covariances_from_normals(const double *normals, int64_t n, double eps,
 /* One linearisation of TransformationEstimationForGeneralizedICP (A.6) on a
  * given correspondence set.  src_* must already be in the target frame.
  * JTJ: 36, JTr: 6, r2: 1.                                                     */
+/* test knob: size of the fixed summation chunks of orc_gicp_linearize (default 256); returns the previous value */
+int orc_set_sum_chunk(int chunk);
 int orc_gicp_linearize(const double *src_xyz, const double *src_cov9,
                        const double *tgt_xyz, const double *tgt_cov9,
                        const int32_t *corr, int64_t n_corr, int loss, double loss_k,

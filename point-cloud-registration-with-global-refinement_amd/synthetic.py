@@ -265,3 +265,25 @@ def derive_pair(p: SyntheticPair, k: int, seed: int = SEED) -> SyntheticPair:
         x = x.astype(np.float64) @ G[:3, :3].T + G[:3, 3]
         return x[rng.permutation(len(x))].astype(np.float32)
     return SyntheticPair(move(p.source), move(p.target), G @ p.T_true @ Gi, G @ p.T_init @ Gi, p.voxel_sizes, p.max_distances_script)
+
+
+def make_loop(p: SyntheticPair, n_clouds: int = 4, copies: int = 5, keep: float = 0.97, jitter: float = 0.003, seed: int = SEED):
+    """A closed circuit of `n_clouds` dense scans for BASELINE config 4 (the reference ships only two of the dense Courtyard scans):
+    the world is the target cloud of `p` tiled `copies` times (copies x 200k points); scan i is a random `keep` share of it with
+    `jitter` metres of isotropic noise, seen from the absolute pose A_i (A_0 = I, A_(i+1) = A_i M_i with NCLT-like motions M_i).
+    Returns (clouds, A, T_true, T_init): pair i registers scan i+1 onto scan i (T_true[i] = A_i^-1 A_(i+1)), the last pair closes
+    the loop (scan 0 onto scan n-1), T_init is the true relative pose perturbed by 0.5 deg / 0.15 m."""
+    rng = np.random.default_rng([seed, 4, n_clouds, copies])
+    world = tile_pair(p, copies).target.astype(np.float64)
+    A = [np.eye(4)]
+    for _ in range(n_clouds - 1):
+        A.append(A[-1] @ planted_motion(rng))
+    clouds = []
+    for i in range(n_clouds):
+        idx = np.nonzero(rng.random(len(world)) < keep)[0]
+        w = world[idx] + rng.normal(0.0, jitter, (len(idx), 3))
+        Ai = np.linalg.inv(A[i])
+        clouds.append((w @ Ai[:3, :3].T + Ai[:3, 3]).astype(np.float32))
+    T_true = [np.linalg.inv(A[i]) @ A[(i + 1) % n_clouds] for i in range(n_clouds)]
+    T_init = [perturbation(rng) @ T for T in T_true]
+    return clouds, A, T_true, T_init

@@ -35,15 +35,22 @@ def test_config2_counts_exact_and_l2_pose_matches_oracle(P, oracle, pair200k):
 
 
 def test_config2_reference_parameters_l1(P, oracle, pair200k):
-    """The benchmark configuration itself (L1, 1e-6/1e-6/100): against the oracle within the north-star tolerance where
-    the attractor allows (the L1 path is chaotic in the last bits, DESIGN.md 'Noise floor'), and against the planted motion."""
+    """The benchmark configuration itself (L1, 1e-6/1e-6/100) against the oracle.  The bound is DERIVED in the test: the oracle is
+    re-run on this very pair with other float64 summation chunkings (conftest.l1_tolerance); the device must agree with the oracle
+    within max(north-star tolerance 1e-4 rad / 1e-3 m, twice that measured spread), and both must recover the planted motion."""
+    from conftest import TOL_M, TOL_RAD, l1_tolerance
     p = pair200k
     est = P.registration.TransformationEstimationForGeneralizedICP(P.registration.L1Loss())
     crit = P.registration.ICPConvergenceCriteria(1e-6, 1e-6, 100)
     res = P.registration.multiscale_gicp(P.PointCloud(p.source), P.PointCloud(p.target), p.voxel_sizes, p.max_distances_script, p.T_init, est, crit)
-    ref = oracle.multiscale_gicp(p.source, p.target, p.voxel_sizes, p.max_distances_script, p.T_init, loss=oracle.LOSS_L1)
+    ref, tol_rad, tol_m, spread = l1_tolerance(oracle, lambda: oracle.multiscale_gicp(p.source, p.target, p.voxel_sizes, p.max_distances_script, p.T_init, loss=oracle.LOSS_L1),
+                                               chunks=(64, 1024, 4096))
     ang, dt = pose_error(res.transformation, ref.transformation)
-    assert ang < 3e-4 and dt < 5e-3, (ang, dt)
+    print(f"config 2 L1: device vs oracle {ang:.2e} rad {dt:.2e} m; oracle summation-order spread {spread[0]:.2e} rad {spread[1]:.2e} m")
+    assert ang <= tol_rad and dt <= tol_m, (ang, dt, spread)
+    assert tol_rad <= 1e-3 and tol_m <= 1e-2, spread       # the derived bound itself must stay meaningful
+    for a, b in zip(res.scales, ref.extra["scales"]):
+        assert a["n_voxel"] == tuple(b["n_voxel"]) and a["n_clean"] == tuple(b["n_clean"])
     for T in (res.transformation, ref.transformation):
         ang, dt = pose_error(T, p.T_true)
         assert ang < 2e-3 and dt < 2e-2, (ang, dt)
@@ -51,6 +58,26 @@ def test_config2_reference_parameters_l1(P, oracle, pair200k):
     ev = P.registration.evaluate_registration(P.PointCloud(p.source), P.PointCloud(p.target), 0.1, res.transformation)
     rv = oracle.evaluate_registration(p.source, p.target, 0.1, res.transformation)
     assert ev.fitness == rv.fitness and abs(ev.inlier_rmse - rv.inlier_rmse) < 1e-9
+
+
+def test_config2_af_radius_rule_matches_oracle(P, oracle, pair200k):
+    """Config 2 with the ALL_FUNCTIONS search radii (radius_from_cloud_pair * 2^-i = 87 / 44 / 22 m here: an effectively unbounded
+    1-NN, SURVEY 'hard part 1'): L2 pose on the oracle's, stage counts exact."""
+    p = pair200k
+    src, tgt = P.PointCloud(p.source), P.PointCloud(p.target)
+    r = P.radius_from_cloud_pair(src, tgt)
+    assert abs(r - oracle.radius_from_cloud_pair(p.source, p.target)) < 1e-9 * r and r > 50
+    dists = [r * 2.0 ** -i for i in range(3)]
+    est = P.registration.TransformationEstimationForGeneralizedICP(P.registration.L2Loss())
+    crit = P.registration.ICPConvergenceCriteria(1e-6, 1e-6, 100)
+    res = P.registration.multiscale_gicp(src, tgt, p.voxel_sizes, dists, p.T_init, est, crit)
+    ref = oracle.multiscale_gicp(p.source, p.target, p.voxel_sizes, dists, p.T_init, loss=oracle.LOSS_L2)
+    for a, b in zip(res.scales, ref.extra["scales"]):
+        assert a["n_clean"] == tuple(b["n_clean"]) and a["n_corr"] == b["n_corr"]
+    ang, dt = pose_error(res.transformation, ref.transformation)
+    assert ang < 1e-5 and dt < 1e-4, (ang, dt)
+    plan = P.registration.register_pairs_plan([(src, tgt, p.T_init)], "gicp", p.voxel_sizes, None, est, crit, radius_rule="af", inflight=1)[0]
+    assert np.array_equal(plan.transformation, res.transformation) and [s["max_dist"] for s in plan.scales] == dists
 
 
 def test_config5_two_million_points_recovers_planted_motion(P, pair200k):

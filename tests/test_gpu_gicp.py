@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import pkg, pose_error
+from conftest import SCRIPT2_DISTS, SCRIPT2_VOXELS, pkg, pose_error
 
 pytestmark = pytest.mark.gpu
 
@@ -138,35 +138,56 @@ def test_multiscale_stagecounts_and_l2_pose_match_oracle(P, oracle, small_pair):
     assert ang < 1e-5 and dt < 1e-4, (ang, dt)
 
 
-def test_multiscale_gicp_reproduces_shipped_pose(P, golden_pair):
-    """The reference path itself: script-2 parameters (5 scales, L1), shipped FGR pose in, shipped GICP pose out."""
+def test_multiscale_gicp_reproduces_shipped_pose(P, oracle, golden_pair):
+    """The reference path itself: script-2 parameters (5 scales, L1), shipped FGR pose in, shipped GICP pose out.  On the pairs
+    with a tight L1 attractor the device lands on the shipped pose inside the north-star tolerance.  Pairs 0 and 899 scatter by
+    more than that under a mere change of the float64 summation order (tests/test_oracle_golden.py measures it): there the device
+    must sit inside the oracle's own measured spread (conftest.l1_tolerance), i.e. be one more sample of the same scatter."""
+    from conftest import l1_tolerance
     g = golden_pair
     res = P.script2.Multiscale_GICP(P.PointCloud(g["source"]), P.PointCloud(g["target"]), 5, 100, g["T_fgr"])
     ang, dt = pose_error(res.transformation, g["T_gicp"])
-    # pair 899 is the committed example of a pair whose L1-IRLS attractor is wide (the float64 oracle itself lands
-    # 0.3-8 mm from the shipped pose depending on summation order; DESIGN.md "Parity"): sanity bound only
-    noisy = int(g["pair"]) in (899,)
-    assert ang <= (3e-3 if noisy else TOL_RAD) and dt <= (3e-2 if noisy else TOL_M), (int(g["pair"]), ang, dt)
+    if int(g["pair"]) not in (0, 899):
+        assert ang <= TOL_RAD and dt <= TOL_M, (int(g["pair"]), ang, dt)
+        return
+    ref, tol_rad, tol_m, spread = l1_tolerance(oracle, lambda: oracle.multiscale_gicp(g["source"], g["target"], SCRIPT2_VOXELS, SCRIPT2_DISTS, g["T_fgr"]))
+    assert spread[0] > TOL_RAD or spread[1] > TOL_M, spread            # the pair is noisy for the oracle itself, not for the device only
+    a, d = pose_error(res.transformation, ref.transformation)
+    assert a <= tol_rad and d <= tol_m, (int(g["pair"]), a, d, spread)
+    assert ang <= 2e-3 and dt <= 2e-2, (int(g["pair"]), ang, dt)     # the bound the oracle's own variants keep to the shipped pose
+
+
+def _facade_loop():
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "facade_loop.npz"))
+    clouds = [g[f"s{i}"] for i in range(7)]
+    pairs = [((i + 1) % 7, i) for i in range(7)]            # pair i: cloud i+1 onto cloud i; the last one closes the loop (0 onto 6)
+    return clouds, pairs, g["T_fgr"], g["T_gicp"]
 
 
 def test_facade_pair_matches_oracle(P, oracle):
     """BASELINE config 4's data: one pair of the shipped Facade loop (terrestrial scanner, 84k / 45k points, denser and
     more anisotropic than NCLT).  Stage counts bit-exact at all 5 script-2 scales, L2 pose on the oracle's to f32-search
-    accuracy, L1 pose inside the north-star tolerance of the oracle's."""
-    import os
-    from conftest import GOLDEN
-    g = np.load(os.path.join(GOLDEN, "facade_pair_1_0.npz"))
-    src, tgt, T0 = g["source"], g["target"], g["T_fgr"]
+    accuracy, L1 pose inside the tolerance derived from the oracle's own summation-order spread on this pair."""
+    from conftest import l1_tolerance
+    clouds, pairs, T_fgr, _ = _facade_loop()
+    src, tgt, T0 = clouds[1], clouds[0], T_fgr[0]
     vox = P.script2.create_scales(5); dst = P.script2.max_correspondence_distances(vox)
     crit = P.registration.ICPConvergenceCriteria(1e-6, 1e-6, 100)
-    for loss, oloss, tol in ((P.registration.L2Loss(), oracle.LOSS_L2, (1e-5, 1e-4)), (P.registration.L1Loss(), oracle.LOSS_L1, (TOL_RAD, TOL_M))):
+    for loss, oloss in ((P.registration.L2Loss(), oracle.LOSS_L2), (P.registration.L1Loss(), oracle.LOSS_L1)):
         est = P.registration.TransformationEstimationForGeneralizedICP(loss)
         res = P.registration.multiscale_gicp(P.PointCloud(src), P.PointCloud(tgt), vox, dst, T0, est, crit)
-        ref = oracle.multiscale_gicp(src, tgt, vox, dst, T0, loss=oloss)
+        run = lambda: oracle.multiscale_gicp(src, tgt, vox, dst, T0, loss=oloss)      # noqa: E731
+        if oloss == oracle.LOSS_L2:
+            ref, tol = run(), (1e-5, 1e-4)
+        else:
+            ref, tr, tm, _ = l1_tolerance(oracle, run, chunks=(64, 1024))
+            tol = (tr, tm)
         for a, b in zip(res.scales, ref.extra["scales"]):
             assert a["n_voxel"] == tuple(b["n_voxel"]) and a["n_clean"] == tuple(b["n_clean"])
         ang, dt = pose_error(res.transformation, ref.transformation)
-        assert ang <= tol[0] and dt <= tol[1], (type(loss).__name__, ang, dt)
+        assert ang <= tol[0] and dt <= tol[1], (type(loss).__name__, ang, dt, tol)
 
 
 def test_stepwise_call_sequence_equals_fused_call(P, small_pair):
