@@ -253,6 +253,10 @@ int pcr_debug_gicp_linearize(pcr_context *ctx, const float *src_xyz, const float
                              const double *T, const pcr_gicp_params *params, double *JTJ36, double *JTr6,
                              double *stats3, int32_t *match /* device n_src, optional */);
 
+/* the mutual nearest-feature search of registro_FGR alone (33-D float32 rows, device): out_1to0[j] = row of f0 nearest to row j of f1,
+ * out_0to1 likewise.  mode 0: f16-split MFMA screen + exact float64 re-check (production), 1: all-pairs float64 MFMA, 2: float32 brute force */
+int pcr_debug_feature_nn(pcr_context *ctx, const float *f0, int64_t n0, const float *f1, int64_t n1, int32_t *out_1to0, int32_t *out_0to1, int mode);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,7 +73,7 @@ EXPORTS = [
     "pcr_registration_generalized_icp", "pcr_multiscale_gicp", "pcr_evaluate_registration", "pcr_information_matrix",
     "pcr_compute_fpfh_feature", "pcr_registration_fgr", "pcr_debug_knn", "pcr_debug_gicp_linearize",
     "pcr_profile_enable", "pcr_profile_read", "pcr_registration_generalized_icp_cov", "pcr_register_pairs", "pcr_pool_profile",
-    "pcr_registro_fgr", "pcr_register_pairs_plan",
+    "pcr_registro_fgr", "pcr_register_pairs_plan", "pcr_debug_feature_nn",
 ]
 
 _lib = None

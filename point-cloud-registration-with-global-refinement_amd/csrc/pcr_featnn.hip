@@ -1,0 +1,466 @@
+// pcr_featnn.hip -- exact nearest neighbour in the 33-D FPFH feature space (K7, the one GEMM-shaped step of the path) as a
+// SCREEN on the f16 matrix cores followed by an exact float64 re-check of the few survivors.
+// Reference behaviour: the two KDTreeFlann searches of Open3D's FastGlobalRegistration AdvancedMatching, reached from
+// ALL_FUNCTIONS.py:198-202 / 1_FGR_pairwise_registration_in_NCLT_dataset.py:61-65: for every feature row of
+// one cloud the row of the other cloud with the smallest sum_k (a_k - b_k)^2 in float64, ties -> the smaller index.
+//
+// Why a screen.  All Ns x Nt distances in float64 (v_mfma_f64_16x16x4, 78.6 TFLOP/s peak on MI355X) took 2 x 55 ms at 200k x 200k
+// points -- 80 % of registro_FGR.  The f16 matrix pipe is 32x faster but 11 bits wide.  So every centred feature x = (f - mu) * 128
+// is split into two halves, hi = f16(x), lo = f16(x - hi) (22 bits together), and
+//     x_q . x_b  ~=  hi_q.hi_b + lo_q.hi_b + hi_q.lo_b
+// is ONE dot product of length 99 (padded to K = 128) between the rows [hi | hi | lo] of the database and [hi | lo | hi] of the
+// queries: 4 v_mfma_f32_16x16x32_f16 per 16 x 16 block of the distance matrix instead of 9 float64 MFMAs of 4x the cycles each.
+// With the exact float64 norms, d~(q, b) = |x_q|^2 + |x_b|^2 - 2 dot  satisfies  |d~ - d| <= c (|x_q|^2 + |x_b|^2)  (c = FN_C below:
+// split truncation 3 * 2^-22 |x_q||x_b|, f32 accumulation and combination), so with L = d~ - E a lower and U = min_b (d~ + E) an upper
+// bound of the true minimum, every row with L(b) <= U is a CANDIDATE and the true nearest row (and every exact tie of it) is among
+// them.  The screen keeps U per query in registers and writes every candidate as a RECORD (query, row, lower bound) into a pool
+// (a few dozen per query: the running minimum of a sequence improves ~ln N times; wavefronts take 64-record chunks of the pool with
+// one atomic per chunk and fill them with plain stores, so the hot loop never waits for a returning atomic).  k_fn_exact_min /
+// k_fn_exact_arg then evaluate sum_k (a_k - b_k)^2 in float64, in index order with separately rounded products and sums exactly like
+// the oracle's kd-tree leaf loop, on the records that survive the FINAL bound of their query: minimum distance first, then the
+// smallest row among the records that attain it.  The result is therefore the exact float64 nearest row whatever the screen's
+// rounding does inside its bound; if the pool overflows (pathological duplicate structure) the caller falls back to the all-pairs
+// float64 path.  PCR_FEATNN_CHECK=1 measures the bound's slack.
+//
+// Kernel shape (gfx950): workgroup = 8 wavefronts = 512 queries; a wavefront keeps the B operands of its 64 queries (4 blocks of
+// 16) in 64 VGPRs for the whole kernel; the database streams through LDS in steps of 64 rows (16 KB), staged once per workgroup,
+// double buffered, in a [k-group][row] image with a 72-byte row pitch on which the 8-byte operand reads are conflict free;
+// per 16-row tile a wavefront issues 16 MFMAs (256 cycles on its SIMD) and 29 VALU instructions of bound tests and keeps only one
+// hit bit per 16 x 16 block; blocks with a hit (a few per cent) are recomputed after the step's four tiles by the candidate path,
+// so that nothing but the barrier separates the MFMA streams of consecutive tiles.
+#include <cmath>
+#include <cstring>
+#include <cstdlib>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+#include "pcr_device.h"
+
+#define FN_D 33
+#define FN_K 128                 // [hi | hi | lo] / [hi | lo | hi] padded: 3 * 33 = 99 -> 128
+#define FN_WG 512
+#define FN_QB 4                  // query blocks of 16 per wavefront
+#define FN_QPW (16 * FN_QB)      // queries per wavefront
+#define FN_QPG (FN_QPW * (FN_WG / 64))
+#define FN_STEP 64               // database rows per staged step (four 16-row MFMA tiles)
+#define FN_SUBS (FN_STEP / 16)
+#define FN_CHUNK 64              // records a wavefront takes from the pool at a time
+#define FN_POOL_PER_QUERY 96     // pool capacity = this many records per query (expected: 20-40)
+#define FN_SCALE 128.0           // features are centred and scaled by a power of two before the split (keeps lo out of the f16 subnormals)
+#define FN_C 2.0e-6              // |d~ - d| <= FN_C (|x_q|^2 + |x_b|^2); worst case of the analysis above is 0.8e-6
+#define FN_SUB_BYTES 4608        // LDS image of one 16-row tile: 4 k-groups x 1152 B, row pitch 72 B
+#define FN_PITCH 72
+#define FN_GROUP 1152
+
+// 32-bit LDS byte address of a __shared__ object (what ds_read takes)
+__device__ static inline unsigned fn_lds_addr(const void *p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p; }
+
+// order-preserving map float <-> int (its own inverse): atomicMin on the image is a minimum of the floats, negative ones included
+__device__ static inline int fn_ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
+__device__ static inline float fn_unord(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+typedef _Float16 fn_h8 __attribute__((ext_vector_type(8)));
+typedef float fn_f4 __attribute__((ext_vector_type(4)));
+
+// ---- column means of a feature matrix (the centring vector; any vector is valid, the mean keeps the norms small) -------------
+// part: gridDim.x rows of 34 = 33 column sums + the largest |value| (the f16 split needs |f - mu| * 128 < 65504)
+#define FN_PC (FN_D + 1)
+__global__ void __launch_bounds__(256) k_fn_colsum(const float *__restrict__ f, int n, double *__restrict__ part) {
+    __shared__ double sh[256 / 64][FN_PC];
+    double s[FN_D], mx = 0.0;
+#pragma unroll
+    for (int k = 0; k < FN_D; k++) s[k] = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+#pragma unroll
+        for (int k = 0; k < FN_D; k++) { const double v = (double)f[(size_t)i * FN_D + k]; s[k] += v; mx = fmax(mx, fabs(v)); }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < FN_D; k++) { const double v = pcr_wave_sum(s[k]); if (lane == 0) sh[w][k] = v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
+    if (lane == 0) sh[w][FN_D] = mx;
+    __syncthreads();
+    if (threadIdx.x < FN_PC) {
+        double v = 0;
+        for (int k = 0; k < 256 / 64; k++) v = threadIdx.x < FN_D ? v + sh[k][threadIdx.x] : fmax(v, sh[k][threadIdx.x]);
+        part[blockIdx.x * FN_PC + threadIdx.x] = v;
+    }
+}
+// mu[0..32] = column means of the first matrix, mu[33] = largest |value| over both
+__global__ void k_fn_mean(const double *__restrict__ part, int nb, int n, double *__restrict__ mu) {
+    if (threadIdx.x < FN_PC) {
+        double v = 0;
+        for (int k = 0; k < 2 * nb; k++) {
+            const double x = part[k * FN_PC + threadIdx.x];
+            if (threadIdx.x == FN_D) v = fmax(v, x); else if (k < nb) v += x;
+        }
+        mu[threadIdx.x] = threadIdx.x == FN_D ? v : (n > 0 ? v / (double)n : 0.0);
+    }
+}
+
+// ---- split: one thread per row.  A-form (database role) [hi | hi | lo | 0], B-form (query role) [hi | lo | hi | 0]; norm of the
+// exact centred, scaled row; nlo = (1 - c) |x|^2 rounded down (the lower-bound test needs no per-row multiply in the hot loop).
+// Padded rows: zeros with nlo = +huge (can never be a candidate).
+// All-zero rows (Open3D leaves the FPFH of a point without neighbours at zero; 1-2 % of an outdoor scan) are exact duplicates in bulk:
+// every zero query ties with every zero row and its candidate list would overflow.  Their answer is known -- the first zero row of
+// the database, at distance exactly 0 -- so the split marks them (sign bit of nrm) and records the first zero row of each matrix.
+__global__ void __launch_bounds__(256) k_fn_split(const float *__restrict__ f, int n, int n_pad, const double *__restrict__ mu,
+                                                  _Float16 *__restrict__ A, _Float16 *__restrict__ B, float *__restrict__ nlo, float *__restrict__ nrm,
+                                                  int *__restrict__ first_zero) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pad) return;
+    _Float16 hi[FN_D], lo[FN_D];
+    double s = 0.0;
+    bool zero = i < n;
+#pragma unroll
+    for (int k = 0; k < FN_D; k++) {
+        zero = zero && (i < n ? f[(size_t)i * FN_D + k] == 0.0f : false);
+        const double x = i < n ? ((double)f[(size_t)i * FN_D + k] - mu[k]) * FN_SCALE : 0.0;
+        const _Float16 h = (_Float16)(float)x;
+        hi[k] = h;
+        lo[k] = (_Float16)(float)(x - (double)(float)h);
+        s += x * x;
+    }
+    _Float16 *a = A + (size_t)i * FN_K, *b = B + (size_t)i * FN_K;
+#pragma unroll
+    for (int k = 0; k < FN_D; k++) { a[k] = hi[k]; a[FN_D + k] = hi[k]; a[2 * FN_D + k] = lo[k]; b[k] = hi[k]; b[FN_D + k] = lo[k]; b[2 * FN_D + k] = hi[k]; }
+    for (int k = 3 * FN_D; k < FN_K; k++) { a[k] = (_Float16)0.0f; b[k] = (_Float16)0.0f; }
+    if (i < n) {
+        nlo[i] = __double2float_rd(s * (1.0 - FN_C));
+        nrm[i] = zero ? -__double2float_ru(s) : __double2float_ru(s);
+        if (zero) atomicMin(first_zero, i);
+    } else { nlo[i] = 1.0e30f; nrm[i] = 0.0f; }
+}
+
+struct FnnArgs {
+    const _Float16 *dbA; const float *db_nlo; int n_db_pad;        // database rows (A-form) and (1 - c)|x|^2
+    const _Float16 *qB; const float *q_nrm; int n_q, n_q_pad;      // query rows (B-form) and |x|^2 (sign bit set: all-zero feature row)
+    const int *db_first_zero;                                      // first all-zero row of the database (INT_MAX: none)
+    int variant;                                                   // diagnostics (PCR_FEATNN_VARIANT, timing only, results wrong): 1 no candidate path
+    int step0, steps_per_split, step_end;                          // 64-row steps [step0 + split * sps, +sps) clipped to step_end
+    int *Ug;                                                       // per query: upper bound of (minimum - |x_q|^2): read when a workgroup starts, lowered
+                                                                   //   (atomicMin on the order-preserving int image) when it ends
+    // record pool: chunk c holds records [c * FN_CHUNK, +chunk_fill[c]); pool_used counts allocated records; flags[0] = overflow
+    int *pool_used; int pool_cap; int *chunk_fill; int *rec_q; int *rec_row; float *rec_w; int *flags;
+};
+
+// ---- the screen.  grid = (query groups of 512, splits of the database)
+__global__ void __launch_bounds__(FN_WG) k_feature_nn_screen(FnnArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][FN_SUBS * FN_SUB_BYTES];
+    __shared__ __attribute__((aligned(16))) float lnlo[2][FN_STEP];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int col = lane & 15, g = lane >> 4;
+    const int q0 = (blockIdx.x * (FN_WG / 64) + wv) * FN_QPW;
+    const int s0 = a.step0 + blockIdx.y * a.steps_per_split;
+    const int s1 = min(a.step_end, s0 + a.steps_per_split);
+    if (s0 >= s1) return;
+    // B operands of the wavefront's 64 queries: block b, MFMA m <- k-chunk (g, m) of query q0 + 16 b + col
+    fn_h8 qb[FN_QB][4];
+    float cq[FN_QB], U[FN_QB], thr[FN_QB];
+#pragma unroll
+    for (int b = 0; b < FN_QB; b++) {
+        const int q = q0 + 16 * b + col;
+        const int qc = q < a.n_q_pad ? q : 0;
+        const uint4 *src = (const uint4 *)(a.qB + (size_t)qc * FN_K + g * 32);
+#pragma unroll
+        for (int m = 0; m < 4; m++) { union { uint4 u; fn_h8 h; } x; x.u = src[m]; qb[b][m] = x.h; }
+        // candidate iff (lower bound of d~ - nq) < U + 2 c nq ; queries beyond n_q and zero queries with a known answer never produce candidates
+        const float nr = a.q_nrm[qc];
+        const bool known = __builtin_signbit(nr) && *a.db_first_zero != 0x7fffffff;
+        cq[b] = (q < a.n_q && !known) ? (float)(2.0 * FN_C * 1.001) * fabsf(nr) : -__builtin_inff();
+        U[b] = fn_unord(a.Ug[qc]);                        // what the pre-pass has established
+        thr[b] = U[b] + cq[b];
+    }
+    // staging: thread t moves two 16-byte k-chunks (rows r and r + 32 of the step, chunk j); norms by the first 64 threads
+    const int st_r = tid >> 4, st_j = tid & 15;             // r = 0..31
+    auto st_dst = [&](int r) { return (r >> 4) * FN_SUB_BYTES + (st_j >> 2) * FN_GROUP + (r & 15) * FN_PITCH + (st_j & 3) * 16; };
+    struct Slot { uint4 v0, v1; float nv; };
+    auto fetch = [&](int step, Slot &x) {
+        const _Float16 *src = a.dbA + ((size_t)step * FN_STEP + st_r) * FN_K + st_j * 8;
+        x.v0 = *(const uint4 *)src;
+        x.v1 = *(const uint4 *)(src + (size_t)32 * FN_K);
+        x.nv = tid < FN_STEP ? a.db_nlo[(size_t)step * FN_STEP + tid] : 0.0f;
+    };
+    auto stash = [&](int buf, const Slot &x) {
+        unsigned char *d0 = &lds[buf][st_dst(st_r)], *d1 = &lds[buf][st_dst(st_r + 32)];
+        *(uint2 *)d0 = make_uint2(x.v0.x, x.v0.y); *(uint2 *)(d0 + 8) = make_uint2(x.v0.z, x.v0.w);
+        *(uint2 *)d1 = make_uint2(x.v1.x, x.v1.y); *(uint2 *)(d1 + 8) = make_uint2(x.v1.z, x.v1.w);
+        if (tid < FN_STEP) lnlo[buf][tid] = x.nv;
+    };
+    // The database does not fit the L2s (51 MB at 200k rows): a row block comes from the Infinity Cache or HBM, 1-2 us away, while a
+    // step computes for ~1 us.  The global loads run TWO steps ahead through two register slots, the LDS image is double buffered,
+    // and the step loop is unrolled by two so that slots and buffers are named.
+    Slot slot[2];
+    fetch(s0, slot[0]);
+    stash(0, slot[0]);
+    if (s0 + 1 < s1) fetch(s0 + 1, slot[1]);
+    const float kc = (float)(2.0 * FN_C * 1.002);          // whi = wlo + kc * nlo  >=  d~ + E - nq
+    const unsigned a_off = (unsigned)(g * FN_GROUP + col * FN_PITCH);
+    int chunk_base = -1, chunk_fill = FN_CHUNK;            // wave-uniform: current chunk of the record pool (none yet)
+    bool dead = false;                                      // the pool overflowed: flags[0] is set and the caller falls back
+    for (int step2 = s0; step2 < s1; step2 += 2) {
+#pragma unroll
+      for (int ph = 0; ph < 2; ph++) {
+        const int step = step2 + ph;
+        if (step >= s1) break;
+        const int buf = ph;
+        if (step + 2 < s1) fetch(step + 2, slot[ph]);     // slot ph held this step's rows, which are in LDS already
+        __syncthreads();                                  // buffer `buf` is complete; buffer buf^1 is no longer read by anyone
+        // ---- fast path: 4 tiles x 4 query blocks, one hit bit per 16 x 16 block, nothing else kept
+        unsigned hits = 0;
+#pragma unroll
+        for (int sub = 0; sub < FN_SUBS; sub++) {
+            // A operands: 4 k-chunks x 16 bytes per lane, 8-byte LDS reads on the conflict-free image (plain loads: the compiler keeps
+            // counted waits for them and runs the next tile's reads under this tile's MFMAs)
+            union { uint2 u[2]; fn_h8 h; } av[4];
+            const unsigned char *base = &lds[buf][sub * FN_SUB_BYTES + a_off];
+#pragma unroll
+            for (int m = 0; m < 4; m++) { av[m].u[0] = *(const uint2 *)(base + m * 16); av[m].u[1] = *(const uint2 *)(base + m * 16 + 8); }
+            const fn_f4 nl = *(const fn_f4 *)(&lnlo[buf][sub * 16 + 4 * g]);       // rows 4 g .. 4 g + 3 of the tile: this lane's accumulator rows
+#pragma unroll
+            for (int b = 0; b < FN_QB; b++) {
+                fn_f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int m = 0; m < 4; m++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[m].h, qb[b][m], acc, 0, 0, 0);
+                const float mn = fminf(fminf(__fmaf_rn(-2.0f, acc[0], nl[0]), __fmaf_rn(-2.0f, acc[1], nl[1])),
+                                       fminf(__fmaf_rn(-2.0f, acc[2], nl[2]), __fmaf_rn(-2.0f, acc[3], nl[3])));
+                hits |= (mn < thr[b]) ? (1u << (sub * FN_QB + b)) : 0u;
+            }
+        }
+        // ---- candidate path: blocks in which some lane saw a value under its threshold are recomputed from the LDS image
+        unsigned long long any = __ballot(hits != 0u);
+        if (any != 0ull && !(a.variant & 1) && !dead) {
+            unsigned wave_hits = hits;                    // union over the wavefront, by a 6-step or-butterfly
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) wave_hits |= (unsigned)__shfl_xor((int)wave_hits, o, 64);
+            while (wave_hits != 0u) {
+                const int blk = __builtin_ctz(wave_hits);
+                wave_hits &= wave_hits - 1u;
+                const int sub = blk / FN_QB, b = blk % FN_QB;
+                union { uint2 u[2]; fn_h8 h; } av[4];
+                const unsigned char *base = &lds[buf][sub * FN_SUB_BYTES + a_off];
+#pragma unroll
+                for (int m = 0; m < 4; m++) { av[m].u[0] = *(const uint2 *)(base + m * 16); av[m].u[1] = *(const uint2 *)(base + m * 16 + 8); }
+                const fn_f4 nl = *(const fn_f4 *)(&lnlo[buf][sub * 16 + 4 * g]);
+                // block b is a run-time index here: select its operands and state with uniform branches (registers stay registers)
+                fn_f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                float Ub = 0.0f, cqb = 0.0f;
+#pragma unroll
+                for (int bb = 0; bb < FN_QB; bb++) if (b == bb) {
+#pragma unroll
+                    for (int m = 0; m < 4; m++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[m].h, qb[bb][m], acc, 0, 0, 0);
+                    Ub = U[bb]; cqb = cq[bb];
+                }
+                float tb = Ub + cqb;
+                const int q = q0 + 16 * b + col;
+                const int row0 = step * FN_STEP + sub * 16 + 4 * g;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float w = __fmaf_rn(-2.0f, acc[i], nl[i]);
+                    const bool h = w < tb;
+                    const unsigned long long mask = __ballot(h);
+                    const int n_new = __builtin_popcountll(mask);
+                    if (n_new) {
+                        if (chunk_fill + n_new > FN_CHUNK) {          // wave-uniform: close the chunk, take a new one (one atomic per chunk)
+                            int nb_ = 0;
+                            if (lane == 0) {
+                                if (chunk_base >= 0) a.chunk_fill[chunk_base / FN_CHUNK] = chunk_fill;
+                                nb_ = atomicAdd(a.pool_used, FN_CHUNK);
+                            }
+                            chunk_base = __shfl(nb_, 0, 64); chunk_fill = 0;
+                            if (chunk_base + FN_CHUNK > a.pool_cap) { if (lane == 0) a.flags[0] = 1; dead = true; chunk_base = -1; chunk_fill = FN_CHUNK; }
+                        }
+                        if (!dead) {
+                            if (h) {
+                                const int slot_ = chunk_base + chunk_fill + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                                a.rec_q[slot_] = q; a.rec_row[slot_] = row0 + i; a.rec_w[slot_] = w;
+                            }
+                            chunk_fill += n_new;
+                        }
+                    }
+                    if (h) { Ub = fminf(Ub, __fmaf_rn(kc, nl[i], w)); tb = Ub + cqb; }
+                }
+                // share the improved bound between the 4 row groups of a query, then store it back into the block's state
+                Ub = fminf(Ub, __shfl_xor(Ub, 16, 64));
+                Ub = fminf(Ub, __shfl_xor(Ub, 32, 64));
+#pragma unroll
+                for (int bb = 0; bb < FN_QB; bb++) if (b == bb) { U[bb] = Ub; thr[bb] = Ub + cq[bb]; }
+            }
+        }
+        if (step + 1 < s1) stash(buf ^ 1, slot[ph ^ 1]);  // everyone passed this step's barrier, so buf^1 (read in step - 1) is free
+      }
+    }
+    if (lane == 0 && chunk_base >= 0) a.chunk_fill[chunk_base / FN_CHUNK] = chunk_fill;
+    if (g == 0)
+#pragma unroll
+        for (int b = 0; b < FN_QB; b++) {
+            const int q = q0 + 16 * b + col;
+            if (q < a.n_q) atomicMin(&a.Ug[q], fn_ord(U[b]));
+        }
+}
+
+// ---- exact float64 distance exactly as the oracle's kd-tree leaf loop computes it: d2 += e * e with the product and the sum
+// rounded separately, k = 0 .. 32 in order
+__device__ static inline double fn_exact_d2(const float *__restrict__ x, const float *__restrict__ y) {
+    double d2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < FN_D; k++) { const double e = (double)x[k] - (double)y[k]; d2 = __dadd_rn(d2, __dmul_rn(e, e)); }
+    return d2;
+}
+
+struct FnxArgs {
+    const float *q; const float *q_nrm; int n_q;        // original float32 query rows; scaled centred norms (sign bit: zero row)
+    const float *db; int n_db; const float *db_nlo; const int *db_first_zero;
+    const int *Ug;                                      // final bound of the screen per query
+    const int *pool_used; const int *chunk_fill; const int *rec_q; const int *rec_row; const float *rec_w;
+    unsigned long long *best_d;                         // per query: bits of the smallest exact distance (non-negative doubles order like their bits)
+    int32_t *out;                                       // per query: smallest row attaining it (INT_MAX until found)
+    float *dbg;                                         // PCR_FEATNN_CHECK: [0] max |d~ - d| / (nq + nb) seen on records, [1] records that survived the final bound
+};
+__device__ static inline bool fn_record(const FnxArgs &a, int r, int *q, int *row, double *d) {
+    if (r >= *a.pool_used || (r % FN_CHUNK) >= a.chunk_fill[r / FN_CHUNK]) return false;
+    *q = a.rec_q[r]; *row = a.rec_row[r];
+    if (*q >= a.n_q || *row >= a.n_db) return false;
+    const float nr = a.q_nrm[*q];
+    const float thr = fn_unord(a.Ug[*q]) + (float)(2.0 * FN_C * 1.001) * fabsf(nr);
+    if (!(a.rec_w[r] <= thr)) return false;               // could not be the minimum given the final bound
+    *d = fn_exact_d2(a.q + (size_t)*q * FN_D, a.db + (size_t)*row * FN_D);
+    return true;
+}
+// pass 1: smallest exact distance per query
+__global__ void __launch_bounds__(256) k_fn_exact_min(FnxArgs a, int n_rec_cap) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    int q, row; double d;
+    if (r >= n_rec_cap || !fn_record(a, r, &q, &row, &d)) return;
+    atomicMin(&a.best_d[q], (unsigned long long)__double_as_longlong(d));
+    if (a.dbg) {          // the screen's value of this pair against the exact one, in units of the bound
+        const double nq = fabs((double)a.q_nrm[q]), nb = (double)a.db_nlo[row] / (1.0 - FN_C);
+        const double dt = (double)a.rec_w[r] + FN_C * nb + nq;                    // d~ in scaled units
+        atomicMax((unsigned int *)&a.dbg[0], __float_as_uint((float)(fabs(dt - d * FN_SCALE * FN_SCALE) / (nq + nb))));
+        atomicAdd(&a.dbg[1], 1.0f);
+    }
+}
+// pass 2: smallest row among the records that attain it (exact ties -> smaller index, as the oracle's heap orders them)
+__global__ void __launch_bounds__(256) k_fn_exact_arg(FnxArgs a, int n_rec_cap) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    int q, row; double d;
+    if (r >= n_rec_cap || !fn_record(a, r, &q, &row, &d)) return;
+    if ((unsigned long long)__double_as_longlong(d) == a.best_d[q]) atomicMin(&a.out[q], row);
+}
+// pass 3: zero queries take the first zero row; a query without any record (empty database) gets -1
+__global__ void __launch_bounds__(256) k_fn_finish(FnxArgs a) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= a.n_q) return;
+    if (__builtin_signbit(a.q_nrm[q]) && *a.db_first_zero != 0x7fffffff) a.out[q] = *a.db_first_zero;
+    else if (a.out[q] == 0x7fffffff) a.out[q] = -1;
+}
+
+// ------------------------------------------------------------------------------------------------------------------ driver
+size_t pcr_feature_nn_scratch_bytes(int64_t n0, int64_t n1) {
+    const size_t p0 = ((size_t)n0 + FN_QPG) / FN_QPG * FN_QPG, p1 = ((size_t)n1 + FN_QPG) / FN_QPG * FN_QPG;
+    const size_t per_row = 2 * FN_K * sizeof(_Float16) + 2 * sizeof(float);                 // both forms + two norms
+    const size_t per_query = (size_t)FN_POOL_PER_QUERY * 13 + 8 + 4 + 16;                   // records, best distance, bound, chunk table share
+    return (p0 + p1) * per_row + (p0 > p1 ? p0 : p1) * per_query + (size_t)(2048 + 64 * 9) * 8 * FN_CHUNK * 13 + (1u << 22);
+}
+
+// For every row of cloud 1 its exact nearest row of cloud 0 (out_1to0, n1 entries) and vice versa (out_0to1, n0 entries).
+// f0 / f1: device float32 (n x 33).  Scratch from the arena above the current mark.  PCR_ECAPACITY: feature values outside the
+// f16 range or record pool exhausted -- the caller takes the all-pairs float64 path.
+int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float *f1, int n1, int32_t *out_1to0, int32_t *out_0to1) {
+    if (n0 <= 0 || n1 <= 0) return PCR_OK;
+    ArenaMark mark(ctx);
+    const float *f[2] = {f0, f1}; const int n[2] = {n0, n1}; int np[2];
+    _Float16 *A[2], *B[2]; float *nlo[2], *nrm[2];
+    static const bool check = getenv("PCR_FEATNN_CHECK") != nullptr;
+    const int nbm = 64;
+    double *part = arena<double>(ctx, (size_t)2 * nbm * FN_PC + FN_PC);
+    if (!part) return PCR_ENOMEM;
+    double *mu = part + (size_t)2 * nbm * FN_PC;
+    PCR_LAUNCH(ctx, k_fn_colsum, dim3(nbm), dim3(256), 0, ctx->stream, f0, n0, part);
+    PCR_LAUNCH(ctx, k_fn_colsum, dim3(nbm), dim3(256), 0, ctx->stream, f1, n1, part + (size_t)nbm * FN_PC);
+    PCR_LAUNCH(ctx, k_fn_mean, dim3(1), dim3(64), 0, ctx->stream, part, nbm, n0, mu);
+    {   // the f16 split holds |f - mu| * 128 < 65504: true for FPFH (bins <= 200); anything else takes the float64 path
+        double h[FN_PC];
+        PCR_HIP_CHECK(ctx, hipMemcpyAsync(h, mu, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        double mm = 0; for (int k = 0; k < FN_D; k++) mm = fmax(mm, fabs(h[k]));
+        if (!((h[FN_D] + mm) * FN_SCALE < 60000.0)) return PCR_ECAPACITY;
+    }
+    int *first_zero = arena<int>(ctx, 2), *flags = arena<int>(ctx, 2);
+    if (!first_zero || !flags) return PCR_ENOMEM;
+    PCR_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)first_zero, 0x7fffffff, 2, ctx->stream));
+    PCR_HIP_CHECK(ctx, hipMemsetAsync(flags, 0, 2 * sizeof(int), ctx->stream));
+    for (int c = 0; c < 2; c++) {
+        np[c] = (n[c] + FN_QPG - 1) / FN_QPG * FN_QPG;                        // multiple of 512 (queries per workgroup) and of 64 (rows per step)
+        A[c] = arena<_Float16>(ctx, (size_t)np[c] * FN_K); B[c] = arena<_Float16>(ctx, (size_t)np[c] * FN_K);
+        nlo[c] = arena<float>(ctx, np[c]); nrm[c] = arena<float>(ctx, np[c]);
+        if (!A[c] || !B[c] || !nlo[c] || !nrm[c]) return PCR_ENOMEM;
+        PCR_LAUNCH(ctx, k_fn_split, dim3((np[c] + 255) / 256), dim3(256), 0, ctx->stream, f[c], n[c], np[c], mu, A[c], B[c], nlo[c], nrm[c], first_zero + c);
+    }
+    float *dbg = nullptr;
+    if (check) { dbg = arena<float>(ctx, 2); if (!dbg) return PCR_ENOMEM; }
+    for (int dir = 0; dir < 2; dir++) {
+        const int qc = dir == 0 ? 1 : 0, dc = 1 - qc;                          // dir 0: queries = cloud 1, database = cloud 0
+        int32_t *out = dir == 0 ? out_1to0 : out_0to1;
+        ArenaMark m2(ctx);
+        const int nq = n[qc], nqp = np[qc], steps = np[dc] / FN_STEP;
+        const int groups = nqp / FN_QPG;
+        // a pre-pass over the first 4096 rows seeds the bound of every query; the main pass splits the rest so that the grid has ~8
+        // workgroups per CU (one workgroup = 512 queries x one split)
+        const int pre = steps <= 128 ? steps : 64;
+        const int rest = steps - pre;
+        int splits = rest > 0 ? (2048 + groups - 1) / groups : 1;
+        if (splits > 64) splits = 64;
+        if (splits > rest) splits = rest > 0 ? rest : 1;
+        const int sps = rest > 0 ? (rest + splits - 1) / splits : 0;
+        // capacity: records per query plus the chunk every wavefront of either pass may leave partly filled
+        const size_t waves = (size_t)groups * (FN_WG / 64) * (size_t)(1 + (rest > 0 ? splits : 0));
+        const int pool_cap = (int)(((size_t)nqp * FN_POOL_PER_QUERY + waves * FN_CHUNK + FN_CHUNK - 1) / FN_CHUNK * FN_CHUNK);
+        int *pool_used = arena<int>(ctx, 1), *chunk_fill = arena<int>(ctx, pool_cap / FN_CHUNK);
+        int *rec_q = arena<int>(ctx, pool_cap), *rec_row = arena<int>(ctx, pool_cap); float *rec_w = arena<float>(ctx, pool_cap);
+        int *Ug = arena<int>(ctx, nqp);
+        unsigned long long *best_d = arena<unsigned long long>(ctx, nq);
+        if (!pool_used || !chunk_fill || !rec_q || !rec_row || !rec_w || !Ug || !best_d) return PCR_ENOMEM;
+        PCR_HIP_CHECK(ctx, hipMemsetAsync(pool_used, 0, sizeof(int), ctx->stream));
+        PCR_HIP_CHECK(ctx, hipMemsetAsync(chunk_fill, 0, sizeof(int) * (size_t)(pool_cap / FN_CHUNK), ctx->stream));
+        PCR_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)Ug, 0x7f800000, nqp, ctx->stream));       // +inf
+        PCR_HIP_CHECK(ctx, hipMemsetAsync(best_d, 0xff, sizeof(unsigned long long) * (size_t)nq, ctx->stream));
+        PCR_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)out, 0x7fffffff, nq, ctx->stream));
+        if (dbg) PCR_HIP_CHECK(ctx, hipMemsetAsync(dbg, 0, 8, ctx->stream));
+        FnnArgs a;
+        a.dbA = A[dc]; a.db_nlo = nlo[dc]; a.n_db_pad = np[dc]; a.qB = B[qc]; a.q_nrm = nrm[qc]; a.n_q = nq; a.n_q_pad = nqp;
+        a.db_first_zero = first_zero + dc; a.Ug = Ug;
+        a.pool_used = pool_used; a.pool_cap = pool_cap; a.chunk_fill = chunk_fill; a.rec_q = rec_q; a.rec_row = rec_row; a.rec_w = rec_w; a.flags = flags;
+        a.variant = getenv("PCR_FEATNN_VARIANT") ? atoi(getenv("PCR_FEATNN_VARIANT")) : 0;
+        a.step0 = 0; a.steps_per_split = pre; a.step_end = pre;
+        PCR_LAUNCH(ctx, k_feature_nn_screen, dim3(groups, 1), dim3(FN_WG), 0, ctx->stream, a);
+        if (rest > 0) {
+            a.step0 = pre; a.steps_per_split = sps; a.step_end = steps;
+            PCR_LAUNCH(ctx, k_feature_nn_screen, dim3(groups, splits), dim3(FN_WG), 0, ctx->stream, a);
+        }
+        FnxArgs x;
+        x.q = f[qc]; x.q_nrm = nrm[qc]; x.n_q = nq; x.db = f[dc]; x.n_db = n[dc]; x.db_nlo = nlo[dc]; x.db_first_zero = first_zero + dc; x.Ug = Ug;
+        x.pool_used = pool_used; x.chunk_fill = chunk_fill; x.rec_q = rec_q; x.rec_row = rec_row; x.rec_w = rec_w; x.best_d = best_d; x.out = out; x.dbg = dbg;
+        // the record kernels cover the whole pool capacity (the used part is only known on the device); unused slots exit at once
+        PCR_LAUNCH(ctx, k_fn_exact_min, dim3((pool_cap + 255) / 256), dim3(256), 0, ctx->stream, x, pool_cap);
+        PCR_LAUNCH(ctx, k_fn_exact_arg, dim3((pool_cap + 255) / 256), dim3(256), 0, ctx->stream, x, pool_cap);
+        PCR_LAUNCH(ctx, k_fn_finish, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, x);
+        if (check) {
+            int h[2] = {0, 0}; float hd[2] = {0, 0};
+            PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h[0], pool_used, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h[1], flags, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            PCR_HIP_CHECK(ctx, hipMemcpyAsync(hd, dbg, 8, hipMemcpyDeviceToHost, ctx->stream));
+            PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            fprintf(stderr, "featnn dir %d: %d queries x %d rows, pre %d + %d splits x %d steps of %d rows; pool %d of %d records allocated (%.1f per query)%s, %.0f survived the final bound (%.2f per query); "
+                            "max |d~-d|/(nq+nb) = %.3e (bound %.1e)\n", dir, nq, n[dc], pre, rest > 0 ? splits : 0, sps, FN_STEP, h[0], pool_cap, (double)h[0] / nq,
+                    h[1] ? " OVERFLOW" : "", hd[1], hd[1] / nq, hd[0], FN_C);
+        }
+    }
+    {   // pool overflow (either direction): the results are incomplete, the caller recomputes on the float64 path
+        int h = 0;
+        PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h, flags, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        if (h) return PCR_ECAPACITY;
+    }
+    return PCR_OK;
+}

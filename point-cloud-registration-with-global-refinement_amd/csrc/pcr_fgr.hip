@@ -326,6 +326,23 @@ static int feature_nn(pcr_context *ctx, const float *db, int n_db, const float *
     return PCR_OK;
 }
 
+// test hook: the mutual nearest-feature search alone.  mode 0: f16-split screen + exact re-check (the production path), 1: all-pairs
+// float64 MFMA, 2: float32 brute force
+extern "C" int pcr_debug_feature_nn(pcr_context *ctx, const float *f0, int64_t n0, const float *f1, int64_t n1, int32_t *out_1to0, int32_t *out_0to1, int mode) {
+    return pcr_api_call(ctx, [&]() -> int {
+        if (n0 <= 0 || n1 <= 0 || !f0 || !f1 || !out_1to0 || !out_0to1) return PCR_EINVAL;
+        PCR_TRY(pcr_arena_reserve(ctx, pcr_feature_nn_scratch_bytes(n0, n1) + (size_t)(n0 + n1) * (FK * 16 + 32 * 12 + 64) + (64u << 20)));
+        if (mode == 0) return pcr_feature_nn_mutual(ctx, f0, (int)n0, f1, (int)n1, out_1to0, out_0to1);
+        if (mode == 2) {
+            PCR_LAUNCH(ctx, k_feature_nn, dim3((unsigned)((n1 + FB - 1) / FB)), dim3(FB), 0, ctx->stream, f0, (int)n0, f1, (int)n1, out_1to0);
+            PCR_LAUNCH(ctx, k_feature_nn, dim3((unsigned)((n0 + FB - 1) / FB)), dim3(FB), 0, ctx->stream, f1, (int)n1, f0, (int)n0, out_0to1);
+            return PCR_OK;
+        }
+        PCR_TRY(feature_nn(ctx, f0, (int)n0, f1, (int)n1, out_1to0));
+        return feature_nn(ctx, f1, (int)n1, f0, (int)n0, out_0to1);
+    });
+}
+
 // cross check: pair (i, i_to_j[i]) survives iff j_to_i[i_to_j[i]] == i      
 __global__ void __launch_bounds__(FB) k_cross_flags(const int32_t *__restrict__ i_to_j, const int32_t *__restrict__ j_to_i, int n_i, uint8_t *__restrict__ flags) {
     const int i = blockIdx.x * FB + threadIdx.x;
@@ -790,7 +807,8 @@ static int normalise(pcr_context *ctx, const float *xyz, int64_t n, double *out6
 static size_t fgr_scratch_bytes(int64_t ns, int64_t nt, const pcr_fgr_option *opt) {
     const int64_t nmax = ns > nt ? ns : nt;
     const long long trial_cap = opt->tuple_test ? 100ll * nmax : 0;
-    return (size_t)(ns + nt) * (24 + 8 + 16) + (size_t)nmax * 32 + (size_t)trial_cap * 5 + (size_t)nmax * 64 + (size_t)nmax * (FK * 16 + 32 * 12 + 64) + (64u << 20);
+    return (size_t)(ns + nt) * (24 + 8 + 16) + (size_t)nmax * 32 + (size_t)trial_cap * 5 + (size_t)nmax * 64 + (size_t)nmax * (FK * 16 + 32 * 12 + 64) + (64u << 20)
+           + pcr_feature_nn_scratch_bytes(ns, nt);
 }
 
 // AdvancedMatching + OptimizePairwiseRegistration: the source -> target pose from the two clouds and their features (caller-order
@@ -825,8 +843,15 @@ static int fgr_pose(pcr_context *ctx, const float *src_xyz, const float *src_fea
         if (!j_to_i || !i_to_j || !cflags || !cpos || !ncross_dev || !cross) return PCR_ENOMEM;
         hipEvent_t pe[2] = {nullptr, nullptr};
         if (ctx->profiling) { PCR_HIP_CHECK(ctx, hipEventCreate(&pe[0])); PCR_HIP_CHECK(ctx, hipEventCreate(&pe[1])); PCR_HIP_CHECK(ctx, hipEventRecord(pe[0], ctx->stream)); }
-        PCR_TRY(feature_nn(ctx, fi, nPti, fj, nPtj, j_to_i));
-        PCR_TRY(feature_nn(ctx, fj, nPtj, fi, nPti, i_to_j));
+        // both directions: f16-split screen on the matrix cores + exact float64 re-check (pcr_featnn.hip); PCR_FEATURE_NN=f64 keeps
+        // the all-pairs float64 MFMA path (also taken for feature values outside the f16 range), PCR_FEATURE_NN_BRUTE the float32 one
+        static const bool nn_f64 = getenv("PCR_FEATURE_NN") && !strcmp(getenv("PCR_FEATURE_NN"), "f64");
+        int nn_rc = PCR_ECAPACITY;
+        if (!nn_f64 && !getenv("PCR_FEATURE_NN_BRUTE") && nPti >= 64 && nPtj >= 64) nn_rc = pcr_feature_nn_mutual(ctx, fi, nPti, fj, nPtj, j_to_i, i_to_j);
+        if (nn_rc == PCR_ECAPACITY) {
+            PCR_TRY(feature_nn(ctx, fi, nPti, fj, nPtj, j_to_i));
+            PCR_TRY(feature_nn(ctx, fj, nPtj, fi, nPti, i_to_j));
+        } else if (nn_rc != PCR_OK) return nn_rc;
         if (ctx->profiling) {             // bench instrumentation: HIP-event time over the two matching passes (pcr_hip.h, out16[8..10])
             PCR_HIP_CHECK(ctx, hipEventRecord(pe[1], ctx->stream));
             PCR_HIP_CHECK(ctx, hipEventSynchronize(pe[1]));

@@ -159,6 +159,10 @@ int pcr_registro_fgr_impl(pcr_context *ctx, const float *src_xyz, const float *s
 int pcr_evaluate_registration_impl(pcr_context *ctx, const float *src_xyz, int64_t n_src, const float *tgt_xyz, int64_t n_tgt,
                                    double max_dist, const double *T, pcr_result *result, int32_t *correspondences);
 
+// ---- feature matching (pcr_featnn.hip): exact nearest feature rows in both directions; PCR_ECAPACITY = values outside the f16 range
+size_t pcr_feature_nn_scratch_bytes(int64_t n0, int64_t n1);
+int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float *f1, int n1, int32_t *out_1to0, int32_t *out_0to1);
+
 // ---- gicp (pcr_gicp.hip) --------------------------------------------------------------------------
 struct IcpOutputs { pcr_result res; };
 int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, double max_dist, const double *T0,

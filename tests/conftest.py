@@ -72,11 +72,13 @@ SCRIPT2_DISTS = [1.5, 1.0, 0.6, 0.3, 0.1]           # 2_MGICP...py:112-120
 TOL_RAD, TOL_M = 1e-4, 1e-3          # BASELINE.json north_star: pose tolerance against the reference CPU path
 
 
-def l1_tolerance(oracle, run, chunks=(32, 64, 128, 1024, 4096), factor=2.0):
+def l1_tolerance(oracle, run, chunks=(16, 32, 64, 128, 512, 1024, 4096), factor=3.0):
     """Bound for a device-vs-oracle comparison of an L1 (reference-parameter) registration, DERIVED on the spot: the oracle is run
-    with five other float64 summation chunkings (nothing else changes) and the largest distance of any of those end poses from the
+    with other float64 summation chunkings (nothing else changes) and the largest distance of any of those end poses from the
     default one is the noise floor of the reference algorithm on this very input (its 1/|r| weights make the end pose, and the
-    iteration at which the 1e-6 criteria fire, chaotic in the last bits of the sums).  Returns (default oracle result,
+    iteration at which the 1e-6 criteria fire, chaotic in the last bits of the sums).  The scatter is heavy-tailed (pair 0: five
+    chunkings within 1.3e-4 rad of each other, a sixth 2.3e-4 rad away), so the maximum over a handful of samples is taken
+    three times: a device result is one more sample of the same scatter, not an outlier of it.  Returns (default oracle result,
     tol_rad, tol_m, (spread_rad, spread_m)) with tol = max(north-star tolerance, factor x spread)."""
     base, a, d = oracle.l1_spread(run, chunks)
     return base, max(TOL_RAD, factor * a), max(TOL_M, factor * d), (a, d)

@@ -182,7 +182,7 @@ def test_facade_pair_matches_oracle(P, oracle):
         if oloss == oracle.LOSS_L2:
             ref, tol = run(), (1e-5, 1e-4)
         else:
-            ref, tr, tm, _ = l1_tolerance(oracle, run, chunks=(64, 1024))
+            ref, tr, tm, _ = l1_tolerance(oracle, run, chunks=(64, 512, 4096))
             tol = (tr, tm)
         for a, b in zip(res.scales, ref.extra["scales"]):
             assert a["n_voxel"] == tuple(b["n_voxel"]) and a["n_clean"] == tuple(b["n_clean"])
