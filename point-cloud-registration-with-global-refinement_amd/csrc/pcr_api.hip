@@ -441,6 +441,94 @@ static int prep_scale(pcr_context *ctx, const float *xyz, const float *nrm, int6
     return PCR_OK;
 }
 
+// ---- Multiscale_GICP with the preprocessing of ALL scales of a cloud in one set of batched launches (blockIdx.y = scale):
+// voxel grids (one key / sort / scan / mean pass), voxel trees (6 launches), SOR chain (7), cleaned target trees (6), exact fallback
+// normals (1): ~33 launches per cloud whatever the number of scales, instead of 13 + 20 per scale.  The two clouds run on their own
+// lanes; the GICP loops of the scales follow on the caller's stream.  Returns 1 (nothing enqueued) when the scales cannot share a
+// pass (pcr_dev_voxel_multi declines): the caller then takes the scale-by-scale path.
+static int multiscale_batched(pcr_context *ctx, const float *src_xyz, const float *src_normals, int64_t n_src, const float *tgt_xyz, const float *tgt_normals,
+                              int64_t n_tgt, const double *voxels, const double *dists, int n_scales, int sor_k, double sor_std, int normal_k, const double *init_T,
+                              const pcr_gicp_params *params, pcr_scale_record *records, int32_t *correspondences, const double *bs, const double *bt) {
+    if (n_scales < 2 || n_scales > 8 || sor_k > 32 || normal_k > 32 || n_src <= 0 || n_tgt <= 0) return 1;
+    auto lane_bytes = [&](int64_t n) { return (size_t)n_scales * ((size_t)n + 512) * 1100 + pcr_sort_temp_bytes((size_t)n * n_scales) + (size_t)n * n_scales * 40 + (32u << 20); };
+    const size_t blk_s = lane_bytes(n_src), blk_t = lane_bytes(n_tgt);
+    PCR_TRY(pcr_arena_reserve(ctx, blk_s + blk_t + pcr_scratch_bytes_for(n_src) + (1u << 20)));
+    char *block_s = (char *)pcr_arena_alloc(ctx, blk_s), *block_t = (char *)pcr_arena_alloc(ctx, blk_t);
+    int *cnt4 = arena<int>(ctx, 4 * 8);                  // per scale: voxel counts (source, target), clean counts (source, target)
+    if (!block_s || !block_t || !cnt4) return PCR_ENOMEM;
+    PCR_TRY(ensure_lanes(ctx, 2));
+    hipStream_t lane_t = ctx->side_stream, lane_s = ctx->side_stream2;
+    struct LaneGuard {            // an early error return must not leave lane work running over a recycled arena
+        hipStream_t a, b;
+        ~LaneGuard() { (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b); }
+    } guard{lane_t, lane_s};
+    PCR_HIP_CHECK(ctx, hipEventRecord(ctx->side_ev[0], ctx->stream));       // inputs are ready once the caller's stream gets here
+    PCR_HIP_CHECK(ctx, hipStreamWaitEvent(lane_t, ctx->side_ev[0], 0));
+    PCR_HIP_CHECK(ctx, hipStreamWaitEvent(lane_s, ctx->side_ev[0], 0));
+    DevCloud clean[2][8];
+    bool declined = false;
+    auto prep_cloud = [&](int which, const float *xyz, const float *nrm, int64_t n, const double *b6, char *block, size_t bytes, hipStream_t lane) -> int {
+        SideLane sl(ctx, block, bytes, lane);
+        const bool need_tree = which == 1;               // a GICP target: its tree serves the correspondence search
+        DevCloud vox[8], tmp[8];
+        const DevCloud *ins[8]; DevCloud *outs[8], *trees[8];
+        const float4 *priors[8]; uint8_t *todos[8]; int *todo_counts[8], *cnt_in[8], *cnt_kept[8];
+        float4 *nouts[8];
+        for (int s = 0; s < n_scales; s++) {
+            PCR_TRY(pcr_alloc_cloud(ctx, &vox[s], (int)n, nrm != nullptr, true));
+            PCR_TRY(pcr_alloc_cloud(ctx, &clean[which][s], (int)n, true, need_tree));
+            float4 *prior = nrm ? arena<float4>(ctx, n) : nullptr;
+            uint8_t *todo = arena<uint8_t>(ctx, n);
+            int *tc = arena<int>(ctx, 2);
+            if (!todo || !tc || (nrm && !prior)) return PCR_ENOMEM;
+            tmp[s] = clean[which][s];
+            tmp[s].nrm = prior;                          // compacted voxel-mean normals = orientation prior
+            tmp[s].nrm_final = clean[which][s].nrm;      // normals of the cleaned cloud, straight from the SOR lists
+            ins[s] = &vox[s]; outs[s] = &tmp[s]; trees[s] = &clean[which][s];
+            priors[s] = prior; todos[s] = todo; todo_counts[s] = tc + 1;
+            cnt_in[s] = cnt4 + 4 * s + which; cnt_kept[s] = cnt4 + 4 * s + 2 + which;
+            nouts[s] = clean[which][s].nrm;
+        }
+        bool merged = false;
+        PCR_TRY(pcr_dev_voxel_multi(ctx, xyz, nrm, n, b6, voxels, n_scales, vox, &merged));
+        if (!merged) { declined = true; return PCR_OK; }
+        DevCloud *vp[8];
+        for (int s = 0; s < n_scales; s++) vp[s] = &vox[s];
+        PCR_TRY(pcr_dev_build_bvh_batch(ctx, vp, n_scales));
+        PCR_TRY(pcr_dev_sor_batch(ctx, ins, outs, n_scales, sor_k, sor_std, normal_k, priors, todos, todo_counts, cnt_in, cnt_kept, !need_tree));
+        for (int s = 0; s < n_scales; s++) for (int d = 0; d < 3; d++) { clean[which][s].key_org[d] = tmp[s].key_org[d]; clean[which][s].key_unit[d] = tmp[s].key_unit[d]; }
+        if (need_tree) {
+            PCR_TRY(pcr_dev_build_bvh_batch(ctx, trees, n_scales));
+            PCR_TRY(pcr_dev_normals_knn_batch(ctx, trees, n_scales, normal_k, priors, nouts, todos));
+        }
+        PCR_HIP_CHECK(ctx, hipEventRecord(ctx->lane_ev[which], ctx->stream));
+        return PCR_OK;
+    };
+    PCR_TRY(prep_cloud(1, tgt_xyz, tgt_normals, n_tgt, bt, block_t, blk_t, lane_t));
+    if (declined) return 1;
+    PCR_TRY(prep_cloud(0, src_xyz, src_normals, n_src, bs, block_s, blk_s, lane_s));
+    if (declined) { ctx->err = "voxel pass accepted one cloud and declined the other"; return PCR_EINVAL; }      // same scales, same key width: cannot happen
+    PCR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_ev[0], 0));
+    PCR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_ev[1], 0));
+    double T[16];
+    memcpy(T, init_T, sizeof T);
+    int32_t *match = arena<int32_t>(ctx, n_src);
+    if (!match) return PCR_ENOMEM;
+    for (int s = 0; s < n_scales; s++) {
+        PCR_TRY(pcr_dev_gicp(ctx, &clean[0][s], &clean[1][s], dists[s], T, params, &records[s].icp, match));
+        memcpy(T, records[s].icp.transformation, sizeof T);
+    }
+    if (correspondences) {
+        int64_t nc = 0;
+        PCR_TRY(pcr_dev_compact_matches(ctx, match, clean[0][n_scales - 1].n, clean[0][n_scales - 1].cap, nullptr, nullptr, correspondences, &nc));
+    }
+    int h[32];
+    PCR_HIP_CHECK(ctx, hipMemcpyAsync(h, cnt4, 4 * n_scales * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int s = 0; s < n_scales; s++) { records[s].n_voxel[0] = h[4 * s]; records[s].n_voxel[1] = h[4 * s + 1]; records[s].n_clean[0] = h[4 * s + 2]; records[s].n_clean[1] = h[4 * s + 3]; }
+    return PCR_OK;
+}
+
 static int multiscale_gicp_impl(pcr_context *ctx, const float *src_xyz, const float *src_normals, int64_t n_src,
                                 const float *tgt_xyz, const float *tgt_normals, int64_t n_tgt, const double *voxels,
                                 const double *dists, int n_scales, int sor_k, double sor_std, int normal_k,
@@ -466,6 +554,14 @@ static int multiscale_gicp_impl(pcr_context *ctx, const float *src_xyz, const fl
     double bs[6], bt[6];
     PCR_TRY(pcr_dev_bounds(ctx, src_xyz, n_src, bs));
     PCR_TRY(pcr_dev_bounds(ctx, tgt_xyz, n_tgt, bt));
+    // all scales of a cloud in one set of batched launches (PCR_SOR_BATCH=0: scale by scale, overlapped with the GICP loops)
+    static const bool batch_env = !(getenv("PCR_SOR_BATCH") && atoi(getenv("PCR_SOR_BATCH")) == 0);
+    if (batch_env && try_merged) {
+        const int rc = multiscale_batched(ctx, src_xyz, src_normals, n_src, tgt_xyz, tgt_normals, n_tgt, voxels, dists, n_scales, sor_k, sor_std, normal_k, init_T, params,
+                                          records, correspondences, bs, bt);
+        if (rc != 1) return rc;
+        PCR_TRY(pcr_arena_reserve(ctx, (size_t)ring * (blk_s + blk_t) + pcr_scratch_bytes_for(n_src) + vox_bytes));      // declined: the path below
+    }
     double T[16];
     memcpy(T, init_T, sizeof T);
     // Preprocessing never depends on the pose, so it runs AHEAD of the GICP loop, each cloud on its own lane (stream +

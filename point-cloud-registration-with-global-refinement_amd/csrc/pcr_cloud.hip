@@ -88,8 +88,12 @@ __device__ static inline int block_exclusive_scan(int v, int *total) {   // BS t
 // Optional flag producers fused into the counting pass (each saved a launch of its own): head flags of sorted keys
 // (voxel grid), or the SOR keep test on the mean neighbour distances.  The flags are stored for the later kernels.
 struct FlagSrc { const uint64_t *keys; const double *avg; const double *stats3; };
-__global__ void __launch_bounds__(BS) k_scan_tile_count(uint8_t *__restrict__ flags, const int *__restrict__ n_ptr, int n_host, int *__restrict__ tile_sums, FlagSrc src) {
-    const int n = n_ptr ? *n_ptr : n_host;
+#define PCR_MAX_BATCH 8          // problems one batched launch serves (blockIdx.y picks the problem): the scales of a multiscale registration
+struct ScanArgs { uint8_t *flags; const int *n_ptr; int n_host; int *tile_cnt; int *pos; int *total; FlagSrc src; int n_tiles; };
+struct ScanBatch { ScanArgs a[PCR_MAX_BATCH]; };
+__device__ static inline void d_scan_tile_count(const ScanArgs &a) {
+    if ((int)blockIdx.x >= a.n_tiles) return;
+    const int n = a.n_ptr ? *a.n_ptr : a.n_host;
     const int base = blockIdx.x * TILE + threadIdx.x * 4;
     int c = 0;
 #pragma unroll
@@ -97,24 +101,23 @@ __global__ void __launch_bounds__(BS) k_scan_tile_count(uint8_t *__restrict__ fl
         const int i = base + j;
         if (i < n) {
             int f;
-            if (src.keys) { f = (i == 0 || src.keys[i] != src.keys[i - 1]) ? 1 : 0; flags[i] = (uint8_t)f; }
-            else if (src.avg) { const double v = src.avg[i]; f = (v > 0 && v < src.stats3[2]) ? 1 : 0; flags[i] = (uint8_t)f; }
-            else f = flags[i] ? 1 : 0;
+            if (a.src.keys) { f = (i == 0 || a.src.keys[i] != a.src.keys[i - 1]) ? 1 : 0; a.flags[i] = (uint8_t)f; }
+            else if (a.src.avg) { const double v = a.src.avg[i]; f = (v > 0 && v < a.src.stats3[2]) ? 1 : 0; a.flags[i] = (uint8_t)f; }
+            else f = a.flags[i] ? 1 : 0;
             c += f;
         }
     }
     int tot; (void)block_exclusive_scan(c, &tot);
-    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+    if (threadIdx.x == 0) a.tile_cnt[blockIdx.x] = tot;
 }
 // exclusive positions: every tile first adds up the counts of the tiles before it (a few hundred ints, one read per lane)
-// instead of waiting for a separate single-workgroup scan of the tile counts -- one launch less per scan, and launches
-// are what bounds the throughput with several pairs in flight
-__global__ void __launch_bounds__(BS) k_scan_tile_apply(const uint8_t *__restrict__ flags, const int *__restrict__ n_ptr, int n_host, const int *__restrict__ tile_cnt,
-                                                        int *__restrict__ pos, int *__restrict__ total_out) {
+// instead of waiting for a separate single-workgroup scan of the tile counts -- one launch less per scan
+__device__ static inline void d_scan_tile_apply(const ScanArgs &a) {
     __shared__ int wsum[BS / 64];
-    const int n = n_ptr ? *n_ptr : n_host;
+    if ((int)blockIdx.x >= a.n_tiles) return;
+    const int n = a.n_ptr ? *a.n_ptr : a.n_host;
     int before = 0;
-    for (int t = threadIdx.x; t < (int)blockIdx.x; t += BS) before += tile_cnt[t];
+    for (int t = threadIdx.x; t < (int)blockIdx.x; t += BS) before += a.tile_cnt[t];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) before += __shfl_down(before, o, 64);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = before;
@@ -125,19 +128,37 @@ __global__ void __launch_bounds__(BS) k_scan_tile_apply(const uint8_t *__restric
     const int base = blockIdx.x * TILE + threadIdx.x * 4;
     int f[4], c = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) { f[j] = (base + j < n && flags[base + j]) ? 1 : 0; c += f[j]; }
+    for (int j = 0; j < 4; j++) { f[j] = (base + j < n && a.flags[base + j]) ? 1 : 0; c += f[j]; }
     int tot; int ex = block_exclusive_scan(c, &tot) + offset;
 #pragma unroll
-    for (int j = 0; j < 4; j++) { if (base + j < n) pos[base + j] = ex; ex += f[j]; }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = offset + tot;
+    for (int j = 0; j < 4; j++) { if (base + j < n) a.pos[base + j] = ex; ex += f[j]; }
+    if ((int)blockIdx.x == a.n_tiles - 1 && threadIdx.x == 0) *a.total = offset + tot;
 }
+__global__ void __launch_bounds__(BS) k_scan_tile_count(ScanArgs a) { d_scan_tile_count(a); }
+__global__ void __launch_bounds__(BS) k_scan_tile_apply(ScanArgs a) { d_scan_tile_apply(a); }
+__global__ void __launch_bounds__(BS) k_scan_tile_count_batch(ScanBatch b) { d_scan_tile_count(b.a[blockIdx.y]); }
+__global__ void __launch_bounds__(BS) k_scan_tile_apply_batch(ScanBatch b) { d_scan_tile_apply(b.a[blockIdx.y]); }
 
+static int scan_args(pcr_context *ctx, ScanArgs *a, uint8_t *flags, const int *n_ptr, int n_cap, int *pos, int *total_dev, FlagSrc src) {
+    a->n_tiles = (n_cap + TILE - 1) / TILE;
+    a->tile_cnt = arena<int>(ctx, (size_t)a->n_tiles + 1);
+    if (!a->tile_cnt) return PCR_ENOMEM;
+    a->flags = flags; a->n_ptr = n_ptr; a->n_host = n_cap; a->pos = pos; a->total = total_dev; a->src = src;
+    return PCR_OK;
+}
 static int flag_scan(pcr_context *ctx, uint8_t *flags, const int *n_ptr, int n_cap, int *pos, int *total_dev, FlagSrc src) {
-    const int n_tiles = (n_cap + TILE - 1) / TILE;
-    int *tile_cnt = arena<int>(ctx, (size_t)n_tiles + 1);
-    if (!tile_cnt) return PCR_ENOMEM;
-    PCR_LAUNCH(ctx, k_scan_tile_count, dim3(n_tiles), dim3(BS), 0, ctx->stream, flags, n_ptr, n_cap, tile_cnt, src);
-    PCR_LAUNCH(ctx, k_scan_tile_apply, dim3(n_tiles), dim3(BS), 0, ctx->stream, flags, n_ptr, n_cap, tile_cnt, pos, total_dev);
+    ScanArgs a;
+    PCR_TRY(scan_args(ctx, &a, flags, n_ptr, n_cap, pos, total_dev, src));
+    PCR_LAUNCH(ctx, k_scan_tile_count, dim3(a.n_tiles), dim3(BS), 0, ctx->stream, a);
+    PCR_LAUNCH(ctx, k_scan_tile_apply, dim3(a.n_tiles), dim3(BS), 0, ctx->stream, a);
+    return PCR_OK;
+}
+static int flag_scan_batch(pcr_context *ctx, const ScanBatch &b, int count) {
+    int mt = 0;
+    for (int k = 0; k < count; k++) mt = b.a[k].n_tiles > mt ? b.a[k].n_tiles : mt;
+    if (mt == 0) return PCR_OK;
+    PCR_LAUNCH(ctx, k_scan_tile_count_batch, dim3(mt, count), dim3(BS), 0, ctx->stream, b);
+    PCR_LAUNCH(ctx, k_scan_tile_apply_batch, dim3(mt, count), dim3(BS), 0, ctx->stream, b);
     return PCR_OK;
 }
 int pcr_dev_flag_scan(pcr_context *ctx, const uint8_t *flags, const int *n_ptr, int n_cap, int *pos, int *total_dev) {
@@ -766,8 +787,9 @@ struct KnnArgs {
 
 __device__ static inline double octet_sum(double v) { return pcr_octet_sum(v); }
 
+struct KnnBatch { KnnArgs a[PCR_MAX_BATCH]; };
 template <int MODE, int SLOTS>
-__global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) {
+__device__ static inline void d_knn(const KnnArgs &a) {
     constexpr int OPB = KNN_BS / OCT;
     __shared__ OctMeta m;
     __shared__ OctGroupStack gstk[KNN_BS / 64];
@@ -935,6 +957,23 @@ __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) {
     }
 }
 
+template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) { d_knn<MODE, SLOTS>(a); }
+template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn_batch(KnnBatch b) { d_knn<MODE, SLOTS>(b.a[blockIdx.y]); }
+
+// `count` searches in ONE launch (blockIdx.y picks the problem; k <= 32): the SOR / normals searches of all scales of a cloud
+template <int MODE>
+static int launch_knn_batch(pcr_context *ctx, KnnBatch &b, const int *caps, int count) {
+    int mc = 0;
+    for (int k = 0; k < count; k++) {
+        if (b.a[k].k < 1 || b.a[k].k > 32) { ctx->err = "batched k-NN: k must be in 1..32"; return PCR_EINVAL; }
+        { static const int ss = getenv("PCR_KNN_SEED") ? atoi(getenv("PCR_KNN_SEED")) : -1; b.a[k].seed_span = ss; }
+        mc = caps[k] > mc ? caps[k] : mc;
+    }
+    if (mc <= 0) return PCR_OK;
+    PCR_LAUNCH(ctx, k_knn_batch<MODE, 4>, dim3((unsigned)(((size_t)mc * OCT + KNN_BS - 1) / KNN_BS), count), dim3(KNN_BS), 0, ctx->stream, b);
+    return PCR_OK;
+}
+
 template <int MODE>
 static int launch_knn(pcr_context *ctx, const DevCloud *c, KnnArgs a) {
     if (c->cap <= 0) return PCR_OK;
@@ -1059,7 +1098,8 @@ struct NflArgs {
     const float4 *prior; float4 *normals;            // cleaned order
     uint8_t *todo; int *todo_count;
 };
-__global__ void __launch_bounds__(KNN_BS) k_normals_from_lists(NflArgs a) {
+struct NflBatch { NflArgs a[PCR_MAX_BATCH]; };
+__device__ static inline void d_normals_from_lists(const NflArgs &a) {
     const int n = *a.n_ptr;
     const int ol = threadIdx.x & 7;
     const int i = blockIdx.x * (KNN_BS / OCT) + (threadIdx.x >> 3);
@@ -1127,13 +1167,19 @@ __global__ void __launch_bounds__(KNN_BS) k_normals_from_lists(NflArgs a) {
     }
 }
 
+__global__ void __launch_bounds__(KNN_BS) k_normals_from_lists(NflArgs a) { d_normals_from_lists(a); }
+__global__ void __launch_bounds__(KNN_BS) k_normals_from_lists_batch(NflBatch b) { d_normals_from_lists(b.a[blockIdx.y]); }
+
 // ============================================================================ SOR (K4)
 // mean / Bessel std of the per-point mean neighbour distance in ONE pass over <= 128 workgroups: shifted moments
 // sum(v-c), sum((v-c)^2), count with c = the first valid value (no cancellation: |mean-c| ~ sigma), fixed summation
 // tree, write-through partial rows + ticket, the last workgroup gathers them with sc1 loads (no fence) and finishes.
 #define SOR_STAT_BLOCKS 128
-__global__ void __launch_bounds__(256) k_sor_stats(const double *__restrict__ avg, const int *__restrict__ n_ptr, double std_ratio, double *__restrict__ out3,
-                                                   double *__restrict__ partials /* SOR_STAT_BLOCKS x 4 */, unsigned int *__restrict__ ticket) {
+struct SorStatArgs { const double *avg; const int *n_ptr; double std_ratio; double *out3; double *partials /* SOR_STAT_BLOCKS x 4 */; unsigned int *ticket; };
+struct SorStatBatch { SorStatArgs a[PCR_MAX_BATCH]; };
+__device__ static inline void d_sor_stats(const SorStatArgs &aa) {
+    const double *__restrict__ avg = aa.avg; const int *__restrict__ n_ptr = aa.n_ptr; const double std_ratio = aa.std_ratio;
+    double *__restrict__ out3 = aa.out3; double *__restrict__ partials = aa.partials; unsigned int *__restrict__ ticket = aa.ticket;
     __shared__ double red[16][3];
     __shared__ double rows[SOR_STAT_BLOCKS * 3];
     __shared__ int is_last;
@@ -1173,65 +1219,140 @@ __global__ void __launch_bounds__(256) k_sor_stats(const double *__restrict__ av
         *ticket = 0u;
     }
 }
-__global__ void __launch_bounds__(BS) k_compact_cloud(const float4 *__restrict__ pts, const float4 *__restrict__ nrm, const uint8_t *__restrict__ flags, const int *__restrict__ pos,
-                                                      const int *__restrict__ n_ptr, float4 *__restrict__ out_pts, float4 *__restrict__ out_nrm,
-                                                      const uint64_t *__restrict__ keys, uint64_t *__restrict__ out_keys,
-                                                      int *__restrict__ cnt_in_out, int *__restrict__ cnt_kept_out, const int *__restrict__ kept_n) {
+__global__ void __launch_bounds__(256) k_sor_stats(SorStatArgs a) { d_sor_stats(a); }
+__global__ void __launch_bounds__(256) k_sor_stats_batch(SorStatBatch b) { d_sor_stats(b.a[blockIdx.y]); }
+
+struct CompactArgs {
+    const float4 *pts, *nrm; const uint8_t *flags; const int *pos; const int *n_ptr; float4 *out_pts, *out_nrm;
+    const uint64_t *keys; uint64_t *out_keys; int *cnt_in_out, *cnt_kept_out; const int *kept_n;
+};
+struct CompactBatch { CompactArgs a[PCR_MAX_BATCH]; };
+__device__ static inline void d_compact_cloud(const CompactArgs &a) {
     const int i = blockIdx.x * BS + threadIdx.x;
-    if (i == 0) { if (cnt_in_out) *cnt_in_out = *n_ptr; if (cnt_kept_out) *cnt_kept_out = *kept_n; }    // counts for the host, one copy later
-    if (i >= *n_ptr || !flags[i]) return;
-    const int o = pos[i];
-    out_pts[o] = pts[i];
-    out_keys[o] = keys[i];
-    if (nrm && out_nrm) out_nrm[o] = nrm[i];
+    if (i == 0) { if (a.cnt_in_out) *a.cnt_in_out = *a.n_ptr; if (a.cnt_kept_out) *a.cnt_kept_out = *a.kept_n; }    // counts for the host, one copy later
+    if (i >= *a.n_ptr || !a.flags[i]) return;
+    const int o = a.pos[i];
+    a.out_pts[o] = a.pts[i];
+    a.out_keys[o] = a.keys[i];
+    if (a.nrm && a.out_nrm) a.out_nrm[o] = a.nrm[i];
+}
+__global__ void __launch_bounds__(BS) k_compact_cloud(CompactArgs a) { d_compact_cloud(a); }
+__global__ void __launch_bounds__(BS) k_compact_cloud_batch(CompactBatch b) { d_compact_cloud(b.a[blockIdx.y]); }
+
+// The SOR chain of `count` clouds in ONE launch per stage (blockIdx.y picks the cloud): k-NN + k-best lists, statistics, keep flags
+// inside the two-kernel scan, compaction, normals of the cleaned cloud from the lists, exact fallback search for the incomplete lists.
+// count == 1 is the single-cloud call; count > 1 serves the voxel clouds of all scales of a multiscale registration (they do not
+// depend on each other), 7 launches instead of 7 per scale.  Per-problem arguments as in pcr_dev_sor.
+struct SorProblem {
+    const DevCloud *in; DevCloud *out; uint8_t *keep_sorted; double *avg_sorted; const float4 *prior_out; uint8_t *todo_out; int *todo_count;
+    int *cnt_in_out, *cnt_kept_out;
+};
+static int sor_batch(pcr_context *ctx, SorProblem *pr, int count, int nb_neighbors, double std_ratio, int normal_k, bool fallback_here) {
+    if (nb_neighbors < 1 || !(std_ratio > 0.0)) { ctx->err = "nb_neighbors < 1 or std_ratio <= 0"; return PCR_EINVAL; }
+    if (count < 1 || count > PCR_MAX_BATCH) { ctx->err = "SOR batch size"; return PCR_EINVAL; }
+    KnnBatch kb{}, fb{}; SorStatBatch sb{}; ScanBatch cb{}; CompactBatch mb{}; NflBatch nb_{};
+    int caps[PCR_MAX_BATCH], m = 0;
+    bool any_todo = false, fuse_all = true;
+    for (int k = 0; k < count; k++) {
+        SorProblem &q = pr[k];
+        const DevCloud *in = q.in; DevCloud *out = q.out;
+        for (int d = 0; d < 3; d++) { out->key_org[d] = in->key_org[d]; out->key_unit[d] = in->key_unit[d]; }
+        if (in->cap <= 0) { PCR_HIP_CHECK(ctx, hipMemsetAsync(out->n, 0, sizeof(int), ctx->stream)); continue; }
+        double *avg = q.avg_sorted ? q.avg_sorted : arena<double>(ctx, in->cap);
+        double *stats3 = arena<double>(ctx, 4);
+        double *stat_partials = arena<double>(ctx, SOR_STAT_BLOCKS * 4);
+        unsigned int *stat_ticket = arena<unsigned int>(ctx, 1);
+        uint8_t *flags = q.keep_sorted ? q.keep_sorted : arena<uint8_t>(ctx, in->cap);
+        int *pos = arena<int>(ctx, in->cap);
+        if (!avg || !stats3 || !stat_partials || !stat_ticket || !flags || !pos) return PCR_ENOMEM;
+        // normals of the cleaned cloud straight from this pass's lists when they can be exact (see k_normals_from_lists)
+        const bool fuse = normal_k > 0 && q.todo_out && nb_neighbors <= 32 && normal_k <= nb_neighbors;
+        int32_t *lidx = fuse ? arena<int32_t>(ctx, (size_t)in->cap * 32) : nullptr;
+        float *ld2 = fuse ? arena<float>(ctx, (size_t)in->cap * 32) : nullptr;
+        if (fuse && (!lidx || !ld2)) return PCR_ENOMEM;
+        KnnArgs &a = kb.a[m];
+        a.t = oct_view(in); a.n_ptr = in->n; a.k = nb_neighbors; a.avg = avg; a.list_idx = lidx; a.list_d2 = ld2;
+        a.zero_a = (int *)stat_ticket; a.zero_b = (fuse && q.todo_out) ? q.todo_count : nullptr;      // zeroed by the search kernel for the kernels after it
+        a.seed_span = -1;
+        knn_radius(a, PCR_SEARCH_KNN, 0);
+        sb.a[m] = SorStatArgs{avg, in->n, std_ratio, stats3, stat_partials, stat_ticket};
+        PCR_TRY(scan_args(ctx, &cb.a[m], flags, in->n, in->cap, pos, out->n, FlagSrc{nullptr, avg, stats3}));      // keep flags produced inside the scan
+        mb.a[m] = CompactArgs{in->pts, in->nrm, flags, pos, in->n, out->pts, out->nrm, in->keys, out->keys, q.cnt_in_out, q.cnt_kept_out, out->n};
+        if (q.todo_out) {
+            any_todo = true;
+            if (fuse) {
+                NflArgs &f = nb_.a[m];
+                f.pts = in->pts; f.n_ptr = in->n; f.lidx = lidx; f.ld2 = ld2; f.keep = flags; f.pos = pos; f.k_list = nb_neighbors; f.k_nrm = normal_k;
+                f.prior = q.prior_out; f.normals = out->nrm_final; f.todo = q.todo_out; f.todo_count = q.todo_count;
+            } else {
+                fuse_all = false;
+                PCR_HIP_CHECK(ctx, hipMemsetAsync(q.todo_out, 1, (size_t)in->cap, ctx->stream));
+            }
+            if (fallback_here && normal_k > 0) {
+                // the incomplete lists are searched right here, over the INPUT cloud's tree restricted to the kept points: the
+                // cleaned cloud then needs no tree of its own (7 launches less; only a GICP target needs one)
+                KnnArgs &b = fb.a[m];
+                b.t = oct_view(in); b.n_ptr = in->n; b.k = normal_k; b.prior = q.prior_out; b.normals = out->nrm_final; b.todo = q.todo_out;
+                b.keep = flags; b.pos = pos; b.seed_span = -1;
+                knn_radius(b, PCR_SEARCH_KNN, 0);
+            }
+        } else fuse_all = false;
+        caps[m] = in->cap;
+        m++;
+    }
+    if (m == 0) return PCR_OK;
+    int mc = 0;
+    for (int k = 0; k < m; k++) mc = caps[k] > mc ? caps[k] : mc;
+    if (m == 1 && nb_neighbors > 32) {      // the single-cloud call with a long list: the wide-slot kernels
+        DevCloud tmp; tmp.cap = caps[0];
+        PCR_TRY(launch_knn<KNN_MODE_SOR>(ctx, &tmp, kb.a[0]));
+    } else {
+        if (nb_neighbors > 32) { ctx->err = "batched SOR: nb_neighbors must be <= 32"; return PCR_EINVAL; }
+        PCR_TRY(launch_knn_batch<KNN_MODE_SOR>(ctx, kb, caps, m));
+    }
+    PCR_LAUNCH(ctx, k_sor_stats_batch, dim3(SOR_STAT_BLOCKS, m), dim3(256), 0, ctx->stream, sb);
+    PCR_TRY(flag_scan_batch(ctx, cb, m));
+    PCR_LAUNCH(ctx, k_compact_cloud_batch, dim3((mc + BS - 1) / BS, m), dim3(BS), 0, ctx->stream, mb);
+    if (any_todo) {
+        if (fuse_all) PCR_LAUNCH(ctx, k_normals_from_lists_batch, dim3((unsigned)(((size_t)mc * OCT + KNN_BS - 1) / KNN_BS), m), dim3(KNN_BS), 0, ctx->stream, nb_);
+        else for (int k = 0; k < m; k++) if (nb_.a[k].pts) PCR_LAUNCH(ctx, k_normals_from_lists, dim3((unsigned)(((size_t)caps[k] * OCT + KNN_BS - 1) / KNN_BS)), dim3(KNN_BS), 0, ctx->stream, nb_.a[k]);
+        if (fallback_here && normal_k > 0) {
+            if (normal_k <= 32) PCR_TRY(launch_knn_batch<KNN_MODE_NORMALS>(ctx, fb, caps, m));
+            else for (int k = 0; k < m; k++) { DevCloud tmp; tmp.cap = caps[k]; PCR_TRY(launch_knn<KNN_MODE_NORMALS>(ctx, &tmp, fb.a[k])); }
+        }
+    }
+    return PCR_OK;
 }
 
 int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double std_ratio, DevCloud *out, uint8_t *keep_sorted, double *avg_sorted,
                 int normal_k, const float4 *prior_out, uint8_t *todo_out, int *todo_count, int *cnt_in_out, int *cnt_kept_out, bool fallback_here) {
-    if (nb_neighbors < 1 || !(std_ratio > 0.0)) { ctx->err = "nb_neighbors < 1 or std_ratio <= 0"; return PCR_EINVAL; }
-    for (int d = 0; d < 3; d++) { out->key_org[d] = in->key_org[d]; out->key_unit[d] = in->key_unit[d]; }
-    if (in->cap <= 0) { PCR_HIP_CHECK(ctx, hipMemsetAsync(out->n, 0, sizeof(int), ctx->stream)); return PCR_OK; }
     ArenaMark mark(ctx);
-    double *avg = avg_sorted ? avg_sorted : arena<double>(ctx, in->cap);
-    double *stats3 = arena<double>(ctx, 4);
-    double *stat_partials = arena<double>(ctx, SOR_STAT_BLOCKS * 4);
-    unsigned int *stat_ticket = arena<unsigned int>(ctx, 1);
-    uint8_t *flags = keep_sorted ? keep_sorted : arena<uint8_t>(ctx, in->cap);
-    int *pos = arena<int>(ctx, in->cap);
-    if (!avg || !stats3 || !stat_partials || !stat_ticket || !flags || !pos) return PCR_ENOMEM;
-    // normals of the cleaned cloud straight from this pass's lists when they can be exact (see k_normals_from_lists)
-    const bool fuse = normal_k > 0 && todo_out && nb_neighbors <= 32 && normal_k <= nb_neighbors;
-    int32_t *lidx = fuse ? arena<int32_t>(ctx, (size_t)in->cap * 32) : nullptr;
-    float *ld2 = fuse ? arena<float>(ctx, (size_t)in->cap * 32) : nullptr;
-    if (fuse && (!lidx || !ld2)) return PCR_ENOMEM;
-    KnnArgs a = {};
-    a.t = oct_view(in); a.n_ptr = in->n; a.k = nb_neighbors; a.avg = avg; a.list_idx = lidx; a.list_d2 = ld2;
-    a.zero_a = (int *)stat_ticket; a.zero_b = (fuse && todo_out) ? todo_count : nullptr;      // zeroed by the search kernel for the kernels after it
-    knn_radius(a, PCR_SEARCH_KNN, 0);
-    PCR_TRY(launch_knn<KNN_MODE_SOR>(ctx, in, a));
-    PCR_LAUNCH(ctx, k_sor_stats, dim3(SOR_STAT_BLOCKS), dim3(256), 0, ctx->stream, avg, in->n, std_ratio, stats3, stat_partials, stat_ticket);
-    const int nb = (in->cap + BS - 1) / BS;
-    PCR_TRY(flag_scan(ctx, flags, in->n, in->cap, pos, out->n, FlagSrc{nullptr, avg, stats3}));      // keep flags produced inside the scan
-    PCR_LAUNCH(ctx, k_compact_cloud, dim3(nb), dim3(BS), 0, ctx->stream, in->pts, in->nrm, flags, pos, in->n, out->pts, out->nrm, in->keys, out->keys, cnt_in_out, cnt_kept_out, out->n);
-    if (todo_out) {
-        if (fuse) {
-            NflArgs f;
-            f.pts = in->pts; f.n_ptr = in->n; f.lidx = lidx; f.ld2 = ld2; f.keep = flags; f.pos = pos; f.k_list = nb_neighbors; f.k_nrm = normal_k;
-            f.prior = prior_out; f.normals = out->nrm_final; f.todo = todo_out; f.todo_count = todo_count;
-            PCR_LAUNCH(ctx, k_normals_from_lists, dim3((unsigned)(((size_t)in->cap * OCT + KNN_BS - 1) / KNN_BS)), dim3(KNN_BS), 0, ctx->stream, f);
-        } else {
-            PCR_HIP_CHECK(ctx, hipMemsetAsync(todo_out, 1, (size_t)in->cap, ctx->stream));
-        }
-        if (fallback_here && normal_k > 0) {
-            // the incomplete lists are searched right here, over the INPUT cloud's tree restricted to the kept points: the
-            // cleaned cloud then needs no tree of its own (7 launches less; only a GICP target needs one)
-            KnnArgs b = {};
-            b.t = oct_view(in); b.n_ptr = in->n; b.k = normal_k; b.prior = prior_out; b.normals = out->nrm_final; b.todo = todo_out;
-            b.keep = flags; b.pos = pos;
-            knn_radius(b, PCR_SEARCH_KNN, 0);
-            PCR_TRY(launch_knn<KNN_MODE_NORMALS>(ctx, in, b));
-        }
+    SorProblem p{in, out, keep_sorted, avg_sorted, prior_out, todo_out, todo_count, cnt_in_out, cnt_kept_out};
+    return sor_batch(ctx, &p, 1, nb_neighbors, std_ratio, normal_k, fallback_here);
+}
+// the SOR chains of `count` clouds (the voxel clouds of all scales) in one set of launches; scratch above the caller's mark
+int pcr_dev_sor_batch(pcr_context *ctx, const DevCloud *const *ins, DevCloud *const *outs, int count, int nb_neighbors, double std_ratio, int normal_k,
+                      const float4 *const *priors, uint8_t *const *todos, int *const *todo_counts, int *const *cnt_in, int *const *cnt_kept, bool fallback_here) {
+    SorProblem p[PCR_MAX_BATCH];
+    if (count > PCR_MAX_BATCH) { ctx->err = "SOR batch size"; return PCR_EINVAL; }
+    for (int k = 0; k < count; k++) p[k] = SorProblem{ins[k], outs[k], nullptr, nullptr, priors ? priors[k] : nullptr, todos[k], todo_counts[k], cnt_in ? cnt_in[k] : nullptr, cnt_kept ? cnt_kept[k] : nullptr};
+    return sor_batch(ctx, p, count, nb_neighbors, std_ratio, normal_k, fallback_here);
+}
+// k-NN normals of `count` clouds over their own trees in one launch (todo masks optional): the incomplete lists of the cleaned targets
+int pcr_dev_normals_knn_batch(pcr_context *ctx, DevCloud *const *cs, int count, int knn, const float4 *const *priors, float4 *const *normals_out, const uint8_t *const *todos) {
+    if (knn < 1) { ctx->err = "knn < 1"; return PCR_EINVAL; }
+    if (count > PCR_MAX_BATCH) { ctx->err = "normals batch size"; return PCR_EINVAL; }
+    KnnBatch b{}; int caps[PCR_MAX_BATCH], m = 0;
+    for (int k = 0; k < count; k++) {
+        if (cs[k]->cap <= 0) continue;
+        KnnArgs &a = b.a[m];
+        a.t = oct_view(cs[k]); a.n_ptr = cs[k]->n; a.k = knn; a.prior = priors ? priors[k] : nullptr; a.normals = normals_out[k]; a.todo = todos ? todos[k] : nullptr; a.seed_span = -1;
+        knn_radius(a, PCR_SEARCH_KNN, 0);
+        caps[m++] = cs[k]->cap;
     }
+    if (m == 0) return PCR_OK;
+    if (knn <= 32) return launch_knn_batch<KNN_MODE_NORMALS>(ctx, b, caps, m);
+    for (int k = 0; k < m; k++) { DevCloud tmp; tmp.cap = caps[k]; PCR_TRY(launch_knn<KNN_MODE_NORMALS>(ctx, &tmp, b.a[k])); }
     return PCR_OK;
 }
 

@@ -136,6 +136,9 @@ int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double s
                 int normal_k = 0, const float4 *prior_out = nullptr, uint8_t *todo_out = nullptr, int *todo_count = nullptr,
                 int *cnt_in_out = nullptr, int *cnt_kept_out = nullptr /* optional device ints: input and kept counts */,
                 bool fallback_here = false /* search the incomplete lists over `in`'s tree restricted to kept points */);
+int pcr_dev_sor_batch(pcr_context *ctx, const DevCloud *const *ins, DevCloud *const *outs, int count, int nb_neighbors, double std_ratio, int normal_k,
+                      const float4 *const *priors, uint8_t *const *todos, int *const *todo_counts, int *const *cnt_in, int *const *cnt_kept, bool fallback_here);
+int pcr_dev_normals_knn_batch(pcr_context *ctx, DevCloud *const *cs, int count, int knn, const float4 *const *priors, float4 *const *normals_out, const uint8_t *const *todos);
 // normals (and optionally covariances) by k-NN / hybrid / radius neighbourhoods over the BVH
 int pcr_dev_normals(pcr_context *ctx, DevCloud *c, int search_kind, int knn, double radius, const float4 *prior,
                     float4 *normals_out, float *cov6_out /*optional, sorted order, 6 per point*/, const uint8_t *todo = nullptr);
