@@ -6,7 +6,7 @@ The directory name contains hyphens; import it with ``importlib.import_module`` 
 ``pcr_amd`` alias module at the repository root.
 """
 from . import _lib, drivers, functions, geometry, io, o3d, posegraph, refinement, registration, sharding  # noqa: F401
-from .functions import (Coarse_to_fine_FGR_M_GICP, GICP_robusto, Multiscale_GICP, calculate_RMSE_and_fitness,  # noqa: F401
+from .functions import (Coarse_to_fine_FGR_M_GICP, GICP_robusto, Multiscale_GICP, amostragem_multiescala_otimizada, calculate_RMSE_and_fitness,  # noqa: F401
                         create_scales, radius_from_cloud_pair, registro_FGR, script1, script2)
 from .geometry import (KDTreeSearchParamHybrid, KDTreeSearchParamKNN, KDTreeSearchParamRadius, PointCloud)  # noqa: F401
 

@@ -61,6 +61,27 @@ def GICP_robusto(source, target, max_corres_dist, initial_T, iterations):
                                _r.ICPConvergenceCriteria(max_iteration=iterations))
 
 
+def amostragem_multiescala_otimizada(nuvem, n_escalas, voxel_inicial, seed=None):
+    """ALL_FUNCTIONS.py:233-254: one voxel grid at ``voxel_inicial`` and ``n_escalas - 1`` random subsets of it whose sizes imitate
+    coarser voxel grids (retention model a*exp(-b*voxel), a = 1.18397758, b = 5.09388767, normalised as the reference does);
+    returned as the reference returns them: the random subsets in reverse order of creation, the voxel cloud last.  ``seed``
+    (not in the reference, whose draws come from Open3D's random device) makes the subsets repeatable."""
+    nuvem_amostrada_inicial = nuvem.voxel_down_sample(voxel_inicial)
+    total_pts = len(np.asarray(nuvem.points))
+    pts_inici = len(np.asarray(nuvem_amostrada_inicial.points))
+    escalas = np.asarray([voxel_inicial + voxel_inicial * i for i in range(n_escalas)])
+    a, b = 1.18397758, 5.09388767
+    porcentagens = a * np.exp(-b * escalas)
+    porcentagens_escalonadas = porcentagens * total_pts / pts_inici
+    porcentagens_normalizadas = porcentagens_escalonadas / np.linalg.norm(porcentagens_escalonadas)
+    porcentagens_normalizadas = porcentagens_normalizadas[1:10]
+    lista_nuvens_amostradas = []
+    for i in range(n_escalas - 1):
+        lista_nuvens_amostradas.append(nuvem_amostrada_inicial.random_down_sample(porcentagens_normalizadas[i], seed=None if seed is None else seed + i))
+    lista_nuvens_amostradas.insert(0, nuvem_amostrada_inicial)
+    return list(reversed(lista_nuvens_amostradas))
+
+
 def create_scales(n_scales):
     """ALL_FUNCTIONS.py:260-264: doubling voxel sizes [0.1, 0.2, 0.4, ...]."""
     voxel_radius = [0.1]

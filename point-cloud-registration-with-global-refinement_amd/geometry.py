@@ -197,6 +197,22 @@ class PointCloud:
             out._cov = self._cov[idx].contiguous()
         return out
 
+    def random_down_sample(self, sampling_ratio: float, seed=None) -> "PointCloud":
+        """``PointCloud.random_down_sample`` (ALL_FUNCTIONS.py:248): a uniformly random subset of ``int(n * sampling_ratio)`` points
+        in shuffled order (Open3D shuffles the index list with a ``random_device``-seeded engine and keeps its head; ``seed`` makes
+        the draw repeatable here).  Raises like Open3D for a ratio outside (0, 1]."""
+        if not (0.0 < sampling_ratio <= 1.0):
+            raise RuntimeError("Illegal sampling_ratio, sampling_ratio must be between 0 and 1.")
+        torch = _torch()
+        n = len(self)
+        m = int(n * sampling_ratio)
+        g = torch.Generator(device="cuda")
+        if seed is None:
+            g.seed()
+        else:
+            g.manual_seed(int(seed))
+        return self.select_by_index(torch.randperm(n, device="cuda", generator=g)[:m])
+
     def estimate_normals(self, search_param=None, fast_normal_computation: bool = True):
         ctx = _lib.Context.current()
         torch = _torch()

@@ -93,6 +93,15 @@ def test_facade_loop_stage2_on_device_and_global_refinement_on_host(P, oracle):
     for k in range(7):                                                # the optimised nodes stay next to the LUM solution (same loop, same edges)
         ang, dt = pose_error(g.nodes[k].pose, lum[k])
         assert ang < 2e-2 and dt < 0.2, (k, ang, dt)
+    # the shipped absolute Facade poses are not the output of any host variant on the shipped relative poses (tests/test_refinement.py);
+    # the pose graph over the device's poses lands in the same neighbourhood, no closer: reported, loosely bounded
+    import os
+    from conftest import GOLDEN
+    d = np.load(os.path.join(GOLDEN, "poses_facade.npz"))
+    an = list(d["absolute_names"]); shipped = [d["absolute"][an.index(f"pose{i}.txt")] for i in range(7)]
+    e = np.array([pose_error(g.nodes[k].pose, shipped[k]) for k in range(7)])
+    print(f"pose graph over device poses vs shipped absolute Facade poses: max {e[:, 0].max():.2e} rad {e[:, 1].max():.2e} m")
+    assert e[:, 0].max() < 5e-2 and e[:, 1].max() < 1.0
 
 
 def test_dense_one_million_point_loop(P, oracle):

@@ -156,3 +156,30 @@ def test_covariances_match_oracle(P, oracle, small_pair):
     dev = pc.covariances
     scale = np.abs(ref).max(axis=(1, 2), keepdims=True)
     assert (np.abs(dev - ref) <= 2e-6 * scale + 1e-9).mean() > 0.999
+
+
+def test_amostragem_multiescala_otimizada_and_random_down_sample(P, oracle, small_pair):
+    """ALL_FUNCTIONS.py:233-254 (SURVEY f-4): the voxel cloud plus n-1 random subsets of it with the reference's size model, in the
+    reference's order (subsets reversed, voxel cloud last); `random_down_sample` keeps int(n * ratio) points of the cloud, each once,
+    and raises like Open3D outside (0, 1]."""
+    pts = small_pair["source"]
+    pc = P.PointCloud(pts)
+    out = P.amostragem_multiescala_otimizada(pc, 4, 0.1, seed=3)
+    vox = oracle.voxel_down_sample(pts, 0.1)
+    assert len(out) == 4 and len(out[-1]) == len(vox)
+    esc = np.array([0.1 + 0.1 * i for i in range(4)])
+    pct = 1.18397758 * np.exp(-5.09388767 * esc) * len(pts) / len(vox)
+    pct = (pct / np.linalg.norm(pct))[1:10]
+    assert [len(c) for c in out[:3]] == [int(len(vox) * pct[i]) for i in (2, 1, 0)]
+    allv = {tuple(r) for r in out[-1].points.tolist()}
+    for c in out[:3]:
+        rows = [tuple(r) for r in c.points.tolist()]
+        assert len(set(rows)) == len(rows) and set(rows) <= allv          # a subset of the voxel cloud, no point twice
+    again = P.amostragem_multiescala_otimizada(P.PointCloud(pts), 4, 0.1, seed=3)
+    assert all(np.array_equal(a.points, b.points) for a, b in zip(out, again))
+    half = pc.random_down_sample(0.5)
+    assert len(half) == int(len(pts) * 0.5)
+    assert len(pc.random_down_sample(1.0)) == len(pts)
+    for bad in (0.0, -0.1, 1.5):
+        with pytest.raises(RuntimeError):
+            pc.random_down_sample(bad)

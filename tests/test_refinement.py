@@ -162,3 +162,35 @@ def test_three_cloud_hand_case():
     np.testing.assert_allclose(np.array(dR) * np.sqrt(2), dR0)
     with pytest.raises(Exception):
         rf.subtract_squared_poses(lum, sl[:2])
+
+
+def test_which_variant_made_the_shipped_absolute_poses():
+    """VERDICT r1 #9 / SURVEY f-2: the reference ships `absolute_poses_FGR_GICP/{Facade,Courtyard}` next to the relative poses of
+    the same circuits.  Every host-side variant (plain composition, LUM, SLERP, SLERP+LUM, in the ALL_FUNCTIONS and the script-3
+    flavours) was run on the shipped relative poses: NONE reproduces the shipped absolute poses -- the closest stays 9e-3 rad /
+    0.25 m away on Facade and 1.6e-2 rad / 0.95 m on Courtyard, and the relative poses implied by the shipped absolutes
+    (A_i^-1 A_(i+1)) differ from the shipped relative poses by 8e-3 rad / 0.21 m and 2e-2 rad / 0.8 m.  The shipped absolute poses
+    therefore come from another run (other relative poses, or the pose-graph optimiser, whose inputs are not shipped) and cannot pin
+    these functions; the distances are recorded here so that the statement stays checked."""
+    import os
+    from conftest import GOLDEN, pose_error
+    R = pcr_amd.refinement
+    measured = {"facade": {"best": (9.08e-3, 0.248), "implied": (7.82e-3, 0.210)}, "courtyard": {"best": (1.645e-2, 0.953), "implied": (1.93e-2, 0.815)}}
+    for name in ("facade", "courtyard"):
+        d = np.load(os.path.join(GOLDEN, f"poses_{name}.npz"))
+        names = list(d["relative_names"]); n = len(names)
+        rel = [d["relative"][names.index(f"pose_{i + 1}_{i}.txt")] for i in range(n - 1)] + [d["relative"][names.index(f"pose_0_{n - 1}.txt")]]
+        an = list(d["absolute_names"]); ab = [d["absolute"][an.index(f"pose{i}.txt")] for i in range(n)]
+        assert np.allclose(ab[0], np.eye(4))
+        variants = {"plain": R.poses_relativas_para_absolutas(rel), "LUM": R.reconstruir_Ts_para_origem_LUM(rel, np.ones(n)),
+                    "SLERP": R.reconstruir_Ts_para_origem_SLERP(rel), "SLERP_LUM": R.reconstruir_Ts_para_origem_SLERP_LUM(rel, np.ones(n)),
+                    "LUM_S3": R.script3.reconstruir_Ts_para_origem_LUM(rel), "SLERP_S3": R.script3.reconstruir_Ts_para_origem_SLERP(rel),
+                    "SLERP_LUM_S3": R.script3.reconstruir_Ts_para_origem_SLERP_LUM(rel)}
+        err = {k: np.array([pose_error(v[i], ab[i]) for i in range(n)]).max(0) for k, v in variants.items()}
+        best_rot = min(e[0] for e in err.values()); best_tr = min(e[1] for e in err.values())
+        assert best_rot > 5e-3 and best_tr > 0.2, (name, err)                                   # nobody reproduces them ...
+        assert abs(best_rot - measured[name]["best"][0]) < 2e-4 and abs(best_tr - measured[name]["best"][1]) < 5e-3, (name, best_rot, best_tr)
+        implied = np.array([pose_error(np.linalg.inv(ab[i]) @ ab[i + 1], rel[i]) for i in range(n - 1)]).max(0)
+        assert abs(implied[0] - measured[name]["implied"][0]) < 3e-4 and abs(implied[1] - measured[name]["implied"][1]) < 5e-3, (name, implied)
+        # ... although all of them stay in the neighbourhood (same circuit): a sanity bound on the host functions themselves
+        assert max(e[0] for e in err.values()) < 3e-2 and max(e[1] for e in err.values()) < 1.5
