@@ -7,6 +7,7 @@
 #include <atomic>
 #include <mutex>
 #include <thread>
+#include <chrono>
 #include "pcr_octree.h"
 
 // ------------------------------------------------------------------------------------------- context
@@ -450,6 +451,7 @@ static int multiscale_batched(pcr_context *ctx, const float *src_xyz, const floa
                               int64_t n_tgt, const double *voxels, const double *dists, int n_scales, int sor_k, double sor_std, int normal_k, const double *init_T,
                               const pcr_gicp_params *params, pcr_scale_record *records, int32_t *correspondences, const double *bs, const double *bt) {
     if (n_scales < 2 || n_scales > 8 || sor_k > 32 || normal_k > 32 || n_src <= 0 || n_tgt <= 0) return 1;
+    const double t_entry = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     auto lane_bytes = [&](int64_t n) { return (size_t)n_scales * ((size_t)n + 512) * 1100 + pcr_sort_temp_bytes((size_t)n * n_scales) + (size_t)n * n_scales * 40 + (32u << 20); };
     const size_t blk_s = lane_bytes(n_src), blk_t = lane_bytes(n_tgt);
     PCR_TRY(pcr_arena_reserve(ctx, blk_s + blk_t + pcr_scratch_bytes_for(n_src) + (1u << 20)));
@@ -510,6 +512,14 @@ static int multiscale_batched(pcr_context *ctx, const float *src_xyz, const floa
     if (declined) { ctx->err = "voxel pass accepted one cloud and declined the other"; return PCR_EINVAL; }      // same scales, same key width: cannot happen
     PCR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_ev[0], 0));
     PCR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_ev[1], 0));
+    // diagnostics (PCR_PAIR_TIMELINE=1, with profiling on): host-clock breakdown of a pair: enqueue of the preprocessing, wait for it,
+    // the GICP loops of the scales (out16[11..14], seconds; [15] pairs).  The extra synchronisation serialises prep and loop.
+    static const bool timeline = getenv("PCR_PAIR_TIMELINE") != nullptr;
+    const bool tl = timeline && ctx->profiling;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_enq = now();
+    if (tl) { PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); }
+    const double t_prep = now();
     double T[16];
     memcpy(T, init_T, sizeof T);
     int32_t *match = arena<int32_t>(ctx, n_src);
@@ -518,6 +528,7 @@ static int multiscale_batched(pcr_context *ctx, const float *src_xyz, const floa
         PCR_TRY(pcr_dev_gicp(ctx, &clean[0][s], &clean[1][s], dists[s], T, params, &records[s].icp, match));
         memcpy(T, records[s].icp.transformation, sizeof T);
     }
+    if (tl) { ctx->prof[11] += t_enq - t_entry; ctx->prof[12] += t_prep - t_enq; ctx->prof[13] += now() - t_prep; ctx->prof[15] += 1.0; }
     if (correspondences) {
         int64_t nc = 0;
         PCR_TRY(pcr_dev_compact_matches(ctx, match, clean[0][n_scales - 1].n, clean[0][n_scales - 1].cap, nullptr, nullptr, correspondences, &nc));

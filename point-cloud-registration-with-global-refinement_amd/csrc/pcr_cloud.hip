@@ -512,55 +512,84 @@ __device__ static inline void d_oct_apply(const signed char *__restrict__ ls, co
         }
     }
 }
-// F/G: tight boxes, bottom-up
+// F/G: tight boxes, bottom-up.  ONE OCTET (8 lanes) PER NODE: lane c reads point c, c + 8, ... of a leaf (coalesced 128-byte rows) or
+// child c of an inner node (one 256-byte read per octet); min / max over the octet by DPP.  (A thread per node walked its points or
+// children serially and, at level 1, wrote the fat-leaf record of up to ~400 points in one loop: 95 + 78 us per build in flight.)
+__device__ static inline float pcr_octet_minf(float v) {
+    v = fminf(v, pcr_dpp_f<PCR_DPP_XOR1>(v)); v = fminf(v, pcr_dpp_f<PCR_DPP_XOR2>(v)); v = fminf(v, pcr_dpp_f<PCR_DPP_HMIRROR>(v));
+    return v;
+}
+__device__ static inline float pcr_octet_maxf(float v) {
+    v = fmaxf(v, pcr_dpp_f<PCR_DPP_XOR1>(v)); v = fmaxf(v, pcr_dpp_f<PCR_DPP_XOR2>(v)); v = fmaxf(v, pcr_dpp_f<PCR_DPP_HMIRROR>(v));
+    return v;
+}
 __device__ static inline void d_oct_leaf_boxes(const float4 *__restrict__ pts, const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up,
                                                        int4 *__restrict__ pinfo) {
-    const int j = blockIdx.x * BS + threadIdx.x;
-    if (meta->nl < 1 || j >= meta->cnt[0]) return;
-    const int a = child[j], b = child[j + 1];
-    float4 lo = make_float4(3.4e38f, 3.4e38f, 3.4e38f, 0), hi = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, 0);
-    for (int i = a; i < b; i++) {
+    const int ol = threadIdx.x & 7;
+    const int j = blockIdx.x * (BS / OCT) + (threadIdx.x >> 3);
+    const bool live = meta->nl >= 1 && j < meta->cnt[0];
+    if (__ballot(live) == 0ull) return;
+    const int a = live ? child[j] : 0, b = live ? child[j + 1] : 0;
+    const bool one_level = meta->nl == 1;
+    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (int i = a + ol; i < b; i += OCT) {
         const float4 p = pts[i];
-        lo.x = fminf(lo.x, p.x); lo.y = fminf(lo.y, p.y); lo.z = fminf(lo.z, p.z);
-        hi.x = fmaxf(hi.x, p.x); hi.y = fmaxf(hi.y, p.y); hi.z = fmaxf(hi.z, p.z);
-        if (meta->nl == 1) pinfo[i] = make_int4(j, a, b - a, 0);     // one-level tree: the leaf is the start node
+        lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z);
+        hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z);
+        if (one_level) pinfo[i] = make_int4(j, a, b - a, 0);     // one-level tree: the leaf is the start node
     }
-    lo.w = __int_as_float(a); hi.w = __int_as_float(b - a);
-    boxes[2 * (size_t)j] = lo; boxes[2 * (size_t)j + 1] = hi;
-    if (meta->nl == 1) up[j] = make_int4(0, 0, 1, 0);
+#pragma unroll
+    for (int d = 0; d < 3; d++) { lo[d] = pcr_octet_minf(lo[d]); hi[d] = pcr_octet_maxf(hi[d]); }
+    if (live && ol == 0) {
+        boxes[2 * (size_t)j] = make_float4(lo[0], lo[1], lo[2], __int_as_float(a));
+        boxes[2 * (size_t)j + 1] = make_float4(hi[0], hi[1], hi[2], __int_as_float(b - a));
+        if (one_level) up[j] = make_int4(0, 0, 1, 0);
+    }
 }
-__device__ static inline void oct_node_box(const OctMeta &m, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up, int li, int j,
+// node j of level li (li >= 1), all 64 lanes of the wavefront call it with their octet's j (live: octet-uniform)
+__device__ static inline void oct_node_box(const OctMeta &m, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up, int li, int j, bool live, int ol,
                                            int4 *__restrict__ pinfo = nullptr) {
-    const int a = child[m.off[li] + j], b = child[m.off[li] + j + 1];
-    if (li == 1 && pinfo) {       // point -> (level-1 node, its first point, its point count, 1)
-        const int pfirst = __float_as_int(boxes[2 * (size_t)(m.off[0] + a)].w);
-        const int plast = __float_as_int(boxes[2 * (size_t)(m.off[0] + b - 1)].w) + __float_as_int(boxes[2 * (size_t)(m.off[0] + b - 1) + 1].w);
-        for (int i = pfirst; i < plast; i++) pinfo[i] = make_int4(j, pfirst, plast - pfirst, 1);
-    }
-    float4 lo = make_float4(3.4e38f, 3.4e38f, 3.4e38f, 0), hi = make_float4(-3.4e38f, -3.4e38f, -3.4e38f, 0);
-    for (int c = a; c < b; c++) {
+    const int a = live ? child[m.off[li] + j] : 0, b = live ? child[m.off[li] + j + 1] : 0;
+    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    int pf = 0x7fffffff, pl = 0;                                   // first point / one past the last point of the node (level 1 only)
+    const int c = a + ol;
+    if (c < b) {                                                   // <= 8 children: one per lane
         const float4 x = boxes[2 * (size_t)(m.off[li - 1] + c)], y = boxes[2 * (size_t)(m.off[li - 1] + c) + 1];
-        lo.x = fminf(lo.x, x.x); lo.y = fminf(lo.y, x.y); lo.z = fminf(lo.z, x.z);
-        hi.x = fmaxf(hi.x, y.x); hi.y = fmaxf(hi.y, y.y); hi.z = fmaxf(hi.z, y.z);
+        lo[0] = x.x; lo[1] = x.y; lo[2] = x.z; hi[0] = y.x; hi[1] = y.y; hi[2] = y.z;
         up[m.off[li - 1] + c] = make_int4(j, a, b - a, 0);          // child -> (parent, first sibling, sibling count)
+        if (li == 1 && pinfo) { pf = __float_as_int(x.w); pl = pf + __float_as_int(y.w); }
     }
-    if (li == m.nl - 1) up[m.off[li] + j] = make_int4(0, 0, 1, 0);
-    lo.w = __int_as_float(a); hi.w = __int_as_float(b - a);
-    boxes[2 * (size_t)(m.off[li] + j)] = lo; boxes[2 * (size_t)(m.off[li] + j) + 1] = hi;
+#pragma unroll
+    for (int d = 0; d < 3; d++) { lo[d] = pcr_octet_minf(lo[d]); hi[d] = pcr_octet_maxf(hi[d]); }
+    if (li == 1 && pinfo) {       // point -> (level-1 node, its first point, its point count, 1): the octet writes the node's points together
+        pf = min(pf, pcr_dpp_i<PCR_DPP_XOR1>(pf)); pf = min(pf, pcr_dpp_i<PCR_DPP_XOR2>(pf)); pf = min(pf, pcr_dpp_i<PCR_DPP_HMIRROR>(pf));
+        pl = max(pl, pcr_dpp_i<PCR_DPP_XOR1>(pl)); pl = max(pl, pcr_dpp_i<PCR_DPP_XOR2>(pl)); pl = max(pl, pcr_dpp_i<PCR_DPP_HMIRROR>(pl));
+        if (live) for (int i = pf + ol; i < pl; i += OCT) pinfo[i] = make_int4(j, pf, pl - pf, 1);
+    }
+    if (live && ol == 0) {
+        if (li == m.nl - 1) up[m.off[li] + j] = make_int4(0, 0, 1, 0);
+        boxes[2 * (size_t)(m.off[li] + j)] = make_float4(lo[0], lo[1], lo[2], __int_as_float(a));
+        boxes[2 * (size_t)(m.off[li] + j) + 1] = make_float4(hi[0], hi[1], hi[2], __int_as_float(b - a));
+    }
 }
 __device__ static inline void d_oct_level_boxes(const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up, int li,
                                                         int4 *__restrict__ pinfo) {
-    const int j = blockIdx.x * BS + threadIdx.x;
-    if (li >= meta->nl || j >= meta->cnt[li]) return;
-    oct_node_box(*meta, child, boxes, up, li, j, pinfo);
+    const int j = blockIdx.x * (BS / OCT) + (threadIdx.x >> 3);
+    const bool live = li < meta->nl && j < meta->cnt[li];
+    if (__ballot(live) == 0ull) return;
+    oct_node_box(*meta, child, boxes, up, li, j, live, threadIdx.x & 7, pinfo);
 }
-// remaining (small) levels in ONE workgroup, level by level
+// remaining (small) levels in ONE workgroup of 1024 threads = 128 octets, level by level
 __device__ static inline void d_oct_upper_boxes(const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up, int first_li) {
     __shared__ OctMeta m;
     if (threadIdx.x == 0) m = *meta;
     __syncthreads();
     for (int li = first_li; li < m.nl; li++) {
-        for (int j = threadIdx.x; j < m.cnt[li]; j += 1024) oct_node_box(m, child, boxes, up, li, j);
+        const int rounds = (m.cnt[li] + 127) / 128;
+        for (int r = 0; r < rounds; r++) {
+            const int j = r * 128 + (threadIdx.x >> 3);
+            oct_node_box(m, child, boxes, up, li, j, j < m.cnt[li], threadIdx.x & 7);
+        }
         __threadfence_block();
         __syncthreads();
     }
@@ -619,7 +648,7 @@ int pcr_dev_build_bvh_batch(pcr_context *ctx, DevCloud *const *cs, int count) {
         d.pts = c->pts; d.nodes = c->oct_nodes; d.up = c->oct_up; d.pinfo = c->pinfo;
         for (int a = 0; a < 3; a++) { d.g.org[a] = c->key_org[a]; d.g.unit[a] = c->key_unit[a]; }
         d.g.leaf_div = div;
-        const int nbl = (c->cap / 2 + 1 + BS - 1) / BS;       // <= n/2 leaves (or 1)
+        const int nbl = (int)((((size_t)c->cap / 2 + 1) * OCT + BS - 1) / BS);       // <= n/2 leaves (or 1), one octet each
         if (d.n_tiles > max_tiles) max_tiles = d.n_tiles;
         if (nbl > max_nbl) max_nbl = nbl;
     }
@@ -1099,72 +1128,82 @@ struct NflArgs {
     uint8_t *todo; int *todo_count;
 };
 struct NflBatch { NflArgs a[PCR_MAX_BATCH]; };
+// A wavefront serves 64 points: octet o takes points base + 8 o + r in rounds r = 0..7 (list filtering, farthest-survivor drops, raw
+// moments: 8 lanes per point as before), lane r of the octet keeps the moments of round r, and after the eighth round ALL 64 lanes
+// run the analytic eigen solver at once -- it is ~2/3 of this kernel's instructions and used to run with one live lane per octet.
 __device__ static inline void d_normals_from_lists(const NflArgs &a) {
     const int n = *a.n_ptr;
-    const int ol = threadIdx.x & 7;
-    const int i = blockIdx.x * (KNN_BS / OCT) + (threadIdx.x >> 3);
-    const bool act = i < n && a.keep[i];
-    int id[4]; float d[4]; bool ok[4];
-    int lc = 0, vc = 0;
+    const int ol = threadIdx.x & 7, oct_id = (threadIdx.x & 63) >> 3;
+    const int base = (blockIdx.x * (KNN_BS / 64) + (threadIdx.x >> 6)) * 64;
+    if (base >= n) return;
+    double myC[6] = {1, 0, 0, 1, 0, 1};
+    bool my_exact = false; int my_j = 0;
+#pragma unroll 1
+    for (int r = 0; r < OCT; r++) {
+        const int i = base + oct_id * OCT + r;
+        const bool act = i < n && a.keep[i];
+        int id[4]; float d[4]; bool ok[4];
+        int lc = 0, vc = 0;
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-        const int slot = ol + OCT * s;
-        id[s] = (act && slot < a.k_list) ? a.lidx[(size_t)i * 32 + slot] : -1;
-        d[s] = id[s] >= 0 ? a.ld2[(size_t)i * 32 + slot] : -1.0f;
-        ok[s] = id[s] >= 0 && a.keep[id[s]];
-        lc += id[s] >= 0 ? 1 : 0; vc += ok[s] ? 1 : 0;
-    }
-    lc = pcr_octet_sum_i(lc); vc = pcr_octet_sum_i(vc);
-    const bool exact = act && (vc >= a.k_nrm || lc < a.k_list);
-    const int j = act ? a.pos[i] : 0;
-    if (act && ol == 0) {
-        a.todo[j] = exact ? 0 : 1;
-        if (!exact) atomicAdd(a.todo_count, 1);
-    }
-    // drop the farthest survivors until k_nrm remain (octet arg-max rounds; octets that are done idle along)
-    int excess = exact ? vc - a.k_nrm : 0;
-    while (__ballot(excess > 0) != 0ull) {
-        float m = -1.0f; int ms = 0;
+        for (int s = 0; s < 4; s++) {
+            const int slot = ol + OCT * s;
+            id[s] = (act && slot < a.k_list) ? a.lidx[(size_t)i * 32 + slot] : -1;
+            d[s] = id[s] >= 0 ? a.ld2[(size_t)i * 32 + slot] : -1.0f;
+            ok[s] = id[s] >= 0 && a.keep[id[s]];
+            lc += id[s] >= 0 ? 1 : 0; vc += ok[s] ? 1 : 0;
+        }
+        lc = pcr_octet_sum_i(lc); vc = pcr_octet_sum_i(vc);
+        const bool exact = act && (vc >= a.k_nrm || lc < a.k_list);
+        const int j = act ? a.pos[i] : 0;
+        if (act && ol == 0) {
+            a.todo[j] = exact ? 0 : 1;
+            if (!exact) atomicAdd(a.todo_count, 1);
+        }
+        // drop the farthest survivors until k_nrm remain (octet arg-max rounds; octets that are done idle along)
+        int excess = exact ? vc - a.k_nrm : 0;
+        while (__ballot(excess > 0) != 0ull) {
+            float m = -1.0f; int ms = 0;
 #pragma unroll
-        for (int s = 0; s < 4; s++) if (ok[s] && d[s] > m) { m = d[s]; ms = s; }
-        const float om = pcr_octet_max(m);                                   // DPP, no LDS hop; ties -> lowest lane
-        const int ml = __builtin_ctz((uint32_t)(__ballot(m == om) >> (threadIdx.x & 56)) & 0xffu);
-        const bool hit = excess > 0 && ol == ml;
+            for (int s = 0; s < 4; s++) if (ok[s] && d[s] > m) { m = d[s]; ms = s; }
+            const float om = pcr_octet_max(m);                                   // DPP, no LDS hop; ties -> lowest lane
+            const int ml = __builtin_ctz((uint32_t)(__ballot(m == om) >> (threadIdx.x & 56)) & 0xffu);
+            const bool hit = excess > 0 && ol == ml;
 #pragma unroll
-        for (int s = 0; s < 4; s++) ok[s] = ok[s] && !(hit && s == ms);
-        excess -= excess > 0 ? 1 : 0;
-    }
-    if (!exact) return;
-    double cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, c = 0;
+            for (int s = 0; s < 4; s++) ok[s] = ok[s] && !(hit && s == ms);
+            excess -= excess > 0 ? 1 : 0;
+        }
+        double cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, c = 0;
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-        if (ok[s]) {
-            const float4 p = a.pts[id[s]];
-            const double x = p.x, y = p.y, z = p.z;
-            cu[0] += x; cu[1] += y; cu[2] += z;
-            cu[3] += x * x; cu[4] += x * y; cu[5] += x * z; cu[6] += y * y; cu[7] += y * z; cu[8] += z * z;
-            c += 1.0;
+        for (int s = 0; s < 4; s++) {
+            if (exact && ok[s]) {
+                const float4 p = a.pts[id[s]];
+                const double x = p.x, y = p.y, z = p.z;
+                cu[0] += x; cu[1] += y; cu[2] += z;
+                cu[3] += x * x; cu[4] += x * y; cu[5] += x * z; cu[6] += y * y; cu[7] += y * z; cu[8] += z * z;
+                c += 1.0;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; t++) cu[t] = octet_sum(cu[t]);
+        c = octet_sum(c);
+        if (ol == r) {                                  // this lane solves the point of round r
+            my_exact = exact; my_j = j;
+            if (c >= 3.0) {
+                for (int t = 0; t < 9; t++) cu[t] = cu[t] / c;
+                myC[0] = cu[3] - cu[0] * cu[0]; myC[1] = cu[4] - cu[0] * cu[1]; myC[2] = cu[5] - cu[0] * cu[2];
+                myC[3] = cu[6] - cu[1] * cu[1]; myC[4] = cu[7] - cu[1] * cu[2]; myC[5] = cu[8] - cu[2] * cu[2];
+            }
         }
     }
-#pragma unroll
-    for (int t = 0; t < 9; t++) cu[t] = octet_sum(cu[t]);
-    c = octet_sum(c);
-    if (ol == 0) {
-        double C6[6];
-        if (c >= 3.0) {
-            for (int t = 0; t < 9; t++) cu[t] = cu[t] / c;
-            C6[0] = cu[3] - cu[0] * cu[0]; C6[1] = cu[4] - cu[0] * cu[1]; C6[2] = cu[5] - cu[0] * cu[2];
-            C6[3] = cu[6] - cu[1] * cu[1]; C6[4] = cu[7] - cu[1] * cu[2]; C6[5] = cu[8] - cu[2] * cu[2];
-        } else { C6[0] = 1; C6[1] = 0; C6[2] = 0; C6[3] = 1; C6[4] = 0; C6[5] = 1; }
-        double nv[3];
-        d_fast_eigen3x3(C6, nv);
-        const double nn = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
-        double px = 0, py = 0, pz = 0;
-        if (a.prior) { const float4 pr = a.prior[j]; px = pr.x; py = pr.y; pz = pr.z; }
-        if (nn == 0.0 || !(nn == nn)) { if (a.prior) { nv[0] = px; nv[1] = py; nv[2] = pz; } else { nv[0] = 0; nv[1] = 0; nv[2] = 1; } }
-        if (a.prior && nv[0] * px + nv[1] * py + nv[2] * pz < 0.0) { nv[0] = -nv[0]; nv[1] = -nv[1]; nv[2] = -nv[2]; }
-        a.normals[j] = make_float4((float)nv[0], (float)nv[1], (float)nv[2], 0.0f);
-    }
+    if (!my_exact) return;
+    double nv[3];
+    d_fast_eigen3x3(myC, nv);
+    const double nn = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+    double px = 0, py = 0, pz = 0;
+    if (a.prior) { const float4 pr = a.prior[my_j]; px = pr.x; py = pr.y; pz = pr.z; }
+    if (nn == 0.0 || !(nn == nn)) { if (a.prior) { nv[0] = px; nv[1] = py; nv[2] = pz; } else { nv[0] = 0; nv[1] = 0; nv[2] = 1; } }
+    if (a.prior && nv[0] * px + nv[1] * py + nv[2] * pz < 0.0) { nv[0] = -nv[0]; nv[1] = -nv[1]; nv[2] = -nv[2]; }
+    a.normals[my_j] = make_float4((float)nv[0], (float)nv[1], (float)nv[2], 0.0f);
 }
 
 __global__ void __launch_bounds__(KNN_BS) k_normals_from_lists(NflArgs a) { d_normals_from_lists(a); }
@@ -1314,8 +1353,8 @@ static int sor_batch(pcr_context *ctx, SorProblem *pr, int count, int nb_neighbo
     PCR_TRY(flag_scan_batch(ctx, cb, m));
     PCR_LAUNCH(ctx, k_compact_cloud_batch, dim3((mc + BS - 1) / BS, m), dim3(BS), 0, ctx->stream, mb);
     if (any_todo) {
-        if (fuse_all) PCR_LAUNCH(ctx, k_normals_from_lists_batch, dim3((unsigned)(((size_t)mc * OCT + KNN_BS - 1) / KNN_BS), m), dim3(KNN_BS), 0, ctx->stream, nb_);
-        else for (int k = 0; k < m; k++) if (nb_.a[k].pts) PCR_LAUNCH(ctx, k_normals_from_lists, dim3((unsigned)(((size_t)caps[k] * OCT + KNN_BS - 1) / KNN_BS)), dim3(KNN_BS), 0, ctx->stream, nb_.a[k]);
+        if (fuse_all) PCR_LAUNCH(ctx, k_normals_from_lists_batch, dim3((unsigned)(((size_t)mc + KNN_BS - 1) / KNN_BS), m), dim3(KNN_BS), 0, ctx->stream, nb_);
+        else for (int k = 0; k < m; k++) if (nb_.a[k].pts) PCR_LAUNCH(ctx, k_normals_from_lists, dim3((unsigned)(((size_t)caps[k] + KNN_BS - 1) / KNN_BS)), dim3(KNN_BS), 0, ctx->stream, nb_.a[k]);
         if (fallback_here && normal_k > 0) {
             if (normal_k <= 32) PCR_TRY(launch_knn_batch<KNN_MODE_NORMALS>(ctx, fb, caps, m));
             else for (int k = 0; k < m; k++) { DevCloud tmp; tmp.cap = caps[k]; PCR_TRY(launch_knn<KNN_MODE_NORMALS>(ctx, &tmp, fb.a[k])); }

@@ -499,23 +499,26 @@ __device__ static inline void icp_finish(const IcpArgs &a, IcpState *st, const d
     unsigned long long *wl = (a.stamps_it && launches < ICP_STAMP_LAUNCHES) ? a.stamps_it + 12 * ((size_t)launches * gridDim.x * (BS / 64) + (size_t)blockIdx.x * (BS / 64)) : nullptr;
     if (!is_last) return;
 
-    // ---- last workgroup: gather the partial rows with sc1 loads (coherent at agent scope without invalidating this XCD's
-    // L2: the acquire fence that plain loads would need took ~10 us here), eight rows per lane and wait, 128 rows per round
+    // ---- last workgroup: gather the partial rows with sc0 sc1 loads (coherent at agent scope without invalidating this XCD's
+    // L2: the acquire fence that plain loads would need took ~10 us here).  Buffer loads through a raw descriptor are visible to the
+    // compiler, which keeps all 20 of a lane in flight behind counted waits: 320 rows (160k source points) in ONE round trip where
+    // hand-written 8-load groups took three.
     {
+        typedef unsigned int icp_u2 __attribute__((ext_vector_type(2)));
         const int vcol = threadIdx.x & 31, chunk = threadIdx.x >> 5;      // 16 chunks x 32 columns; chunk c <- rows c, c+16, ...
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.partials, 0, nb * NVP * 8, 0x00020000);
         double s = 0.0;
-        for (int b0 = 0; b0 < nb; b0 += 128) {
-            const double *p[8]; double v[8];
+        for (int b0 = 0; b0 < nb; b0 += 320) {
+            double v[20];
 #pragma unroll
-            for (int r = 0; r < 8; r++) p[r] = a.partials + (size_t)(b0 + chunk + 16 * r < nb ? b0 + chunk + 16 * r : 0) * NVP + vcol;
-            asm volatile("global_load_dwordx2 %0, %8, off sc0 sc1\n\tglobal_load_dwordx2 %1, %9, off sc0 sc1\n\t"
-                         "global_load_dwordx2 %2, %10, off sc0 sc1\n\tglobal_load_dwordx2 %3, %11, off sc0 sc1\n\t"
-                         "global_load_dwordx2 %4, %12, off sc0 sc1\n\tglobal_load_dwordx2 %5, %13, off sc0 sc1\n\t"
-                         "global_load_dwordx2 %6, %14, off sc0 sc1\n\tglobal_load_dwordx2 %7, %15, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
-                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
-                         : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]) : "memory");
+            for (int r = 0; r < 20; r++) {
+                const int row = b0 + chunk + 16 * r;
+                union { icp_u2 u; double d; } x;
+                x.u = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (row < nb ? row : 0) * (NVP * 8) + vcol * 8, 0, 17 /* sc0 | sc1 */);
+                v[r] = x.d;
+            }
 #pragma unroll
-            for (int r = 0; r < 8; r++) { const double x = b0 + chunk + 16 * r < nb ? v[r] : 0.0; s = vcol < NV ? s + x : fmax(s, x); }
+            for (int r = 0; r < 20; r++) { const double x = b0 + chunk + 16 * r < nb ? v[r] : 0.0; s = vcol < NV ? s + x : fmax(s, x); }
         }
         fin[chunk][vcol] = s;
     }
@@ -615,52 +618,64 @@ __global__ void __launch_bounds__(LIN_BS) k_icp_iter(IcpArgs a) {
 // launches of the loop (the in-flight throughput is bound by the dispatch rate of small dependent kernels, ~90k/s
 // system-wide) and removes the match[] round trip between the two kernels.
 #define FUSED_BS 512
+// PPL = source points per lane (PCR_ICP_PPL, default 1).  The kernel is latency-bound (dependent loads, publish -> ticket -> gather), so
+// its wavefronts mostly wait, and at one point per lane a 160k-point launch is 312 workgroups of 8 wavefronts at 122 VGPRs -- 61 % of
+// the chip's wavefront slots for ONE pair's iteration.  Two / four points per lane (half / a quarter of the wavefronts, partial rows
+// and tickets; a lane's certificate tests and float64 linearisations back to back) were measured: 4 pairs in flight 327 / 318 / 293
+// pairs/s for PPL 1 / 2 / 4, 8 in flight 314 / 334 / 313, one pair alone 178 / 158 / 125 -- the wavefront slots are not what bounds the
+// pairs in flight ("what bounds the throughput"), and alone the longer lanes cost what they cost.  Kept as a switch.
+template <int PPL>
 __global__ void __launch_bounds__(FUSED_BS) k_icp_fused(IcpArgs a) {
     IcpState *st = a.state;
     constexpr int OPB = FUSED_BS / OCT;
+    constexpr int TILE_PTS = FUSED_BS * PPL;
     __shared__ OctMeta m;
     __shared__ OctStack<OPB> stk;
-    __shared__ float4 rec_q[FUSED_BS];         // pending queries of the workgroup: position + hint
-    __shared__ short rec_l[FUSED_BS];          //   and their lane (local point index)
-    __shared__ int cand_l[FUSED_BS];           // candidate target point per local point after the search phase
+    __shared__ float4 rec_q[TILE_PTS];         // pending queries of the workgroup: position + hint
+    __shared__ short rec_l[TILE_PTS];          //   and their local point index
+    __shared__ int cand_l[TILE_PTS];           // candidate target point per local point after the search phase
     __shared__ int n_rec;
     const int done = st->done, launches = st->launches;
     const int ns = *a.ns_ptr, nt = *a.nt_ptr;
     const int tid = threadIdx.x, lane = tid & 63, oct = lane >> 3, ol = lane & 7, ob = tid >> 3;
-    const int i = blockIdx.x * FUSED_BS + tid;
-    const int ic = i < a.src_cap ? i : 0;
-    const float4 pf = a.src_pts[ic];
-    const int mraw = a.match[ic];
-    const float4 refv = a.ref[ic];
-    const int rb = a.rbest[ic];
+    const int tile0 = blockIdx.x * TILE_PTS;
+    float4 pf[PPL], refv[PPL]; int mraw[PPL], rb[PPL];
+#pragma unroll
+    for (int p = 0; p < PPL; p++) {
+        const int i = tile0 + p * FUSED_BS + tid;
+        const int ic = i < a.src_cap ? i : 0;
+        pf[p] = a.src_pts[ic]; mraw[p] = a.match[ic]; refv[p] = a.ref[ic]; rb[p] = a.rbest[ic];
+    }
     double T[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) T[k] = st->T[k];
     int mword = 0;
     if (tid < (int)(sizeof(OctMeta) / 4)) mword = ((const int *)a.tgt.meta)[tid];
     if (done) return;
-    const int nb = (ns + FUSED_BS - 1) / FUSED_BS > 0 ? (ns + FUSED_BS - 1) / FUSED_BS : 1;
+    const int nb = (ns + TILE_PTS - 1) / TILE_PTS > 0 ? (ns + TILE_PTS - 1) / TILE_PTS : 1;
     if ((int)blockIdx.x >= nb) return;
     const unsigned long long t_entry = wall_clock64();
     if (blockIdx.x == 0 && tid == 0) st->t_start = t_entry;
     if (tid < (int)(sizeof(OctMeta) / 4)) ((int *)&m)[tid] = mword;
     if (tid == 0) n_rec = 0;
     __syncthreads();
-    // ---- phase A: one lane per point -- certificate or a place in the pending list
-    bool need = false;
-    int cand = -1;
-    {
+    // ---- phase A: per point -- certificate or a place in the pending list
+#pragma unroll
+    for (int p = 0; p < PPL; p++) {
+        const int i = tile0 + p * FUSED_BS + tid;
+        bool need = false;
+        int cand = -1;
         float qx = 0, qy = 0, qz = 0; int hint = -1;
         if (i < ns) {
-            const double px = pf.x, py = pf.y, pz = pf.z;
+            const double px = pf[p].x, py = pf[p].y, pz = pf[p].z;
             qx = (float)(T[0] * px + T[1] * py + T[2] * pz + T[3]);
             qy = (float)(T[4] * px + T[5] * py + T[6] * pz + T[7]);
             qz = (float)(T[8] * px + T[9] * py + T[10] * pz + T[11]);
-            hint = mraw >= 0 ? mraw : (mraw <= -2 ? -(mraw + 2) : -1);
-            const float ex = qx - refv.x, ey = qy - refv.y, ez = qz - refv.z;
-            const bool certified = refv.w > 0.0f && pcr_d2(ex, ey, ez) < refv.w * refv.w;
+            hint = mraw[p] >= 0 ? mraw[p] : (mraw[p] <= -2 ? -(mraw[p] + 2) : -1);
+            const float ex = qx - refv[p].x, ey = qy - refv[p].y, ez = qz - refv[p].z;
+            const bool certified = refv[p].w > 0.0f && pcr_d2(ex, ey, ez) < refv[p].w * refv[p].w;
             need = nt > 0 && !certified;
-            cand = certified ? rb : -1;                 // rb < 0: certified unmatched
+            cand = certified ? rb[p] : -1;                 // rb < 0: certified unmatched
         }
         const unsigned long long nbm = __ballot(need);
         int base = 0;
@@ -668,9 +683,9 @@ __global__ void __launch_bounds__(FUSED_BS) k_icp_fused(IcpArgs a) {
         base = __shfl(base, 0, 64);
         if (need) {
             const int slot = base + __builtin_popcountll(nbm & ((1ull << lane) - 1ull));
-            rec_q[slot] = make_float4(qx, qy, qz, __int_as_float(hint)); rec_l[slot] = (short)tid;
+            rec_q[slot] = make_float4(qx, qy, qz, __int_as_float(hint)); rec_l[slot] = (short)(p * FUSED_BS + tid);
         }
-        cand_l[tid] = cand;
+        cand_l[p * FUSED_BS + tid] = cand;
     }
     __syncthreads();
     // ---- phase B: the 64 octets work through the pending list
@@ -684,7 +699,7 @@ __global__ void __launch_bounds__(FUSED_BS) k_icp_fused(IcpArgs a) {
         int start_pt = 0; float d1 = 0, d2 = 0;
         const int best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.r2s, hint, ol, oct, ob, &start_pt, nullptr, &d1, &d2);
         if (ol == 0 && live) {
-            const int qi = blockIdx.x * FUSED_BS + l;
+            const int qi = tile0 + l;
             const float slack = 2e-5f + 1e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz));
             const float margin = best >= 0 ? 0.5f * (sqrtf(d2) - sqrtf(d1)) - slack : a.rs_minus_r - slack;
             a.ref[qi] = make_float4(qx, qy, qz, margin > 0.0f ? margin : 0.0f);
@@ -694,14 +709,18 @@ __global__ void __launch_bounds__(FUSED_BS) k_icp_fused(IcpArgs a) {
         }
     }
     __syncthreads();
-    // ---- phase C: one correspondence per lane (icp_point stores the match, or the hint when the radius test fails)
+    // ---- phase C: the lane's correspondences one after the other (icp_point stores the match, or the hint when the radius test fails)
     double acc[NV];
 #pragma unroll
     for (int k = 0; k < NV; k++) acc[k] = 0.0;
-    if (i < ns) {
-        const int c = cand_l[tid];
-        if (c >= 0 && c != mraw) a.match[i] = c;
-        icp_point<ICP_MODE_GICP>(a, T, i, ns, c, acc);
+#pragma unroll
+    for (int p = 0; p < PPL; p++) {
+        const int i = tile0 + p * FUSED_BS + tid;
+        if (i < ns) {
+            const int c = cand_l[p * FUSED_BS + tid];
+            if (c >= 0 && c != mraw[p]) a.match[i] = c;
+            icp_point<ICP_MODE_GICP>(a, T, i, ns, c, acc);
+        }
     }
     icp_finish<ICP_MODE_GICP, FUSED_BS>(a, st, T, acc, nb, ns, launches, t_entry);
 }
@@ -750,7 +769,9 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     const int cap = src->cap > 0 ? src->cap : 1;
     const int nbmax = (cap + LIN_BS - 1) / LIN_BS < LIN_MAX_BLOCKS ? (cap + LIN_BS - 1) / LIN_BS : LIN_MAX_BLOCKS;
     const int nbnn = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT);
-    const int nbf = (cap + FUSED_BS - 1) / FUSED_BS;                 // workgroups of the fused kernel: one per 512 source points
+    static const int ppl = getenv("PCR_ICP_PPL") ? atoi(getenv("PCR_ICP_PPL")) : 1;      // source points per lane of the fused kernel (1, 2 or 4)
+    const int tile_pts = FUSED_BS * (ppl >= 4 ? 4 : (ppl >= 2 ? 2 : 1));
+    const int nbf = (cap + tile_pts - 1) / tile_pts;                 // workgroups of the fused kernel: one per 512 * PPL source points
     IcpState *st = arena<IcpState>(ctx, 1);
     double *partials = arena<double>(ctx, (size_t)(nbmax > nbf ? nbmax : nbf) * NVP);
     int32_t *match = match_dev ? match_dev : arena<int32_t>(ctx, cap);
@@ -789,7 +810,12 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     // launch 0 of a scale searches every query (cold): two kernels at full occupancy; later launches: the fused kernel
     const bool fused = use_fused && a.ref && !use_cov && !stamp_path && nbf <= 4096;
     auto enqueue = [&](int launch_index) {
-        if (fused && launch_index > 0) { PCR_LAUNCH(ctx, k_icp_fused, dim3(nbf), dim3(FUSED_BS), 0, ctx->stream, a); return; }
+        if (fused && launch_index > 0) {
+            if (tile_pts == FUSED_BS * 4) PCR_LAUNCH(ctx, k_icp_fused<4>, dim3(nbf), dim3(FUSED_BS), 0, ctx->stream, a);
+            else if (tile_pts == FUSED_BS * 2) PCR_LAUNCH(ctx, k_icp_fused<2>, dim3(nbf), dim3(FUSED_BS), 0, ctx->stream, a);
+            else PCR_LAUNCH(ctx, k_icp_fused<1>, dim3(nbf), dim3(FUSED_BS), 0, ctx->stream, a);
+            return;
+        }
         PCR_LAUNCH(ctx, k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
         if (use_cov) PCR_LAUNCH(ctx, k_icp_iter<ICP_MODE_GICP_COV>, dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
         else PCR_LAUNCH(ctx, k_icp_iter<ICP_MODE_GICP>, dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
@@ -798,7 +824,7 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     if (use_graph && !stamp_path) {
         for (int which = 0; which < 2; which++) {
             std::string key((const char *)&a, sizeof a);
-            const int extra[6] = {nbnn, nbmax, use_cov ? 1 : 0, CHUNK, fused ? nbf : 0, which};
+            const int extra[6] = {nbnn, nbmax, use_cov ? 1 : 0, CHUNK, fused ? nbf + (tile_pts << 16) : 0, which};
             key.append((const char *)extra, sizeof extra);
             for (auto &g : ctx->icp_graphs) if (g.first == key) { chunk_exec[which] = g.second; break; }
             if (!chunk_exec[which]) {

@@ -276,11 +276,11 @@ def test_register_pairs_ragged_sizes_stress(P, small_pair):
 
 
 def test_switches_do_not_change_the_result():
-    """Every execution switch (merged voxel pass, fused iteration kernel, skip certificates, hipGraph replay, ring depth, lanes)
-    only changes HOW the same arithmetic is scheduled: pose bits, iteration counts and cloud counts are identical."""
+    """Every execution switch (merged voxel pass, batched SOR chain, fused iteration kernel, skip certificates, hipGraph replay, ring
+    depth, lanes) only changes HOW the same arithmetic is scheduled: pose bits, iteration counts and cloud counts are identical."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    variants = [{}, {"PCR_VOXEL_MERGED": "0"}, {"PCR_ICP_FUSED": "0"}, {"PCR_ICP_SKIP": "0"}, {"PCR_ICP_GRAPH": "0"},
+    variants = [{}, {"PCR_VOXEL_MERGED": "0"}, {"PCR_SOR_BATCH": "0"}, {"PCR_ICP_FUSED": "0"}, {"PCR_ICP_SKIP": "0"}, {"PCR_ICP_GRAPH": "0"},
                 {"PCR_PIPELINE": "1", "PCR_LANES": "1"}, {"PCR_VOXEL_MERGED": "0", "PCR_ICP_FUSED": "0", "PCR_ICP_GRAPH": "0", "PCR_PIPELINE": "2"}]
     lines = []
     for env in variants:
@@ -296,3 +296,12 @@ def test_switches_do_not_change_the_result():
         assert out.returncode == 0, (env, out.stderr[-2000:])
         with_n.append([l for l in out.stdout.splitlines() if l.startswith("GICP ")][-1])
     assert with_n[0] == with_n[1]
+    # two / four source points per lane in the iteration kernel regroup the float64 sums (other workgroup tiles): same pose up to that
+    def pose(env):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "gicp_pose.py")], env=dict(os.environ, GICP_POSE_LOSS="l2", **env), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (env, out.stderr[-2000:])
+        return np.array([float(v) for v in [l for l in out.stdout.splitlines() if l.startswith("POSE ")][-1].split()[1:]]).reshape(4, 4)
+    base = pose({})
+    for ppl in ("2", "4"):
+        a, d = pose_error(pose({"PCR_ICP_PPL": ppl}), base)
+        assert a < 1e-7 and d < 1e-6, (ppl, a, d)

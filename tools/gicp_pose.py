@@ -9,5 +9,11 @@ g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "test
 src, tgt = P.PointCloud(g["source"]), P.PointCloud(g["target"])
 if os.environ.get("GICP_POSE_WITH_NORMALS"):      # the clouds carry normals: the voxel stage averages them and they orient the estimated ones
     src.estimate_normals(P.KDTreeSearchParamKNN(knn=12)); tgt.estimate_normals(P.KDTreeSearchParamKNN(knn=12))
-r = P.script2.Multiscale_GICP(src, tgt, 5, 100, g["T_fgr"])
+if os.environ.get("GICP_POSE_LOSS") == "l2":      # smooth loss: variants that regroup the float64 sums agree to rounding
+    vox = P.script2.create_scales(5)
+    r = P.registration.multiscale_gicp(src, tgt, vox, P.script2.max_correspondence_distances(vox), g["T_fgr"],
+                                       P.registration.TransformationEstimationForGeneralizedICP(P.registration.L2Loss()), P.registration.ICPConvergenceCriteria(1e-6, 1e-6, 100))
+else:
+    r = P.script2.Multiscale_GICP(src, tgt, 5, 100, g["T_fgr"])
+print("POSE " + " ".join(repr(float(v)) for v in np.asarray(r.transformation).reshape(16)))
 print("GICP " + np.asarray(r.transformation).tobytes().hex() + " " + str([s["iterations"] for s in r.scales]) + " " + str([s["n_clean"] for s in r.scales]))
