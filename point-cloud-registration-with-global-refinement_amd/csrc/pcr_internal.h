@@ -110,7 +110,7 @@ struct DevCloud {
 
 static inline size_t oct_node_capacity(int cap_points) { return (size_t)cap_points + 256; }   // entries of child[] / box pairs
 
-// ---- sort (pcr_sort.hip; rocPRIM device radix sort, the one library primitive used) -------------
+// ---- sort (pcr_sort.hip; hand-written stable LSD radix sort) ---------------------------------------
 size_t pcr_sort_temp_bytes(size_t n);
 int pcr_sort_pairs(pcr_context *ctx, void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
                    const uint32_t *vals_in, uint32_t *vals_out, size_t n, int end_bit);

@@ -30,7 +30,7 @@ for c in ("knn_sor", "knn_nrm", "fused"):
     print(f"{c}: n {len(d)} mean {d.mean():.1f} us")
 wall = (max(r[1] for r in rows) - min(r[0] for r in rows)) / 1e6
 print(f"window {wall:.1f} ms")
-targets = sys.argv[2].split(",") if len(sys.argv) > 2 else ("rocprim", "k_oct_apply", "k_oct_level_boxes", "k_voxel_mean", "k_scan_tile_apply", "k_icp_fused")
+targets = sys.argv[2].split(",") if len(sys.argv) > 2 else ("k_rs_scatter", "k_oct_apply", "k_oct_level_boxes", "k_voxel_mean", "k_scan_tile_apply", "k_icp_fused")
 for target in targets:
     tab = collections.defaultdict(list)
     for s, e, n in rows:
