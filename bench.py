@@ -67,7 +67,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("PCR_BENCH_INFLIGHT", "4")),
-                    help="independent pairs in flight per GPU (one library worker thread + context + streams each)")
+                    help="independent pairs (or lockstep groups, see --group) in flight per GPU (one library worker thread + context + streams each)")
+    ap.add_argument("--group", type=int, default=int(os.environ.get("PCR_BENCH_GROUP", "2")),
+                    help="pairs per lockstep group (pcr_pairs_plan.group): that many consecutive pairs of a batch go through the same launches")
     return ap.parse_args(argv)
 
 
@@ -197,12 +199,12 @@ def main(argv=None) -> int:
     if args.fixed_iterations > 0:
         crit = reg.ICPConvergenceCriteria(relative_fitness=0.0, relative_rmse=0.0, max_iteration=args.fixed_iterations)
 
-    def run_batch(n, pairs=pairs, clouds=clouds, variant=args.variant, rule=args.radius_rule, inflight=args.inflight, knn=normal_k):
+    def run_batch(n, pairs=pairs, clouds=clouds, variant=args.variant, rule=args.radius_rule, inflight=args.inflight, knn=normal_k, group=args.group):
         batch = [(clouds[i % len(pairs)][0], clouds[i % len(pairs)][1], pairs[i % len(pairs)].T_init) for i in range(n)]
         p0 = pairs[0]
         return reg.register_pairs_plan(batch, "fgr+gicp" if variant == "fgr" else "gicp", p0.voxel_sizes, p0.max_distances_script, est, crit, 30, 1.0, knn,
                                        inflight=inflight, with_correspondences=False, fgr_voxel_size=0.1, fgr_use_absolute_scale=True, fgr_seed=20241008,
-                                       radius_rule="af" if rule == "af" else "given", prior_from_fgr=(variant == "fgr"))
+                                       radius_rule="af" if rule == "af" else "given", prior_from_fgr=(variant == "fgr"), group=group)
 
     def barrier():
         torch.cuda.synchronize()
@@ -246,9 +248,9 @@ def main(argv=None) -> int:
         # pairs in flight share the GPU, so HIP events around a chunk of launches also count the time its kernels wait for
         # wavefront slots taken by other streams (kept as `us_per_launch_in_flight`); the figure that rocprofv3's per-kernel
         # durations can be checked against is measured here: a few extra steps, one pair at a time, same library path.
-        run_batch(1, inflight=1)
+        run_batch(1, inflight=1, group=1)
         pool_prof(enable=1, reset=True)
-        run_batch(min(4, n_distinct), inflight=1)
+        run_batch(min(4, n_distinct), inflight=1, group=1)
         torch.cuda.synchronize()
         solo = pool_prof(enable=0, reset=True)
         res = results[-1]
@@ -279,7 +281,7 @@ def main(argv=None) -> int:
             "config": {"workload": workload_txt, "variant": args.variant, "radius_rule": args.radius_rule,
                        "points_per_cloud": int(len(pairs[0].source)), "pairs_per_step": B, "distinct_pairs": n_distinct,
                        "distinct_how": f"{min(args.base_pairs, n_distinct)} independently sampled scene pairs, each re-posed by a rigid motion of both clouds and re-ordered (synthetic.derive_pair); every pair has its own buffers",
-                       "parallelism": f"pairs x{world}", "pairs_in_flight_per_gpu": args.inflight,
+                       "parallelism": f"pairs x{world}", "pairs_in_flight_per_gpu": args.inflight * max(1, args.group), "lockstep_group": args.group, "groups_in_flight_per_gpu": args.inflight,
                        "in_flight_by": "pcr_register_pairs_plan (library worker threads)",
                        "scales": [dict(voxel=s["voxel"], max_dist=s["max_dist"], n_voxel=s["n_voxel"], n_clean=s["n_clean"],
                                        iterations=s["iterations"]) for s in res.scales],

@@ -187,7 +187,7 @@ int pcr_registro_fgr(pcr_context *ctx, const float *src_xyz, const float *src_pr
  *    * 2^-scale computed per pair from the two AABBs (max_distances ignored).  gicp_prior_from_fgr: the normals registro_FGR
  *    left on the clouds are the orientation prior of every scale (the ALL_FUNCTIONS flow; the scripts reload the clouds).
  *    info_max_dist > 0: pairs[i].info36 <- get_information_matrix_from_point_clouds(source, target, info_max_dist, final pose)
- *    (ALL_FUNCTIONS.py:327-331).  The library keeps `inflight` pairs in flight exactly as pcr_register_pairs does.              */
+ *    (ALL_FUNCTIONS.py:327-331).  The library keeps `inflight` pairs (or groups, see `group`) in flight exactly as pcr_register_pairs does. */
 typedef enum { PCR_STAGE_GICP = 1, PCR_STAGE_FGR = 2, PCR_STAGE_FGR_GICP = 3 } pcr_stage;
 typedef struct {
     int32_t stage;
@@ -199,6 +199,10 @@ typedef struct {
     int32_t gicp_prior_from_fgr;
     double info_max_dist;
     int32_t inflight;
+    int32_t group;                                      /* > 1 (stage GICP): `group` consecutive pairs run in LOCKSTEP through the same
+                                                           launches (blockIdx.y = pair: preprocessing batched over clouds and scales, one GICP loop per
+                                                           scale for the whole group); `inflight` then counts groups.  Same per-pair arithmetic as the
+                                                           pair-by-pair path (bit-identical at equal PCR_ICP_PPL; groups default to 2 points per lane); <= 32 */
 } pcr_pairs_plan;
 typedef struct {
     pcr_pair base;                                      /* inputs, records (stages with GICP), correspondences of the LAST stage run, status */

@@ -8,10 +8,11 @@
 #include <mutex>
 #include <thread>
 #include <chrono>
+#include <vector>
 #include "pcr_octree.h"
 
 // ------------------------------------------------------------------------------------------- context
-extern "C" int pcr_version(void) { return 200; }
+extern "C" int pcr_version(void) { return 210; }
 
 extern "C" int pcr_create(int device, pcr_context **out) {
     if (!out) return PCR_EINVAL;
@@ -47,6 +48,10 @@ extern "C" int pcr_destroy(pcr_context *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->aux) (void)hipFree(ctx->aux);
+    if (ctx->icp_group_dev) (void)hipFree(ctx->icp_group_dev);
+    if (ctx->icp_group_host) (void)hipHostFree(ctx->icp_group_host);
+    if (ctx->desc_dev) (void)hipFree(ctx->desc_dev);
+    if (ctx->desc_host) (void)hipHostFree(ctx->desc_host);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (int i = 0; i < 2; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < 2; i++) if (ctx->fence_ev[i]) (void)hipEventDestroy(ctx->fence_ev[i]);
@@ -540,6 +545,119 @@ static int multiscale_batched(pcr_context *ctx, const float *src_xyz, const floa
     return PCR_OK;
 }
 
+// ---- Multiscale_GICP of a GROUP of G pairs through the same launches: bounds (2 launches), voxel grids of all clouds and scales
+// (one key / sort / scan / mean pass), voxel trees, SOR chains, cleaned target trees and fallback normals (one batch each, blockIdx.y
+// = cloud x scale), then per scale ONE lockstep GICP loop over the G pairs (pcr_dev_gicp_group).  Everything on the context's stream:
+// the kernels are G times fatter, so they fill the device by themselves.  Same per-problem arithmetic as the pair-by-pair path:
+// bit-identical results.  Returns 1 (nothing enqueued but the bounds) when the merged voxel pass declines: the caller falls back.
+static int multiscale_group(pcr_context *ctx, pcr_pair_ex *const *px, int G, const double *voxels, const double *given_dists /* n_scales, radius_rule 0 */, int radius_rule,
+                            int n_scales, int sor_k, double sor_std, int normal_k, const pcr_gicp_params *params) {
+    if (G < 1 || G > 32 || n_scales < 2 || n_scales > 8 || sor_k > 32 || normal_k > 32) return 1;
+    const int C = 2 * G;                                  // cloud c = 2 g + which (0 source, 1 target)
+    std::vector<const float *> xyz((size_t)C), nrm((size_t)C); std::vector<int64_t> n((size_t)C);
+    bool any_nrm = false;
+    size_t total = 0;
+    for (int g = 0; g < G; g++) {
+        const pcr_pair &p = px[g]->base;
+        if (p.n_src <= 0 || p.n_tgt <= 0 || !p.src_xyz || !p.tgt_xyz || !p.records) return 1;
+        PCR_TRY(check_T(ctx, p.init_T));
+        xyz[2 * g] = p.src_xyz; xyz[2 * g + 1] = p.tgt_xyz; nrm[2 * g] = p.src_normals; nrm[2 * g + 1] = p.tgt_normals;
+        n[2 * g] = p.n_src; n[2 * g + 1] = p.n_tgt;
+        any_nrm = any_nrm || p.src_normals || p.tgt_normals;
+    }
+    for (int c = 0; c < C; c++) total += (size_t)n_scales * ((size_t)n[c] + 512) * 1100 + pcr_sort_temp_bytes((size_t)n[c] * n_scales) + (size_t)n[c] * n_scales * 40 + (8u << 20);
+    PCR_TRY(pcr_arena_reserve(ctx, total + (16u << 20)));
+    std::vector<double> b6((size_t)C * 6);
+    PCR_TRY(pcr_dev_bounds_batch(ctx, C, xyz.data(), n.data(), b6.data()));
+    std::vector<double> dists((size_t)G * n_scales);
+    for (int g = 0; g < G; g++) {
+        if (radius_rule == 1) {              // ALL_FUNCTIONS.py:277-278 + 1092-1101: radius_from_cloud_pair * 2^-scale from the two AABBs
+            const double *bs = &b6[12 * g], *bt = &b6[12 * g + 6];
+            const double r1 = std::pow((bs[3] - bs[0]) * (bs[4] - bs[1]) * (bs[5] - bs[2]), 1.0 / 3.0), r2 = std::pow((bt[3] - bt[0]) * (bt[4] - bt[1]) * (bt[5] - bt[2]), 1.0 / 3.0);
+            for (int s = 0; s < n_scales; s++) dists[(size_t)g * n_scales + s] = (r1 + r2) / 2 * std::pow(2.0, -(double)s);
+        } else for (int s = 0; s < n_scales; s++) dists[(size_t)g * n_scales + s] = given_dists[s];
+        for (int s = 0; s < 8; s++) px[g]->max_distances[s] = s < n_scales ? dists[(size_t)g * n_scales + s] : 0.0;
+        for (int s = 0; s < n_scales; s++) if (!(dists[(size_t)g * n_scales + s] > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
+    }
+    int *cnt = arena<int>(ctx, (size_t)C * n_scales * 2);          // [c][s]: voxel count, clean count
+    if (!cnt) return PCR_ENOMEM;
+    std::vector<DevCloud> vox((size_t)C * n_scales), clean((size_t)C * n_scales), tmp((size_t)C * n_scales);
+    std::vector<const float4 *> priors((size_t)C * n_scales); std::vector<uint8_t *> todos((size_t)C * n_scales);
+    std::vector<int *> tcs((size_t)C * n_scales), cin((size_t)C * n_scales), ckept((size_t)C * n_scales);
+    for (int c = 0; c < C; c++) {
+        const bool need_tree = (c & 1) == 1;
+        for (int s = 0; s < n_scales; s++) {
+            const size_t k = (size_t)c * n_scales + s;
+            PCR_TRY(pcr_alloc_cloud(ctx, &vox[k], (int)n[c], nrm[c] != nullptr, true));
+            PCR_TRY(pcr_alloc_cloud(ctx, &clean[k], (int)n[c], true, need_tree));
+            float4 *prior = nrm[c] ? arena<float4>(ctx, n[c]) : nullptr;
+            uint8_t *todo = arena<uint8_t>(ctx, n[c]);
+            int *tc = arena<int>(ctx, 2);
+            if (!todo || !tc || (nrm[c] && !prior)) return PCR_ENOMEM;
+            tmp[k] = clean[k]; tmp[k].nrm = prior; tmp[k].nrm_final = clean[k].nrm;
+            priors[k] = prior; todos[k] = todo; tcs[k] = tc + 1; cin[k] = cnt + 2 * k; ckept[k] = cnt + 2 * k + 1;
+        }
+    }
+    bool merged = false;
+    PCR_TRY(pcr_dev_voxel_multi_batch(ctx, C, xyz.data(), any_nrm ? nrm.data() : nullptr, n.data(), b6.data(), voxels, n_scales, vox.data(), &merged));
+    if (!merged) return 1;
+    {
+        std::vector<DevCloud *> vp((size_t)C * n_scales);
+        for (size_t k = 0; k < vp.size(); k++) vp[k] = &vox[k];
+        PCR_TRY(pcr_dev_build_bvh_batch(ctx, vp.data(), (int)vp.size()));
+    }
+    for (int which = 0; which < 2; which++) {            // sources: incomplete normal lists searched over the voxel trees; targets: over their own trees below
+        std::vector<const DevCloud *> ins; std::vector<DevCloud *> outs; std::vector<const float4 *> pr; std::vector<uint8_t *> td; std::vector<int *> tc, ci, ck;
+        for (int g = 0; g < G; g++)
+            for (int s = 0; s < n_scales; s++) {
+                const size_t k = (size_t)(2 * g + which) * n_scales + s;
+                ins.push_back(&vox[k]); outs.push_back(&tmp[k]); pr.push_back(priors[k]); td.push_back(todos[k]); tc.push_back(tcs[k]); ci.push_back(cin[k]); ck.push_back(ckept[k]);
+            }
+        PCR_TRY(pcr_dev_sor_batch(ctx, ins.data(), outs.data(), (int)ins.size(), sor_k, sor_std, normal_k, pr.data(), td.data(), tc.data(), ci.data(), ck.data(), which == 0));
+    }
+    for (size_t k = 0; k < clean.size(); k++) for (int d = 0; d < 3; d++) { clean[k].key_org[d] = tmp[k].key_org[d]; clean[k].key_unit[d] = tmp[k].key_unit[d]; }
+    {
+        std::vector<DevCloud *> trees; std::vector<const float4 *> pr; std::vector<float4 *> no; std::vector<const uint8_t *> td;
+        for (int g = 0; g < G; g++)
+            for (int s = 0; s < n_scales; s++) {
+                const size_t k = (size_t)(2 * g + 1) * n_scales + s;
+                trees.push_back(&clean[k]); pr.push_back(priors[k]); no.push_back(clean[k].nrm); td.push_back(todos[k]);
+            }
+        PCR_TRY(pcr_dev_build_bvh_batch(ctx, trees.data(), (int)trees.size()));
+        PCR_TRY(pcr_dev_normals_knn_batch(ctx, trees.data(), (int)trees.size(), normal_k, pr.data(), no.data(), td.data()));
+    }
+    // ---- the GICP loops, one lockstep loop per scale
+    std::vector<double> T((size_t)G * 16), md((size_t)G);
+    std::vector<pcr_result> res((size_t)G);
+    std::vector<int32_t *> match((size_t)G);
+    for (int g = 0; g < G; g++) {
+        memcpy(&T[16 * g], px[g]->base.init_T, 16 * sizeof(double));
+        match[g] = arena<int32_t>(ctx, n[2 * g]);
+        if (!match[g]) return PCR_ENOMEM;
+    }
+    for (int s = 0; s < n_scales; s++) {
+        std::vector<const DevCloud *> ss((size_t)G), tt((size_t)G);
+        for (int g = 0; g < G; g++) { ss[g] = &clean[(size_t)(2 * g) * n_scales + s]; tt[g] = &clean[(size_t)(2 * g + 1) * n_scales + s]; md[g] = dists[(size_t)g * n_scales + s]; }
+        PCR_TRY(pcr_dev_gicp_group(ctx, G, ss.data(), tt.data(), md.data(), T.data(), params, res.data(), match.data()));
+        for (int g = 0; g < G; g++) { px[g]->base.records[s].icp = res[g]; memcpy(&T[16 * g], res[g].transformation, 16 * sizeof(double)); }
+    }
+    for (int g = 0; g < G; g++)
+        if (px[g]->base.correspondences) {
+            int64_t nc = 0;
+            const DevCloud &last = clean[(size_t)(2 * g) * n_scales + n_scales - 1];
+            PCR_TRY(pcr_dev_compact_matches(ctx, match[g], last.n, last.cap, nullptr, nullptr, px[g]->base.correspondences, &nc));
+        }
+    std::vector<int> h((size_t)C * n_scales * 2);
+    PCR_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), cnt, sizeof(int) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int g = 0; g < G; g++)
+        for (int s = 0; s < n_scales; s++) {
+            pcr_scale_record &r = px[g]->base.records[s];
+            for (int w = 0; w < 2; w++) { r.n_voxel[w] = h[2 * ((size_t)(2 * g + w) * n_scales + s)]; r.n_clean[w] = h[2 * ((size_t)(2 * g + w) * n_scales + s) + 1]; }
+        }
+    return PCR_OK;
+}
+
 static int multiscale_gicp_impl(pcr_context *ctx, const float *src_xyz, const float *src_normals, int64_t n_src,
                                 const float *tgt_xyz, const float *tgt_normals, int64_t n_tgt, const double *voxels,
                                 const double *dists, int n_scales, int sor_k, double sor_std, int normal_k,
@@ -762,7 +880,10 @@ extern "C" int pcr_register_pairs_plan(int device, pcr_pair_ex *pairs, int n_pai
     if (n_pairs == 0) return PCR_OK;
     if (hipSetDevice(device) != hipSuccess) return PCR_EHIP;
     const int inflight = plan->inflight;
-    const int workers = inflight < 1 ? 1 : (inflight > n_pairs ? n_pairs : (inflight > 16 ? 16 : inflight));
+    // lockstep groups (stage GICP): `group` consecutive pairs go through the same launches, `inflight` groups in flight
+    const int group = (plan->stage == PCR_STAGE_GICP && plan->group > 1) ? (plan->group > 32 ? 32 : plan->group) : 1;
+    const int units = (n_pairs + group - 1) / group;
+    const int workers = inflight < 1 ? 1 : (inflight > units ? units : (inflight > 16 ? 16 : inflight));
     // the workers wait for everything already enqueued on `after_stream` (NULL = the legacy default stream, which is what torch's
     // default stream is): the producers of the clouds, normals and initial poses
     hipEvent_t ready = nullptr;
@@ -777,12 +898,30 @@ extern "C" int pcr_register_pairs_plan(int device, pcr_pair_ex *pairs, int n_pai
         use_private_stream(ctx);
         if (ensure_stream(ctx) == PCR_OK) (void)hipStreamWaitEvent(ctx->stream, ready, 0);
         for (;;) {
-            const int i = next.fetch_add(1);
+            const int i = next.fetch_add(group);
             if (i >= n_pairs) break;
-            pcr_pair &p = pairs[i].base;
-            p.error[0] = 0;
-            p.status = run_pair(ctx, pairs[i], i, *plan);
-            if (p.status != PCR_OK) { failed++; snprintf(p.error, sizeof p.error, "%s", ctx->err.c_str()); }
+            const int cnt = i + group <= n_pairs ? group : n_pairs - i;
+            int rc_group = 1;
+            if (group > 1 && cnt > 1) {
+                // `cnt` consecutive pairs through the same launches (lockstep group); rc 1: declined, pair by pair below
+                std::vector<pcr_pair_ex *> gp((size_t)cnt);
+                for (int k = 0; k < cnt; k++) { gp[k] = &pairs[i + k]; pairs[i + k].base.error[0] = 0; }
+                rc_group = pcr_api_call(ctx, [&]() -> int {
+                    return multiscale_group(ctx, gp.data(), cnt, plan->voxel_sizes, plan->max_distances, plan->radius_rule, plan->n_scales, plan->sor_k, plan->sor_std, plan->normal_k, plan->gicp);
+                });
+                if (rc_group == PCR_OK) {
+                    for (int k = 0; k < cnt; k++) pairs[i + k].base.status = PCR_OK;
+                } else if (rc_group != 1) {
+                    for (int k = 0; k < cnt; k++) { pairs[i + k].base.status = rc_group; failed++; snprintf(pairs[i + k].base.error, sizeof pairs[i + k].base.error, "%s", ctx->err.c_str()); }
+                }
+            }
+            if (rc_group == 1)
+                for (int k = 0; k < cnt; k++) {
+                    pcr_pair &p = pairs[i + k].base;
+                    p.error[0] = 0;
+                    p.status = run_pair(ctx, pairs[i + k], i + k, *plan);
+                    if (p.status != PCR_OK) { failed++; snprintf(p.error, sizeof p.error, "%s", ctx->err.c_str()); }
+                }
         }
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
         pool_give(device, ctx);

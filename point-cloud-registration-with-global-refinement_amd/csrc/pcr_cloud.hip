@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cstdio>
+#include <vector>
 #include "pcr_octree.h"
 
 #define BS 256
@@ -56,6 +57,62 @@ int pcr_dev_bounds(pcr_context *ctx, const float *xyz, int64_t n, double *b6) {
     return PCR_OK;
 }
 
+// bounds of `count` clouds: two launches (blockIdx.y = cloud), one copy, one synchronisation
+struct BoundsArgs { const float *xyz; int64_t n; float *part; float *out6; int nb; };
+__global__ void __launch_bounds__(BS) k_bounds_partial_g(const BoundsArgs *a_) {
+    const BoundsArgs &a = a_[blockIdx.y];
+    if ((int)blockIdx.x >= a.nb) return;
+    float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (int64_t i = blockIdx.x * (int64_t)BS + threadIdx.x; i < a.n; i += (int64_t)a.nb * BS) {
+        float x = a.xyz[i * 3], y = a.xyz[i * 3 + 1], z = a.xyz[i * 3 + 2];
+        mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
+        mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+    }
+    __shared__ float s[BS / PCR_WAVE][6];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 0; d < 3; d++) { mn[d] = pcr_wave_min(mn[d]); mx[d] = pcr_wave_max(mx[d]); }
+    if (lane == 0) { for (int d = 0; d < 3; d++) { s[w][d] = mn[d]; s[w][3 + d] = mx[d]; } }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = s[0][threadIdx.x];
+        for (int k = 1; k < BS / PCR_WAVE; k++) v = threadIdx.x < 3 ? fminf(v, s[k][threadIdx.x]) : fmaxf(v, s[k][threadIdx.x]);
+        a.part[blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+__global__ void k_bounds_final_g(const BoundsArgs *a_) {
+    const BoundsArgs &a = a_[blockIdx.x];
+    if (threadIdx.x < 6) {
+        float v = a.part[threadIdx.x];
+        for (int k = 1; k < a.nb; k++) v = threadIdx.x < 3 ? fminf(v, a.part[k * 6 + threadIdx.x]) : fmaxf(v, a.part[k * 6 + threadIdx.x]);
+        a.out6[threadIdx.x] = v;
+    }
+}
+int pcr_dev_bounds_batch(pcr_context *ctx, int count, const float *const *xyz, const int64_t *n, double *b6 /* count x 6, host */) {
+    if (count < 1) return PCR_OK;
+    ArenaMark mark(ctx);
+    std::vector<BoundsArgs> a((size_t)count);
+    float *out = arena<float>(ctx, (size_t)count * 6);
+    if (!out) return PCR_ENOMEM;
+    int max_nb = 1;
+    for (int c = 0; c < count; c++) {
+        if (n[c] <= 0) { ctx->err = "empty cloud in a group"; return PCR_EINVAL; }
+        const int nb = (int)((n[c] + BS - 1) / BS < 256 ? (n[c] + BS - 1) / BS : 256);
+        a[c].xyz = xyz[c]; a[c].n = n[c]; a[c].nb = nb; a[c].part = arena<float>(ctx, (size_t)nb * 6); a[c].out6 = out + 6 * c;
+        if (!a[c].part) return PCR_ENOMEM;
+        max_nb = nb > max_nb ? nb : max_nb;
+    }
+    const BoundsArgs *d = pcr_desc_upload(ctx, a.data(), count);
+    if (!d) return PCR_ENOMEM;
+    PCR_LAUNCH(ctx, k_bounds_partial_g, dim3(max_nb, count), dim3(BS), 0, ctx->stream, d);
+    PCR_LAUNCH(ctx, k_bounds_final_g, dim3(count), dim3(64), 0, ctx->stream, d);
+    std::vector<float> h((size_t)count * 6);
+    PCR_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), out, sizeof(float) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < h.size(); i++) b6[i] = (double)h[i];
+    return PCR_OK;
+}
+
 int pcr_read_count(pcr_context *ctx, const int *dev_n, int64_t *out) {
     int h = 0;
     PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h, dev_n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -88,7 +145,10 @@ __device__ static inline int block_exclusive_scan(int v, int *total) {   // BS t
 // Optional flag producers fused into the counting pass (each saved a launch of its own): head flags of sorted keys
 // (voxel grid), or the SOR keep test on the mean neighbour distances.  The flags are stored for the later kernels.
 struct FlagSrc { const uint64_t *keys; const double *avg; const double *stats3; };
-#define PCR_MAX_BATCH 8          // problems one batched launch serves (blockIdx.y picks the problem): the scales of a multiscale registration
+#define PCR_MAX_BATCH 8          // problems whose argument structs travel in the kernel arguments (blockIdx.y picks the problem): the scales of
+                                 //   a multiscale registration.  Larger batches (the clouds and scales of a GROUP of pairs) read their argument structs
+                                 //   from device memory: every batched kernel has a by-value and a by-pointer entry point (pcr_batch_launch)
+#define PCR_MAX_GROUP_BATCH 256
 struct ScanArgs { uint8_t *flags; const int *n_ptr; int n_host; int *tile_cnt; int *pos; int *total; FlagSrc src; int n_tiles; };
 struct ScanBatch { ScanArgs a[PCR_MAX_BATCH]; };
 __device__ static inline void d_scan_tile_count(const ScanArgs &a) {
@@ -138,6 +198,25 @@ __global__ void __launch_bounds__(BS) k_scan_tile_count(ScanArgs a) { d_scan_til
 __global__ void __launch_bounds__(BS) k_scan_tile_apply(ScanArgs a) { d_scan_tile_apply(a); }
 __global__ void __launch_bounds__(BS) k_scan_tile_count_batch(ScanBatch b) { d_scan_tile_count(b.a[blockIdx.y]); }
 __global__ void __launch_bounds__(BS) k_scan_tile_apply_batch(ScanBatch b) { d_scan_tile_apply(b.a[blockIdx.y]); }
+__global__ void __launch_bounds__(BS) k_scan_tile_count_batchp(const ScanArgs *a) { d_scan_tile_count(a[blockIdx.y]); }
+__global__ void __launch_bounds__(BS) k_scan_tile_apply_batchp(const ScanArgs *a) { d_scan_tile_apply(a[blockIdx.y]); }
+
+// `count` problems in one launch: argument structs by value up to PCR_MAX_BATCH, else through the context's descriptor buffer
+// (pinned staging -> device, one small asynchronous copy on the launch stream)
+template <class B, class A, class KV, class KP>
+static int pcr_batch_launch(pcr_context *ctx, const char *file, int line, KV by_value, KP by_pointer, const A *args, int count, dim3 grid, dim3 block) {
+    if (count <= PCR_MAX_BATCH) {
+        B b; std::memset(&b, 0, sizeof b);
+        for (int k = 0; k < count; k++) b.a[k] = args[k];
+        pcr_launch(ctx, file, line, by_value, grid, block, 0, ctx->stream, b);
+    } else {
+        const A *dev = pcr_desc_upload(ctx, args, count);
+        if (!dev) return PCR_ENOMEM;
+        pcr_launch(ctx, file, line, by_pointer, grid, block, 0, ctx->stream, dev);
+    }
+    return PCR_OK;
+}
+#define PCR_BATCH_LAUNCH(ctx, B, kv, kp, args, count, grid, block) pcr_batch_launch<B>(ctx, __FILE__, __LINE__, kv, kp, args, count, grid, block)
 
 static int scan_args(pcr_context *ctx, ScanArgs *a, uint8_t *flags, const int *n_ptr, int n_cap, int *pos, int *total_dev, FlagSrc src) {
     a->n_tiles = (n_cap + TILE - 1) / TILE;
@@ -153,12 +232,12 @@ static int flag_scan(pcr_context *ctx, uint8_t *flags, const int *n_ptr, int n_c
     PCR_LAUNCH(ctx, k_scan_tile_apply, dim3(a.n_tiles), dim3(BS), 0, ctx->stream, a);
     return PCR_OK;
 }
-static int flag_scan_batch(pcr_context *ctx, const ScanBatch &b, int count) {
+static int flag_scan_batch(pcr_context *ctx, const ScanArgs *a, int count) {
     int mt = 0;
-    for (int k = 0; k < count; k++) mt = b.a[k].n_tiles > mt ? b.a[k].n_tiles : mt;
+    for (int k = 0; k < count; k++) mt = a[k].n_tiles > mt ? a[k].n_tiles : mt;
     if (mt == 0) return PCR_OK;
-    PCR_LAUNCH(ctx, k_scan_tile_count_batch, dim3(mt, count), dim3(BS), 0, ctx->stream, b);
-    PCR_LAUNCH(ctx, k_scan_tile_apply_batch, dim3(mt, count), dim3(BS), 0, ctx->stream, b);
+    PCR_TRY(PCR_BATCH_LAUNCH(ctx, ScanBatch, k_scan_tile_count_batch, k_scan_tile_count_batchp, a, count, dim3(mt, count), dim3(BS)));
+    PCR_TRY(PCR_BATCH_LAUNCH(ctx, ScanBatch, k_scan_tile_apply_batch, k_scan_tile_apply_batchp, a, count, dim3(mt, count), dim3(BS)));
     return PCR_OK;
 }
 int pcr_dev_flag_scan(pcr_context *ctx, const uint8_t *flags, const int *n_ptr, int n_cap, int *pos, int *total_dev) {
@@ -239,92 +318,134 @@ int pcr_dev_voxel(pcr_context *ctx, const float *xyz, const float *nrm_in, int64
 #define VOX_MAX_SCALES 8
 struct VoxelGrids { double ox[VOX_MAX_SCALES], oy[VOX_MAX_SCALES], oz[VOX_MAX_SCALES], voxel[VOX_MAX_SCALES]; };
 struct VoxelOuts { float4 *pts[VOX_MAX_SCALES]; float4 *nrm[VOX_MAX_SCALES]; uint64_t *keys[VOX_MAX_SCALES]; int *n[VOX_MAX_SCALES]; };
-__global__ void __launch_bounds__(BS) k_voxel_keys_multi(const float *__restrict__ xyz, int n, int n_scales, VoxelGrids g, int shift,
-                                                         uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+struct VoxArgs {
+    const float *xyz, *nrm_in; int n, n_scales, shift; VoxelGrids g;
+    uint64_t *keys_raw; uint32_t *vals_raw;                    // written by the key kernel
+    const uint64_t *keys; const uint32_t *vals;                // sorted
+    const uint8_t *flags; const int *pos; const int *total; VoxelOuts o;
+};
+__device__ static inline void d_voxel_keys_multi(const VoxArgs &a) {
     const int e = blockIdx.x * BS + threadIdx.x;
-    if (e >= n * n_scales) return;
+    const int n = a.n;
+    if (e >= n * a.n_scales) return;
     const int s = e / n, i = e - s * n;
-    const double x = (double)xyz[i * 3], y = (double)xyz[i * 3 + 1], z = (double)xyz[i * 3 + 2];
-    double ox = g.ox[0], oy = g.oy[0], oz = g.oz[0], voxel = g.voxel[0];
+    const double x = (double)a.xyz[i * 3], y = (double)a.xyz[i * 3 + 1], z = (double)a.xyz[i * 3 + 2];
+    double ox = a.g.ox[0], oy = a.g.oy[0], oz = a.g.oz[0], voxel = a.g.voxel[0];
 #pragma unroll
-    for (int k = 1; k < VOX_MAX_SCALES; k++) if (s == k) { ox = g.ox[k]; oy = g.oy[k]; oz = g.oz[k]; voxel = g.voxel[k]; }
+    for (int k = 1; k < VOX_MAX_SCALES; k++) if (s == k) { ox = a.g.ox[k]; oy = a.g.oy[k]; oz = a.g.oz[k]; voxel = a.g.voxel[k]; }
     const uint32_t ix = (uint32_t)(int)floor((x - ox) / voxel);        // identical float64 expression to the one-scale kernel
     const uint32_t iy = (uint32_t)(int)floor((y - oy) / voxel);
     const uint32_t iz = (uint32_t)(int)floor((z - oz) / voxel);
-    keys[e] = ((uint64_t)s << shift) | pcr_morton3(ix, iy, iz);
-    vals[e] = (uint32_t)i;
+    a.keys_raw[e] = ((uint64_t)s << a.shift) | pcr_morton3(ix, iy, iz);
+    a.vals_raw[e] = (uint32_t)i;
 }
-__global__ void __launch_bounds__(BS) k_voxel_mean_multi(const float *__restrict__ xyz, const float *__restrict__ nrm_in, const uint64_t *__restrict__ keys,
-                                                         const uint32_t *__restrict__ vals, const uint8_t *__restrict__ flags, const int *__restrict__ pos,
-                                                         const int *__restrict__ total, int n, int n_scales, int shift, VoxelOuts o) {
+__device__ static inline void d_voxel_mean_multi(const VoxArgs &a) {
     const int p = blockIdx.x * BS + threadIdx.x;
-    const int ne = n * n_scales;
+    const int n = a.n, ne = n * a.n_scales;
     if (p >= ne) return;
     const int s = p / n;
-    const int base = pos[s * n];                       // element s * n starts scale s: always a voxel head
-    float4 *out_pts = o.pts[0], *out_nrm = o.nrm[0]; uint64_t *out_keys = o.keys[0]; int *out_n = o.n[0];
+    const int base = a.pos[s * n];                     // element s * n starts scale s: always a voxel head
+    float4 *out_pts = a.o.pts[0], *out_nrm = a.o.nrm[0]; uint64_t *out_keys = a.o.keys[0]; int *out_n = a.o.n[0];
 #pragma unroll
-    for (int k = 1; k < VOX_MAX_SCALES; k++) if (s == k) { out_pts = o.pts[k]; out_nrm = o.nrm[k]; out_keys = o.keys[k]; out_n = o.n[k]; }
-    if (p == s * n) *out_n = (s + 1 < n_scales ? pos[(s + 1) * n] : *total) - base;
-    if (!flags[p]) return;
-    const uint64_t key = keys[p];
+    for (int k = 1; k < VOX_MAX_SCALES; k++) if (s == k) { out_pts = a.o.pts[k]; out_nrm = a.o.nrm[k]; out_keys = a.o.keys[k]; out_n = a.o.n[k]; }
+    if (p == s * n) *out_n = (s + 1 < a.n_scales ? a.pos[(s + 1) * n] : *a.total) - base;
+    if (!a.flags[p]) return;
+    const uint64_t key = a.keys[p];
     double sx = 0, sy = 0, sz = 0, nx = 0, ny = 0, nz = 0;
     int j = p;
     do {   // members in input order (stable sort) => same float64 sum as the oracle
-        const uint32_t v = vals[j];
-        sx += (double)xyz[v * 3]; sy += (double)xyz[v * 3 + 1]; sz += (double)xyz[v * 3 + 2];
-        if (nrm_in) { nx += (double)nrm_in[v * 3]; ny += (double)nrm_in[v * 3 + 1]; nz += (double)nrm_in[v * 3 + 2]; }
+        const uint32_t v = a.vals[j];
+        sx += (double)a.xyz[v * 3]; sy += (double)a.xyz[v * 3 + 1]; sz += (double)a.xyz[v * 3 + 2];
+        if (a.nrm_in) { nx += (double)a.nrm_in[v * 3]; ny += (double)a.nrm_in[v * 3 + 1]; nz += (double)a.nrm_in[v * 3 + 2]; }
         j++;
-    } while (j < ne && keys[j] == key);
+    } while (j < ne && a.keys[j] == key);
     const double c = (double)(j - p);
-    const int idx = pos[p] - base;
+    const int idx = a.pos[p] - base;
     out_pts[idx] = make_float4((float)(sx / c), (float)(sy / c), (float)(sz / c), 0.0f);
-    out_keys[idx] = key & ((1ull << shift) - 1ull);
-    if (nrm_in && out_nrm) out_nrm[idx] = make_float4((float)(nx / c), (float)(ny / c), (float)(nz / c), 0.0f);
+    out_keys[idx] = key & ((1ull << a.shift) - 1ull);
+    if (a.nrm_in && out_nrm) out_nrm[idx] = make_float4((float)(nx / c), (float)(ny / c), (float)(nz / c), 0.0f);
 }
+__global__ void __launch_bounds__(BS) k_voxel_keys_multi(VoxArgs a) { d_voxel_keys_multi(a); }
+__global__ void __launch_bounds__(BS) k_voxel_mean_multi(VoxArgs a) { d_voxel_mean_multi(a); }
+__global__ void __launch_bounds__(BS) k_voxel_keys_multi_g(const VoxArgs *a) { d_voxel_keys_multi(a[blockIdx.y]); }
+__global__ void __launch_bounds__(BS) k_voxel_mean_multi_g(const VoxArgs *a) { d_voxel_mean_multi(a[blockIdx.y]); }
 
-// *done = false (nothing enqueued) when the scales cannot share one sort key or the scratch block is too small: the caller then runs
-// them one by one; PCR_EINVAL only for the argument errors the one-scale pass reports too
-int pcr_dev_voxel_multi(pcr_context *ctx, const float *xyz, const float *nrm_in, int64_t n, const double *b6, const double *voxels, int n_scales, DevCloud *outs, bool *done) {
+// the voxel stage of `count` clouds x n_scales grids in ONE keys / sort / scan / mean pass each (blockIdx.y = cloud): count == 1 is
+// the per-cloud call.  outs: count x n_scales clouds (pts / keys / n / optional nrm allocated by the caller, cap >= n).  *done = false
+// (and nothing enqueued) when the scales of some cloud cannot share one sort key or the scratch does not fit.
+static int voxel_multi_batch(pcr_context *ctx, int count, const float *const *xyz, const float *const *nrm_in, const int64_t *n, const double *b6 /* count x 6 */, const double *voxels,
+                             int n_scales, DevCloud *outs /* count x n_scales */, bool *done) {
     *done = false;
-    if (n_scales < 2 || n_scales > VOX_MAX_SCALES || n <= 0 || n * n_scales > 0x7fffffff / 4) return PCR_OK;
-    VoxelGrids g; VoxelOuts o;
-    std::memset(&g, 0, sizeof g); std::memset(&o, 0, sizeof o);
-    int shift = 0;
-    for (int s = 0; s < n_scales; s++) {
-        const double voxel = voxels[s];
-        if (!(voxel > 0.0)) { ctx->err = "voxel_size <= 0"; return PCR_EINVAL; }
-        g.ox[s] = b6[0] - voxel * 0.5; g.oy[s] = b6[1] - voxel * 0.5; g.oz[s] = b6[2] - voxel * 0.5; g.voxel[s] = voxel;
-        uint32_t mx = 0;
-        for (int d = 0; d < 3; d++) {
-            double e = floor((b6[3 + d] - (b6[d] - voxel * 0.5)) / voxel);
-            if (!(e < 2097152.0)) { ctx->err = "voxel_size is too small"; return PCR_EINVAL; }
-            if ((uint32_t)e > mx) mx = (uint32_t)e;
+    if (n_scales < 2 || n_scales > VOX_MAX_SCALES || count < 1) return PCR_OK;
+    std::vector<VoxArgs> va((size_t)count); std::vector<ScanArgs> sa((size_t)count);
+    std::vector<void *> temps((size_t)count); std::vector<const uint64_t *> kin((size_t)count); std::vector<uint64_t *> kout((size_t)count);
+    std::vector<const uint32_t *> vin((size_t)count); std::vector<uint32_t *> vout((size_t)count); std::vector<size_t> ne((size_t)count);
+    int end_bit = 1; size_t max_ne = 0;
+    for (int c = 0; c < count; c++) {
+        if (n[c] <= 0 || n[c] * n_scales > 0x7fffffff / 4) return PCR_OK;
+        VoxArgs &a = va[c]; std::memset(&a, 0, sizeof a);
+        int shift = 0;
+        for (int s = 0; s < n_scales; s++) {
+            const double voxel = voxels[s];
+            if (!(voxel > 0.0)) { ctx->err = "voxel_size <= 0"; return PCR_EINVAL; }
+            a.g.ox[s] = b6[6 * c] - voxel * 0.5; a.g.oy[s] = b6[6 * c + 1] - voxel * 0.5; a.g.oz[s] = b6[6 * c + 2] - voxel * 0.5; a.g.voxel[s] = voxel;
+            uint32_t mx = 0;
+            for (int d = 0; d < 3; d++) {
+                double e = floor((b6[6 * c + 3 + d] - (b6[6 * c + d] - voxel * 0.5)) / voxel);
+                if (!(e < 2097152.0)) { ctx->err = "voxel_size is too small"; return PCR_EINVAL; }
+                if ((uint32_t)e > mx) mx = (uint32_t)e;
+            }
+            if (3 * bits_for(mx) > shift) shift = 3 * bits_for(mx);
+            DevCloud &o = outs[c * n_scales + s];
+            o.key_org[0] = (float)a.g.ox[s]; o.key_org[1] = (float)a.g.oy[s]; o.key_org[2] = (float)a.g.oz[s];
+            o.key_unit[0] = o.key_unit[1] = o.key_unit[2] = (float)voxel;
+            a.o.pts[s] = o.pts; a.o.nrm[s] = o.nrm; a.o.keys[s] = o.keys; a.o.n[s] = o.n;
         }
-        if (3 * bits_for(mx) > shift) shift = 3 * bits_for(mx);
-        outs[s].key_org[0] = (float)g.ox[s]; outs[s].key_org[1] = (float)g.oy[s]; outs[s].key_org[2] = (float)g.oz[s];
-        outs[s].key_unit[0] = outs[s].key_unit[1] = outs[s].key_unit[2] = (float)voxel;
-        o.pts[s] = outs[s].pts; o.nrm[s] = outs[s].nrm; o.keys[s] = outs[s].keys; o.n[s] = outs[s].n;
+        if (shift < 1) shift = 1;
+        const int eb = shift + bits_for((uint32_t)(n_scales - 1));
+        if (eb > 64) return PCR_OK;                    // the scale index does not fit above the Morton bits
+        end_bit = eb > end_bit ? eb : end_bit;
+        a.xyz = xyz[c]; a.nrm_in = nrm_in ? nrm_in[c] : nullptr; a.n = (int)n[c]; a.n_scales = n_scales; a.shift = shift;
+        ne[c] = (size_t)n[c] * n_scales; max_ne = ne[c] > max_ne ? ne[c] : max_ne;
     }
-    if (shift < 1) shift = 1;
-    const int end_bit = shift + bits_for((uint32_t)(n_scales - 1));
-    if (end_bit > 64) return PCR_OK;                    // the scale index does not fit above the Morton bits
-    ArenaMark mark(ctx);
-    const size_t ne = (size_t)n * n_scales;
-    uint64_t *k0 = arena<uint64_t>(ctx, ne), *k1 = arena<uint64_t>(ctx, ne);
-    uint32_t *v0 = arena<uint32_t>(ctx, ne), *v1 = arena<uint32_t>(ctx, ne);
-    uint8_t *flags = arena<uint8_t>(ctx, ne);
-    int *pos = arena<int>(ctx, ne), *total = arena<int>(ctx, 1);
-    const size_t tb = pcr_sort_temp_bytes(ne);
-    void *temp = pcr_arena_alloc(ctx, tb);
-    if (!k0 || !k1 || !v0 || !v1 || !flags || !pos || !total || !temp) return PCR_OK;      // not enough scratch in this block: one by one
-    const int nb = (int)((ne + BS - 1) / BS);
-    PCR_LAUNCH(ctx, k_voxel_keys_multi, dim3(nb), dim3(BS), 0, ctx->stream, xyz, (int)n, n_scales, g, shift, k0, v0);
-    PCR_TRY(pcr_sort_pairs(ctx, temp, tb, k0, k1, v0, v1, ne, end_bit));
-    PCR_TRY(flag_scan(ctx, flags, nullptr, (int)ne, pos, total, FlagSrc{k1, nullptr, nullptr}));
-    PCR_LAUNCH(ctx, k_voxel_mean_multi, dim3(nb), dim3(BS), 0, ctx->stream, xyz, nrm_in, k1, v1, flags, pos, total, (int)n, n_scales, shift, o);
+    for (int c = 0; c < count; c++) {
+        VoxArgs &a = va[c];
+        uint64_t *k0 = arena<uint64_t>(ctx, ne[c]), *k1 = arena<uint64_t>(ctx, ne[c]);
+        uint32_t *v0 = arena<uint32_t>(ctx, ne[c]), *v1 = arena<uint32_t>(ctx, ne[c]);
+        uint8_t *flags = arena<uint8_t>(ctx, ne[c]);
+        int *pos = arena<int>(ctx, ne[c]), *total = arena<int>(ctx, 1);
+        const size_t tb = pcr_sort_temp_bytes(ne[c]);
+        void *temp = pcr_arena_alloc(ctx, tb);
+        if (!k0 || !k1 || !v0 || !v1 || !flags || !pos || !total || !temp) return PCR_OK;      // not enough scratch in this block: one by one
+        a.keys_raw = k0; a.vals_raw = v0; a.keys = k1; a.vals = v1; a.flags = flags; a.pos = pos; a.total = total;
+        temps[c] = temp; kin[c] = k0; kout[c] = k1; vin[c] = v0; vout[c] = v1;
+        PCR_TRY(scan_args(ctx, &sa[c], flags, nullptr, (int)ne[c], pos, total, FlagSrc{k1, nullptr, nullptr}));
+    }
+    const int nb = (int)((max_ne + BS - 1) / BS);
+    if (count == 1) {
+        PCR_LAUNCH(ctx, k_voxel_keys_multi, dim3(nb), dim3(BS), 0, ctx->stream, va[0]);
+        PCR_TRY(pcr_sort_pairs(ctx, temps[0], pcr_sort_temp_bytes(ne[0]), kin[0], kout[0], vin[0], vout[0], ne[0], end_bit));
+        PCR_TRY(flag_scan_batch(ctx, sa.data(), 1));
+        PCR_LAUNCH(ctx, k_voxel_mean_multi, dim3(nb), dim3(BS), 0, ctx->stream, va[0]);
+    } else {
+        const VoxArgs *dv = pcr_desc_upload(ctx, va.data(), count);
+        if (!dv) return PCR_ENOMEM;
+        PCR_LAUNCH(ctx, k_voxel_keys_multi_g, dim3(nb, count), dim3(BS), 0, ctx->stream, dv);
+        PCR_TRY(pcr_sort_pairs_batch(ctx, count, temps.data(), kin.data(), kout.data(), vin.data(), vout.data(), ne.data(), end_bit));
+        PCR_TRY(flag_scan_batch(ctx, sa.data(), count));
+        PCR_LAUNCH(ctx, k_voxel_mean_multi_g, dim3(nb, count), dim3(BS), 0, ctx->stream, dv);
+    }
     *done = true;
     return PCR_OK;
+}
+int pcr_dev_voxel_multi(pcr_context *ctx, const float *xyz, const float *nrm_in, int64_t n, const double *b6, const double *voxels, int n_scales, DevCloud *outs, bool *done) {
+    ArenaMark mark(ctx);
+    return voxel_multi_batch(ctx, 1, &xyz, nrm_in ? &nrm_in : nullptr, &n, b6, voxels, n_scales, outs, done);
+}
+// the clouds of a group of pairs: scratch stays allocated above the caller's mark until the caller releases it
+int pcr_dev_voxel_multi_batch(pcr_context *ctx, int count, const float *const *xyz, const float *const *nrm_in, const int64_t *n, const double *b6, const double *voxels,
+                              int n_scales, DevCloud *outs, bool *done) {
+    return voxel_multi_batch(ctx, count, xyz, nrm_in, n, b6, voxels, n_scales, outs, done);
 }
 
 // ===================================================== Morton ordering of a raw cloud (K2, part 1)
@@ -597,50 +718,43 @@ __device__ static inline void d_oct_upper_boxes(const OctMeta *__restrict__ meta
 
 // ---- the six build kernels serve up to OCT_BATCH trees per launch: blockIdx.y picks the tree (the voxel clouds of all scales
 // of a registration are built together: 6 launches instead of 6 per scale)
-#define OCT_BATCH 8
+#define OCT_BATCH PCR_MAX_BATCH
 struct OctBuildDesc {
     const uint64_t *keys; const int *n; signed char *ls; int *rows; OctMeta *meta; int *child; int *leaf_of;
     const float4 *pts; float4 *nodes; int4 *up; int4 *pinfo; OctGeom g; int n_tiles, node_cap;
 };
-struct OctBuildBatch { OctBuildDesc d[OCT_BATCH]; };
-__global__ void __launch_bounds__(BS) k_oct_lstar(OctBuildBatch b) {
-    const OctBuildDesc &d = b.d[blockIdx.y];
-    if ((int)blockIdx.x >= d.n_tiles) return;
-    d_oct_lstar(d.keys, d.n, d.ls, d.rows);
-}
-__global__ void __launch_bounds__(256) k_oct_meta(OctBuildBatch b) {
-    const OctBuildDesc &d = b.d[blockIdx.y];
-    d_oct_meta(d.n, d.rows, d.n_tiles, d.node_cap, d.meta, d.child, d.g);
-}
-__global__ void __launch_bounds__(BS) k_oct_apply(OctBuildBatch b) {
-    const OctBuildDesc &d = b.d[blockIdx.y];
-    if ((int)blockIdx.x >= d.n_tiles) return;
-    d_oct_apply(d.ls, d.meta, d.rows, d.child, d.leaf_of);
-}
-__global__ void __launch_bounds__(BS) k_oct_leaf_boxes(OctBuildBatch b) {
-    const OctBuildDesc &d = b.d[blockIdx.y];
-    d_oct_leaf_boxes(d.pts, d.meta, d.child, d.nodes, d.up, d.pinfo);
-}
-__global__ void __launch_bounds__(BS) k_oct_level_boxes(OctBuildBatch b, int li) {
-    const OctBuildDesc &d = b.d[blockIdx.y];
-    d_oct_level_boxes(d.meta, d.child, d.nodes, d.up, li, d.pinfo);
-}
-__global__ void __launch_bounds__(1024) k_oct_upper_boxes(OctBuildBatch b, int first_li) {
-    const OctBuildDesc &d = b.d[blockIdx.y];
-    d_oct_upper_boxes(d.meta, d.child, d.nodes, d.up, first_li);
-}
+struct OctBuildBatch { OctBuildDesc a[OCT_BATCH]; };
+__device__ static inline void dd_oct_lstar(const OctBuildDesc &d) { if ((int)blockIdx.x >= d.n_tiles) return; d_oct_lstar(d.keys, d.n, d.ls, d.rows); }
+__device__ static inline void dd_oct_meta(const OctBuildDesc &d) { d_oct_meta(d.n, d.rows, d.n_tiles, d.node_cap, d.meta, d.child, d.g); }
+__device__ static inline void dd_oct_apply(const OctBuildDesc &d) { if ((int)blockIdx.x >= d.n_tiles) return; d_oct_apply(d.ls, d.meta, d.rows, d.child, d.leaf_of); }
+__device__ static inline void dd_oct_leaf(const OctBuildDesc &d) { d_oct_leaf_boxes(d.pts, d.meta, d.child, d.nodes, d.up, d.pinfo); }
+__device__ static inline void dd_oct_level1(const OctBuildDesc &d) { d_oct_level_boxes(d.meta, d.child, d.nodes, d.up, 1, d.pinfo); }
+__device__ static inline void dd_oct_upper(const OctBuildDesc &d) { d_oct_upper_boxes(d.meta, d.child, d.nodes, d.up, 2); }
+__global__ void __launch_bounds__(BS) k_oct_lstar(OctBuildBatch b) { dd_oct_lstar(b.a[blockIdx.y]); }
+__global__ void __launch_bounds__(256) k_oct_meta(OctBuildBatch b) { dd_oct_meta(b.a[blockIdx.y]); }
+__global__ void __launch_bounds__(BS) k_oct_apply(OctBuildBatch b) { dd_oct_apply(b.a[blockIdx.y]); }
+__global__ void __launch_bounds__(BS) k_oct_leaf_boxes(OctBuildBatch b) { dd_oct_leaf(b.a[blockIdx.y]); }
+__global__ void __launch_bounds__(BS) k_oct_level_boxes(OctBuildBatch b) { dd_oct_level1(b.a[blockIdx.y]); }
+__global__ void __launch_bounds__(1024) k_oct_upper_boxes(OctBuildBatch b) { dd_oct_upper(b.a[blockIdx.y]); }
+__global__ void __launch_bounds__(BS) k_oct_lstar_p(const OctBuildDesc *a) { dd_oct_lstar(a[blockIdx.y]); }
+__global__ void __launch_bounds__(256) k_oct_meta_p(const OctBuildDesc *a) { dd_oct_meta(a[blockIdx.y]); }
+__global__ void __launch_bounds__(BS) k_oct_apply_p(const OctBuildDesc *a) { dd_oct_apply(a[blockIdx.y]); }
+__global__ void __launch_bounds__(BS) k_oct_leaf_boxes_p(const OctBuildDesc *a) { dd_oct_leaf(a[blockIdx.y]); }
+__global__ void __launch_bounds__(BS) k_oct_level_boxes_p(const OctBuildDesc *a) { dd_oct_level1(a[blockIdx.y]); }
+__global__ void __launch_bounds__(1024) k_oct_upper_boxes_p(const OctBuildDesc *a) { dd_oct_upper(a[blockIdx.y]); }
 
 int pcr_dev_build_bvh_batch(pcr_context *ctx, DevCloud *const *cs, int count) {
     if (count < 1) return PCR_OK;
-    if (count > OCT_BATCH) { ctx->err = "too many trees in one batch"; return PCR_EINVAL; }
+    if (count > PCR_MAX_GROUP_BATCH) { ctx->err = "too many trees in one batch"; return PCR_EINVAL; }
     ArenaMark mark(ctx);
-    OctBuildBatch b; std::memset(&b, 0, sizeof b);
+    std::vector<OctBuildDesc> b((size_t)count);
+    std::memset(b.data(), 0, sizeof(OctBuildDesc) * (size_t)count);
     static const int div = getenv("PCR_OCT_DIV") ? atoi(getenv("PCR_OCT_DIV")) : 6;
     int m = 0, max_tiles = 0, max_nbl = 0;
     for (int k = 0; k < count; k++) {
         DevCloud *c = cs[k];
         if (c->cap <= 0) continue;
-        OctBuildDesc &d = b.d[m++];
+        OctBuildDesc &d = b[m++];
         d.n_tiles = (c->cap + TILE - 1) / TILE; d.node_cap = (int)oct_node_capacity(c->cap);
         d.ls = arena<signed char>(ctx, c->cap); d.rows = arena<int>(ctx, (size_t)d.n_tiles * OCT_ROW);
         if (!d.ls || !d.rows) return PCR_ENOMEM;
@@ -653,13 +767,13 @@ int pcr_dev_build_bvh_batch(pcr_context *ctx, DevCloud *const *cs, int count) {
         if (nbl > max_nbl) max_nbl = nbl;
     }
     if (m == 0) return PCR_OK;
-    PCR_LAUNCH(ctx, k_oct_lstar, dim3(max_tiles, m), dim3(BS), 0, ctx->stream, b);
-    PCR_LAUNCH(ctx, k_oct_meta, dim3(1, m), dim3(256), 0, ctx->stream, b);
-    PCR_LAUNCH(ctx, k_oct_apply, dim3(max_tiles, m), dim3(BS), 0, ctx->stream, b);
-    PCR_LAUNCH(ctx, k_oct_leaf_boxes, dim3(max_nbl, m), dim3(BS), 0, ctx->stream, b);
-    PCR_LAUNCH(ctx, k_oct_level_boxes, dim3(max_nbl, m), dim3(BS), 0, ctx->stream, b, 1);
+    PCR_TRY(PCR_BATCH_LAUNCH(ctx, OctBuildBatch, k_oct_lstar, k_oct_lstar_p, b.data(), m, dim3(max_tiles, m), dim3(BS)));
+    PCR_TRY(PCR_BATCH_LAUNCH(ctx, OctBuildBatch, k_oct_meta, k_oct_meta_p, b.data(), m, dim3(1, m), dim3(256)));
+    PCR_TRY(PCR_BATCH_LAUNCH(ctx, OctBuildBatch, k_oct_apply, k_oct_apply_p, b.data(), m, dim3(max_tiles, m), dim3(BS)));
+    PCR_TRY(PCR_BATCH_LAUNCH(ctx, OctBuildBatch, k_oct_leaf_boxes, k_oct_leaf_boxes_p, b.data(), m, dim3(max_nbl, m), dim3(BS)));
+    PCR_TRY(PCR_BATCH_LAUNCH(ctx, OctBuildBatch, k_oct_level_boxes, k_oct_level_boxes_p, b.data(), m, dim3(max_nbl, m), dim3(BS)));
     // levels >= 2 (n/64 nodes and fewer) in ONE workgroup per tree, level by level: a launch less than one grid per level
-    PCR_LAUNCH(ctx, k_oct_upper_boxes, dim3(1, m), dim3(1024), 0, ctx->stream, b, 2);
+    PCR_TRY(PCR_BATCH_LAUNCH(ctx, OctBuildBatch, k_oct_upper_boxes, k_oct_upper_boxes_p, b.data(), m, dim3(1, m), dim3(1024)));
     return PCR_OK;
 }
 int pcr_dev_build_bvh(pcr_context *ctx, DevCloud *c) { return pcr_dev_build_bvh_batch(ctx, &c, 1); }
@@ -988,19 +1102,19 @@ __device__ static inline void d_knn(const KnnArgs &a) {
 
 template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) { d_knn<MODE, SLOTS>(a); }
 template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn_batch(KnnBatch b) { d_knn<MODE, SLOTS>(b.a[blockIdx.y]); }
+template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn_batchp(const KnnArgs *a) { d_knn<MODE, SLOTS>(a[blockIdx.y]); }
 
 // `count` searches in ONE launch (blockIdx.y picks the problem; k <= 32): the SOR / normals searches of all scales of a cloud
 template <int MODE>
-static int launch_knn_batch(pcr_context *ctx, KnnBatch &b, const int *caps, int count) {
+static int launch_knn_batch(pcr_context *ctx, KnnArgs *a, const int *caps, int count) {
     int mc = 0;
     for (int k = 0; k < count; k++) {
-        if (b.a[k].k < 1 || b.a[k].k > 32) { ctx->err = "batched k-NN: k must be in 1..32"; return PCR_EINVAL; }
-        { static const int ss = getenv("PCR_KNN_SEED") ? atoi(getenv("PCR_KNN_SEED")) : -1; b.a[k].seed_span = ss; }
+        if (a[k].k < 1 || a[k].k > 32) { ctx->err = "batched k-NN: k must be in 1..32"; return PCR_EINVAL; }
+        { static const int ss = getenv("PCR_KNN_SEED") ? atoi(getenv("PCR_KNN_SEED")) : -1; a[k].seed_span = ss; }
         mc = caps[k] > mc ? caps[k] : mc;
     }
     if (mc <= 0) return PCR_OK;
-    PCR_LAUNCH(ctx, k_knn_batch<MODE, 4>, dim3((unsigned)(((size_t)mc * OCT + KNN_BS - 1) / KNN_BS), count), dim3(KNN_BS), 0, ctx->stream, b);
-    return PCR_OK;
+    return PCR_BATCH_LAUNCH(ctx, KnnBatch, (k_knn_batch<MODE, 4>), (k_knn_batchp<MODE, 4>), a, count, dim3((unsigned)(((size_t)mc * OCT + KNN_BS - 1) / KNN_BS), count), dim3(KNN_BS));
 }
 
 template <int MODE>
@@ -1208,6 +1322,7 @@ __device__ static inline void d_normals_from_lists(const NflArgs &a) {
 
 __global__ void __launch_bounds__(KNN_BS) k_normals_from_lists(NflArgs a) { d_normals_from_lists(a); }
 __global__ void __launch_bounds__(KNN_BS) k_normals_from_lists_batch(NflBatch b) { d_normals_from_lists(b.a[blockIdx.y]); }
+__global__ void __launch_bounds__(KNN_BS) k_normals_from_lists_batchp(const NflArgs *a) { d_normals_from_lists(a[blockIdx.y]); }
 
 // ============================================================================ SOR (K4)
 // mean / Bessel std of the per-point mean neighbour distance in ONE pass over <= 128 workgroups: shifted moments
@@ -1260,6 +1375,7 @@ __device__ static inline void d_sor_stats(const SorStatArgs &aa) {
 }
 __global__ void __launch_bounds__(256) k_sor_stats(SorStatArgs a) { d_sor_stats(a); }
 __global__ void __launch_bounds__(256) k_sor_stats_batch(SorStatBatch b) { d_sor_stats(b.a[blockIdx.y]); }
+__global__ void __launch_bounds__(256) k_sor_stats_batchp(const SorStatArgs *a) { d_sor_stats(a[blockIdx.y]); }
 
 struct CompactArgs {
     const float4 *pts, *nrm; const uint8_t *flags; const int *pos; const int *n_ptr; float4 *out_pts, *out_nrm;
@@ -1277,6 +1393,7 @@ __device__ static inline void d_compact_cloud(const CompactArgs &a) {
 }
 __global__ void __launch_bounds__(BS) k_compact_cloud(CompactArgs a) { d_compact_cloud(a); }
 __global__ void __launch_bounds__(BS) k_compact_cloud_batch(CompactBatch b) { d_compact_cloud(b.a[blockIdx.y]); }
+__global__ void __launch_bounds__(BS) k_compact_cloud_batchp(const CompactArgs *a) { d_compact_cloud(a[blockIdx.y]); }
 
 // The SOR chain of `count` clouds in ONE launch per stage (blockIdx.y picks the cloud): k-NN + k-best lists, statistics, keep flags
 // inside the two-kernel scan, compaction, normals of the cleaned cloud from the lists, exact fallback search for the incomplete lists.
@@ -1288,9 +1405,15 @@ struct SorProblem {
 };
 static int sor_batch(pcr_context *ctx, SorProblem *pr, int count, int nb_neighbors, double std_ratio, int normal_k, bool fallback_here) {
     if (nb_neighbors < 1 || !(std_ratio > 0.0)) { ctx->err = "nb_neighbors < 1 or std_ratio <= 0"; return PCR_EINVAL; }
-    if (count < 1 || count > PCR_MAX_BATCH) { ctx->err = "SOR batch size"; return PCR_EINVAL; }
-    KnnBatch kb{}, fb{}; SorStatBatch sb{}; ScanBatch cb{}; CompactBatch mb{}; NflBatch nb_{};
-    int caps[PCR_MAX_BATCH], m = 0;
+    if (count < 1 || count > PCR_MAX_GROUP_BATCH) { ctx->err = "SOR batch size"; return PCR_EINVAL; }
+    std::vector<KnnArgs> kbv((size_t)count), fbv((size_t)count); std::vector<SorStatArgs> sbv((size_t)count); std::vector<ScanArgs> cbv((size_t)count);
+    std::vector<CompactArgs> mbv((size_t)count); std::vector<NflArgs> nbv((size_t)count);
+    std::memset(kbv.data(), 0, sizeof(KnnArgs) * (size_t)count); std::memset(fbv.data(), 0, sizeof(KnnArgs) * (size_t)count);
+    std::memset(sbv.data(), 0, sizeof(SorStatArgs) * (size_t)count); std::memset(cbv.data(), 0, sizeof(ScanArgs) * (size_t)count);
+    std::memset(mbv.data(), 0, sizeof(CompactArgs) * (size_t)count); std::memset(nbv.data(), 0, sizeof(NflArgs) * (size_t)count);
+    struct { KnnArgs *a; } kb{kbv.data()}, fb{fbv.data()}; struct { SorStatArgs *a; } sb{sbv.data()}; struct { ScanArgs *a; } cb{cbv.data()};
+    struct { CompactArgs *a; } mb{mbv.data()}; struct { NflArgs *a; } nb_{nbv.data()};
+    std::vector<int> capsv((size_t)count); int *caps = capsv.data(); int m = 0;
     bool any_todo = false, fuse_all = true;
     for (int k = 0; k < count; k++) {
         SorProblem &q = pr[k];
@@ -1347,16 +1470,16 @@ static int sor_batch(pcr_context *ctx, SorProblem *pr, int count, int nb_neighbo
         PCR_TRY(launch_knn<KNN_MODE_SOR>(ctx, &tmp, kb.a[0]));
     } else {
         if (nb_neighbors > 32) { ctx->err = "batched SOR: nb_neighbors must be <= 32"; return PCR_EINVAL; }
-        PCR_TRY(launch_knn_batch<KNN_MODE_SOR>(ctx, kb, caps, m));
+        PCR_TRY(launch_knn_batch<KNN_MODE_SOR>(ctx, kb.a, caps, m));
     }
-    PCR_LAUNCH(ctx, k_sor_stats_batch, dim3(SOR_STAT_BLOCKS, m), dim3(256), 0, ctx->stream, sb);
-    PCR_TRY(flag_scan_batch(ctx, cb, m));
-    PCR_LAUNCH(ctx, k_compact_cloud_batch, dim3((mc + BS - 1) / BS, m), dim3(BS), 0, ctx->stream, mb);
+    PCR_TRY(PCR_BATCH_LAUNCH(ctx, SorStatBatch, k_sor_stats_batch, k_sor_stats_batchp, sb.a, m, dim3(SOR_STAT_BLOCKS, m), dim3(256)));
+    PCR_TRY(flag_scan_batch(ctx, cb.a, m));
+    PCR_TRY(PCR_BATCH_LAUNCH(ctx, CompactBatch, k_compact_cloud_batch, k_compact_cloud_batchp, mb.a, m, dim3((mc + BS - 1) / BS, m), dim3(BS)));
     if (any_todo) {
-        if (fuse_all) PCR_LAUNCH(ctx, k_normals_from_lists_batch, dim3((unsigned)(((size_t)mc + KNN_BS - 1) / KNN_BS), m), dim3(KNN_BS), 0, ctx->stream, nb_);
+        if (fuse_all) PCR_TRY(PCR_BATCH_LAUNCH(ctx, NflBatch, k_normals_from_lists_batch, k_normals_from_lists_batchp, nb_.a, m, dim3((unsigned)(((size_t)mc + KNN_BS - 1) / KNN_BS), m), dim3(KNN_BS)));
         else for (int k = 0; k < m; k++) if (nb_.a[k].pts) PCR_LAUNCH(ctx, k_normals_from_lists, dim3((unsigned)(((size_t)caps[k] + KNN_BS - 1) / KNN_BS)), dim3(KNN_BS), 0, ctx->stream, nb_.a[k]);
         if (fallback_here && normal_k > 0) {
-            if (normal_k <= 32) PCR_TRY(launch_knn_batch<KNN_MODE_NORMALS>(ctx, fb, caps, m));
+            if (normal_k <= 32) PCR_TRY(launch_knn_batch<KNN_MODE_NORMALS>(ctx, fb.a, caps, m));
             else for (int k = 0; k < m; k++) { DevCloud tmp; tmp.cap = caps[k]; PCR_TRY(launch_knn<KNN_MODE_NORMALS>(ctx, &tmp, fb.a[k])); }
         }
     }
@@ -1372,16 +1495,17 @@ int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double s
 // the SOR chains of `count` clouds (the voxel clouds of all scales) in one set of launches; scratch above the caller's mark
 int pcr_dev_sor_batch(pcr_context *ctx, const DevCloud *const *ins, DevCloud *const *outs, int count, int nb_neighbors, double std_ratio, int normal_k,
                       const float4 *const *priors, uint8_t *const *todos, int *const *todo_counts, int *const *cnt_in, int *const *cnt_kept, bool fallback_here) {
-    SorProblem p[PCR_MAX_BATCH];
-    if (count > PCR_MAX_BATCH) { ctx->err = "SOR batch size"; return PCR_EINVAL; }
+    if (count > PCR_MAX_GROUP_BATCH) { ctx->err = "SOR batch size"; return PCR_EINVAL; }
+    std::vector<SorProblem> pv((size_t)(count > 0 ? count : 1)); SorProblem *p = pv.data();
     for (int k = 0; k < count; k++) p[k] = SorProblem{ins[k], outs[k], nullptr, nullptr, priors ? priors[k] : nullptr, todos[k], todo_counts[k], cnt_in ? cnt_in[k] : nullptr, cnt_kept ? cnt_kept[k] : nullptr};
     return sor_batch(ctx, p, count, nb_neighbors, std_ratio, normal_k, fallback_here);
 }
 // k-NN normals of `count` clouds over their own trees in one launch (todo masks optional): the incomplete lists of the cleaned targets
 int pcr_dev_normals_knn_batch(pcr_context *ctx, DevCloud *const *cs, int count, int knn, const float4 *const *priors, float4 *const *normals_out, const uint8_t *const *todos) {
     if (knn < 1) { ctx->err = "knn < 1"; return PCR_EINVAL; }
-    if (count > PCR_MAX_BATCH) { ctx->err = "normals batch size"; return PCR_EINVAL; }
-    KnnBatch b{}; int caps[PCR_MAX_BATCH], m = 0;
+    if (count > PCR_MAX_GROUP_BATCH) { ctx->err = "normals batch size"; return PCR_EINVAL; }
+    std::vector<KnnArgs> bv((size_t)(count > 0 ? count : 1)); std::memset(bv.data(), 0, sizeof(KnnArgs) * bv.size());
+    struct { KnnArgs *a; } b{bv.data()}; std::vector<int> capsv((size_t)(count > 0 ? count : 1)); int *caps = capsv.data(); int m = 0;
     for (int k = 0; k < count; k++) {
         if (cs[k]->cap <= 0) continue;
         KnnArgs &a = b.a[m];
@@ -1390,7 +1514,7 @@ int pcr_dev_normals_knn_batch(pcr_context *ctx, DevCloud *const *cs, int count, 
         caps[m++] = cs[k]->cap;
     }
     if (m == 0) return PCR_OK;
-    if (knn <= 32) return launch_knn_batch<KNN_MODE_NORMALS>(ctx, b, caps, m);
+    if (knn <= 32) return launch_knn_batch<KNN_MODE_NORMALS>(ctx, b.a, caps, m);
     for (int k = 0; k < m; k++) { DevCloud tmp; tmp.cap = caps[k]; PCR_TRY(launch_knn<KNN_MODE_NORMALS>(ctx, &tmp, b.a[k])); }
     return PCR_OK;
 }
@@ -1419,3 +1543,4 @@ size_t pcr_scratch_bytes_for(int64_t n) {
     // voxel/sort temporaries (2x u64 keys, 2x u32 vals, flags, pos, sort temp) + clouds + boxes, with slack
     return (size_t)(n > 0 ? n : 1) * 320 + pcr_sort_temp_bytes((size_t)(n > 0 ? n : 1)) + (4u << 20);
 }
+

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <vector>
 #include "pcr_octree.h"
 
 #define ICP_BS 256
@@ -57,13 +58,16 @@ struct IcpArgs {
 #define ICP_STAMP_LAUNCHES 16
 
 struct IcpInit { double T[16]; };
-__global__ void k_icp_init(IcpState *st, IcpInit in) {
+__device__ static inline void d_icp_init(IcpState *st, const IcpInit &in) {
     if (threadIdx.x == 0) {
         for (int k = 0; k < 16; k++) st->T[k] = in.T[k];
         st->fitness = 0; st->rmse = 0; st->count = 0; st->iter = 0; st->launches = 0; st->done = 0; st->converged = 0; st->ticket = 0; st->ns = 0; st->t_start = 0; st->t_live = 0; for (int k = 0; k < 4; k++) st->t_dbg[k] = 0;
         for (int k = 0; k < NVP; k++) st->sums[k] = 0;
     }
 }
+__global__ void k_icp_init(IcpState *st, IcpInit in) { d_icp_init(st, in); }
+// group form: state g of a lockstep group starts from pose g (poses in device memory)
+__global__ void k_icp_init_g(IcpState *st, const IcpInit *in) { d_icp_init(st + blockIdx.x, in[blockIdx.x]); }
 
 // ---- exact 1-NN of one query per octet over the target's linear octree.  Called by all 64 lanes of a wavefront;
 // `live` is octet-uniform.  hint >= 0: a target point near the answer (previous match, or the previous start point of
@@ -259,7 +263,7 @@ __device__ static bool icp_ldlt6_pivoted(const double *S, const double *b6, doub
 
 // ---- kernel 1 of an iteration: exact 1-NN of every transformed source point, ONE query per octet (32 per
 // workgroup).  Latency-bound pointer chasing, so it runs at full occupancy (few registers, many wavefronts).
-__global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_icp_nn(IcpArgs a) {
+__device__ static inline void d_icp_nn(const IcpArgs &a) {
     IcpState *st = a.state;
     constexpr int OPB = ICP_BS / OCT;
     __shared__ OctMeta m;
@@ -348,6 +352,10 @@ __global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 
         w[0] = t_wave0; w[1] = wall_clock64();
     }
 }
+
+__global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_icp_nn(IcpArgs a) { d_icp_nn(a); }
+// group form (lockstep group of pairs, blockIdx.y = pair; arguments in device memory)
+__global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_icp_nn_g(const IcpArgs *a) { d_icp_nn(a[blockIdx.y]); }
 
 // ---- one correspondence in float64: accumulates its 30 sums into acc[]; `cand` = candidate target point (or < 0)
 template <int MODE>
@@ -592,7 +600,7 @@ __device__ static inline void icp_finish(const IcpArgs &a, IcpState *st, const d
 // ---- kernel 2 of an iteration: one correspondence per lane in float64 -> wave/LDS reduction -> last workgroup
 // finishes the iteration (sum partials, convergence test, 6x6 solve, pose update).
 template <int MODE>
-__global__ void __launch_bounds__(LIN_BS) k_icp_iter(IcpArgs a) {
+__device__ static inline void d_icp_iter(const IcpArgs &a) {
     IcpState *st = a.state;
     if (st->done) return;
     const int ns = *a.ns_ptr;
@@ -611,6 +619,8 @@ __global__ void __launch_bounds__(LIN_BS) k_icp_iter(IcpArgs a) {
     for (int i = blockIdx.x * LIN_BS + threadIdx.x; i < ns; i += nb * LIN_BS) icp_point<MODE>(a, T, i, ns, a.match[i], acc);
     icp_finish<MODE, LIN_BS>(a, st, T, acc, nb, ns, launches, t_entry);
 }
+template <int MODE> __global__ void __launch_bounds__(LIN_BS) k_icp_iter(IcpArgs a) { d_icp_iter<MODE>(a); }
+template <int MODE> __global__ void __launch_bounds__(LIN_BS) k_icp_iter_g(const IcpArgs *a) { d_icp_iter<MODE>(a[blockIdx.y]); }
 
 // ---- ONE kernel per iteration (launches after the first of a scale): workgroup b owns source points [512 b, 512 b + 512):
 // certificates per lane -> its pending queries compacted into LDS -> the workgroup's 64 octets search them -> barrier ->
@@ -625,7 +635,7 @@ __global__ void __launch_bounds__(LIN_BS) k_icp_iter(IcpArgs a) {
 // pairs/s for PPL 1 / 2 / 4, 8 in flight 314 / 334 / 313, one pair alone 178 / 158 / 125 -- the wavefront slots are not what bounds the
 // pairs in flight ("what bounds the throughput"), and alone the longer lanes cost what they cost.  Kept as a switch.
 template <int PPL>
-__global__ void __launch_bounds__(FUSED_BS) k_icp_fused(IcpArgs a) {
+__device__ static inline void d_icp_fused(const IcpArgs &a) {
     IcpState *st = a.state;
     constexpr int OPB = FUSED_BS / OCT;
     constexpr int TILE_PTS = FUSED_BS * PPL;
@@ -724,6 +734,8 @@ __global__ void __launch_bounds__(FUSED_BS) k_icp_fused(IcpArgs a) {
     }
     icp_finish<ICP_MODE_GICP, FUSED_BS>(a, st, T, acc, nb, ns, launches, t_entry);
 }
+template <int PPL> __global__ void __launch_bounds__(FUSED_BS) k_icp_fused(IcpArgs a) { d_icp_fused<PPL>(a); }
+template <int PPL> __global__ void __launch_bounds__(FUSED_BS) k_icp_fused_g(const IcpArgs *a) { d_icp_fused<PPL>(a[blockIdx.y]); }
 
 static void fill_args(IcpArgs &a, const DevCloud *src, const DevCloud *tgt, double max_dist, const pcr_gicp_params *p,
                       int32_t *match, IcpState *st, double *partials, int single) {
@@ -901,6 +913,154 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     }
     state_to_result(fin, out);
     for (int k = 0; k < 16; k++) if (!std::isfinite(fin.T[k])) { ctx->err = "non-finite pose"; return PCR_ENUMERIC; }
+    return PCR_OK;
+}
+
+// ---- the GICP loops of a GROUP of pairs in lockstep: every launch serves all G problems (blockIdx.y = pair; argument structs and
+// states in device memory), a problem that has converged returns at its first instruction, the group ends when all have.  One chain of
+// dependent kernels per GROUP instead of one per pair: the kernels are G times fatter, the device retires small dependent kernels at
+// a fixed rate whatever feeds it, and the replayed graph reads its arguments from a fixed device buffer, so it
+// is captured once per (G, grid) and never again.  Per-problem arithmetic, tiles and summation order are those of pcr_dev_gicp:
+// the results are bit-identical to registering the pairs one by one.
+int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, const DevCloud *const *tgt, const double *max_dists, const double *T0,
+                       const pcr_gicp_params *p, pcr_result *out, int32_t *const *match_dev) {
+    for (int g = 0; g < G; g++) if (!(max_dists[g] > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
+    if (G < 1 || G > 32) { ctx->err = "GICP group size must be in 1..32"; return PCR_EINVAL; }
+    for (int g = 0; g < G; g++) if (!src[g]->nrm || !tgt[g]->nrm) { ctx->err = "GICP needs normals on both clouds"; return PCR_EINVAL; }
+    ArenaMark mark(ctx);
+    // two source points per lane in lockstep groups (G x the workgroups per launch: half of them leave more of the chip to the other
+    // groups in flight: 200k points, groups of 2, 4 groups in flight 367 -> 408 pairs/s); PCR_ICP_PPL overrides
+    static const int ppl = getenv("PCR_ICP_PPL") ? atoi(getenv("PCR_ICP_PPL")) : (G > 1 ? 2 : 1);
+    const int tile_pts = FUSED_BS * (ppl >= 4 ? 4 : (ppl >= 2 ? 2 : 1));
+    int nbmax = 1, nbnn = 1, nbf = 1;
+    std::vector<IcpArgs> args((size_t)G); std::vector<IcpInit> inits((size_t)G);
+    IcpState *st = arena<IcpState>(ctx, G);
+    if (!st) return PCR_ENOMEM;
+    static const double gfrac = getenv("PCR_ICP_GAP") ? atof(getenv("PCR_ICP_GAP")) : 0.25;
+    for (int g = 0; g < G; g++) {
+        const int cap = src[g]->cap > 0 ? src[g]->cap : 1;
+        const int m_ = (cap + LIN_BS - 1) / LIN_BS < LIN_MAX_BLOCKS ? (cap + LIN_BS - 1) / LIN_BS : LIN_MAX_BLOCKS;
+        const int n_ = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT), f_ = (cap + tile_pts - 1) / tile_pts;
+        nbmax = m_ > nbmax ? m_ : nbmax; nbnn = n_ > nbnn ? n_ : nbnn; nbf = f_ > nbf ? f_ : nbf;
+        double *partials = arena<double>(ctx, (size_t)(m_ > f_ ? m_ : f_) * NVP);
+        int32_t *match = (match_dev && match_dev[g]) ? match_dev[g] : arena<int32_t>(ctx, cap);
+        if (!partials || !match) return PCR_ENOMEM;
+        IcpArgs &a = args[g]; memset(&a, 0, sizeof a);
+        const double max_dist = max_dists[g];
+        fill_args(a, src[g], tgt[g], max_dist, p, match, st + g, partials, 0);
+        a.ref = arena<float4>(ctx, cap); a.rbest = arena<int32_t>(ctx, cap);
+        if (!a.ref || !a.rbest) return PCR_ENOMEM;
+        double gg = gfrac * max_dist; gg = gg < 0.01 ? 0.01 : (gg > 0.05 ? 0.05 : gg);
+        const double rs = max_dist + gg;
+        a.r2s = (float)(rs * rs * (1.0 + 1e-6)); a.rs_minus_r = (float)gg;
+        memcpy(inits[g].T, T0 + 16 * g, sizeof inits[g].T);
+    }
+    if (nbf > 4096) { ctx->err = "GICP group: cloud too large for the fused iteration kernel"; return PCR_EINVAL; }
+    // arguments and start poses live in a per-context device buffer at a FIXED address (the captured graph reads them there)
+    const size_t args_bytes = sizeof(IcpArgs) * 32 + sizeof(IcpInit) * 32;
+    if (!ctx->icp_group_dev) {
+        if (hipMalloc((void **)&ctx->icp_group_dev, args_bytes) != hipSuccess || hipHostMalloc((void **)&ctx->icp_group_host, args_bytes, hipHostMallocDefault) != hipSuccess) {
+            ctx->err = "GICP group: argument buffers"; return PCR_ENOMEM;
+        }
+    }
+    memcpy(ctx->icp_group_host, args.data(), sizeof(IcpArgs) * (size_t)G);
+    memcpy(ctx->icp_group_host + sizeof(IcpArgs) * 32, inits.data(), sizeof(IcpInit) * (size_t)G);
+    PCR_HIP_CHECK(ctx, hipMemcpyAsync(ctx->icp_group_dev, ctx->icp_group_host, args_bytes, hipMemcpyHostToDevice, ctx->stream));
+    const IcpArgs *dargs = (const IcpArgs *)ctx->icp_group_dev;
+    const IcpInit *dinit = (const IcpInit *)(ctx->icp_group_dev + sizeof(IcpArgs) * 32);
+    PCR_LAUNCH(ctx, k_icp_init_g, dim3(G), dim3(64), 0, ctx->stream, st, dinit);
+    static const int chunk_env = getenv("PCR_ICP_CHUNK") ? atoi(getenv("PCR_ICP_CHUNK")) : 8;
+    const int max_it = p ? p->max_iteration : 30;
+    const int total = max_it + 1, CHUNK = chunk_env < 1 ? 1 : (chunk_env > 32 ? 32 : chunk_env);
+    static const bool use_graph = !(getenv("PCR_ICP_GRAPH") && atoi(getenv("PCR_ICP_GRAPH")) == 0);
+    auto enqueue = [&](int launch_index) {
+        if (launch_index > 0) {
+            if (tile_pts == FUSED_BS * 4) PCR_LAUNCH(ctx, k_icp_fused_g<4>, dim3(nbf, G), dim3(FUSED_BS), 0, ctx->stream, dargs);
+            else if (tile_pts == FUSED_BS * 2) PCR_LAUNCH(ctx, k_icp_fused_g<2>, dim3(nbf, G), dim3(FUSED_BS), 0, ctx->stream, dargs);
+            else PCR_LAUNCH(ctx, k_icp_fused_g<1>, dim3(nbf, G), dim3(FUSED_BS), 0, ctx->stream, dargs);
+            return;
+        }
+        PCR_LAUNCH(ctx, k_icp_nn_g, dim3(nbnn, G), dim3(ICP_BS), 0, ctx->stream, dargs);
+        PCR_LAUNCH(ctx, k_icp_iter_g<ICP_MODE_GICP>, dim3(nbmax, G), dim3(LIN_BS), 0, ctx->stream, dargs);
+    };
+    hipGraphExec_t chunk_exec[2] = {nullptr, nullptr};
+    if (use_graph) {
+        for (int which = 0; which < 2; which++) {
+            const long long kv[8] = {0x47525550ll /* "GRUP" */, G, nbnn, nbmax, nbf, tile_pts, CHUNK, which};
+            std::string key((const char *)kv, sizeof kv);
+            key.append((const char *)&dargs, sizeof dargs);
+            for (auto &gr : ctx->icp_graphs) if (gr.first == key) { chunk_exec[which] = gr.second; break; }
+            if (!chunk_exec[which]) {
+                hipGraph_t graph = nullptr;
+                PCR_HIP_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+                for (int k = 0; k < CHUNK; k++) enqueue(which == 0 ? k : CHUNK + k);
+                PCR_HIP_CHECK(ctx, hipStreamEndCapture(ctx->stream, &graph));
+                PCR_HIP_CHECK(ctx, hipGraphInstantiate(&chunk_exec[which], graph, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(graph);
+                if (ctx->icp_graphs.size() >= 32) {
+                    size_t victim = 0;
+                    while (victim < ctx->icp_graphs.size() && ctx->icp_graphs[victim].second == chunk_exec[0]) victim++;
+                    if (victim < ctx->icp_graphs.size()) { (void)hipGraphExecDestroy(ctx->icp_graphs[victim].second); ctx->icp_graphs.erase(ctx->icp_graphs.begin() + victim); }
+                }
+                ctx->icp_graphs.emplace_back(std::move(key), chunk_exec[which]);
+            }
+        }
+    }
+    // two read-back slots of G states each in the pinned window
+    const size_t slot_bytes = sizeof(IcpState) * (size_t)G;
+    if (2 * slot_bytes > ctx->pinned_cap) { ctx->err = "GICP group: pinned window too small"; return PCR_ENOMEM; }
+    IcpState *slots[2] = {(IcpState *)ctx->pinned, (IcpState *)(ctx->pinned + slot_bytes)};
+    int launched = 0, cur = 0, prev = -1, n_chunks = 0;
+    std::vector<IcpState> fin((size_t)G); bool have = false;
+    for (;;) {
+        const bool enq = launched < total;
+        if (enq) {
+            const int c = total - launched < CHUNK ? total - launched : CHUNK;
+            if (ctx->profiling) {
+                while ((int)ctx->prof_events.size() < 2 * (n_chunks + 1)) { hipEvent_t e; PCR_HIP_CHECK(ctx, hipEventCreate(&e)); ctx->prof_events.push_back(e); }
+                PCR_HIP_CHECK(ctx, hipEventRecord(ctx->prof_events[2 * n_chunks], ctx->stream));
+            }
+            hipGraphExec_t ge = chunk_exec[launched == 0 ? 0 : 1];
+            if (ge && c == CHUNK) PCR_HIP_CHECK(ctx, hipGraphLaunch(ge, ctx->stream));
+            else for (int k = 0; k < c; k++) enqueue(launched + k);
+            if (ctx->profiling) PCR_HIP_CHECK(ctx, hipEventRecord(ctx->prof_events[2 * n_chunks + 1], ctx->stream));
+            n_chunks++;
+            launched += c;
+            PCR_HIP_CHECK(ctx, hipMemcpyAsync(slots[cur], st, slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
+            PCR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[cur], ctx->stream));
+        }
+        if (prev >= 0) {
+            PCR_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev[prev]));
+            bool all = true;
+            for (int g = 0; g < G; g++) all = all && slots[prev][g].done;
+            if (all) { memcpy(fin.data(), slots[prev], slot_bytes); have = true; break; }
+        }
+        if (!enq) break;
+        prev = cur; cur ^= 1;
+    }
+    if (!have) { ctx->err = "GICP group loop ended without a final state"; return PCR_EHIP; }
+    PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));      // drain the no-op tail: pinned slots, argument buffer and arena are reused
+    if (ctx->profiling) {
+        int longest = 0;
+        for (int g = 0; g < G; g++) longest = fin[g].launches > longest ? fin[g].launches : longest;
+        for (int c = 0; c < n_chunks; c++) {
+            const int first = c * CHUNK, last = first + CHUNK < total ? first + CHUNK : total;
+            if (last <= longest) {
+                float ms = 0;
+                PCR_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->prof_events[2 * c], ctx->prof_events[2 * c + 1]));
+                ctx->prof[0] += ms; ctx->prof[1] += last - first;
+            }
+        }
+        for (int g = 0; g < G; g++) {
+            ctx->prof[2] += (double)fin[g].t_live * 0.01; ctx->prof[3] += fin[g].launches;
+            ctx->prof[4] += 48.0 * (double)fin[g].ns * (double)fin[g].launches;
+        }
+        ctx->prof[5] += launched;
+    }
+    for (int g = 0; g < G; g++) {
+        state_to_result(fin[g], &out[g]);
+        for (int k = 0; k < 16; k++) if (!std::isfinite(fin[g].T[k])) { ctx->err = "non-finite pose"; return PCR_ENUMERIC; }
+    }
     return PCR_OK;
 }
 

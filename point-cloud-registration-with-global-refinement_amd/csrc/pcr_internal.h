@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <cstring>
 #include <vector>
 #include "../../include/pcr_hip.h"
 
@@ -19,6 +20,9 @@ struct pcr_context {
     size_t arena_cap = 0, arena_off = 0;
     char *aux = nullptr;           // side buffer that outlives the arena within one pair of a plan (normals left by registro_FGR)
     size_t aux_cap = 0;
+    char *desc_host = nullptr, *desc_dev = nullptr;   // argument structs of large batches: pinned staging ring and its device image
+    size_t desc_cap = 0, desc_off = 0;
+    char *icp_group_dev = nullptr, *icp_group_host = nullptr;     // argument structs + start poses of a lockstep GICP group (fixed address: graphs read it)
     char *pinned = nullptr;        // host-pinned read-back window
     size_t pinned_cap = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -72,6 +76,32 @@ static inline void pcr_launch(pcr_context *ctx, const char *file, int line, void
         if (_rc != PCR_OK) return _rc;                                                             \
     } while (0)
 
+// ---- descriptor buffer: argument structs of batches too large for the kernel arguments.  A ring in pinned host memory is the
+// staging area of small asynchronous copies into a device ring of the same layout; when the ring wraps, the streams that may still
+// be copying from it are drained first.
+template <class A> static inline const A *pcr_desc_upload(pcr_context *ctx, const A *host, int count) {
+    const size_t bytes = (sizeof(A) * (size_t)count + 255) & ~(size_t)255;
+    if (!ctx->desc_host) {
+        ctx->desc_cap = 8u << 20;
+        if (hipHostMalloc((void **)&ctx->desc_host, ctx->desc_cap, hipHostMallocDefault) != hipSuccess) { ctx->desc_host = nullptr; ctx->err = "hipHostMalloc(descriptors)"; return nullptr; }
+        if (hipMalloc((void **)&ctx->desc_dev, ctx->desc_cap) != hipSuccess) { ctx->desc_dev = nullptr; ctx->err = "hipMalloc(descriptors)"; return nullptr; }
+        ctx->desc_off = 0;
+    }
+    if (bytes > ctx->desc_cap) { ctx->err = "descriptor batch too large"; return nullptr; }
+    if (ctx->desc_off + bytes > ctx->desc_cap) {
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
+        if (ctx->side_stream2) (void)hipStreamSynchronize(ctx->side_stream2);
+        if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+        ctx->desc_off = 0;
+    }
+    char *h = ctx->desc_host + ctx->desc_off, *d = ctx->desc_dev + ctx->desc_off;
+    memcpy(h, host, sizeof(A) * (size_t)count);
+    if (hipMemcpyAsync(d, h, sizeof(A) * (size_t)count, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "descriptor upload failed"; return nullptr; }
+    ctx->desc_off += bytes;
+    return (const A *)d;
+}
+
 // ---- arena ------------------------------------------------------------------------------------
 int pcr_arena_reserve(pcr_context *ctx, size_t bytes);       // grow (sync + realloc) if needed, reset offset
 void *pcr_arena_alloc(pcr_context *ctx, size_t bytes);       // bump, 256-B aligned; nullptr if exhausted
@@ -115,6 +145,9 @@ size_t pcr_sort_temp_bytes(size_t n);
 int pcr_sort_pairs(pcr_context *ctx, void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
                    const uint32_t *vals_in, uint32_t *vals_out, size_t n, int end_bit);
 
+int pcr_sort_pairs_batch(pcr_context *ctx, int count, void *const *temps, const uint64_t *const *keys_in, uint64_t *const *keys_out,
+                         const uint32_t *const *vals_in, uint32_t *const *vals_out, const size_t *n, int end_bit);
+
 // ---- cloud ops (pcr_cloud.hip) -------------------------------------------------------------------
 size_t pcr_scratch_bytes_for(int64_t n);                       // generous per-cloud scratch estimate
 int pcr_dev_bounds(pcr_context *ctx, const float *xyz, int64_t n, double *bounds6_host);
@@ -125,6 +158,9 @@ int pcr_dev_voxel(pcr_context *ctx, const float *xyz, const float *nrm_in, int64
 // (and nothing enqueued) when the scales cannot share one sort key or the scratch does not fit: run them one by one then
 int pcr_dev_voxel_multi(pcr_context *ctx, const float *xyz, const float *nrm_in, int64_t n, const double *bounds6, const double *voxels,
                         int n_scales, DevCloud *outs, bool *done);
+int pcr_dev_voxel_multi_batch(pcr_context *ctx, int count, const float *const *xyz, const float *const *nrm_in, const int64_t *n, const double *b6, const double *voxels,
+                              int n_scales, DevCloud *outs /* count x n_scales */, bool *done);
+int pcr_dev_bounds_batch(pcr_context *ctx, int count, const float *const *xyz, const int64_t *n, double *b6 /* count x 6, host */);
 // Morton-sort a raw packed cloud (for kNN on un-voxelised input); perm[i] = original index of sorted point i
 int pcr_dev_sort_cloud(pcr_context *ctx, const float *xyz, int64_t n, const double *bounds6, DevCloud *out,
                        uint32_t *perm);
@@ -170,6 +206,8 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
 struct IcpOutputs { pcr_result res; };
 int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, double max_dist, const double *T0,
                  const pcr_gicp_params *p, pcr_result *out, int32_t *match_dev /*optional src.cap*/);
+int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, const DevCloud *const *tgt, const double *max_dists /* G */, const double *T0 /* G x 16 */,
+                       const pcr_gicp_params *p, pcr_result *out /* G */, int32_t *const *match_dev /* optional, G */);
 int pcr_dev_linearize_once(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, double max_dist, const double *T,
                            const pcr_gicp_params *p, double *JTJ36, double *JTr6, double *stats3, int32_t *match_dev);
 int pcr_dev_evaluate(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, double max_dist, const double *T,

@@ -15,6 +15,7 @@
 // ~0.2 ms alone), which is why they are few and fat rather than many and tuned.
 #include <cstring>
 #include <cstdlib>
+#include <vector>
 #include "pcr_internal.h"
 
 #define RS_WAVES 4
@@ -107,6 +108,98 @@ __global__ void __launch_bounds__(RS_WAVES * 64) k_rs_scatter(const uint64_t *__
     }
 }
 
+// ---- several independent sorts through the same launches (blockIdx.y = problem; argument structs in device memory): the voxel
+// passes of all clouds of a group of pairs.  Every problem runs the same number of passes (digits above a problem's keys are zero:
+// a stable pass on them is the identity).
+struct RsArgs { const uint64_t *keys_in; const uint32_t *vals_in; uint64_t *keys_out; uint32_t *vals_out; int *tile_hist; int *tile_off; int n; int tiles; int shift; };
+__global__ void __launch_bounds__(RS_WAVES * 64) k_rs_count_g(const RsArgs *a_) {
+    const RsArgs &a = a_[blockIdx.y];
+    if ((int)blockIdx.x >= a.tiles) return;
+    __shared__ int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * RS_TILE;
+#pragma unroll 4
+    for (int r = 0; r < RS_WAVES * RS_ROWS; r += RS_WAVES) {
+        const int i = base + (r + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 63);
+        if (i < a.n) atomicAdd(&h[(int)((a.keys_in[i] >> a.shift) & 255ull)], 1);
+    }
+    __syncthreads();
+    a.tile_hist[blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
+}
+__global__ void __launch_bounds__(1024) k_rs_scan_g(const RsArgs *a_) {
+    const RsArgs &a = a_[blockIdx.y];
+    const int *__restrict__ tile_hist = a.tile_hist; int *__restrict__ tile_off = a.tile_off; const int n_tiles = a.tiles;
+    __shared__ int part[4][256];
+    __shared__ int basev[256];
+    const int d = threadIdx.x & 255, q = threadIdx.x >> 8;
+    const int per = (n_tiles + 3) / 4, t0 = q * per, t1 = min(n_tiles, t0 + per);
+    int s = 0;
+    for (int t = t0; t < t1; t++) s += tile_hist[t * 256 + d];
+    part[q][d] = s;
+    __syncthreads();
+    if (q == 0) basev[d] = part[0][d] + part[1][d] + part[2][d] + part[3][d];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int l = threadIdx.x;
+        const int v0 = basev[4 * l], v1 = basev[4 * l + 1], v2 = basev[4 * l + 2], v3 = basev[4 * l + 3];
+        int inc = v0 + v1 + v2 + v3;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o, 64); if (l >= o) inc += t; }
+        const int ex = inc - (v0 + v1 + v2 + v3);
+        basev[4 * l] = ex; basev[4 * l + 1] = ex + v0; basev[4 * l + 2] = ex + v0 + v1; basev[4 * l + 3] = ex + v0 + v1 + v2;
+    }
+    __syncthreads();
+    int run = basev[d];
+    for (int k = 0; k < q; k++) run += part[k][d];
+    for (int t = t0; t < t1; t++) { const int c = tile_hist[t * 256 + d]; tile_off[t * 256 + d] = run; run += c; }
+}
+__global__ void __launch_bounds__(RS_WAVES * 64) k_rs_scatter_g(const RsArgs *a_) {
+    const RsArgs &a = a_[blockIdx.y];
+    if ((int)blockIdx.x >= a.tiles) return;
+    const uint64_t *__restrict__ keys_in = a.keys_in; const uint32_t *__restrict__ vals_in = a.vals_in; const int n = a.n, shift = a.shift;
+    __shared__ int cnt[RS_WAVES][256];
+    __shared__ int off[RS_WAVES][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < RS_WAVES; k++) cnt[k][threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * RS_TILE + w * (RS_ROWS * 64);
+    uint64_t key[RS_ROWS]; uint32_t val[RS_ROWS]; int rank[RS_ROWS];
+    const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; r++) {
+        const int i = base + r * 64 + lane;
+        const bool live = i < n;
+        key[r] = live ? keys_in[i] : ~0ull;
+        val[r] = live ? vals_in[i] : 0u;
+        const int d = (int)((key[r] >> shift) & 255ull);
+        unsigned long long same = __ballot(live) ^ (live ? 0ull : ~0ull);
+#pragma unroll
+        for (int b = 0; b < 8; b++) { const unsigned long long bal = __ballot((d >> b) & 1); same &= ((d >> b) & 1) ? bal : ~bal; }
+        const int before = __builtin_popcountll(same & lt);
+        int pre = 0;
+        if (live) pre = cnt[w][d];
+        if (live && before == 0) cnt[w][d] = pre + __builtin_popcountll(same);
+        rank[r] = pre + before;
+    }
+    __syncthreads();
+    {
+        int run = a.tile_off[blockIdx.x * 256 + threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < RS_WAVES; k++) { off[k][threadIdx.x] = run; run += cnt[k][threadIdx.x]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; r++) {
+        const int i = base + r * 64 + lane;
+        if (i < n) {
+            const int o = off[w][(int)((key[r] >> shift) & 255ull)] + rank[r];
+            a.keys_out[o] = key[r]; a.vals_out[o] = val[r];
+        }
+    }
+}
+
 static inline size_t rs_tiles(size_t n) { return (n + RS_TILE - 1) / RS_TILE; }
 
 size_t pcr_sort_temp_bytes(size_t n) {
@@ -138,6 +231,42 @@ int pcr_sort_pairs(pcr_context *ctx, void *temp, size_t temp_bytes, const uint64
         PCR_LAUNCH(ctx, k_rs_scan, dim3(1), dim3(1024), 0, ctx->stream, tile_hist, tiles, tile_off);
         PCR_LAUNCH(ctx, k_rs_scatter, dim3(tiles), dim3(RS_WAVES * 64), 0, ctx->stream, ki, vi, (int)n, shift, tile_off, ko, vo);
         ki = ko; vi = vo;
+    }
+    return PCR_OK;
+}
+
+// `count` independent sorts in 3 launches per digit; temps[k] holds pcr_sort_temp_bytes(n[k]) bytes; end_bit = the widest key
+int pcr_sort_pairs_batch(pcr_context *ctx, int count, void *const *temps, const uint64_t *const *keys_in, uint64_t *const *keys_out,
+                         const uint32_t *const *vals_in, uint32_t *const *vals_out, const size_t *n, int end_bit) {
+    if (count < 1) return PCR_OK;
+    if (end_bit < 1) end_bit = 1;
+    if (end_bit > 64) end_bit = 64;
+    const int passes = (end_bit + 7) / 8;
+    std::vector<RsArgs> a((size_t)count);
+    std::vector<uint64_t *> ktmp((size_t)count); std::vector<uint32_t *> vtmp((size_t)count);
+    int max_tiles = 0;
+    for (int k = 0; k < count; k++) {
+        if (n[k] > 0x7fffffffull) { ctx->err = "sort: too many keys"; return PCR_EINVAL; }
+        const int tiles = (int)rs_tiles(n[k]);
+        char *p = (char *)temps[k];
+        ktmp[k] = (uint64_t *)p; p += ((n[k] + 64) * sizeof(uint64_t) + 255) & ~(size_t)255;
+        vtmp[k] = (uint32_t *)p; p += ((n[k] + 64) * sizeof(uint32_t) + 255) & ~(size_t)255;
+        a[k].tile_hist = (int *)p; p += (size_t)(tiles + 1) * 256 * sizeof(int);
+        a[k].tile_off = (int *)p;
+        a[k].n = (int)n[k]; a[k].tiles = tiles;
+        a[k].keys_in = keys_in[k]; a[k].vals_in = vals_in[k];
+        max_tiles = tiles > max_tiles ? tiles : max_tiles;
+    }
+    if (max_tiles == 0) return PCR_OK;
+    for (int ps = 0; ps < passes; ps++) {
+        const bool to_out = ((passes - 1 - ps) & 1) == 0;
+        for (int k = 0; k < count; k++) { a[k].keys_out = to_out ? keys_out[k] : ktmp[k]; a[k].vals_out = to_out ? vals_out[k] : vtmp[k]; a[k].shift = 8 * ps; }
+        const RsArgs *d = pcr_desc_upload(ctx, a.data(), count);
+        if (!d) return PCR_ENOMEM;
+        PCR_LAUNCH(ctx, k_rs_count_g, dim3(max_tiles, count), dim3(RS_WAVES * 64), 0, ctx->stream, d);
+        PCR_LAUNCH(ctx, k_rs_scan_g, dim3(1, count), dim3(1024), 0, ctx->stream, d);
+        PCR_LAUNCH(ctx, k_rs_scatter_g, dim3(max_tiles, count), dim3(RS_WAVES * 64), 0, ctx->stream, d);
+        for (int k = 0; k < count; k++) { a[k].keys_in = a[k].keys_out; a[k].vals_in = a[k].vals_out; }
     }
     return PCR_OK;
 }

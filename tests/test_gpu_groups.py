@@ -1,0 +1,68 @@
+"""Lockstep groups of pairs (``pcr_pairs_plan.group``): the same per-pair arithmetic as the pair-by-pair path, batched over the
+launches.  The pair loop itself is 2_MGICP...py:187-214; the reference has no grouping, so the checks are (i) bit identity with the
+pair-by-pair path at equal summation grouping and (ii) the oracle on the golden pairs."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, pkg, pose_error, l1_tolerance
+
+pytestmark = pytest.mark.gpu
+
+
+def _helper(env):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "group_pose.py")], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (env, out.stderr[-2000:])
+    lines = out.stdout.splitlines()
+    groups = [l for l in lines if l.startswith("GROUP ")]
+    poses = {l.split()[0]: np.array([float(v) for v in l.split()[1:]]).reshape(-1, 4, 4) for l in lines if l.startswith("POSES")}
+    return groups, poses
+
+
+@pytest.mark.parametrize("rule", ["given", "af"])
+def test_groups_are_bit_identical_at_equal_summation_grouping(rule):
+    """Groups of 1, 2, 3 and 8 over 5 pairs of different sizes (ragged last group, group larger than the batch): poses, iteration
+    counts, cloud counts, radii and correspondence sets are the same bits when the iteration kernel's tile is the same (PCR_ICP_PPL)."""
+    for ppl in ("1", "2"):
+        groups, _ = _helper({"PCR_ICP_PPL": ppl, "GROUP_POSE_RULE": rule})
+        assert len(groups) == 4
+        assert all(g == groups[0] for g in groups), (ppl, groups)
+
+
+def test_default_groups_agree_with_pair_by_pair():
+    """Default policy (two source points per lane inside groups, one outside) only regroups the float64 sums: smooth loss, 1e-7."""
+    _, poses = _helper({"GROUP_POSE_LOSS": "l2"})
+    for a, b in zip(poses["POSES1"], poses["POSES3"]):
+        ang, d = pose_error(a, b)
+        assert ang < 1e-7 and d < 1e-6, (ang, d)
+
+
+def test_grouped_pairs_against_the_oracle(oracle, golden_pair_list):
+    """Script-2 configuration (L1) in one lockstep group against the CPU oracle, tolerance derived from the oracle's own spread."""
+    P = pkg(); reg = P.registration
+    vox = P.script2.create_scales(5); dst = P.script2.max_correspondence_distances(vox)
+    work = [(P.PointCloud(g["source"]), P.PointCloud(g["target"]), g["T_fgr"]) for g in golden_pair_list]
+    rs = reg.register_pairs_plan(work, "gicp", vox, dst, reg.TransformationEstimationForGeneralizedICP(reg.L1Loss()), reg.ICPConvergenceCriteria(1e-6, 1e-6, 100),
+                                 inflight=1, group=len(work))
+    for g, r in zip(golden_pair_list, rs):
+        ref, tol_r, tol_t, _ = l1_tolerance(oracle, lambda: oracle.multiscale_gicp(g["source"], g["target"], vox, dst, g["T_fgr"]), chunks=(64, 512, 4096))
+        for a, b in zip(r.scales, ref.extra["scales"]):
+            assert a["n_voxel"] == tuple(b["n_voxel"]) and a["n_clean"] == tuple(b["n_clean"])
+        ang, d = pose_error(r.transformation, ref.transformation)
+        assert ang <= tol_r and d <= tol_t, (int(g["pair"]), ang, d, tol_r, tol_t)
+
+
+def test_group_of_empty_and_tiny_clouds_reports_per_pair():
+    """A pair the grouped path cannot take (a cloud too small for the SOR / covariance neighbourhoods) fails alone, like pair by pair."""
+    P = pkg(); reg = P.registration
+    rng = np.random.default_rng(3)
+    good = rng.uniform(-5, 5, (4000, 3)); T = np.eye(4); T[0, 3] = 0.05
+    pairs = [(P.PointCloud(good), P.PointCloud(good + [0.05, 0, 0]), np.eye(4)), (P.PointCloud(good[:5]), P.PointCloud(good[:5]), np.eye(4))]
+    with pytest.raises(RuntimeError) as one:
+        reg.register_pairs_plan(pairs, "gicp", [1.0, 0.5], [2.0, 1.0], inflight=1, group=1)
+    with pytest.raises(RuntimeError) as two:
+        reg.register_pairs_plan(pairs, "gicp", [1.0, 0.5], [2.0, 1.0], inflight=1, group=2)
+    assert "pair 1" in str(one.value) and "pair 1" in str(two.value)

@@ -3,18 +3,28 @@
 #   profiles/rNN_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the DEFAULT bench command
 #   profiles/rNN_pmc_hbm_traffic.csv      per-kernel HBM traffic from separate --pmc passes (FETCH_SIZE, WRITE_SIZE, TCC hit/miss)
 #   profiles/rNN_traffic.json             the same numbers keyed by kernel (bench.py reads it for roofline.traffic)
-# usage: tools/make_profiles.sh r01
-TAG=${1:-r01}
+# usage: tools/make_profiles.sh r02
+TAG=${1:-r02}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/profiles_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT" "$ROOT/profiles" "$ROOT/gpurun_out/profiles_export"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 2 --warmup 1 > "$OUT/bench_stats.log" 2> "$OUT/bench_stats.err" || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 2 --warmup 1 > "$OUT/bench_stats.log" 2> "$OUT/bench_stats.err" || exit 1
 cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$ROOT/profiles/${TAG}_bench_kernel_stats.csv"
+python3 "$ROOT/tools/icp_gap_hist.py" "$OUT/stats" "$ROOT/profiles/${TAG}_icp_gaps_inflight4.txt" > /dev/null
+python3 "$ROOT/tools/trace_overview.py" "$OUT/stats" 0.4 > "$ROOT/profiles/${TAG}_trace_overview_inflight4.txt"
+# config 2's FGR variant (registro_FGR + the same GICP): kernel summary of the same command the bench line of that variant comes from
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/fgr" -o run -- python3 "$ROOT/bench.py" --variant fgr --no-cpu-baseline --steps 1 --warmup 1 --pairs-per-step 16 > "$OUT/bench_fgr.log" 2> "$OUT/bench_fgr.err" || exit 1
+cp "$(find "$OUT/fgr" -name '*kernel_stats.csv' | head -1)" "$ROOT/profiles/${TAG}_fgr_kernel_stats.csv"
+grep '^{"metric' "$OUT/bench_fgr.log" | tail -1 > "$ROOT/profiles/${TAG}_bench_line_fgr_under_rocprof.json"
+# one pair at a time: gaps of the iteration chain without other pairs
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/solo" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 1 --warmup 1 --pairs-per-step 8 --inflight 1 > "$OUT/bench_solo.log" 2> "$OUT/bench_solo.err" || exit 1
+python3 "$ROOT/tools/icp_gap_hist.py" "$OUT/solo" "$ROOT/profiles/${TAG}_icp_gaps_solo.txt" > /dev/null
+cp "$(find "$OUT/solo" -name '*kernel_stats.csv' | head -1)" "$ROOT/profiles/${TAG}_solo_kernel_stats.csv"
 for pass in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   d=$OUT/pmc_$(echo $pass | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$d" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 1 --warmup 1 --pairs-per-step 4 --inflight 1 > "$d.log" 2> "$d.err" || exit 1
+  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$d" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 1 --warmup 1 --pairs-per-step 4 --inflight 1 > "$d.log" 2> "$d.err" || exit 1
   echo "pmc pass [$pass] done"
 done
 python3 - "$OUT" "$ROOT/profiles/${TAG}" <<'PY'
@@ -28,15 +38,15 @@ def load(pat):
         d[r["Kernel_Name"]][r["Counter_Name"]].append((float(r["Counter_Value"]), dur))
     return d
 fetch, write, tcc = load("pmc_FETCH_SIZE"), load("pmc_WRITE_SIZE"), load("pmc_TCC_HIT_sum_TCC_MISS_sum")
-short = {"k_icp_fused(IcpArgs)": "k_icp_fused", "k_icp_nn(IcpArgs)": "k_icp_nn", "void k_icp_iter<0>(IcpArgs)": "k_icp_iter<GICP>", "void k_knn<0, 4>(KnnArgs)": "k_knn<SOR,4>",
-         "void k_knn<1, 4>(KnnArgs)": "k_knn<NORMALS,4>", "k_normals_from_lists(NflArgs)": "k_normals_from_lists"}
+short = {"void k_icp_fused<1>(IcpArgs)": "k_icp_fused", "k_icp_nn(IcpArgs)": "k_icp_nn", "void k_icp_iter<0>(IcpArgs)": "k_icp_iter<GICP>", "void k_knn_batch<0, 4>(KnnBatch)": "k_knn_batch<SOR,4>",
+         "void k_knn_batch<1, 4>(KnnBatch)": "k_knn_batch<NORMALS,4>", "k_normals_from_lists_batch(NflBatch)": "k_normals_from_lists_batch", "k_rs_scatter(unsigned long const*, unsigned int const*, int, int, int const*, unsigned long*, unsigned int*)": "k_rs_scatter"}
 rows, js = [], {}
 for full, name in short.items():
     live = lambda lst: [v for v, dur in lst if dur > 6.0]            # launches after 'done' return at once: not live
     f = live(fetch[full]["FETCH_SIZE"]); w = live(write[full]["WRITE_SIZE"])
     h = live(tcc[full]["TCC_HIT_sum"]); m = live(tcc[full]["TCC_MISS_sum"])
     us = [dur for v, dur in fetch[full]["FETCH_SIZE"] if dur > 6.0]
-    if not f: continue
+    if not f or not w or not h: continue
     fk, wk = sum(f) / len(f), sum(w) / len(w)
     hbm = int((2.0 * fk + wk) * 1024)                                # gfx950: FETCH_SIZE counts 64 B per 128-B request (guide, HBM section)
     hit = sum(h) / max(1.0, sum(h) + sum(m))
@@ -49,5 +59,5 @@ for r in rows: print(r)
 PY
 grep '^{"metric' "$OUT/bench_stats.log" | tail -1 > "$ROOT/gpurun_out/bench_under_rocprof_$TAG.json"
 # gpurun only merges gpurun_out/ back: export the files to commit there as well
-cp "$ROOT/profiles/${TAG}_bench_kernel_stats.csv" "$ROOT/profiles/${TAG}_pmc_hbm_traffic.csv" "$ROOT/profiles/${TAG}_traffic.json" "$ROOT/gpurun_out/profiles_export/"
+cp "$ROOT"/profiles/${TAG}_* "$ROOT/gpurun_out/profiles_export/"
 head -12 "$ROOT/profiles/${TAG}_bench_kernel_stats.csv" | cut -c1-150
