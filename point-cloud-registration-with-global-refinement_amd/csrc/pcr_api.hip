@@ -911,9 +911,9 @@ extern "C" int pcr_register_pairs_plan(int device, pcr_pair_ex *pairs, int n_pai
                 });
                 if (rc_group == PCR_OK) {
                     for (int k = 0; k < cnt; k++) pairs[i + k].base.status = PCR_OK;
-                } else if (rc_group != 1) {
+                } else if (rc_group == PCR_EHIP) {          // a device error is not one pair's fault
                     for (int k = 0; k < cnt; k++) { pairs[i + k].base.status = rc_group; failed++; snprintf(pairs[i + k].base.error, sizeof pairs[i + k].base.error, "%s", ctx->err.c_str()); }
-                }
+                } else rc_group = 1;                        // an argument / capacity error: pair by pair, so that it lands on the pair that has it
             }
             if (rc_group == 1)
                 for (int k = 0; k < cnt; k++) {

@@ -95,7 +95,8 @@ def stage2_mgicp(cloud_dir: str, init_dir: str, out_dir: str, n_clouds: int, n_s
     batch = [(clouds[sharding.circuit_pair(i, n_clouds)[0]], clouds[sharding.circuit_pair(i, n_clouds)[1]], initial_T[i]) for i in mine]
     t0 = time.perf_counter()
     res = reg.register_pairs(batch, vox, dst, reg.TransformationEstimationForGeneralizedICP(reg.L1Loss()),
-                             reg.ICPConvergenceCriteria(relative_fitness=1e-6, relative_rmse=1e-6, max_iteration=iterations), inflight=inflight)
+                             reg.ICPConvergenceCriteria(relative_fitness=1e-6, relative_rmse=1e-6, max_iteration=iterations), inflight=inflight,
+                             group=None)            # lockstep groups sized by the clouds (registration.register_pairs_plan)
     dt = time.perf_counter() - t0
     if verbose:
         for i, r in zip(mine, res):

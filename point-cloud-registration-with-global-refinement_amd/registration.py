@@ -349,7 +349,7 @@ def register_pairs_plan(pairs, stage: str = "gicp", voxel_sizes=None, max_corres
 
 
 def register_pairs(pairs, voxel_sizes, max_correspondence_distances, estimation_method=None, criteria=None, nb_neighbors: int = 30,
-                   std_ratio: float = 1.0, normal_knn: int = 20, inflight: int = 3, with_correspondences: bool = True, group: int = 1) -> list:
+                   std_ratio: float = 1.0, normal_knn: int = 20, inflight: int = 3, with_correspondences: bool = True, group=1) -> list:
     """The per-pair loop of script 2 (2_MGICP...py:187-214) as ONE library call: every pair gets the body of ``multiscale_gicp``
     from its initial pose; see ``register_pairs_plan``."""
     return register_pairs_plan(pairs, "gicp", voxel_sizes, max_correspondence_distances, estimation_method, criteria, nb_neighbors, std_ratio,

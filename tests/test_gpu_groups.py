@@ -55,14 +55,24 @@ def test_grouped_pairs_against_the_oracle(oracle, golden_pair_list):
         assert ang <= tol_r and d <= tol_t, (int(g["pair"]), ang, d, tol_r, tol_t)
 
 
-def test_group_of_empty_and_tiny_clouds_reports_per_pair():
-    """A pair the grouped path cannot take (a cloud too small for the SOR / covariance neighbourhoods) fails alone, like pair by pair."""
+def test_a_bad_pair_in_a_group_fails_alone():
+    """An argument error (NaN initial pose) inside a lockstep group lands on that pair only, like pair by pair; pairs the grouped
+    path does not take (an empty cloud) run pair by pair with the same outcome."""
     P = pkg(); reg = P.registration
     rng = np.random.default_rng(3)
-    good = rng.uniform(-5, 5, (4000, 3)); T = np.eye(4); T[0, 3] = 0.05
-    pairs = [(P.PointCloud(good), P.PointCloud(good + [0.05, 0, 0]), np.eye(4)), (P.PointCloud(good[:5]), P.PointCloud(good[:5]), np.eye(4))]
-    with pytest.raises(RuntimeError) as one:
-        reg.register_pairs_plan(pairs, "gicp", [1.0, 0.5], [2.0, 1.0], inflight=1, group=1)
-    with pytest.raises(RuntimeError) as two:
-        reg.register_pairs_plan(pairs, "gicp", [1.0, 0.5], [2.0, 1.0], inflight=1, group=2)
-    assert "pair 1" in str(one.value) and "pair 1" in str(two.value)
+    good = rng.uniform(-5, 5, (4000, 3))
+    bad = np.eye(4); bad[0, 0] = np.nan
+    pairs = [(P.PointCloud(good), P.PointCloud(good + [0.05, 0, 0]), np.eye(4)), (P.PointCloud(good), P.PointCloud(good), bad)]
+    for group in (1, 2):
+        with pytest.raises(RuntimeError) as e:
+            reg.register_pairs_plan(pairs, "gicp", [1.0, 0.5], [2.0, 1.0], inflight=1, group=group)
+        assert "pair 1" in str(e.value), str(e.value)
+    pairs[1] = (P.PointCloud(np.zeros((0, 3))), P.PointCloud(good), np.eye(4))
+    outs = []
+    for group in (1, 2):
+        try:
+            rs = reg.register_pairs_plan(pairs, "gicp", [1.0, 0.5], [2.0, 1.0], inflight=1, group=group)
+            outs.append(("ok", rs[0].transformation.tobytes(), rs[1].fitness))
+        except RuntimeError as e:
+            outs.append(("error", str(e)))
+    assert outs[0] == outs[1]

@@ -20,7 +20,7 @@ for g in (1, 2, 3, 8):
     h = hashlib.sha256()
     for r in rs:
         h.update(np.asarray(r.transformation).tobytes()); h.update(np.ascontiguousarray(r.correspondence_set).tobytes())
-        h.update(repr([(s["iterations"], s["n_clean"], s["max_correspondence_distance"]) for s in r.scales]).encode())
+        h.update(repr([(s["iterations"], s["n_clean"], s["max_dist"]) for s in r.scales]).encode())
     print(f"GROUP {h.hexdigest()} fitness " + " ".join(f"{r.fitness:.6f}" for r in rs))
     if g == 1 or g == 3:
         print(f"POSES{g} " + " ".join(repr(float(v)) for r in rs for v in np.asarray(r.transformation).reshape(16)))
