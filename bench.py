@@ -262,7 +262,7 @@ def main(argv=None) -> int:
         us_kernel = ik_us / live if live else None                                 # kernels' own s_memrealtime stamps
         achieved = bytes_per_launch / (us_event * 1e-6) / 1e9 if ev_launches else 0.0
         traffic_file = None
-        for name in ("r02_traffic.json", "r01_traffic.json"):                      # rocprofv3 --pmc passes (profiles/README.md); NOT measured in this run
+        for name in ("r02_traffic.json", "r02_traffic.json"):                      # rocprofv3 --pmc passes (profiles/README.md); NOT measured in this run
             tj = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tj):
                 t = json.load(open(tj))

@@ -1105,8 +1105,13 @@ template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn_b
 template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn_batchp(const KnnArgs *a) { d_knn<MODE, SLOTS>(a[blockIdx.y]); }
 
 // `count` searches in ONE launch (blockIdx.y picks the problem; k <= 32): the SOR / normals searches of all scales of a cloud
+template <int MODE> static int launch_knn_cap(pcr_context *ctx, int cap, KnnArgs a);
 template <int MODE>
 static int launch_knn_batch(pcr_context *ctx, KnnArgs *a, const int *caps, int count) {
+    if (getenv("PCR_KNN_STAMPS")) {                          // diagnostics: one stamped launch per problem
+        for (int k = 0; k < count; k++) PCR_TRY(launch_knn_cap<MODE>(ctx, caps[k], a[k]));
+        return PCR_OK;
+    }
     int mc = 0;
     for (int k = 0; k < count; k++) {
         if (a[k].k < 1 || a[k].k > 32) { ctx->err = "batched k-NN: k must be in 1..32"; return PCR_EINVAL; }
@@ -1118,10 +1123,12 @@ static int launch_knn_batch(pcr_context *ctx, KnnArgs *a, const int *caps, int c
 }
 
 template <int MODE>
-static int launch_knn(pcr_context *ctx, const DevCloud *c, KnnArgs a) {
-    if (c->cap <= 0) return PCR_OK;
+static int launch_knn(pcr_context *ctx, const DevCloud *c, KnnArgs a) { return launch_knn_cap<MODE>(ctx, c->cap, a); }
+template <int MODE>
+static int launch_knn_cap(pcr_context *ctx, int cap, KnnArgs a) {
+    if (cap <= 0) return PCR_OK;
     if (a.k < 1 || a.k > 200) { ctx->err = "k out of range for the octet k-NN kernel (1..200)"; return PCR_EINVAL; }
-    const dim3 grid((unsigned)(((size_t)c->cap * OCT + KNN_BS - 1) / KNN_BS)), block(KNN_BS);
+    const dim3 grid((unsigned)(((size_t)cap * OCT + KNN_BS - 1) / KNN_BS)), block(KNN_BS);
     const char *stamp_path = getenv("PCR_KNN_STAMPS");      // diagnostics only: per-wavefront begin/end clocks and hardware ids
     const size_t stamp_words = (size_t)grid.x * (KNN_BS / 64) * 24;
     if (stamp_path) {

@@ -634,11 +634,11 @@ template <int MODE> __global__ void __launch_bounds__(LIN_BS) k_icp_iter_g(const
 // and tickets; a lane's certificate tests and float64 linearisations back to back) were measured: 4 pairs in flight 327 / 318 / 293
 // pairs/s for PPL 1 / 2 / 4, 8 in flight 314 / 334 / 313, one pair alone 178 / 158 / 125 -- the wavefront slots are not what bounds the
 // pairs in flight ("what bounds the throughput"), and alone the longer lanes cost what they cost.  Kept as a switch.
-template <int PPL>
+template <int TILE_PTS>
 __device__ static inline void d_icp_fused(const IcpArgs &a) {
     IcpState *st = a.state;
     constexpr int OPB = FUSED_BS / OCT;
-    constexpr int TILE_PTS = FUSED_BS * PPL;
+    constexpr int PPL = TILE_PTS >= FUSED_BS ? TILE_PTS / FUSED_BS : 1;      // source points per lane; tiles under 512 points leave lanes without one
     __shared__ OctMeta m;
     __shared__ OctStack<OPB> stk;
     __shared__ float4 rec_q[TILE_PTS];         // pending queries of the workgroup: position + hint
@@ -653,7 +653,7 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
         const int i = tile0 + p * FUSED_BS + tid;
-        const int ic = i < a.src_cap ? i : 0;
+        const int ic = (i < a.src_cap && p * FUSED_BS + tid < TILE_PTS) ? i : 0;
         pf[p] = a.src_pts[ic]; mraw[p] = a.match[ic]; refv[p] = a.ref[ic]; rb[p] = a.rbest[ic];
     }
     double T[12];
@@ -673,10 +673,11 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
         const int i = tile0 + p * FUSED_BS + tid;
+        const bool mine = p * FUSED_BS + tid < TILE_PTS;
         bool need = false;
         int cand = -1;
         float qx = 0, qy = 0, qz = 0; int hint = -1;
-        if (i < ns) {
+        if (mine && i < ns) {
             const double px = pf[p].x, py = pf[p].y, pz = pf[p].z;
             qx = (float)(T[0] * px + T[1] * py + T[2] * pz + T[3]);
             qy = (float)(T[4] * px + T[5] * py + T[6] * pz + T[7]);
@@ -695,7 +696,7 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
             const int slot = base + __builtin_popcountll(nbm & ((1ull << lane) - 1ull));
             rec_q[slot] = make_float4(qx, qy, qz, __int_as_float(hint)); rec_l[slot] = (short)(p * FUSED_BS + tid);
         }
-        cand_l[p * FUSED_BS + tid] = cand;
+        if (mine) cand_l[p * FUSED_BS + tid] = cand;
     }
     __syncthreads();
     // ---- phase B: the 64 octets work through the pending list
@@ -726,7 +727,7 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
         const int i = tile0 + p * FUSED_BS + tid;
-        if (i < ns) {
+        if (p * FUSED_BS + tid < TILE_PTS && i < ns) {
             const int c = cand_l[p * FUSED_BS + tid];
             if (c >= 0 && c != mraw[p]) a.match[i] = c;
             icp_point<ICP_MODE_GICP>(a, T, i, ns, c, acc);
@@ -734,8 +735,34 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
     }
     icp_finish<ICP_MODE_GICP, FUSED_BS>(a, st, T, acc, nb, ns, launches, t_entry);
 }
-template <int PPL> __global__ void __launch_bounds__(FUSED_BS) k_icp_fused(IcpArgs a) { d_icp_fused<PPL>(a); }
-template <int PPL> __global__ void __launch_bounds__(FUSED_BS) k_icp_fused_g(const IcpArgs *a) { d_icp_fused<PPL>(a[blockIdx.y]); }
+template <int TILE_PTS> __global__ void __launch_bounds__(FUSED_BS) k_icp_fused(IcpArgs a) { d_icp_fused<TILE_PTS>(a); }
+template <int TILE_PTS> __global__ void __launch_bounds__(FUSED_BS) k_icp_fused_g(const IcpArgs *a) { d_icp_fused<TILE_PTS>(a[blockIdx.y]); }
+
+// Source points per workgroup of the fused kernel (PCR_ICP_TILE = 128 ... 2048; PCR_ICP_PPL = 1 / 2 / 4 is the older spelling of
+// 512 / 1024 / 2048).  The workgroup's 64 octets serve its pending queries 64 at a time, so a 512-point tile whose certificates do not
+// hold walks the tree up to 8 times in a row -- but that is NOT what the launch waits for: one pair alone, 25 iterations per scale,
+// 43.6 / 40.7 / 46.0 us per launch for tiles of 512 / 256 / 128 points (the slowest single walk is); lockstep groups of 2, four in
+// flight: 333 / 304 / 258 pairs/s for 1024 / 512 / 256.  One pair: 512 (the tile of k_icp_iter, so that PCR_ICP_FUSED=0 is the same
+// arithmetic); groups: 1024.
+static int fused_tile_points(int cap, int G) {
+    static const int fixed = getenv("PCR_ICP_TILE") ? atoi(getenv("PCR_ICP_TILE")) : (getenv("PCR_ICP_PPL") ? FUSED_BS * atoi(getenv("PCR_ICP_PPL")) : 0);
+    int t = fixed;
+    if (t <= 0) {
+        t = G > 1 ? 1024 : 512;
+        (void)cap;
+    }
+    return t >= 2048 ? 2048 : (t >= 1024 ? 1024 : (t >= 512 ? 512 : (t >= 256 ? 256 : 128)));
+}
+#define PCR_FUSED_LAUNCH(ctx, KERNEL, tile, grid, arg)                                                                 \
+    do {                                                                                                               \
+        switch (tile) {                                                                                                \
+            case 128: PCR_LAUNCH(ctx, KERNEL<128>, grid, dim3(FUSED_BS), 0, (ctx)->stream, arg); break;                \
+            case 256: PCR_LAUNCH(ctx, KERNEL<256>, grid, dim3(FUSED_BS), 0, (ctx)->stream, arg); break;                \
+            case 1024: PCR_LAUNCH(ctx, KERNEL<1024>, grid, dim3(FUSED_BS), 0, (ctx)->stream, arg); break;              \
+            case 2048: PCR_LAUNCH(ctx, KERNEL<2048>, grid, dim3(FUSED_BS), 0, (ctx)->stream, arg); break;              \
+            default: PCR_LAUNCH(ctx, KERNEL<512>, grid, dim3(FUSED_BS), 0, (ctx)->stream, arg); break;                 \
+        }                                                                                                              \
+    } while (0)
 
 static void fill_args(IcpArgs &a, const DevCloud *src, const DevCloud *tgt, double max_dist, const pcr_gicp_params *p,
                       int32_t *match, IcpState *st, double *partials, int single) {
@@ -781,9 +808,8 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     const int cap = src->cap > 0 ? src->cap : 1;
     const int nbmax = (cap + LIN_BS - 1) / LIN_BS < LIN_MAX_BLOCKS ? (cap + LIN_BS - 1) / LIN_BS : LIN_MAX_BLOCKS;
     const int nbnn = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT);
-    static const int ppl = getenv("PCR_ICP_PPL") ? atoi(getenv("PCR_ICP_PPL")) : 1;      // source points per lane of the fused kernel (1, 2 or 4)
-    const int tile_pts = FUSED_BS * (ppl >= 4 ? 4 : (ppl >= 2 ? 2 : 1));
-    const int nbf = (cap + tile_pts - 1) / tile_pts;                 // workgroups of the fused kernel: one per 512 * PPL source points
+    const int tile_pts = fused_tile_points(cap, 1);
+    const int nbf = (cap + tile_pts - 1) / tile_pts;                 // workgroups of the fused kernel: one per tile of source points
     IcpState *st = arena<IcpState>(ctx, 1);
     double *partials = arena<double>(ctx, (size_t)(nbmax > nbf ? nbmax : nbf) * NVP);
     int32_t *match = match_dev ? match_dev : arena<int32_t>(ctx, cap);
@@ -823,9 +849,7 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     const bool fused = use_fused && a.ref && !use_cov && !stamp_path && nbf <= 4096;
     auto enqueue = [&](int launch_index) {
         if (fused && launch_index > 0) {
-            if (tile_pts == FUSED_BS * 4) PCR_LAUNCH(ctx, k_icp_fused<4>, dim3(nbf), dim3(FUSED_BS), 0, ctx->stream, a);
-            else if (tile_pts == FUSED_BS * 2) PCR_LAUNCH(ctx, k_icp_fused<2>, dim3(nbf), dim3(FUSED_BS), 0, ctx->stream, a);
-            else PCR_LAUNCH(ctx, k_icp_fused<1>, dim3(nbf), dim3(FUSED_BS), 0, ctx->stream, a);
+            PCR_FUSED_LAUNCH(ctx, k_icp_fused, tile_pts, dim3(nbf), a);
             return;
         }
         PCR_LAUNCH(ctx, k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
@@ -930,8 +954,9 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
     ArenaMark mark(ctx);
     // two source points per lane in lockstep groups (G x the workgroups per launch: half of them leave more of the chip to the other
     // groups in flight: 200k points, groups of 2, 4 groups in flight 367 -> 408 pairs/s); PCR_ICP_PPL overrides
-    static const int ppl = getenv("PCR_ICP_PPL") ? atoi(getenv("PCR_ICP_PPL")) : (G > 1 ? 2 : 1);
-    const int tile_pts = FUSED_BS * (ppl >= 4 ? 4 : (ppl >= 2 ? 2 : 1));
+    int max_cap = 1;
+    for (int g = 0; g < G; g++) max_cap = src[g]->cap > max_cap ? src[g]->cap : max_cap;
+    const int tile_pts = fused_tile_points(max_cap, G);
     int nbmax = 1, nbnn = 1, nbf = 1;
     std::vector<IcpArgs> args((size_t)G); std::vector<IcpInit> inits((size_t)G);
     IcpState *st = arena<IcpState>(ctx, G);
@@ -975,9 +1000,7 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
     static const bool use_graph = !(getenv("PCR_ICP_GRAPH") && atoi(getenv("PCR_ICP_GRAPH")) == 0);
     auto enqueue = [&](int launch_index) {
         if (launch_index > 0) {
-            if (tile_pts == FUSED_BS * 4) PCR_LAUNCH(ctx, k_icp_fused_g<4>, dim3(nbf, G), dim3(FUSED_BS), 0, ctx->stream, dargs);
-            else if (tile_pts == FUSED_BS * 2) PCR_LAUNCH(ctx, k_icp_fused_g<2>, dim3(nbf, G), dim3(FUSED_BS), 0, ctx->stream, dargs);
-            else PCR_LAUNCH(ctx, k_icp_fused_g<1>, dim3(nbf, G), dim3(FUSED_BS), 0, ctx->stream, dargs);
+            PCR_FUSED_LAUNCH(ctx, k_icp_fused_g, tile_pts, dim3(nbf, G), dargs);
             return;
         }
         PCR_LAUNCH(ctx, k_icp_nn_g, dim3(nbnn, G), dim3(ICP_BS), 0, ctx->stream, dargs);

@@ -12,19 +12,19 @@ rm -rf "$OUT"; mkdir -p "$OUT" "$ROOT/profiles" "$ROOT/gpurun_out/profiles_expor
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 2 --warmup 1 > "$OUT/bench_stats.log" 2> "$OUT/bench_stats.err" || exit 1
 cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$ROOT/profiles/${TAG}_bench_kernel_stats.csv"
-python3 "$ROOT/tools/icp_gap_hist.py" "$OUT/stats" "$ROOT/profiles/${TAG}_icp_gaps_inflight4.txt" > /dev/null
-python3 "$ROOT/tools/trace_overview.py" "$OUT/stats" 0.4 > "$ROOT/profiles/${TAG}_trace_overview_inflight4.txt"
+python3 "$ROOT/tools/icp_gap_hist.py" "$OUT/stats" "$ROOT/profiles/${TAG}_icp_gaps_inflight.txt" > /dev/null
+python3 "$ROOT/tools/trace_overview.py" "$OUT/stats" 0.4 > "$ROOT/profiles/${TAG}_trace_overview_inflight.txt"
 # config 2's FGR variant (registro_FGR + the same GICP): kernel summary of the same command the bench line of that variant comes from
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/fgr" -o run -- python3 "$ROOT/bench.py" --variant fgr --no-cpu-baseline --steps 1 --warmup 1 --pairs-per-step 16 > "$OUT/bench_fgr.log" 2> "$OUT/bench_fgr.err" || exit 1
 cp "$(find "$OUT/fgr" -name '*kernel_stats.csv' | head -1)" "$ROOT/profiles/${TAG}_fgr_kernel_stats.csv"
 grep '^{"metric' "$OUT/bench_fgr.log" | tail -1 > "$ROOT/profiles/${TAG}_bench_line_fgr_under_rocprof.json"
 # one pair at a time: gaps of the iteration chain without other pairs
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/solo" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 1 --warmup 1 --pairs-per-step 8 --inflight 1 > "$OUT/bench_solo.log" 2> "$OUT/bench_solo.err" || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/solo" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 1 --warmup 1 --pairs-per-step 8 --inflight 1 --group 1 > "$OUT/bench_solo.log" 2> "$OUT/bench_solo.err" || exit 1
 python3 "$ROOT/tools/icp_gap_hist.py" "$OUT/solo" "$ROOT/profiles/${TAG}_icp_gaps_solo.txt" > /dev/null
 cp "$(find "$OUT/solo" -name '*kernel_stats.csv' | head -1)" "$ROOT/profiles/${TAG}_solo_kernel_stats.csv"
 for pass in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   d=$OUT/pmc_$(echo $pass | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$d" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 1 --warmup 1 --pairs-per-step 4 --inflight 1 > "$d.log" 2> "$d.err" || exit 1
+  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$d" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 1 --warmup 1 --pairs-per-step 4 --inflight 1 --group 1 > "$d.log" 2> "$d.err" || exit 1
   echo "pmc pass [$pass] done"
 done
 python3 - "$OUT" "$ROOT/profiles/${TAG}" <<'PY'
@@ -61,3 +61,6 @@ grep '^{"metric' "$OUT/bench_stats.log" | tail -1 > "$ROOT/gpurun_out/bench_unde
 # gpurun only merges gpurun_out/ back: export the files to commit there as well
 cp "$ROOT"/profiles/${TAG}_* "$ROOT/gpurun_out/profiles_export/"
 head -12 "$ROOT/profiles/${TAG}_bench_kernel_stats.csv" | cut -c1-150
+# the raw traces are large (gpurun merges at most 64 MiB back): keep the summaries only
+find "$OUT" \( -name '*kernel_trace.csv' -o -name '*counter_collection.csv' -o -name '*.db' \) -delete
+du -sh "$OUT"
