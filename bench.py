@@ -68,9 +68,13 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("PCR_BENCH_INFLIGHT", "4")),
                     help="independent pairs (or lockstep groups, see --group) in flight per GPU (one library worker thread + context + streams each)")
-    ap.add_argument("--group", type=int, default=int(os.environ.get("PCR_BENCH_GROUP", "2")),
-                    help="pairs per lockstep group (pcr_pairs_plan.group): that many consecutive pairs of a batch go through the same launches")
-    return ap.parse_args(argv)
+    ap.add_argument("--group", type=int, default=int(os.environ.get("PCR_BENCH_GROUP", "0")),
+                    help="pairs per lockstep group (pcr_pairs_plan.group): that many consecutive pairs of a batch go through the same launches; "
+                         "0 = by cloud size as registration.register_pairs_plan(group=None) does (about 400k points per group: 2 at 200k points)")
+    args = ap.parse_args(argv)
+    if args.group <= 0:
+        args.group = int(min(16, max(1, round(400_000 / max(args.points * (10 if args.config5 else 1), 1)))))
+    return args
 
 
 # ------------------------------------------------------------------------------------------------ N ranks from one command

@@ -326,13 +326,13 @@ static int feature_nn(pcr_context *ctx, const float *db, int n_db, const float *
     return PCR_OK;
 }
 
-// test hook: the mutual nearest-feature search alone.  mode 0: f16-split screen + exact re-check (the production path), 1: all-pairs
-// float64 MFMA, 2: float32 brute force
+// test hook: the mutual nearest-feature search alone.  mode 0: f16-split screen + exact re-check (the production path; tile pruning
+// from 32k rows per side), 1: all-pairs float64 MFMA, 2: float32 brute force, 3: the screen with tile pruning forced on, 4: forced off
 extern "C" int pcr_debug_feature_nn(pcr_context *ctx, const float *f0, int64_t n0, const float *f1, int64_t n1, int32_t *out_1to0, int32_t *out_0to1, int mode) {
     return pcr_api_call(ctx, [&]() -> int {
         if (n0 <= 0 || n1 <= 0 || !f0 || !f1 || !out_1to0 || !out_0to1) return PCR_EINVAL;
         PCR_TRY(pcr_arena_reserve(ctx, pcr_feature_nn_scratch_bytes(n0, n1) + (size_t)(n0 + n1) * (FK * 16 + 32 * 12 + 64) + (64u << 20)));
-        if (mode == 0) return pcr_feature_nn_mutual(ctx, f0, (int)n0, f1, (int)n1, out_1to0, out_0to1);
+        if (mode == 0 || mode == 3 || mode == 4) return pcr_feature_nn_mutual(ctx, f0, (int)n0, f1, (int)n1, out_1to0, out_0to1, mode == 0 ? -1 : (mode == 3 ? 1 : 0));
         if (mode == 2) {
             PCR_LAUNCH(ctx, k_feature_nn, dim3((unsigned)((n1 + FB - 1) / FB)), dim3(FB), 0, ctx->stream, f0, (int)n0, f1, (int)n1, out_1to0);
             PCR_LAUNCH(ctx, k_feature_nn, dim3((unsigned)((n0 + FB - 1) / FB)), dim3(FB), 0, ctx->stream, f1, (int)n1, f0, (int)n0, out_0to1);
@@ -847,7 +847,7 @@ static int fgr_pose(pcr_context *ctx, const float *src_xyz, const float *src_fea
         // the all-pairs float64 MFMA path (also taken for feature values outside the f16 range), PCR_FEATURE_NN_BRUTE the float32 one
         static const bool nn_f64 = getenv("PCR_FEATURE_NN") && !strcmp(getenv("PCR_FEATURE_NN"), "f64");
         int nn_rc = PCR_ECAPACITY;
-        if (!nn_f64 && !getenv("PCR_FEATURE_NN_BRUTE") && nPti >= 64 && nPtj >= 64) nn_rc = pcr_feature_nn_mutual(ctx, fi, nPti, fj, nPtj, j_to_i, i_to_j);
+        if (!nn_f64 && !getenv("PCR_FEATURE_NN_BRUTE") && nPti >= 64 && nPtj >= 64) nn_rc = pcr_feature_nn_mutual(ctx, fi, nPti, fj, nPtj, j_to_i, i_to_j, -1);
         if (nn_rc == PCR_ECAPACITY) {
             PCR_TRY(feature_nn(ctx, fi, nPti, fj, nPtj, j_to_i));
             PCR_TRY(feature_nn(ctx, fj, nPtj, fi, nPti, i_to_j));

@@ -252,8 +252,9 @@ def register_pairs_plan(pairs, stage: str = "gicp", voxel_sizes=None, max_corres
     radius_rule "af"  = search radii ``radius_from_cloud_pair * 2**-i`` per pair (ALL_FUNCTIONS.py:277-278) instead of the given list.
     ``group`` > 1 (stage "gicp"): that many consecutive pairs run in LOCKSTEP through the same launches (preprocessing batched over
     clouds and scales, one GICP loop per scale for the whole group; same per-pair arithmetic); ``inflight`` counts groups.
-    ``group=None`` picks by cloud size (measured on one MI355X: 20k-point pairs 680 -> 2000 pairs/s with groups of 24, 200k-point
-    pairs 340 -> 408 with groups of 2).
+    ``group=None`` picks by cloud size, about 400k points per group (measured on one MI355X with 4 groups in flight, pair by pair ->
+    groups: 20k-point pairs 680 -> 2190 pairs/s with groups of 12-16, 50k 540 -> 1080 with 6-8, 100k 440 -> 635 with 4, 200k 340 -> 410
+    with 2).
     The library keeps ``inflight`` pairs in flight on the current device.  Returns RegistrationResults in input order (for
     stages with FGR the FGR result is attached as ``.fgr``; ``.information`` when ``info_max_dist > 0``)."""
     estimation = estimation_method or TransformationEstimationForGeneralizedICP()
@@ -274,7 +275,7 @@ def register_pairs_plan(pairs, stage: str = "gicp", voxel_sizes=None, max_corres
         return []
     if group is None:
         mean_pts = float(np.mean([len(s_) + len(t_) for s_, t_, _ in pairs])) / 2
-        group = 24 if mean_pts <= 40_000 else (8 if mean_pts <= 100_000 else (2 if mean_pts <= 500_000 else 1))
+        group = int(min(16, max(1, round(400_000 / max(mean_pts, 1.0)))))
     arr = (_lib.PcrPairEx * n)()
     keep = []                                   # device tensors and record arrays must outlive the call
     for k, (src, tgt, init) in enumerate(pairs):

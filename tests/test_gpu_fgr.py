@@ -235,7 +235,8 @@ def _exact_nn(db, q):
 def test_feature_nn_screen_is_exact(P, fgr_inputs, case):
     """pcr_featnn.hip: the f16-split MFMA screen + float64 re-check returns the exact float64 nearest feature row (ties -> smaller
     index) -- on real FPFH features, on adversarial inputs (blocks of exact duplicates and all-zero rows: candidate lists overflow
-    and the brute-force path serves them; rows of very different norms), and on sizes around the tile and step boundaries."""
+    and the brute-force path serves them; rows of very different norms), and on sizes around the tile and step boundaries.
+    Modes 3 / 4 force the tile-pruned form of the screen on / off: same answers."""
     import ctypes as C
     import torch
     (src, fs), (tgt, ft) = fgr_inputs
@@ -257,12 +258,33 @@ def test_feature_nn_screen_is_exact(P, fgr_inputs, case):
     d0 = torch.as_tensor(f0, device="cuda").contiguous(); d1 = torch.as_tensor(f1, device="cuda").contiguous()
     ctx = P._lib.Context.current()
     res = {}
-    for mode in (0, 1):
+    for mode in (0, 1, 3, 4):
         o10 = torch.full((len(f1),), -7, dtype=torch.int32, device="cuda"); o01 = torch.full((len(f0),), -7, dtype=torch.int32, device="cuda")
         ctx.check(ctx.lib.pcr_debug_feature_nn(ctx.handle, C.c_void_p(d0.data_ptr()), C.c_int64(len(f0)), C.c_void_p(d1.data_ptr()), C.c_int64(len(f1)),
                                                C.c_void_p(o10.data_ptr()), C.c_void_p(o01.data_ptr()), C.c_int(mode)), "pcr_debug_feature_nn")
         res[mode] = (o10.cpu().numpy(), o01.cpu().numpy())
     e10, e01 = _exact_nn(f0, f1), _exact_nn(f1, f0)
-    assert np.array_equal(res[0][0], e10) and np.array_equal(res[0][1], e01), (case, (res[0][0] != e10).sum(), (res[0][1] != e01).sum())
+    for mode in (0, 3, 4):      # production choice, tile pruning forced on (rows in Morton order of their principal coordinates), forced off
+        assert np.array_equal(res[mode][0], e10) and np.array_equal(res[mode][1], e01), (case, mode, (res[mode][0] != e10).sum(), (res[mode][1] != e01).sum())
     if case == "fpfh":          # the float64 MFMA path it replaces agrees wherever the expanded form has no near-tie
         assert (res[1][0] == e10).mean() > 0.999 and (res[1][1] == e01).mean() > 0.999
+
+
+def test_feature_nn_tile_pruning_full_cloud(P, fgr_inputs):
+    """The tile-pruned screen on all rows of a golden pair's FPFH features (several hundred 64-row tiles per side, ragged last tiles,
+    all-zero rows): identical to the unpruned screen and to the exact float64 search in numpy."""
+    import ctypes as C
+    import torch
+    (src, fs), (tgt, ft) = fgr_inputs
+    f0 = fs._dev.cpu().numpy(); f1 = ft._dev.cpu().numpy()
+    d0 = torch.as_tensor(f0, device="cuda").contiguous(); d1 = torch.as_tensor(f1, device="cuda").contiguous()
+    ctx = P._lib.Context.current()
+    res = {}
+    for mode in (3, 4):
+        o10 = torch.full((len(f1),), -7, dtype=torch.int32, device="cuda"); o01 = torch.full((len(f0),), -7, dtype=torch.int32, device="cuda")
+        ctx.check(ctx.lib.pcr_debug_feature_nn(ctx.handle, C.c_void_p(d0.data_ptr()), C.c_int64(len(f0)), C.c_void_p(d1.data_ptr()), C.c_int64(len(f1)),
+                                               C.c_void_p(o10.data_ptr()), C.c_void_p(o01.data_ptr()), C.c_int(mode)), "pcr_debug_feature_nn")
+        res[mode] = (o10.cpu().numpy(), o01.cpu().numpy())
+    assert np.array_equal(res[3][0], res[4][0]) and np.array_equal(res[3][1], res[4][1])
+    sel = np.random.default_rng(11).permutation(len(f1))[:3000]
+    assert np.array_equal(res[3][0][sel], _exact_nn(f0, f1[sel]))

@@ -25,3 +25,5 @@ t0 = time.perf_counter()
 for _ in range(5): run()
 torch.cuda.synchronize()
 print(f"featnn n={n} mode={mode} variant={os.environ.get('PCR_FEATNN_VARIANT', '0')}: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms for both directions")
+if os.environ.get("FEATNN_SUM"):      # order-independent digest of both answers (to compare paths / switches across processes)
+    print("featnn digest", int(o10.to(torch.int64).sum().item()), int(o01.to(torch.int64).sum().item()), int((o10.to(torch.int64) * torch.arange(len(T), device="cuda")).sum().item()))
