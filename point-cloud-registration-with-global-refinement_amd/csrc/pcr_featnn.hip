@@ -151,6 +151,7 @@ __global__ void __launch_bounds__(256) k_fn_split(const float *__restrict__ f_, 
 #define FN_MB 8                            //   bits of each
 #define FN_NPRE 48                         // pre-pass: tiles per workgroup
 #define FN_LIST_CAP 1024                   // steps of one (workgroup, split): capacity of its list
+#define FN_GRAM_SKIP 4                     // the second moments are taken on a quarter of the rows (the axes only have to be good; the means are exact)
 
 // raw second moments sum_i f_i[a] f_i[b], a <= b (thread t owns one pair; rows staged through LDS 32 at a time)
 __global__ void __launch_bounds__(576) k_fn_gram(const float *__restrict__ f, int n, double *__restrict__ part) {
@@ -159,7 +160,7 @@ __global__ void __launch_bounds__(576) k_fn_gram(const float *__restrict__ f, in
     { int t = threadIdx.x; for (pa = 0; pa < FN_D; pa++) { const int len = FN_D - pa; if (t < len) { pb = pa + t; break; } t -= len; } }
     const bool owner = threadIdx.x < FN_NG;
     double acc = 0.0;
-    for (int r0 = blockIdx.x * 32; r0 < n; r0 += gridDim.x * 32) {
+    for (int r0 = blockIdx.x * 32; r0 < n; r0 += gridDim.x * 32 * FN_GRAM_SKIP) {      // every FN_GRAM_SKIP-th block of 32 rows per round of the grid
         __syncthreads();
         for (int e = threadIdx.x; e < 32 * FN_D; e += 576) { const int r = e / FN_D, k = e % FN_D; rows[r][k] = r0 + r < n ? f[(size_t)(r0 + r) * FN_D + k] : 0.0f; }
         __syncthreads();
@@ -185,7 +186,7 @@ static void fn_jacobi(double *C /* 33 x 33, destroyed */, double *V, double *ev)
         for (int p_ = 0; p_ < N; p_++) for (int q = p_ + 1; q < N; q++) off += C[p_ * N + q] * C[p_ * N + q];
         double diag = 0.0;
         for (int i = 0; i < N; i++) diag += C[i * N + i] * C[i * N + i];
-        if (!(off > 1e-24 * diag)) break;
+        if (!(off > 1e-16 * diag)) break;        // V stays orthonormal whatever the residual: the axes only have to be good, not converged
         for (int p_ = 0; p_ < N; p_++)
             for (int q = p_ + 1; q < N; q++) {
                 const double apq = C[p_ * N + q];
@@ -588,26 +589,27 @@ struct FnxArgs {
     const int *Ug;                                      // final bound of the screen per query
     const int *pool_used; const int *chunk_fill; const int *rec_q; const int *rec_row; const float *rec_w;
     const uint32_t *perm_q, *perm_db;                   // tile-pruned screen: query q / row r of the screen is row perm[.] of q / db (null: identity)
+    double *rec_d;                                      // per record: its exact distance, written by pass 1 and read by pass 2 (no second gather of the rows)
     unsigned long long *best_d;                         // per (screen) query: bits of the smallest exact distance (non-negative doubles order like their bits)
     int32_t *out;                                       // per ORIGINAL query: smallest ORIGINAL row attaining it (INT_MAX until found)
     float *dbg;                                         // PCR_FEATNN_CHECK: [0] max |d~ - d| / (nq + nb) seen on records, [1] records that survived the final bound
 };
-__device__ static inline bool fn_record(const FnxArgs &a, int r, int *q, int *row, double *d) {
+__device__ static inline bool fn_record(const FnxArgs &a, int r, int *q, int *row) {
     if (r >= *a.pool_used || (r % FN_CHUNK) >= a.chunk_fill[r / FN_CHUNK]) return false;
     *q = a.rec_q[r]; *row = a.rec_row[r];
     if (*q >= a.n_q || *row >= a.n_db) return false;
     const float nr = a.q_nrm[*q];
     const float thr = fn_unord(a.Ug[*q]) + (float)(2.0 * FN_C * 1.001) * fabsf(nr);
-    if (!(a.rec_w[r] <= thr)) return false;               // could not be the minimum given the final bound
-    const size_t oq = a.perm_q ? a.perm_q[*q] : (size_t)*q, orow = a.perm_db ? a.perm_db[*row] : (size_t)*row;
-    *d = fn_exact_d2(a.q + oq * FN_D, a.db + orow * FN_D);
-    return true;
+    return a.rec_w[r] <= thr;                             // else: could not be the minimum given the final bound
 }
 // pass 1: smallest exact distance per query
 __global__ void __launch_bounds__(256) k_fn_exact_min(FnxArgs a, int n_rec_cap) {
     const int r = blockIdx.x * 256 + threadIdx.x;
-    int q, row; double d;
-    if (r >= n_rec_cap || !fn_record(a, r, &q, &row, &d)) return;
+    int q, row;
+    if (r >= n_rec_cap || !fn_record(a, r, &q, &row)) return;
+    const size_t oq = a.perm_q ? a.perm_q[q] : (size_t)q, orow = a.perm_db ? a.perm_db[row] : (size_t)row;
+    const double d = fn_exact_d2(a.q + oq * FN_D, a.db + orow * FN_D);
+    a.rec_d[r] = d;
     atomicMin(&a.best_d[q], (unsigned long long)__double_as_longlong(d));
     if (a.dbg) {          // the screen's value of this pair against the exact one, in units of the bound
         const double nq = fabs((double)a.q_nrm[q]), nb = (double)a.db_nlo[row] / (1.0 - FN_C);
@@ -619,9 +621,9 @@ __global__ void __launch_bounds__(256) k_fn_exact_min(FnxArgs a, int n_rec_cap) 
 // pass 2: smallest row among the records that attain it (exact ties -> smaller index, as the oracle's heap orders them)
 __global__ void __launch_bounds__(256) k_fn_exact_arg(FnxArgs a, int n_rec_cap) {
     const int r = blockIdx.x * 256 + threadIdx.x;
-    int q, row; double d;
-    if (r >= n_rec_cap || !fn_record(a, r, &q, &row, &d)) return;
-    if ((unsigned long long)__double_as_longlong(d) == a.best_d[q]) atomicMin(&a.out[a.perm_q ? a.perm_q[q] : q], (int)(a.perm_db ? a.perm_db[row] : row));
+    int q, row;
+    if (r >= n_rec_cap || !fn_record(a, r, &q, &row)) return;
+    if ((unsigned long long)__double_as_longlong(a.rec_d[r]) == a.best_d[q]) atomicMin(&a.out[a.perm_q ? a.perm_q[q] : q], (int)(a.perm_db ? a.perm_db[row] : row));
 }
 // pass 3: zero queries take the first zero row; a query without any record (empty database) gets -1
 __global__ void __launch_bounds__(256) k_fn_finish(FnxArgs a) {
@@ -636,11 +638,11 @@ __global__ void __launch_bounds__(256) k_fn_finish(FnxArgs a) {
 size_t pcr_feature_nn_scratch_bytes(int64_t n0, int64_t n1) {
     const size_t p0 = ((size_t)n0 + FN_QPG) / FN_QPG * FN_QPG, p1 = ((size_t)n1 + FN_QPG) / FN_QPG * FN_QPG;
     const size_t per_row = 2 * FN_K * sizeof(_Float16) + 2 * sizeof(float);                 // both forms + two norms
-    const size_t per_query = (size_t)FN_POOL_PER_QUERY * 13 + 8 + 4 + 16;                   // records, best distance, bound, chunk table share
+    const size_t per_query = (size_t)FN_POOL_PER_QUERY * 21 + 8 + 4 + 16;                   // records (+ exact distances), best distance, bound, chunk table share
     // tile pruning: principal coordinates, keys / values (in, out) and sort scratch per row; boxes; the (query tile x row tile) bound matrix
     const size_t prune_rows = (p0 + p1) * (FN_D * sizeof(float) + 2 * (8 + 4)) + pcr_sort_temp_bytes(p0 > p1 ? p0 : p1) + (p0 + p1) / 64 * (2 * FN_D * 4 + 64);
     const size_t lmat = (p0 / 64 + 64) * (p1 / 64 + 64) * sizeof(float);
-    return (p0 + p1) * per_row + (p0 > p1 ? p0 : p1) * per_query + (size_t)(2048 + 64 * 9) * 8 * FN_CHUNK * 13 + (1u << 22) + prune_rows
+    return (p0 + p1) * per_row + (p0 > p1 ? p0 : p1) * per_query + (size_t)(4608 + 64 * 9) * 8 * FN_CHUNK * 21 + (1u << 22) + prune_rows
            + (lmat <= ((size_t)512 << 20) ? lmat : 0) + (1u << 20);
 }
 
@@ -660,45 +662,47 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
     PCR_LAUNCH(ctx, k_fn_colsum, dim3(nbm), dim3(256), 0, ctx->stream, f0, n0, part);
     PCR_LAUNCH(ctx, k_fn_colsum, dim3(nbm), dim3(256), 0, ctx->stream, f1, n1, part + (size_t)nbm * FN_PC);
     PCR_LAUNCH(ctx, k_fn_mean, dim3(1), dim3(64), 0, ctx->stream, part, nbm, n0, mu);
-    {   // the f16 split holds |f - mu| * 128 < 65504: true for FPFH (bins <= 200); anything else takes the float64 path
-        double h[FN_PC];
-        PCR_HIP_CHECK(ctx, hipMemcpyAsync(h, mu, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-        PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        double mm = 0; for (int k = 0; k < FN_D; k++) mm = fmax(mm, fabs(h[k]));
-        if (!((h[FN_D] + mm) * FN_SCALE < 60000.0)) return PCR_ECAPACITY;
-    }
-    int *first_zero = arena<int>(ctx, 2), *flags = arena<int>(ctx, 2);
-    if (!first_zero || !flags) return PCR_ENOMEM;
-    PCR_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)first_zero, 0x7fffffff, 2, ctx->stream));
-    PCR_HIP_CHECK(ctx, hipMemsetAsync(flags, 0, 2 * sizeof(int), ctx->stream));
     for (int c = 0; c < 2; c++) np[c] = (n[c] + FN_QPG - 1) / FN_QPG * FN_QPG;   // multiple of 512 (queries per workgroup) and of 64 (rows per step)
-    // ---- tile pruning: worth its set-up (two small sorts, a host eigen-decomposition) from ~32k rows per side; the bound matrix must fit
+    // ---- tile pruning: worth its set-up (two small sorts, a host eigen-decomposition) from ~55k x 55k rows (40k x 40k: 2.8 ms with, 2.6 ms
+    // without; 100k x 100k: 5.7 / 8.1 ms; 200k x 200k: 12.1 / 25.9 ms); the bound matrix must fit
     static const int prune_env_ = getenv("PCR_FEATNN_PRUNE") ? atoi(getenv("PCR_FEATNN_PRUNE")) : -1;
     const int prune_env = prune_mode >= 0 ? prune_mode : prune_env_;
     const size_t lmat_bytes = (size_t)(np[0] / 64 + 64) * (size_t)(np[1] / 64 + 64) * sizeof(float);
-    const bool prune = prune_env == 0 ? false : ((prune_env > 0 || (n0 >= 32768 && n1 >= 32768)) && lmat_bytes <= ((size_t)512 << 20) && n0 >= 64 && n1 >= 64);
-    uint32_t *perm[2] = {nullptr, nullptr};
-    float *blo[2] = {nullptr, nullptr}, *bhi[2] = {nullptr, nullptr};
-    int tile_stride[2] = {0, 0};
-    float eps2 = 0.0f;
-    if (prune) {
-        // principal axes of the centred features of both clouds together: raw second moments on the device, 33 x 33 Jacobi on the host
-        const int nbg = 128;
-        double *gpart = arena<double>(ctx, (size_t)2 * nbg * FN_NG + 2 * FN_NG);
-        double *rot = arena<double>(ctx, FN_D * FN_D + 2 * FN_MD);
-        if (!gpart || !rot) return PCR_ENOMEM;
-        double *gsum = gpart + (size_t)2 * nbg * FN_NG;
-        std::vector<double> hcs((size_t)2 * nbm * FN_PC), hg((size_t)2 * FN_NG);
+    const bool prune = prune_env == 0 ? false : ((prune_env > 0 || (double)n0 * (double)n1 >= 3.0e9) && lmat_bytes <= ((size_t)512 << 20) && n0 >= 64 && n1 >= 64);
+    const int nbg = 128;
+    double *gpart = nullptr, *gsum = nullptr;
+    std::vector<double> hcs((size_t)2 * nbm * FN_PC), hg((size_t)2 * FN_NG);
+    double hmu[FN_PC];
+    if (prune) {   // raw second moments of both feature matrices (the principal axes come from them on the host)
+        gpart = arena<double>(ctx, (size_t)2 * nbg * FN_NG + 2 * FN_NG);
+        if (!gpart) return PCR_ENOMEM;
+        gsum = gpart + (size_t)2 * nbg * FN_NG;
         for (int c = 0; c < 2; c++) {
             PCR_LAUNCH(ctx, k_fn_gram, dim3(nbg), dim3(576), 0, ctx->stream, f[c], n[c], gpart + (size_t)c * nbg * FN_NG);
             PCR_LAUNCH(ctx, k_fn_gram_final, dim3(1), dim3(576), 0, ctx->stream, gpart + (size_t)c * nbg * FN_NG, nbg, gsum + (size_t)c * FN_NG);
         }
         PCR_HIP_CHECK(ctx, hipMemcpyAsync(hg.data(), gsum, sizeof(double) * hg.size(), hipMemcpyDeviceToHost, ctx->stream));
         PCR_HIP_CHECK(ctx, hipMemcpyAsync(hcs.data(), part, sizeof(double) * hcs.size(), hipMemcpyDeviceToHost, ctx->stream));
-        double hmu[FN_PC];
+    }
+    {   // the f16 split holds |f - mu| * 128 < 65504: true for FPFH (bins <= 200); anything else takes the float64 path
         PCR_HIP_CHECK(ctx, hipMemcpyAsync(hmu, mu, sizeof hmu, hipMemcpyDeviceToHost, ctx->stream));
         PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        double mm = 0; for (int k = 0; k < FN_D; k++) mm = fmax(mm, fabs(hmu[k]));
+        if (!((hmu[FN_D] + mm) * FN_SCALE < 60000.0)) return PCR_ECAPACITY;
+    }
+    int *first_zero = arena<int>(ctx, 2), *flags = arena<int>(ctx, 2);
+    if (!first_zero || !flags) return PCR_ENOMEM;
+    PCR_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)first_zero, 0x7fffffff, 2, ctx->stream));
+    PCR_HIP_CHECK(ctx, hipMemsetAsync(flags, 0, 2 * sizeof(int), ctx->stream));
+    uint32_t *perm[2] = {nullptr, nullptr};
+    float *blo[2] = {nullptr, nullptr}, *bhi[2] = {nullptr, nullptr};
+    int tile_stride[2] = {0, 0};
+    float eps2 = 0.0f;
+    if (prune) {
+        // principal axes of the centred features of both clouds together: 33 x 33 Jacobi on the host
         const double N = (double)n0 + (double)n1;
+        double Ng = 0.0;                 // rows that entered the second moments: blocks of 32 rows, block b taken iff (b / nbg) % FN_GRAM_SKIP == 0
+        for (int c = 0; c < 2; c++) for (long long b = 0; b * 32 < n[c]; b++) if ((b / nbg) % FN_GRAM_SKIP == 0) Ng += (double)std::min<long long>(32, n[c] - b * 32);
         double m[FN_D];
         for (int k = 0; k < FN_D; k++) { double v = 0; for (int b = 0; b < 2 * nbm; b++) v += hcs[(size_t)b * FN_PC + k]; m[k] = v / N; }
         std::vector<double> C((size_t)FN_D * FN_D), V((size_t)FN_D * FN_D);
@@ -706,7 +710,7 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         {
             int t = 0;
             for (int a_ = 0; a_ < FN_D; a_++)
-                for (int b_ = a_; b_ < FN_D; b_++, t++) { const double v = (hg[t] + hg[FN_NG + t]) / N - m[a_] * m[b_]; C[(size_t)a_ * FN_D + b_] = v; C[(size_t)b_ * FN_D + a_] = v; }
+                for (int b_ = a_; b_ < FN_D; b_++, t++) { const double v = (hg[t] + hg[FN_NG + t]) / Ng - m[a_] * m[b_]; C[(size_t)a_ * FN_D + b_] = v; C[(size_t)b_ * FN_D + a_] = v; }
         }
         fn_jacobi(C.data(), V.data(), ev);
         double hrot[FN_D * FN_D + 2 * FN_MD];
@@ -719,8 +723,8 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
             hrot[FN_D * FN_D + 2 * k] = centre - 3.0 * sg;
             hrot[FN_D * FN_D + 2 * k + 1] = sg > 0 ? (double)(1 << FN_MB) / (6.0 * sg) : 0.0;
         }
-        PCR_HIP_CHECK(ctx, hipMemcpyAsync(rot, hrot, sizeof hrot, hipMemcpyHostToDevice, ctx->stream));
-        PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));                                        // hrot is a stack array
+        const double *rot = pcr_desc_upload<double>(ctx, hrot, FN_D * FN_D + 2 * FN_MD);              // through the pinned ring: no second wait
+        if (!rot) return PCR_EHIP;
         // float32 rounding of a stored coordinate: |P| <= |x| <= sqrt(33) * largest |x_k|
         double mm = 0; for (int k = 0; k < FN_D; k++) mm = fmax(mm, fabs(hmu[k]));
         eps2 = (float)(2.0 * 1.2e-7 * std::sqrt((double)FN_D) * (hmu[FN_D] + mm) * FN_SCALE * 1.01);
@@ -759,7 +763,9 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         const int pre = prune ? 0 : (steps <= 128 ? steps : 64);
         const int rest = steps - pre;
         int splits = rest > 0 ? (2048 + groups - 1) / groups : 1;
-        if (prune) splits = (splits + 1) / 2;                                        // a list holds ~1/5 of its range: fewer, longer ranges
+        if (prune && rest > 0) splits = (4608 + groups - 1) / groups;                // lists hold ~1/5 of their range and differ in length: more, shorter
+                                                                                     //   ranges balance better (200k x 200k: 13.4 / 12.6 / 12.1 / 12.3 ms for 4 / 8 / 12 / 16)
+        { static const int se = getenv("PCR_FEATNN_SPLITS") ? atoi(getenv("PCR_FEATNN_SPLITS")) : 0; if (se > 0) splits = se; }
         if (splits > 256) splits = 256;
         if (splits < (rest + FN_LIST_CAP - 1) / FN_LIST_CAP) splits = (rest + FN_LIST_CAP - 1) / FN_LIST_CAP;
         if (splits > rest) splits = rest > 0 ? rest : 1;
@@ -772,7 +778,8 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         int *rec_q = arena<int>(ctx, pool_cap), *rec_row = arena<int>(ctx, pool_cap); float *rec_w = arena<float>(ctx, pool_cap);
         int *Ug = arena<int>(ctx, nqp);
         unsigned long long *best_d = arena<unsigned long long>(ctx, nq);
-        if (!pool_used || !chunk_fill || !rec_q || !rec_row || !rec_w || !Ug || !best_d) return PCR_ENOMEM;
+        double *rec_d = arena<double>(ctx, pool_cap);
+        if (!pool_used || !chunk_fill || !rec_q || !rec_row || !rec_w || !Ug || !best_d || !rec_d) return PCR_ENOMEM;
         PCR_HIP_CHECK(ctx, hipMemsetAsync(pool_used, 0, sizeof(int), ctx->stream));
         PCR_HIP_CHECK(ctx, hipMemsetAsync(chunk_fill, 0, sizeof(int) * (size_t)(pool_cap / FN_CHUNK), ctx->stream));
         PCR_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)Ug, 0x7f800000, nqp, ctx->stream));       // +inf
@@ -815,7 +822,7 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         FnxArgs x;
         x.q = f[qc]; x.q_nrm = nrm[qc]; x.n_q = nq; x.db = f[dc]; x.n_db = n[dc]; x.db_nlo = nlo[dc]; x.db_first_zero = first_zero + dc; x.Ug = Ug;
         x.pool_used = pool_used; x.chunk_fill = chunk_fill; x.rec_q = rec_q; x.rec_row = rec_row; x.rec_w = rec_w; x.best_d = best_d; x.out = out; x.dbg = dbg;
-        x.perm_q = perm[qc]; x.perm_db = perm[dc];
+        x.perm_q = perm[qc]; x.perm_db = perm[dc]; x.rec_d = rec_d;
         // the record kernels cover the whole pool capacity (the used part is only known on the device); unused slots exit at once
         PCR_LAUNCH(ctx, k_fn_exact_min, dim3((pool_cap + 255) / 256), dim3(256), 0, ctx->stream, x, pool_cap);
         PCR_LAUNCH(ctx, k_fn_exact_arg, dim3((pool_cap + 255) / 256), dim3(256), 0, ctx->stream, x, pool_cap);
