@@ -120,7 +120,7 @@ static int ensure_stream(pcr_context *ctx) {
     ctx->stream = ctx->own_stream;
     return PCR_OK;
 }
-static int ensure_lanes(pcr_context *ctx, int lanes) {
+int pcr_ensure_lanes(pcr_context *ctx, int lanes) {
     if (!ctx->side_stream && hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return PCR_EHIP; }
     if (lanes > 1 && !ctx->side_stream2 && hipStreamCreateWithFlags(&ctx->side_stream2, hipStreamNonBlocking) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return PCR_EHIP; }
     return PCR_OK;
@@ -463,7 +463,7 @@ static int multiscale_batched(pcr_context *ctx, const float *src_xyz, const floa
     char *block_s = (char *)pcr_arena_alloc(ctx, blk_s), *block_t = (char *)pcr_arena_alloc(ctx, blk_t);
     int *cnt4 = arena<int>(ctx, 4 * 8);                  // per scale: voxel counts (source, target), clean counts (source, target)
     if (!block_s || !block_t || !cnt4) return PCR_ENOMEM;
-    PCR_TRY(ensure_lanes(ctx, 2));
+    PCR_TRY(pcr_ensure_lanes(ctx, 2));
     hipStream_t lane_t = ctx->side_stream, lane_s = ctx->side_stream2;
     struct LaneGuard {            // an early error return must not leave lane work running over a recycled arena
         hipStream_t a, b;
@@ -704,7 +704,7 @@ static int multiscale_gicp_impl(pcr_context *ctx, const float *src_xyz, const fl
         if (!blocks[r][0] || !blocks[r][1]) return PCR_ENOMEM;
     }
     static const int n_lanes = getenv("PCR_LANES") ? atoi(getenv("PCR_LANES")) : 2;
-    PCR_TRY(ensure_lanes(ctx, n_lanes));
+    PCR_TRY(pcr_ensure_lanes(ctx, n_lanes));
     hipStream_t lane_t = ctx->side_stream, lane_s = n_lanes > 1 ? ctx->side_stream2 : ctx->side_stream;
     struct LaneGuard {            // an early error return must not leave lane work running over a recycled arena
         hipStream_t a, b;

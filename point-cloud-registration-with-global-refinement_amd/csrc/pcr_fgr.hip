@@ -972,6 +972,8 @@ extern "C" int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, cons
 
 // ---- registro_FGR in one call (ALL_FUNCTIONS.py:178-203): every cloud is sorted and indexed once; its tree serves the hybrid
 // normals, the FPFH neighbour lists and (target) the final evaluate_registration
+static int fgr_tail(pcr_context *ctx, DevCloud *c, uint32_t **perm, float **feat, const float *src_xyz, const float *tgt_xyz, int64_t ns, int64_t nt,
+                    const pcr_fgr_params *p, pcr_result *result, int32_t *correspondences);
 int pcr_registro_fgr_impl(pcr_context *ctx, const float *src_xyz, const float *src_prior, int64_t ns, const float *tgt_xyz, const float *tgt_prior, int64_t nt,
                           const pcr_fgr_params *p, float *src_normals_out, float *tgt_normals_out, pcr_result *result, int32_t *correspondences) {
     if (!p || !result) return PCR_EINVAL;
@@ -981,21 +983,46 @@ int pcr_registro_fgr_impl(pcr_context *ctx, const float *src_xyz, const float *s
     const int fk = p->feature_max_nn > 0 && p->feature_max_nn <= 200 ? p->feature_max_nn : 1;
     const size_t per_cloud = fpfh_scratch_bytes(ns > nt ? ns : nt, fk);
     const size_t fgr_b = fgr_scratch_bytes(ns, nt, &p->option);
-    PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(ns) + pcr_scratch_bytes_for(nt) + (size_t)(ns + nt + 2) * (33 * 4 + 16 + 8) + (per_cloud > fgr_b ? per_cloud : fgr_b)));
-    DevCloud c[2]; uint32_t *perm[2] = {nullptr, nullptr}; float *feat[2];
+    // the target cloud's chain (import, normals, FPFH) runs on the side lane in a block of its own while the source's runs on the
+    // context's stream: their k-NN kernels fill the chip either way, the sorts, tree builds and tails overlap
+    const size_t lane_block = nt > 0 ? pcr_scratch_bytes_for(nt) + (size_t)(nt + 2) * (33 * 4 + 16 + 8) + fpfh_scratch_bytes(nt, fk) + (1u << 20) : 0;
+    const size_t own_fpfh = fpfh_scratch_bytes(ns, fk);
+    PCR_TRY(pcr_arena_reserve(ctx, pcr_scratch_bytes_for(ns) + (size_t)(ns + 2) * (33 * 4 + 16 + 8) + lane_block + (own_fpfh > fgr_b ? own_fpfh : fgr_b) + (1u << 20)));
+    DevCloud c[2]; uint32_t *perm[2] = {nullptr, nullptr}; float *feat[2] = {nullptr, nullptr};
     const float *xyz[2] = {src_xyz, tgt_xyz}, *prior[2] = {src_prior, tgt_prior}; float *nout[2] = {src_normals_out, tgt_normals_out};
     const int64_t n[2] = {ns, nt};
-    for (int k = 0; k < 2; k++) {
+    auto cloud_chain = [&](int k) -> int {
         PCR_TRY(pcr_import_cloud(ctx, xyz[k], prior[k], n[k], &c[k], &perm[k], true));
         float4 *nrm_new = arena<float4>(ctx, n[k] > 0 ? n[k] : 1);
         feat[k] = arena<float>(ctx, (size_t)(n[k] > 0 ? n[k] : 1) * 33);
         if (!nrm_new || !feat[k]) return PCR_ENOMEM;
-        if (n[k] == 0) continue;
+        if (n[k] == 0) return PCR_OK;
         PCR_TRY(pcr_dev_normals(ctx, &c[k], PCR_SEARCH_HYBRID, p->normal_max_nn, p->normal_radius, prior[k] ? c[k].nrm : nullptr, nrm_new, nullptr));
         c[k].nrm = nrm_new;
         if (nout[k]) PCR_TRY(pcr_dev_scatter_rows_f4_to_f3(ctx, nrm_new, perm[k], c[k].n, c[k].cap, nout[k]));
-        PCR_TRY(fpfh_of_cloud(ctx, c[k], perm[k], n[k], PCR_SEARCH_HYBRID, p->feature_max_nn, p->feature_radius, feat[k]));
+        return fpfh_of_cloud(ctx, c[k], perm[k], n[k], PCR_SEARCH_HYBRID, p->feature_max_nn, p->feature_radius, feat[k]);
+    };
+    static const bool two_lanes = !(getenv("PCR_FGR_LANES") && atoi(getenv("PCR_FGR_LANES")) < 2);
+    char *block = (two_lanes && nt > 0) ? (char *)pcr_arena_alloc(ctx, lane_block) : nullptr;
+    if (block) {
+        PCR_TRY(pcr_ensure_lanes(ctx, 1));
+        struct LaneGuard { hipStream_t a; ~LaneGuard() { (void)hipStreamSynchronize(a); } } guard{ctx->side_stream};   // no lane work over a recycled arena
+        PCR_HIP_CHECK(ctx, hipEventRecord(ctx->side_ev[0], ctx->stream));       // the inputs are ready once the caller's stream gets here
+        PCR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_ev[0], 0));
+        {
+            SideLane lane(ctx, block, lane_block, ctx->side_stream);
+            PCR_TRY(cloud_chain(1));
+            PCR_HIP_CHECK(ctx, hipEventRecord(ctx->side_ev[1], ctx->stream));
+        }
+        PCR_TRY(cloud_chain(0));
+        PCR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev[1], 0));
+        return fgr_tail(ctx, c, perm, feat, src_xyz, tgt_xyz, ns, nt, p, result, correspondences);
     }
+    for (int k = 0; k < 2; k++) PCR_TRY(cloud_chain(k));
+    return fgr_tail(ctx, c, perm, feat, src_xyz, tgt_xyz, ns, nt, p, result, correspondences);
+}
+static int fgr_tail(pcr_context *ctx, DevCloud *c, uint32_t **perm, float **feat, const float *src_xyz, const float *tgt_xyz, int64_t ns, int64_t nt,
+                    const pcr_fgr_params *p, pcr_result *result, int32_t *correspondences) {
     double T[16];
     PCR_TRY(fgr_pose(ctx, src_xyz, feat[0], ns, tgt_xyz, feat[1], nt, &p->option, T));
     int32_t *match = arena<int32_t>(ctx, ns > 0 ? ns : 1);

@@ -102,6 +102,8 @@ template <class A> static inline const A *pcr_desc_upload(pcr_context *ctx, cons
     return (const A *)d;
 }
 
+int pcr_ensure_lanes(pcr_context *ctx, int lanes);           // create the side stream(s) (pcr_api.hip)
+
 // ---- arena ------------------------------------------------------------------------------------
 int pcr_arena_reserve(pcr_context *ctx, size_t bytes);       // grow (sync + realloc) if needed, reset offset
 void *pcr_arena_alloc(pcr_context *ctx, size_t bytes);       // bump, 256-B aligned; nullptr if exhausted
