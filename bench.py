@@ -319,10 +319,12 @@ def fgr_roofline(prof):
     ms, flops, launches = prof[8], prof[9], prof[10]
     tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     return {"bound": "mfma", "achieved": tf, "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F16_MFMA_PEAK_TFLOPS, "traffic": None,
-            "kernel": "k_feature_nn_screen (33-D nearest feature, f16 hi/lo split MFMA screen; survivors re-checked in float64)",
+            "kernel": "k_feature_nn_screen (33-D nearest feature: f16 hi/lo split MFMA screen over the (query wavefront, 64-row tile) pairs whose "
+                      "boxes in principal coordinates are close enough, ~20 % of them; survivors re-checked in float64)",
             "flops_per_launch": flops / launches if launches else 0.0, "ms_per_launch_hip_events": ms / launches if launches else None,
-            "peak_note": "dense f16 MFMA peak; the screen spends 3 f16 products per float32-accurate product (128 of K per 33 dimensions), so 33/128 of the "
-                         "MFMA work is algorithmic; the float64 MFMA path it replaces peaks at 78.6 TFLOP/s"}
+            "peak_note": "algorithmic flops of the all-pairs search over the dense f16 MFMA peak.  The screen spends 3 f16 products per float32-accurate "
+                         "product (128 of K per 33 dimensions) but, with tile pruning, only on a fifth of the pairs; the float64 MFMA path it replaces "
+                         "peaks at 78.6 TFLOP/s"}
 
 
 def extras(args, P, syn, reg, est, crit, pairs, clouds, run_batch, pool_prof, pose_err, workload):
