@@ -38,7 +38,7 @@ def load(pat):
         d[r["Kernel_Name"]][r["Counter_Name"]].append((float(r["Counter_Value"]), dur))
     return d
 fetch, write, tcc = load("pmc_FETCH_SIZE"), load("pmc_WRITE_SIZE"), load("pmc_TCC_HIT_sum_TCC_MISS_sum")
-short = {"void k_icp_fused<1>(IcpArgs)": "k_icp_fused", "k_icp_nn(IcpArgs)": "k_icp_nn", "void k_icp_iter<0>(IcpArgs)": "k_icp_iter<GICP>", "void k_knn_batch<0, 4>(KnnBatch)": "k_knn_batch<SOR,4>",
+short = {"void k_icp_fused<512>(IcpArgs)": "k_icp_fused", "k_icp_nn(IcpArgs)": "k_icp_nn", "void k_icp_iter<0>(IcpArgs)": "k_icp_iter<GICP>", "void k_knn_batch<0, 4>(KnnBatch)": "k_knn_batch<SOR,4>",
          "void k_knn_batch<1, 4>(KnnBatch)": "k_knn_batch<NORMALS,4>", "k_normals_from_lists_batch(NflBatch)": "k_normals_from_lists_batch", "k_rs_scatter(unsigned long const*, unsigned int const*, int, int, int const*, unsigned long*, unsigned int*)": "k_rs_scatter"}
 rows, js = [], {}
 for full, name in short.items():
@@ -56,6 +56,27 @@ with open(dst + "_pmc_hbm_traffic.csv", "w", newline="") as fcsv:
     wr = csv.writer(fcsv); wr.writerow(["kernel", "live_launches", "FETCH_SIZE_KB_avg", "WRITE_SIZE_KB_avg", "hbm_bytes_per_launch_corrected", "L2_hit_rate", "avg_us_live_under_pmc"]); wr.writerows(rows)
 json.dump(js, open(dst + "_traffic.json", "w"), indent=1)
 for r in rows: print(r)
+PY
+# VALU issue per kernel and pair (one pair at a time, kernels serialised by the counter collection): which kernels the chip's VALU time goes to
+d=$OUT/pmc_valu
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES --output-format csv -d "$d" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 1 --warmup 1 --pairs-per-step 4 --inflight 1 --group 1 > "$d.log" 2> "$d.err" || exit 1
+python3 - "$OUT" "$ROOT/profiles/${TAG}" <<'PY'
+import csv, glob, sys, collections
+out, dst = sys.argv[1], sys.argv[2]
+f = glob.glob(f"{out}/pmc_valu/**/*counter_collection.csv", recursive=True)[0]
+d = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(f)):
+    d[r["Kernel_Name"]][r["Counter_Name"]].append((float(r["Counter_Value"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+npairs = max(1.0, len(d["void k_knn_batch<0, 4>(KnnBatch)"]["SQ_INSTS_VALU"]) / 2)          # two batched SOR searches per pair
+rows = sorted(((sum(x[0] for x in v["SQ_INSTS_VALU"]), k, len(v["SQ_INSTS_VALU"]), sum(x[1] for x in v["SQ_INSTS_VALU"])) for k, v in d.items()), reverse=True)
+tot = sum(r[0] for r in rows)
+PEAK = 256 * 4 * 2400 / 4.0                                                                  # wave64 VALU instructions per us: 1024 SIMDs, 4 cycles each at 2.4 GHz
+with open(dst + "_pmc_valu_per_pair.csv", "w", newline="") as fo:
+    w = csv.writer(fo)
+    w.writerow(["kernel", "launches_per_pair", "kernel_ms_per_pair_serialised", "valu_wave_instructions_per_pair_M", "share_of_valu_instructions", "valu_instructions_per_us", "share_of_peak_issue_614k_per_us"])
+    for insts, k, n, dur in rows[:20]:
+        w.writerow([k[:60], round(n / npairs, 1), round(dur / 1e3 / npairs, 3), round(insts / 1e6 / npairs, 1), round(insts / tot, 3), int(insts / dur), round(insts / dur / PEAK, 3)])
+    w.writerow(["TOTAL", "", round(sum(r[3] for r in rows) / 1e3 / npairs, 3), round(tot / 1e6 / npairs, 1), 1.0, "", ""])
 PY
 grep '^{"metric' "$OUT/bench_stats.log" | tail -1 > "$ROOT/gpurun_out/bench_under_rocprof_$TAG.json"
 # gpurun only merges gpurun_out/ back: export the files to commit there as well
