@@ -54,7 +54,7 @@ def _gather(results, n_pairs):
 
 
 def stage1_fgr(cloud_dir: str, out_dir: str, n_clouds: int, voxel_size: float = 0.1, pattern: str = "s{i}.pcd",
-               inflight: int = 3, seed=None, verbose: bool = True) -> list:
+               inflight: int = 8, seed=None, verbose: bool = True) -> list:
     """FGR over the circuit (script 1).  Returns the n relative poses; rank 0 writes them under `out_dir` with the
     names the later stages READ (`pose_0_{n-1}.txt` for the closure) and `%.10f` (S1:177)."""
     mine, rank = _shard(n_clouds)
@@ -80,7 +80,7 @@ def stage1_fgr(cloud_dir: str, out_dir: str, n_clouds: int, voxel_size: float = 
 
 
 def stage2_mgicp(cloud_dir: str, init_dir: str, out_dir: str, n_clouds: int, n_scales: int = 5, iterations: int = 100,
-                 pattern: str = "s{i}.pcd", inflight: int = 3, absolute_dir: str = None, verbose: bool = True):
+                 pattern: str = "s{i}.pcd", inflight: int = 4, absolute_dir: str = None, verbose: bool = True):
     """Multiscale GICP over the circuit from the stage-1 poses (script 2).  Returns (relative poses, absolute poses,
     per-pair records); rank 0 writes `pose_{i+1}_{i}.txt` (+ `pose_0_{n-1}.txt`) and, if asked, `pose{i}.txt`."""
     initial_T = io.load_relative_poses(init_dir, n_clouds)
@@ -145,11 +145,11 @@ def main(argv=None) -> int:
     ap = argparse.ArgumentParser(description="circuit drivers (stages 1-3 of the reference's scripts)")
     sub = ap.add_subparsers(dest="stage", required=True)
     a = sub.add_parser("stage1"); a.add_argument("--clouds", required=True); a.add_argument("--out", required=True)
-    a.add_argument("--n", type=int, required=True); a.add_argument("--voxel", type=float, default=0.1); a.add_argument("--inflight", type=int, default=3)
+    a.add_argument("--n", type=int, required=True); a.add_argument("--voxel", type=float, default=0.1); a.add_argument("--inflight", type=int, default=8)
     a.add_argument("--seed", type=int, default=None)
     b = sub.add_parser("stage2"); b.add_argument("--clouds", required=True); b.add_argument("--init", required=True); b.add_argument("--out", required=True)
     b.add_argument("--absolute", default=None); b.add_argument("--n", type=int, required=True); b.add_argument("--scales", type=int, default=5)
-    b.add_argument("--iterations", type=int, default=100); b.add_argument("--inflight", type=int, default=3)
+    b.add_argument("--iterations", type=int, default=100); b.add_argument("--inflight", type=int, default=4)
     c = sub.add_parser("stage3"); c.add_argument("--relative", required=True); c.add_argument("--n", type=int, required=True)
     c.add_argument("--out", default=None); c.add_argument("--groundtruth", default=None)
     args = ap.parse_args(argv)
