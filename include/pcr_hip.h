@@ -199,7 +199,7 @@ typedef struct {
     int32_t gicp_prior_from_fgr;
     double info_max_dist;
     int32_t inflight;
-    int32_t group;                                      /* > 1 (stage GICP): `group` consecutive pairs run in LOCKSTEP through the same
+    int32_t group;                                      /* > 1 (stages GICP and FGR + GICP, whose FGR part stays pair by pair): `group` consecutive pairs run in LOCKSTEP through the same
                                                            launches (blockIdx.y = pair: preprocessing batched over clouds and scales, one GICP loop per
                                                            scale for the whole group); `inflight` then counts groups.  Same per-pair arithmetic as the
                                                            pair-by-pair path (bit-identical at equal PCR_ICP_PPL; groups default to 2 points per lane); <= 32 */

@@ -880,8 +880,9 @@ extern "C" int pcr_register_pairs_plan(int device, pcr_pair_ex *pairs, int n_pai
     if (n_pairs == 0) return PCR_OK;
     if (hipSetDevice(device) != hipSuccess) return PCR_EHIP;
     const int inflight = plan->inflight;
-    // lockstep groups (stage GICP): `group` consecutive pairs go through the same launches, `inflight` groups in flight
-    const int group = (plan->stage == PCR_STAGE_GICP && plan->group > 1) ? (plan->group > 32 ? 32 : plan->group) : 1;
+    // lockstep groups: `group` consecutive pairs go through the same GICP launches, `inflight` groups in flight (stage FGR + GICP: the
+    // worker runs registro_FGR pair by pair and then the group's GICP in lockstep from the FGR poses)
+    const int group = ((plan->stage == PCR_STAGE_GICP || plan->stage == PCR_STAGE_FGR_GICP) && plan->group > 1) ? (plan->group > 32 ? 32 : plan->group) : 1;
     const int units = (n_pairs + group - 1) / group;
     const int workers = inflight < 1 ? 1 : (inflight > units ? units : (inflight > 16 ? 16 : inflight));
     // the workers wait for everything already enqueued on `after_stream` (NULL = the legacy default stream, which is what torch's
@@ -905,10 +906,61 @@ extern "C" int pcr_register_pairs_plan(int device, pcr_pair_ex *pairs, int n_pai
             if (group > 1 && cnt > 1) {
                 // `cnt` consecutive pairs through the same launches (lockstep group); rc 1: declined, pair by pair below
                 std::vector<pcr_pair_ex *> gp((size_t)cnt);
+                std::vector<pcr_pair_ex> staged;                   // stage FGR + GICP: copies that carry the FGR pose and normals into the group's GICP
                 for (int k = 0; k < cnt; k++) { gp[k] = &pairs[i + k]; pairs[i + k].base.error[0] = 0; }
+                rc_group = PCR_OK;
+                if (plan->stage == PCR_STAGE_FGR_GICP) {
+                    if (!plan->fgr) rc_group = 1;
+                    size_t need = 0;
+                    std::vector<size_t> off((size_t)cnt + 1, 0);
+                    for (int k = 0; k < cnt && rc_group == PCR_OK; k++) {
+                        const pcr_pair &p = pairs[i + k].base;
+                        if (plan->gicp_prior_from_fgr && !(pairs[i + k].src_normals_out && pairs[i + k].tgt_normals_out)) need += (size_t)(p.n_src + p.n_tgt + 2) * 3;
+                        off[k + 1] = need;
+                    }
+                    if (rc_group == PCR_OK && need * sizeof(float) > ctx->aux_cap)
+                        rc_group = pcr_api_call(ctx, [&]() -> int {
+                            PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                            if (ctx->aux) { PCR_HIP_CHECK(ctx, hipFree(ctx->aux)); ctx->aux = nullptr; ctx->aux_cap = 0; }
+                            if (hipMalloc((void **)&ctx->aux, need * sizeof(float) * 5 / 4) != hipSuccess) { ctx->err = "hipMalloc(aux)"; return PCR_ENOMEM; }
+                            ctx->aux_cap = need * sizeof(float) * 5 / 4;
+                            return PCR_OK;
+                        });
+                    staged.resize((size_t)cnt);
+                    for (int k = 0; k < cnt && rc_group == PCR_OK; k++) {
+                        pcr_pair_ex &px = pairs[i + k];
+                        float *sno = px.src_normals_out, *tno = px.tgt_normals_out;
+                        if (plan->gicp_prior_from_fgr && !(sno && tno)) {
+                            float *base = (float *)ctx->aux + off[k];
+                            if (!sno) sno = base;
+                            if (!tno) tno = base + (size_t)(px.base.n_src + 1) * 3;
+                        }
+                        const int rc = pcr_api_call(ctx, [&]() -> int {
+                            pcr_fgr_params fp = *plan->fgr;
+                            fp.option.seed = plan->fgr->option.seed + (uint64_t)(i + k);
+                            return pcr_registro_fgr_impl(ctx, px.base.src_xyz, px.base.src_normals, px.base.n_src, px.base.tgt_xyz, px.base.tgt_normals, px.base.n_tgt, &fp, sno, tno, &px.fgr, nullptr);
+                        });
+                        if (rc != PCR_OK) { rc_group = rc == PCR_EHIP ? rc : 1; break; }       // an argument error: pair by pair, so that it lands on its pair
+                        staged[k] = px;
+                        memcpy(staged[k].base.init_T, px.fgr.transformation, sizeof staged[k].base.init_T);
+                        if (plan->gicp_prior_from_fgr) { staged[k].base.src_normals = sno; staged[k].base.tgt_normals = tno; }
+                        gp[k] = &staged[k];
+                    }
+                }
+                if (rc_group == PCR_OK)
                 rc_group = pcr_api_call(ctx, [&]() -> int {
                     return multiscale_group(ctx, gp.data(), cnt, plan->voxel_sizes, plan->max_distances, plan->radius_rule, plan->n_scales, plan->sor_k, plan->sor_std, plan->normal_k, plan->gicp);
                 });
+                if (rc_group == PCR_OK && plan->stage == PCR_STAGE_FGR_GICP)
+                    for (int k = 0; k < cnt; k++) memcpy(pairs[i + k].max_distances, staged[k].max_distances, sizeof staged[k].max_distances);
+                if (rc_group == PCR_OK && plan->info_max_dist > 0.0)
+                    for (int k = 0; k < cnt && rc_group == PCR_OK; k++) {
+                        pcr_pair_ex &px = pairs[i + k];
+                        rc_group = pcr_api_call(ctx, [&]() -> int {
+                            return information_matrix_impl(ctx, px.base.src_xyz, px.base.n_src, px.base.tgt_xyz, px.base.n_tgt, plan->info_max_dist,
+                                                           px.base.records[plan->n_scales - 1].icp.transformation, px.info36);
+                        });
+                    }
                 if (rc_group == PCR_OK) {
                     for (int k = 0; k < cnt; k++) pairs[i + k].base.status = PCR_OK;
                 } else if (rc_group == PCR_EHIP) {          // a device error is not one pair's fault

@@ -250,8 +250,9 @@ def register_pairs_plan(pairs, stage: str = "gicp", voxel_sizes=None, max_corres
     stage "gicp"      = script 2 (2_MGICP...py:187-214): ``Multiscale_GICP`` from the given initial pose;
     stage "fgr+gicp"  = ``Coarse_to_fine_FGR_M_GICP`` / ``full_registration`` (ALL_FUNCTIONS.py:317-332, 349-392).
     radius_rule "af"  = search radii ``radius_from_cloud_pair * 2**-i`` per pair (ALL_FUNCTIONS.py:277-278) instead of the given list.
-    ``group`` > 1 (stage "gicp"): that many consecutive pairs run in LOCKSTEP through the same launches (preprocessing batched over
-    clouds and scales, one GICP loop per scale for the whole group; same per-pair arithmetic); ``inflight`` counts groups.
+    ``group`` > 1 (stages "gicp" and "fgr+gicp"): that many consecutive pairs run in LOCKSTEP through the same GICP launches (preprocessing
+    batched over clouds and scales, one GICP loop per scale for the whole group; same per-pair arithmetic; with "fgr+gicp" the worker runs
+    registro_FGR pair by pair first); ``inflight`` counts groups.
     ``group=None`` picks by cloud size, about 400k points per group (measured on one MI355X with 4 groups in flight, pair by pair ->
     groups: 20k-point pairs 680 -> 2190 pairs/s with groups of 12-16, 50k 540 -> 1080 with 6-8, 100k 440 -> 635 with 4, 200k 340 -> 410
     with 2).
@@ -276,6 +277,27 @@ def register_pairs_plan(pairs, stage: str = "gicp", voxel_sizes=None, max_corres
     if group is None:
         mean_pts = float(np.mean([len(s_) + len(t_) for s_, t_, _ in pairs])) / 2
         group = int(min(16, max(1, round(400_000 / max(mean_pts, 1.0)))))
+    if stage == "fgr+gicp" and group > 1 and n > 1:
+        # Two passes over the batch instead of FGR -> GICP pair by pair: registro_FGR is a chain of ~150 small launches with a few host
+        # waits and wants MANY pairs in flight (20k-point pairs: 230 / 590 / 700 pairs/s with 1 / 4 / 8), the GICP wants lockstep groups.
+        # Same arithmetic as the single call (same seeds per pair, the FGR normals as the orientation prior, the same radius rule).
+        def view(pc):                         # a cloud object of our own on the caller's tensors: the FGR normals land here, not on the caller's cloud
+            v = PointCloud(); v._xyz = pc.device_xyz(); v._nrm = pc.device_normals() if pc.has_normals() else None
+            return v
+        views = [(view(s_), view(t_), None) for s_, t_, _ in pairs]
+        fg = register_pairs_plan(views, "fgr", None, None, estimation, criteria, nb_neighbors, std_ratio, normal_knn, max(int(inflight), 8), False,
+                                 fgr_voxel_size, fgr_use_absolute_scale, fgr_seed, "given", False, 0.0, True, 1)
+        second = [((vs if prior_from_fgr else s_), (vt if prior_from_fgr else t_), f.transformation) for (vs, vt, _), (s_, t_, _), f in zip(views, pairs, fg)]
+        out = register_pairs_plan(second, "gicp", voxel_sizes, max_correspondence_distances, estimation, criteria, nb_neighbors, std_ratio, normal_knn, inflight,
+                                  with_correspondences, radius_rule=radius_rule, info_max_dist=info_max_dist, group=group)
+        for r, f, (vs, vt, _), (s_, t_, _) in zip(out, fg, views, pairs):
+            r.fgr = f
+            if keep_fgr_normals:              # the reference's side effect: both inputs gain normals
+                if len(s_):
+                    s_._nrm = vs._nrm
+                if len(t_):
+                    t_._nrm = vt._nrm
+        return out
     arr = (_lib.PcrPairEx * n)()
     keep = []                                   # device tensors and record arrays must outlive the call
     for k, (src, tgt, init) in enumerate(pairs):

@@ -32,6 +32,15 @@ def test_groups_are_bit_identical_at_equal_summation_grouping(rule):
         assert all(g == groups[0] for g in groups), (ppl, groups)
 
 
+def test_fgr_plus_gicp_groups_are_bit_identical():
+    """Stage FGR + GICP (Coarse_to_fine / full_registration, ALL_FUNCTIONS.py:317-332, 349-392) with lockstep groups: registro_FGR runs
+    pair by pair, the GICP of the group in lockstep from the FGR poses with the FGR normals as orientation prior and the AF radius rule,
+    then the information matrices -- the same bits as pair by pair when the iteration kernel's tile is the same."""
+    groups, _ = _helper({"PCR_ICP_TILE": "512", "GROUP_POSE_STAGE": "fgr+gicp", "GROUP_POSE_RULE": "af"})
+    assert len(groups) == 4
+    assert all(g == groups[0] for g in groups), groups
+
+
 def test_default_groups_agree_with_pair_by_pair():
     """Default policy (two source points per lane inside groups, one outside) only regroups the float64 sums: smooth loss, 1e-7."""
     _, poses = _helper({"GROUP_POSE_LOSS": "l2"})

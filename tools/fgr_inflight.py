@@ -1,5 +1,5 @@
 """registro_FGR (stage "fgr" of pcr_register_pairs_plan) on NCLT-size pairs: pairs/s against the pairs the library keeps in flight.
-usage: fgr_inflight.py [points] "f1 f2 ..." """
+usage: fgr_inflight.py [points] "f1 f2 ..." [stage: fgr | fgr+gicp] [group] """
 import importlib, os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,6 +9,8 @@ syn = importlib.import_module("point-cloud-registration-with-global-refinement_a
 reg = P.registration
 npts = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 fl = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "1 2 4 8 12 16").split()]
+stage = sys.argv[3] if len(sys.argv) > 3 else "fgr"
+group = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 base = [syn.make_pair(200000, index=i) for i in range(2)]
 import dataclasses
 sub = np.random.default_rng(7).permutation(200000)[:npts]
@@ -16,10 +18,12 @@ base = [dataclasses.replace(b, source=b.source[sub], target=b.target[sub]) for b
 pairs = [syn.derive_pair(base[k % 2], k // 2) for k in range(48)]
 clouds = [(P.PointCloud(p.source), P.PointCloud(p.target)) for p in pairs]
 def run(n, f):
-    return reg.register_pairs_plan([(clouds[i % 48][0], clouds[i % 48][1], None) for i in range(n)], "fgr", inflight=f, fgr_voxel_size=0.1, fgr_use_absolute_scale=False, fgr_seed=7,
-                                   with_correspondences=False)
+    return reg.register_pairs_plan([(clouds[i % 48][0], clouds[i % 48][1], None) for i in range(n)], stage, pairs[0].voxel_sizes, pairs[0].max_distances_script,
+                                   reg.TransformationEstimationForGeneralizedICP(reg.L1Loss()), reg.ICPConvergenceCriteria(1e-6, 1e-6, 100),
+                                   inflight=f, fgr_voxel_size=0.1, fgr_use_absolute_scale=False, fgr_seed=7, with_correspondences=False, radius_rule="af" if stage != "fgr" else "given",
+                                   prior_from_fgr=(stage != "fgr"), group=group)
 for f in fl:
     run(48, f); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(2): run(48, f)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"points {npts} stage fgr, {f} in flight: {96 / dt:.1f} pairs/s", flush=True)
+    print(f"points {npts} stage {stage}, groups of {group}, {f} in flight: {96 / dt:.1f} pairs/s", flush=True)

@@ -14,13 +14,17 @@ work = work + [(t, s, np.linalg.inv(T)) for s, t, T in work[:2]]        # 5 pair
 vox = P.script2.create_scales(5)
 loss = reg.L2Loss() if os.environ.get("GROUP_POSE_LOSS") == "l2" else reg.L1Loss()
 rule = "af" if os.environ.get("GROUP_POSE_RULE") == "af" else "given"
+stage = os.environ.get("GROUP_POSE_STAGE", "gicp")          # "fgr+gicp": registro_FGR per pair (fixed seeds), then the group's GICP from its poses, information matrices
 for g in (1, 2, 3, 8):
-    rs = reg.register_pairs_plan(work, "gicp", vox, P.script2.max_correspondence_distances(vox), reg.TransformationEstimationForGeneralizedICP(loss),
-                                 reg.ICPConvergenceCriteria(1e-6, 1e-6, 100), inflight=2, with_correspondences=True, group=g, radius_rule=rule)
+    rs = reg.register_pairs_plan(work, stage, vox, P.script2.max_correspondence_distances(vox), reg.TransformationEstimationForGeneralizedICP(loss),
+                                 reg.ICPConvergenceCriteria(1e-6, 1e-6, 100), inflight=2, with_correspondences=True, group=g, radius_rule=rule,
+                                 fgr_seed=77, prior_from_fgr=(stage != "gicp"), info_max_dist=(0.1 if stage != "gicp" else 0.0))
     h = hashlib.sha256()
     for r in rs:
         h.update(np.asarray(r.transformation).tobytes()); h.update(np.ascontiguousarray(r.correspondence_set).tobytes())
         h.update(repr([(s["iterations"], s["n_clean"], s["max_dist"]) for s in r.scales]).encode())
+        if stage != "gicp":
+            h.update(np.asarray(r.fgr.transformation).tobytes()); h.update(np.asarray(r.information).tobytes())
     print(f"GROUP {h.hexdigest()} fitness " + " ".join(f"{r.fitness:.6f}" for r in rs))
     if g == 1 or g == 3:
         print(f"POSES{g} " + " ".join(repr(float(v)) for r in rs for v in np.asarray(r.transformation).reshape(16)))
