@@ -13,16 +13,21 @@ est = P.registration.TransformationEstimationForGeneralizedICP(P.registration.L1
 crit = P.registration.ICPConvergenceCriteria(1e-6, 1e-6, 100)
 batch = [clouds[i % 2] for i in range(48)]
 n_blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-P.registration.register_pairs(batch, pairs[0].voxel_sizes, pairs[0].max_distances_script, est, crit, inflight=4)
+group = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+stage = sys.argv[3] if len(sys.argv) > 3 else "gicp"          # "fgr+gicp": registro_FGR (fixed seeds) in front, both passes of the Python mirror
+def run(corr):
+    return P.registration.register_pairs_plan(batch, stage, pairs[0].voxel_sizes, pairs[0].max_distances_script, est, crit, inflight=4, with_correspondences=corr, group=group,
+                                              fgr_seed=5, prior_from_fgr=(stage != "gicp"))
+run(True)
 torch.cuda.synchronize()
 free0 = torch.cuda.mem_get_info()[0]
 ref = None
 for b in range(n_blocks):
     t0 = time.perf_counter()
     for _ in range(5):
-        res = P.registration.register_pairs(batch, pairs[0].voxel_sizes, pairs[0].max_distances_script, est, crit, inflight=4, with_correspondences=False)
+        res = run(False)
     dt = time.perf_counter() - t0
     bits = [np.asarray(r.transformation).tobytes() for r in res[:2]]
     if ref is None: ref = bits
     assert bits == ref, "results changed between batches"
-    print(f"block {b}: {240 / dt:.1f} pairs/s, free device memory {torch.cuda.mem_get_info()[0] / 2**20:.0f} MiB (start {free0 / 2**20:.0f})", flush=True)
+    print(f"block {b} ({stage}, groups of {group}): {240 / dt:.1f} pairs/s, free device memory {torch.cuda.mem_get_info()[0] / 2**20:.0f} MiB (start {free0 / 2**20:.0f})", flush=True)
