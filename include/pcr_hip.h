@@ -258,7 +258,7 @@ int pcr_debug_gicp_linearize(pcr_context *ctx, const float *src_xyz, const float
                              double *stats3, int32_t *match /* device n_src, optional */);
 
 /* the mutual nearest-feature search of registro_FGR alone (33-D float32 rows, device): out_1to0[j] = row of f0 nearest to row j of f1,
- * out_0to1 likewise.  mode 0: f16-split MFMA screen + exact float64 re-check (production; with tile pruning from 32k rows per side),
+ * out_0to1 likewise.  mode 0: f16-split MFMA screen + exact float64 re-check (production; with tile pruning from ~70k rows per side),
  * 1: all-pairs float64 MFMA, 2: float32 brute force, 3 / 4: the screen with tile pruning forced on / off */
 int pcr_debug_feature_nn(pcr_context *ctx, const float *f0, int64_t n0, const float *f1, int64_t n1, int32_t *out_1to0, int32_t *out_0to1, int mode);
 

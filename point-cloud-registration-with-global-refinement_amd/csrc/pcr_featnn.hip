@@ -663,12 +663,12 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
     PCR_LAUNCH(ctx, k_fn_colsum, dim3(nbm), dim3(256), 0, ctx->stream, f1, n1, part + (size_t)nbm * FN_PC);
     PCR_LAUNCH(ctx, k_fn_mean, dim3(1), dim3(64), 0, ctx->stream, part, nbm, n0, mu);
     for (int c = 0; c < 2; c++) np[c] = (n[c] + FN_QPG - 1) / FN_QPG * FN_QPG;   // multiple of 512 (queries per workgroup) and of 64 (rows per step)
-    // ---- tile pruning: worth its set-up (two small sorts, a host eigen-decomposition) from ~55k x 55k rows (40k x 40k: 2.8 ms with, 2.6 ms
-    // without; 100k x 100k: 5.7 / 8.1 ms; 200k x 200k: 12.1 / 25.9 ms); the bound matrix must fit
+    // ---- tile pruning: worth its set-up (two small sorts, a host eigen-decomposition) from ~70k x 70k rows (60k x 60k: 4.1 ms with, 3.5 ms
+    // without; 80k: 4.6 / 5.4; 100k: 5.6 / 7.5; 200k x 200k: 12.1 / 25.9 ms); the bound matrix must fit
     static const int prune_env_ = getenv("PCR_FEATNN_PRUNE") ? atoi(getenv("PCR_FEATNN_PRUNE")) : -1;
     const int prune_env = prune_mode >= 0 ? prune_mode : prune_env_;
     const size_t lmat_bytes = (size_t)(np[0] / 64 + 64) * (size_t)(np[1] / 64 + 64) * sizeof(float);
-    const bool prune = prune_env == 0 ? false : ((prune_env > 0 || (double)n0 * (double)n1 >= 3.0e9) && lmat_bytes <= ((size_t)512 << 20) && n0 >= 64 && n1 >= 64);
+    const bool prune = prune_env == 0 ? false : ((prune_env > 0 || (double)n0 * (double)n1 >= 5.0e9) && lmat_bytes <= ((size_t)512 << 20) && n0 >= 64 && n1 >= 64);
     const int nbg = 128;
     double *gpart = nullptr, *gsum = nullptr;
     std::vector<double> hcs((size_t)2 * nbm * FN_PC), hg((size_t)2 * FN_NG);
@@ -771,8 +771,14 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         if (splits > rest) splits = rest > 0 ? rest : 1;
         const int sps = rest > 0 ? (rest + splits - 1) / splits : 0;
         if (sps > FN_LIST_CAP || pre > FN_LIST_CAP) return PCR_ECAPACITY;
+        int splits_all = (2048 + groups - 1) / groups;                                // the pass with records over ALL steps (unpruned form)
+        if (splits_all > 256) splits_all = 256;
+        if (splits_all < (steps + FN_LIST_CAP - 1) / FN_LIST_CAP) splits_all = (steps + FN_LIST_CAP - 1) / FN_LIST_CAP;
+        if (splits_all > steps) splits_all = steps;
+        const int sps_all = (steps + splits_all - 1) / splits_all;
+        if (sps_all > FN_LIST_CAP) return PCR_ECAPACITY;
         // capacity: records per query plus the chunk every wavefront of either pass may leave partly filled
-        const size_t waves = (size_t)groups * (FN_WG / 64) * (size_t)(1 + (rest > 0 ? splits : 0));
+        const size_t waves = (size_t)groups * (FN_WG / 64) * (size_t)(1 + (splits > splits_all ? splits : splits_all));
         const int pool_cap = (int)(((size_t)nqp * FN_POOL_PER_QUERY + waves * FN_CHUNK + FN_CHUNK - 1) / FN_CHUNK * FN_CHUNK);
         int *pool_used = arena<int>(ctx, 1), *chunk_fill = arena<int>(ctx, pool_cap / FN_CHUNK);
         int *rec_q = arena<int>(ctx, pool_cap), *rec_row = arena<int>(ctx, pool_cap); float *rec_w = arena<float>(ctx, pool_cap);
@@ -812,11 +818,25 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
             a.pre_mode = 0; a.step0 = 0; a.steps_per_split = sps; a.step_end = steps;
             PCR_LAUNCH(ctx, k_feature_nn_screen<false>, dim3(groups, splits), dim3(FN_WG), 0, ctx->stream, a);
         } else {
-            a.step0 = 0; a.steps_per_split = pre; a.step_end = pre;
-            PCR_LAUNCH(ctx, k_feature_nn_screen<false>, dim3(groups, 1), dim3(FN_WG), 0, ctx->stream, a);
-            if (rest > 0) {
-                a.step0 = pre; a.steps_per_split = sps; a.step_end = steps;
-                PCR_LAUNCH(ctx, k_feature_nn_screen<false>, dim3(groups, splits), dim3(FN_WG), 0, ctx->stream, a);
+            // Seeding the bounds: a sweep over the first 4096 rows that only lowers the queries' upper bounds (no candidates, no records)
+            // can be split over many workgroups -- the bounds meet in Ug by atomicMin -- where a pre-pass WITH records had to be one
+            // workgroup per 512 queries walking its 64 steps one after the other (200 us per direction when the grid is small: 20k rows are
+            // 40 workgroups).  The pass with records then covers every step, under those bounds.
+            static const int pre_bound = getenv("PCR_FEATNN_PREBOUND") ? atoi(getenv("PCR_FEATNN_PREBOUND")) : 2;
+            if (pre_bound == 2) {
+                const int pre_b = steps < 64 ? steps : 64, pb_splits = pre_b < 8 ? pre_b : 8, pb_sps = (pre_b + pb_splits - 1) / pb_splits;
+                a.step0 = 0; a.steps_per_split = pb_sps; a.step_end = pre_b;
+                PCR_LAUNCH(ctx, k_feature_nn_screen<true>, dim3(groups, pb_splits), dim3(FN_WG), 0, ctx->stream, a);
+                a.step0 = 0; a.steps_per_split = sps_all; a.step_end = steps;
+                PCR_LAUNCH(ctx, k_feature_nn_screen<false>, dim3(groups, splits_all), dim3(FN_WG), 0, ctx->stream, a);
+            } else {
+                a.step0 = 0; a.steps_per_split = pre; a.step_end = pre;
+                if (pre_bound == 1) PCR_LAUNCH(ctx, k_feature_nn_screen<true>, dim3(groups, 1), dim3(FN_WG), 0, ctx->stream, a);
+                PCR_LAUNCH(ctx, k_feature_nn_screen<false>, dim3(groups, 1), dim3(FN_WG), 0, ctx->stream, a);
+                if (rest > 0) {
+                    a.step0 = pre; a.steps_per_split = sps; a.step_end = steps;
+                    PCR_LAUNCH(ctx, k_feature_nn_screen<false>, dim3(groups, splits), dim3(FN_WG), 0, ctx->stream, a);
+                }
             }
         }
         FnxArgs x;

@@ -327,7 +327,7 @@ static int feature_nn(pcr_context *ctx, const float *db, int n_db, const float *
 }
 
 // test hook: the mutual nearest-feature search alone.  mode 0: f16-split screen + exact re-check (the production path; tile pruning
-// from 32k rows per side), 1: all-pairs float64 MFMA, 2: float32 brute force, 3: the screen with tile pruning forced on, 4: forced off
+// from ~70k rows per side), 1: all-pairs float64 MFMA, 2: float32 brute force, 3: the screen with tile pruning forced on, 4: forced off
 extern "C" int pcr_debug_feature_nn(pcr_context *ctx, const float *f0, int64_t n0, const float *f1, int64_t n1, int32_t *out_1to0, int32_t *out_0to1, int mode) {
     return pcr_api_call(ctx, [&]() -> int {
         if (n0 <= 0 || n1 <= 0 || !f0 || !f1 || !out_1to0 || !out_0to1) return PCR_EINVAL;
