@@ -65,6 +65,29 @@ def test_fgr_matches_oracle_on_identical_features(P, oracle, fgr_inputs, small_p
         assert a < 3e-2 and d < 0.5, (a, d)
 
 
+def test_fgr_with_features_that_overflow_the_record_pool(P, oracle, fgr_inputs):
+    """Blocks of hundreds of identical feature rows tie by the hundred: the screen's record pool overflows (PCR_ECAPACITY from the
+    search alone, checked) and the FGR entry point falls back to the all-pairs float64 search -- same pose as the oracle."""
+    import ctypes as C
+    import torch
+    (src, fs), (tgt, ft) = fgr_inputs
+    n = 3000
+    s_, t_ = src.select_by_index(np.arange(n)), tgt.select_by_index(np.arange(n))
+    f0 = fs._dev[:n].clone(); f1 = ft._dev[:n].clone()
+    f0[:900] = f0[0]; f1[:900] = f0[0]              # 900 x 900 exact ties
+    ctx = P._lib.Context.current()
+    o10 = torch.empty(n, dtype=torch.int32, device="cuda"); o01 = torch.empty(n, dtype=torch.int32, device="cuda")
+    rc = ctx.lib.pcr_debug_feature_nn(ctx.handle, C.c_void_p(f0.data_ptr()), C.c_int64(n), C.c_void_p(f1.data_ptr()), C.c_int64(n),
+                                      C.c_void_p(o10.data_ptr()), C.c_void_p(o01.data_ptr()), C.c_int(0))
+    assert rc == -5, rc                               # PCR_ECAPACITY: the screen alone reports the overflow
+    opt = P.registration.FastGlobalRegistrationOption(1.4, False, True, 0.2, 300, 0.95, int(n * 0.2), seed=99)
+    res = P.registration.registration_fgr_based_on_feature_matching(s_, t_, P.registration.Feature(f0), P.registration.Feature(f1), opt)
+    ref = oracle.registration_fgr(s_.points, f0.cpu().numpy().astype(np.float64), t_.points, f1.cpu().numpy().astype(np.float64), 1.4, False, True, 0.2, 300, 0.95,
+                                  int(n * 0.2), True, 99)
+    a, d = pose_error(res.transformation, ref.transformation)
+    assert a < 1e-7 and d < 1e-6, (a, d)
+
+
 def test_fgr_degenerate_centroid_alignment(P, fgr_inputs):
     (src, fs), (tgt, ft) = fgr_inputs
     # < 10 correspondences: identity in the normalised frame == centroid alignment only (Open3D behaviour)
@@ -231,7 +254,7 @@ def _exact_nn(db, q):
     return out
 
 
-@pytest.mark.parametrize("case", ["fpfh", "ties", "wide_norms", "small"])
+@pytest.mark.parametrize("case", ["fpfh", "ties", "wide_norms", "small", "degenerate", "lopsided"])
 def test_feature_nn_screen_is_exact(P, fgr_inputs, case):
     """pcr_featnn.hip: the f16-split MFMA screen + float64 re-check returns the exact float64 nearest feature row (ties -> smaller
     index) -- on real FPFH features, on adversarial inputs (blocks of exact duplicates and all-zero rows: candidate lists overflow
@@ -253,6 +276,12 @@ def test_feature_nn_screen_is_exact(P, fgr_inputs, case):
         f0 = f0[:2100].copy(); f1 = f1[:2000].copy()
         f0[::7] *= 0.01; f1[::5] *= 0.02      # tiny rows next to full-size ones
         f0[3::11] = np.minimum(f0[3::11] * 3.0, 200.0)
+    elif case == "degenerate":      # 25 distinct rows repeated (rank-deficient covariance: most principal axes are arbitrary; 40 exact ties per
+        f0 = np.tile(f0[:25], (40, 1)).copy(); f1 = np.tile(f1[:30], (20, 1)).copy()      # query, inside the record pool), one constant column
+        f0[:, 7] = 3.0; f1[:, 7] = 3.0
+        f1[::50] = f0[1]
+    elif case == "lopsided":        # 4000 rows against 130: many query tiles against three row tiles and the other way round
+        f0, f1 = f0[:4000], f1[:130]
     else:
         f0, f1 = f0[:65], f1[:67]
     d0 = torch.as_tensor(f0, device="cuda").contiguous(); d1 = torch.as_tensor(f1, device="cuda").contiguous()
