@@ -668,7 +668,8 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
     static const int prune_env_ = getenv("PCR_FEATNN_PRUNE") ? atoi(getenv("PCR_FEATNN_PRUNE")) : -1;
     const int prune_env = prune_mode >= 0 ? prune_mode : prune_env_;
     const size_t lmat_bytes = (size_t)(np[0] / 64 + 64) * (size_t)(np[1] / 64 + 64) * sizeof(float);
-    const bool prune = prune_env == 0 ? false : ((prune_env > 0 || (double)n0 * (double)n1 >= 5.0e9) && lmat_bytes <= ((size_t)512 << 20) && n0 >= 64 && n1 >= 64);
+    const bool prune = prune_env == 0 ? false : ((prune_env > 0 || (double)n0 * (double)n1 >= 5.0e9) && lmat_bytes <= ((size_t)512 << 20) && n0 >= 64 && n1 >= 64
+                                                   && np[0] / 64 < 65536 && np[1] / 64 < 65536);        // query tiles are blockIdx.y of k_fn_boxlb
     const int nbg = 128;
     double *gpart = nullptr, *gsum = nullptr;
     std::vector<double> hcs((size_t)2 * nbm * FN_PC), hg((size_t)2 * FN_NG);
