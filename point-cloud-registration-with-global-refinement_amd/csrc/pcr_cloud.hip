@@ -1157,20 +1157,20 @@ static int launch_knn_cap(pcr_context *ctx, int cap, KnnArgs a) {
     const size_t stamp_words = (size_t)grid.x * (KNN_BS / 64) * 24;
     if (stamp_path) {
         if (hipMalloc(&a.stamps, stamp_words * 8) != hipSuccess) return PCR_ENOMEM;
-        hipMemsetAsync(a.stamps, 0, stamp_words * 8, ctx->stream);
+        (void)hipMemsetAsync(a.stamps, 0, stamp_words * 8, ctx->stream);
     }
     struct StampDump {
         pcr_context *ctx; const char *path; unsigned long long *dev; size_t words; int mode, k;
         ~StampDump() {
             if (!path) return;
-            hipStreamSynchronize(ctx->stream);
+            (void)hipStreamSynchronize(ctx->stream);
             unsigned long long *h = (unsigned long long *)malloc(words * 8);
-            hipMemcpy(h, dev, words * 8, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(h, dev, words * 8, hipMemcpyDeviceToHost);
             if (FILE *f = fopen(path, "ab")) {
                 const unsigned long long hdr[4] = {0x5354414d50ull, (unsigned long long)mode, (unsigned long long)k, words / 24};
                 fwrite(hdr, 8, 4, f); fwrite(h, 8, words, f); fclose(f);
             }
-            free(h); hipFree(dev);
+            free(h); (void)hipFree(dev);
         }
     } dump{ctx, stamp_path, a.stamps, stamp_words, MODE, a.k};
     { static const int ss = getenv("PCR_KNN_SEED") ? atoi(getenv("PCR_KNN_SEED")) : -1; a.seed_span = ss; }
