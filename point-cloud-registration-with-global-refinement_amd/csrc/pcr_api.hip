@@ -793,9 +793,13 @@ std::mutex g_pool_mutex;
 std::vector<std::pair<int, pcr_context *>> g_pool;        // (device, idle context)
 pcr_context *pool_take(int device) {
     {
+        // the pooled context with the LARGEST arena: a call with fewer workers than the pool holds then reuses the same grown
+        // contexts every time (taking them in turn made every call re-grow arenas after a call with more workers had filled the pool)
         std::lock_guard<std::mutex> lock(g_pool_mutex);
+        size_t best = g_pool.size();
         for (size_t k = 0; k < g_pool.size(); k++)
-            if (g_pool[k].first == device) { pcr_context *c = g_pool[k].second; g_pool.erase(g_pool.begin() + k); return c; }
+            if (g_pool[k].first == device && (best == g_pool.size() || g_pool[k].second->arena_cap > g_pool[best].second->arena_cap)) best = k;
+        if (best < g_pool.size()) { pcr_context *c = g_pool[best].second; g_pool.erase(g_pool.begin() + best); return c; }
     }
     pcr_context *c = nullptr;
     return pcr_create(device, &c) == PCR_OK ? c : nullptr;
