@@ -742,14 +742,13 @@ template <int TILE_PTS> __global__ void __launch_bounds__(FUSED_BS) k_icp_fused_
 // 512 / 1024 / 2048).  The workgroup's 64 octets serve its pending queries 64 at a time, so a 512-point tile whose certificates do not
 // hold walks the tree up to 8 times in a row -- but that is NOT what the launch waits for: one pair alone, 25 iterations per scale,
 // 43.6 / 40.7 / 46.0 us per launch for tiles of 512 / 256 / 128 points (the slowest single walk is); lockstep groups of 2, four in
-// flight: 333 / 304 / 258 pairs/s for 1024 / 512 / 256.  One pair: 512 (the tile of k_icp_iter, so that PCR_ICP_FUSED=0 is the same
-// arithmetic); groups: 1024.
+// flight: 333 / 304 / 258 pairs/s for 1024 / 512 / 256.  One pair: 256 from 40k points (below: 512, the tile of k_icp_iter, so that
+// PCR_ICP_FUSED=0 stays the same arithmetic on NCLT-size clouds); groups: 1024.
 static int fused_tile_points(int cap, int G) {
     static const int fixed = getenv("PCR_ICP_TILE") ? atoi(getenv("PCR_ICP_TILE")) : (getenv("PCR_ICP_PPL") ? FUSED_BS * atoi(getenv("PCR_ICP_PPL")) : 0);
     int t = fixed;
     if (t <= 0) {
-        t = G > 1 ? 1024 : 512;
-        (void)cap;
+        t = G > 1 ? 1024 : (cap >= 40000 ? 256 : 512);
     }
     return t >= 2048 ? 2048 : (t >= 1024 ? 1024 : (t >= 512 ? 512 : (t >= 256 ? 256 : 128)));
 }
