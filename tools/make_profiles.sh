@@ -35,7 +35,9 @@ def load(pat):
     d = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-        d[r["Kernel_Name"]][r["Counter_Name"]].append((float(r["Counter_Value"]), dur))
+        name = r["Kernel_Name"]
+        if name.startswith("void k_icp_fused<") and name.endswith("(IcpArgs)"): name = "void k_icp_fused<512>(IcpArgs)"      # whatever the tile
+        d[name][r["Counter_Name"]].append((float(r["Counter_Value"]), dur))
     return d
 fetch, write, tcc = load("pmc_FETCH_SIZE"), load("pmc_WRITE_SIZE"), load("pmc_TCC_HIT_sum_TCC_MISS_sum")
 short = {"void k_icp_fused<512>(IcpArgs)": "k_icp_fused", "k_icp_nn(IcpArgs)": "k_icp_nn", "void k_icp_iter<0>(IcpArgs)": "k_icp_iter<GICP>", "void k_knn_batch<0, 4>(KnnBatch)": "k_knn_batch<SOR,4>",
