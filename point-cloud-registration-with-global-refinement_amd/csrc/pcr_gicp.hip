@@ -466,7 +466,7 @@ __device__ static inline void icp_point(const IcpArgs &a, const double *T, int i
 // ---- workgroup reduction of acc[], write-through partial row + ticket, and -- in the last-arriving workgroup -- the end of
 // the iteration: gather the rows, fixed-order sums, convergence test, 6x6 solve, pose update.  BS = workgroup size.
 template <int MODE, int BS>
-__device__ static inline void icp_finish(const IcpArgs &a, IcpState *st, const double *T, double *acc, int nb, int ns, int launches, unsigned long long t_entry) {
+__device__ static inline void icp_finish(const IcpArgs &a, IcpState *st, const double *T, double *acc, int nb, int ns, int launches, unsigned long long t_entry, int row) {
     __shared__ double red[BS / 16][NVP];           // one row per 16-lane DPP row
     __shared__ double fin[16][NVP];
     __shared__ int is_last;
@@ -485,11 +485,11 @@ __device__ static inline void icp_finish(const IcpArgs &a, IcpState *st, const d
         for (int w = 1; w < BS / 16; w++) s += red[w][threadIdx.x];
         // publish write-through (sc1): no per-workgroup release fence (a release = whole-L2 write-back; ~700 of
         // them per launch serialised to >100 us).  cdna_hip_programming.md Guideline 16, recipe R1.
-        __hip_atomic_store(&a.partials[(size_t)blockIdx.x * NVP + threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.partials[(size_t)row * NVP + threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (threadIdx.x == 63) {   // diagnostics in the two padding columns: ticks to end-of-search / end-of-reduction
-        __hip_atomic_store(&a.partials[(size_t)blockIdx.x * NVP + 30], (double)t_search, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&a.partials[(size_t)blockIdx.x * NVP + 31], (double)(wall_clock64() - t_entry), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.partials[(size_t)row * NVP + 30], (double)t_search, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.partials[(size_t)row * NVP + 31], (double)(wall_clock64() - t_entry), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its stores ...
     const unsigned long long t_drain = wall_clock64();
@@ -617,7 +617,7 @@ __device__ static inline void d_icp_iter(const IcpArgs &a) {
 #pragma unroll
     for (int k = 0; k < NV; k++) acc[k] = 0.0;
     for (int i = blockIdx.x * LIN_BS + threadIdx.x; i < ns; i += nb * LIN_BS) icp_point<MODE>(a, T, i, ns, a.match[i], acc);
-    icp_finish<MODE, LIN_BS>(a, st, T, acc, nb, ns, launches, t_entry);
+    icp_finish<MODE, LIN_BS>(a, st, T, acc, nb, ns, launches, t_entry, (int)blockIdx.x);
 }
 template <int MODE> __global__ void __launch_bounds__(LIN_BS) k_icp_iter(IcpArgs a) { d_icp_iter<MODE>(a); }
 template <int MODE> __global__ void __launch_bounds__(LIN_BS) k_icp_iter_g(const IcpArgs *a) { d_icp_iter<MODE>(a[blockIdx.y]); }
@@ -646,9 +646,16 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
     __shared__ int cand_l[TILE_PTS];           // candidate target point per local point after the search phase
     __shared__ int n_rec;
     const int done = st->done, launches = st->launches;
-    const int ns = *a.ns_ptr, nt = *a.nt_ptr;
     const int tid = threadIdx.x, lane = tid & 63, oct = lane >> 3, ol = lane & 7, ob = tid >> 3;
-    const int tile0 = blockIdx.x * TILE_PTS;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (round-robin dispatch), so XCD x takes the CONTIGUOUS tiles [x per, (x + 1) per) of
+    // the nb live ones: source tiles are in Morton order, an eighth of them is a compact region, and every XCD's L2 then holds its own
+    // part of the target tree instead of all of it (the grid is a multiple of 8 and covers 8 per; rows of the partial sums stay in tile
+    // order: same arithmetic)
+    const int ns = *a.ns_ptr, nt = *a.nt_ptr;
+    const int nb = (ns + TILE_PTS - 1) / TILE_PTS > 0 ? (ns + TILE_PTS - 1) / TILE_PTS : 1;
+    const int per = (nb + 7) >> 3;
+    const int bid = (int)(blockIdx.x >> 3) < per ? (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3) : nb;
+    const int tile0 = (bid < nb ? bid : 0) * TILE_PTS;
     float4 pf[PPL], refv[PPL]; int mraw[PPL], rb[PPL];
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
@@ -662,10 +669,9 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
     int mword = 0;
     if (tid < (int)(sizeof(OctMeta) / 4)) mword = ((const int *)a.tgt.meta)[tid];
     if (done) return;
-    const int nb = (ns + TILE_PTS - 1) / TILE_PTS > 0 ? (ns + TILE_PTS - 1) / TILE_PTS : 1;
-    if ((int)blockIdx.x >= nb) return;
+    if (bid >= nb) return;
     const unsigned long long t_entry = wall_clock64();
-    if (blockIdx.x == 0 && tid == 0) st->t_start = t_entry;
+    if (bid == 0 && tid == 0) st->t_start = t_entry;
     if (tid < (int)(sizeof(OctMeta) / 4)) ((int *)&m)[tid] = mword;
     if (tid == 0) n_rec = 0;
     __syncthreads();
@@ -733,7 +739,7 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
             icp_point<ICP_MODE_GICP>(a, T, i, ns, c, acc);
         }
     }
-    icp_finish<ICP_MODE_GICP, FUSED_BS>(a, st, T, acc, nb, ns, launches, t_entry);
+    icp_finish<ICP_MODE_GICP, FUSED_BS>(a, st, T, acc, nb, ns, launches, t_entry, bid);
 }
 template <int TILE_PTS> __global__ void __launch_bounds__(FUSED_BS) k_icp_fused(IcpArgs a) { d_icp_fused<TILE_PTS>(a); }
 template <int TILE_PTS> __global__ void __launch_bounds__(FUSED_BS) k_icp_fused_g(const IcpArgs *a) { d_icp_fused<TILE_PTS>(a[blockIdx.y]); }
@@ -808,7 +814,7 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     const int nbmax = (cap + LIN_BS - 1) / LIN_BS < LIN_MAX_BLOCKS ? (cap + LIN_BS - 1) / LIN_BS : LIN_MAX_BLOCKS;
     const int nbnn = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT);
     const int tile_pts = fused_tile_points(cap, 1);
-    const int nbf = (cap + tile_pts - 1) / tile_pts;                 // workgroups of the fused kernel: one per tile of source points
+    const int nbf = ((cap + tile_pts - 1) / tile_pts + 7) & ~7;      // workgroups of the fused kernel: one per tile of source points, a multiple of 8 (XCD order)
     IcpState *st = arena<IcpState>(ctx, 1);
     double *partials = arena<double>(ctx, (size_t)(nbmax > nbf ? nbmax : nbf) * NVP);
     int32_t *match = match_dev ? match_dev : arena<int32_t>(ctx, cap);
@@ -964,7 +970,7 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
     for (int g = 0; g < G; g++) {
         const int cap = src[g]->cap > 0 ? src[g]->cap : 1;
         const int m_ = (cap + LIN_BS - 1) / LIN_BS < LIN_MAX_BLOCKS ? (cap + LIN_BS - 1) / LIN_BS : LIN_MAX_BLOCKS;
-        const int n_ = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT), f_ = (cap + tile_pts - 1) / tile_pts;
+        const int n_ = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT), f_ = ((cap + tile_pts - 1) / tile_pts + 7) & ~7;
         nbmax = m_ > nbmax ? m_ : nbmax; nbnn = n_ > nbnn ? n_ : nbnn; nbf = f_ > nbf ? f_ : nbf;
         double *partials = arena<double>(ctx, (size_t)(m_ > f_ ? m_ : f_) * NVP);
         int32_t *match = (match_dev && match_dev[g]) ? match_dev[g] : arena<int32_t>(ctx, cap);
