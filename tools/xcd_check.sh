@@ -1,3 +1,4 @@
+# Diagnostic: one pair alone / default bench / FETCH_SIZE per launch of the fused iteration kernel (used for the XCD-aware tile order).
 ROOT=$(pwd)
 python bench.py --inflight 1 --group 1 --no-extras --no-cpu-baseline --steps 2 --warmup 1 --pairs-per-step 16 2>/dev/null | python -c "
 import sys, json
