@@ -87,7 +87,9 @@ __global__ void __launch_bounds__(256) k_fn_colsum(const float *__restrict__ f, 
     }
 }
 // mu[0..32] = column means of the first matrix, mu[33] = largest |value| over both
-__global__ void k_fn_mean(const double *__restrict__ part, int nb, int n, double *__restrict__ mu) {
+// (also resets the first-zero-row words and the overflow flags of the call: it runs before the splits that use them)
+__global__ void k_fn_mean(const double *__restrict__ part, int nb, int n, double *__restrict__ mu, int *__restrict__ first_zero, int *__restrict__ flags) {
+    if (threadIdx.x == 63) { first_zero[0] = 0x7fffffff; first_zero[1] = 0x7fffffff; flags[0] = 0; flags[1] = 0; }
     if (threadIdx.x < FN_PC) {
         double v = 0;
         for (int k = 0; k < 2 * nb; k++) {
@@ -634,6 +636,16 @@ __global__ void __launch_bounds__(256) k_fn_finish(FnxArgs a) {
     else if (a.out[oq] == 0x7fffffff) a.out[oq] = -1;
 }
 
+// one launch instead of five memsets per direction (registro_FGR on NCLT-size clouds is bound by the rate of small dependent launches)
+__global__ void __launch_bounds__(256) k_fn_init(int *pool_used, int *chunk_fill, int n_chunks, int *Ug, int n_ug, unsigned long long *best_d, int32_t *out, int n_q,
+                                                 int *first_zero, int *flags) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) { *pool_used = 0; if (first_zero) { first_zero[0] = 0x7fffffff; first_zero[1] = 0x7fffffff; flags[0] = 0; flags[1] = 0; } }
+    if (i < n_chunks) chunk_fill[i] = 0;
+    if (i < n_ug) Ug[i] = 0x7f800000;                      // +inf
+    if (i < n_q) { best_d[i] = ~0ull; out[i] = 0x7fffffff; }
+}
+
 // ------------------------------------------------------------------------------------------------------------------ driver
 size_t pcr_feature_nn_scratch_bytes(int64_t n0, int64_t n1) {
     const size_t p0 = ((size_t)n0 + FN_QPG) / FN_QPG * FN_QPG, p1 = ((size_t)n1 + FN_QPG) / FN_QPG * FN_QPG;
@@ -661,7 +673,9 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
     double *mu = part + (size_t)2 * nbm * FN_PC;
     PCR_LAUNCH(ctx, k_fn_colsum, dim3(nbm), dim3(256), 0, ctx->stream, f0, n0, part);
     PCR_LAUNCH(ctx, k_fn_colsum, dim3(nbm), dim3(256), 0, ctx->stream, f1, n1, part + (size_t)nbm * FN_PC);
-    PCR_LAUNCH(ctx, k_fn_mean, dim3(1), dim3(64), 0, ctx->stream, part, nbm, n0, mu);
+    int *first_zero = arena<int>(ctx, 2), *flags = arena<int>(ctx, 2);
+    if (!first_zero || !flags) return PCR_ENOMEM;
+    PCR_LAUNCH(ctx, k_fn_mean, dim3(1), dim3(64), 0, ctx->stream, part, nbm, n0, mu, first_zero, flags);
     for (int c = 0; c < 2; c++) np[c] = (n[c] + FN_QPG - 1) / FN_QPG * FN_QPG;   // multiple of 512 (queries per workgroup) and of 64 (rows per step)
     // ---- tile pruning: worth its set-up (two small sorts, a host eigen-decomposition) from ~70k x 70k rows (60k x 60k: 4.1 ms with, 3.5 ms
     // without; 80k: 4.6 / 5.4; 100k: 5.6 / 7.5; 200k x 200k: 12.1 / 25.9 ms); the bound matrix must fit
@@ -691,10 +705,6 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         double mm = 0; for (int k = 0; k < FN_D; k++) mm = fmax(mm, fabs(hmu[k]));
         if (!((hmu[FN_D] + mm) * FN_SCALE < 60000.0)) return PCR_ECAPACITY;
     }
-    int *first_zero = arena<int>(ctx, 2), *flags = arena<int>(ctx, 2);
-    if (!first_zero || !flags) return PCR_ENOMEM;
-    PCR_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)first_zero, 0x7fffffff, 2, ctx->stream));
-    PCR_HIP_CHECK(ctx, hipMemsetAsync(flags, 0, 2 * sizeof(int), ctx->stream));
     uint32_t *perm[2] = {nullptr, nullptr};
     float *blo[2] = {nullptr, nullptr}, *bhi[2] = {nullptr, nullptr};
     int tile_stride[2] = {0, 0};
@@ -787,11 +797,11 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         unsigned long long *best_d = arena<unsigned long long>(ctx, nq);
         double *rec_d = arena<double>(ctx, pool_cap);
         if (!pool_used || !chunk_fill || !rec_q || !rec_row || !rec_w || !Ug || !best_d || !rec_d) return PCR_ENOMEM;
-        PCR_HIP_CHECK(ctx, hipMemsetAsync(pool_used, 0, sizeof(int), ctx->stream));
-        PCR_HIP_CHECK(ctx, hipMemsetAsync(chunk_fill, 0, sizeof(int) * (size_t)(pool_cap / FN_CHUNK), ctx->stream));
-        PCR_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)Ug, 0x7f800000, nqp, ctx->stream));       // +inf
-        PCR_HIP_CHECK(ctx, hipMemsetAsync(best_d, 0xff, sizeof(unsigned long long) * (size_t)nq, ctx->stream));
-        PCR_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)out, 0x7fffffff, nq, ctx->stream));
+        {
+            const int n_chunks = pool_cap / FN_CHUNK, n_init = std::max(std::max(n_chunks, nqp), nq);
+            PCR_LAUNCH(ctx, k_fn_init, dim3((n_init + 255) / 256), dim3(256), 0, ctx->stream, pool_used, chunk_fill, n_chunks, Ug, nqp, best_d, out, nq,
+                       (int *)nullptr, (int *)nullptr);
+        }
         if (dbg) PCR_HIP_CHECK(ctx, hipMemsetAsync(dbg, 0, 8, ctx->stream));
         FnnArgs a;
         a.dbA = A[dc]; a.db_nlo = nlo[dc]; a.n_db_pad = np[dc]; a.qB = B[qc]; a.q_nrm = nrm[qc]; a.n_q = nq; a.n_q_pad = nqp;
