@@ -3,13 +3,14 @@
 (BASELINE.json metric, config 2).
 
 One "step" = one pass of the hot path over one BATCH of --pairs-per-step (48) independent, DISTINCT pairs already resident in
-HBM, issued as ONE pcr_register_pairs_plan call (the library keeps --inflight pairs in flight); per pair the whole
+HBM, issued as ONE pcr_register_pairs_plan call (the library runs them as lockstep groups of --group pairs -- 2 at 200k
+points -- and keeps --inflight groups in flight); per pair the whole
 Multiscale_GICP body runs (voxel_down_sample -> remove_statistical_outlier(30, 1.0) -> estimate_normals(KNN 20) ->
 registration_generalized_icp(L1, 1e-6/1e-6/100) for voxels 0.4/0.2/0.1 m), exactly the reference's pair-time definition
 (2_MGICP...py:190-199).  value = pairs registered / wall time of the K steps.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--variant gicp|fgr] [--radius-rule script|af] [--config5]
-                    [--pairs-per-step 48] [--inflight 4] [--points 200000] [--no-cpu-baseline] [--no-extras]
+                    [--pairs-per-step 48] [--inflight 4] [--group 0=by size] [--points 200000] [--no-cpu-baseline] [--no-extras]
 
 --gpus N > 1: when no launcher has set RANK, this process starts N ranks itself (python -m torch.distributed.run, one fresh
 process per GPU) BEFORE anything touches HIP, forwards rank 0's JSON line and exits with the launcher's code.  Every rank
@@ -29,7 +30,7 @@ import subprocess
 import sys
 import time
 
-# Pairs in flight use 3 HIP streams each (GICP loop + two preprocessing lanes); the runtime maps streams onto
+# Pairs in flight use up to 3 HIP streams each (GICP loop + two preprocessing lanes; one in lockstep groups); the runtime maps streams onto
 # GPU_MAX_HW_QUEUES hardware queues (default 4) and streams sharing a queue serialise.  Must be set before HIP starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
