@@ -267,6 +267,20 @@ def main(argv=None) -> int:
         us_kernel = ik_us / live if live else None                                 # kernels' own s_memrealtime stamps
         achieved = bytes_per_launch / (us_event * 1e-6) / 1e9 if ev_launches else 0.0
         traffic_file = None
+        valu_file = None
+        vcsv = os.path.join(ROOT, "profiles", "r02_pmc_valu_per_pair.csv")         # what the PATH is bound by (the iteration kernel itself is latency-bound)
+        if os.path.exists(vcsv):
+            try:
+                import csv as _csv
+                rows = list(_csv.DictReader(open(vcsv)))
+                tot = [r for r in rows if r["kernel"] == "TOTAL"][0]
+                minst = float(tot["valu_wave_instructions_per_pair_M"])
+                valu_file = {"file": "profiles/r02_pmc_valu_per_pair.csv", "valu_wave_instructions_per_pair_M": minst,
+                             "ms_per_pair_at_peak_issue": minst / 614.4, "largest": {"kernel": rows[0]["kernel"], "share": float(rows[0]["share_of_valu_instructions"])},
+                             "note": "tracked rocprofv3 --pmc SQ_INSTS_VALU result, one pair at a time, not this run: the pairs/s of the path are bound by VALU issue "
+                                     "(1024 SIMDs x 1 wave64 instruction per 4 cycles at 2.4 GHz = 614.4 k instructions per us)"}
+            except Exception:       # noqa: BLE001 -- a tracked file must never cost the line
+                valu_file = None
         for name in ("r02_traffic.json", "r02_traffic.json"):                      # rocprofv3 --pmc passes (profiles/README.md); NOT measured in this run
             tj = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tj):
@@ -295,7 +309,7 @@ def main(argv=None) -> int:
                        "err_vs_planted_max_over_last_step": {k: float(max(pose_err(r, pairs[i % len(pairs)])[k] for i, r in enumerate(results))) for k in ("rad", "m")},
                        "gathered_records": int(len(gathered))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_from_profiles": traffic_file,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_from_profiles": traffic_file, "valu_from_profiles": valu_file,
                          "kernel": "k_icp_fused (one GICP iteration; the first launch of a scale is k_icp_nn + k_icp_iter)",
                          "bytes_per_launch": bytes_per_launch, "us_per_launch_hip_events": us_event,
                          "us_per_launch_in_kernel_clock": us_kernel, "us_per_launch_in_flight": us_in_flight,
