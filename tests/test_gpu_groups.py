@@ -85,3 +85,18 @@ def test_a_bad_pair_in_a_group_fails_alone():
         except RuntimeError as e:
             outs.append(("error", str(e)))
     assert outs[0] == outs[1]
+
+
+def test_group_none_sizes_groups_by_the_clouds(golden_pair_list):
+    """``group=None`` (what the stage-2 driver passes) picks about 400k points per group: on NCLT-size pairs one group holds all of them;
+    smooth loss: the poses agree with pair by pair to rounding."""
+    P = pkg(); reg = P.registration
+    vox = P.script2.create_scales(3); dst = P.script2.max_correspondence_distances(vox)
+    work = [(P.PointCloud(g["source"]), P.PointCloud(g["target"]), g["T_fgr"]) for g in golden_pair_list[:4]]
+    est = reg.TransformationEstimationForGeneralizedICP(reg.L2Loss()); crit = reg.ICPConvergenceCriteria(1e-6, 1e-6, 50)
+    a = reg.register_pairs_plan(work, "gicp", vox, dst, est, crit, inflight=2, group=None)
+    b = reg.register_pairs_plan(work, "gicp", vox, dst, est, crit, inflight=2, group=1)
+    for x, y in zip(a, b):
+        ang, d = pose_error(x.transformation, y.transformation)
+        assert ang < 1e-7 and d < 1e-6, (ang, d)
+        assert [s["n_clean"] for s in x.scales] == [s["n_clean"] for s in y.scales]
