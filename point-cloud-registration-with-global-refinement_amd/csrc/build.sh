@@ -8,7 +8,9 @@ OUT=../libpcr_hip.so
 objs=""
 for f in pcr_sort pcr_cloud pcr_gicp pcr_featnn pcr_fgr pcr_api; do
   [ -f $f.hip ] || continue
-  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ pcr_internal.h -nt $f.o ] || [ pcr_device.h -nt $f.o ] || [ pcr_octree.h -nt $f.o ] || [ ../../include/pcr_hip.h -nt $f.o ]; then
+  stale=0
+  for h in $f.hip *.h ../../include/pcr_hip.h; do [ $h -nt $f.o ] && stale=1; done
+  if [ ! -f $f.o ] || [ $stale = 1 ]; then
     echo "hipcc $f.hip"
     hipcc $FLAGS -c $f.hip -o $f.o
   fi

@@ -159,7 +159,7 @@ int pcr_alloc_cloud(pcr_context *ctx, DevCloud *c, int cap, bool with_nrm, bool 
     c->n = arena<int>(ctx, 1);
     c->keys = arena<uint64_t>(ctx, cc);
     if (!c->pts || !c->n || !c->keys || (with_nrm && !c->nrm)) return PCR_ENOMEM;
-    c->oct_child = nullptr; c->oct_nodes = nullptr; c->oct_up = nullptr; c->oct_meta = nullptr; c->leaf_of = nullptr; c->pinfo = nullptr;
+    c->oct_child = nullptr; c->oct_nodes = nullptr; c->oct_up = nullptr; c->oct_meta = nullptr; c->leaf_of = nullptr; c->pinfo = nullptr; c->oct_l1 = nullptr;
     if (with_tree) {
         const size_t nodes = oct_node_capacity(cc);
         c->oct_child = arena<int>(ctx, nodes);
@@ -168,7 +168,8 @@ int pcr_alloc_cloud(pcr_context *ctx, DevCloud *c, int cap, bool with_nrm, bool 
         c->oct_meta = arena<OctMeta>(ctx, 1);
         c->leaf_of = arena<int>(ctx, cc);
         c->pinfo = arena<int4>(ctx, cc);
-        if (!c->oct_child || !c->oct_nodes || !c->oct_up || !c->oct_meta || !c->leaf_of || !c->pinfo) return PCR_ENOMEM;
+        c->oct_l1 = arena<int2>(ctx, cc);
+        if (!c->oct_child || !c->oct_nodes || !c->oct_up || !c->oct_meta || !c->leaf_of || !c->pinfo || !c->oct_l1) return PCR_ENOMEM;
     }
     return PCR_OK;
 }

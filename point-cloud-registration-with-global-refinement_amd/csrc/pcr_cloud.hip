@@ -499,9 +499,16 @@ int pcr_dev_sort_cloud(pcr_context *ctx, const float *xyz, int64_t n, const doub
     const size_t tb = pcr_sort_temp_bytes(n);
     void *temp = pcr_arena_alloc(ctx, tb);
     if (!k0 || !k1 || !v0 || !temp) return PCR_ENOMEM;
+    // ONE lattice unit for the three axes (the largest extent over 2^16 cells): cubic Morton cells.  A unit per axis (round 1-2) made
+    // the cells of an NCLT-shaped cloud (235 x 235 x 12 m) 20 x flatter than wide, and the curve then cuts a ground patch into contour
+    // strips: 64 consecutive points had 408 distinct 30-NN neighbours instead of 209 (tools/knnw_stats.py).
     float s[3];
+    double emax = 0.0;
+    for (int d = 0; d < 3; d++) emax = b6[3 + d] - b6[d] > emax ? b6[3 + d] - b6[d] : emax;
+    static const bool iso = !(getenv("PCR_RAW_ISO") && atoi(getenv("PCR_RAW_ISO")) == 0);
     for (int d = 0; d < 3; d++) {
-        double e = b6[3 + d] - b6[d]; s[d] = e > 0 ? (float)(65535.0 / e) : 0.0f;
+        const double e = iso ? emax : b6[3 + d] - b6[d];
+        s[d] = e > 0 ? (float)(65535.0 / e) : 0.0f;
         out->key_org[d] = (float)b6[d]; out->key_unit[d] = e > 0 ? (float)(e / 65535.0) : 1.0f;
     }
     const int nb = (int)((n + BS - 1) / BS);
@@ -669,7 +676,7 @@ __device__ static inline void d_oct_leaf_boxes(const float4 *__restrict__ pts, c
 }
 // node j of level li (li >= 1), all 64 lanes of the wavefront call it with their octet's j (live: octet-uniform)
 __device__ static inline void oct_node_box(const OctMeta &m, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up, int li, int j, bool live, int ol,
-                                           int4 *__restrict__ pinfo = nullptr) {
+                                           int4 *__restrict__ pinfo = nullptr, int2 *__restrict__ l1 = nullptr) {
     const int a = live ? child[m.off[li] + j] : 0, b = live ? child[m.off[li] + j + 1] : 0;
     float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
     int pf = 0x7fffffff, pl = 0;                                   // first point / one past the last point of the node (level 1 only)
@@ -686,6 +693,7 @@ __device__ static inline void oct_node_box(const OctMeta &m, const int *__restri
         pf = min(pf, pcr_dpp_i<PCR_DPP_XOR1>(pf)); pf = min(pf, pcr_dpp_i<PCR_DPP_XOR2>(pf)); pf = min(pf, pcr_dpp_i<PCR_DPP_HMIRROR>(pf));
         pl = max(pl, pcr_dpp_i<PCR_DPP_XOR1>(pl)); pl = max(pl, pcr_dpp_i<PCR_DPP_XOR2>(pl)); pl = max(pl, pcr_dpp_i<PCR_DPP_HMIRROR>(pl));
         if (live) for (int i = pf + ol; i < pl; i += OCT) pinfo[i] = make_int4(j, pf, pl - pf, 1);
+        if (live && ol == 0 && l1) l1[j] = make_int2(pf, pl - pf);
     }
     if (live && ol == 0) {
         if (li == m.nl - 1) up[m.off[li] + j] = make_int4(0, 0, 1, 0);
@@ -694,11 +702,11 @@ __device__ static inline void oct_node_box(const OctMeta &m, const int *__restri
     }
 }
 __device__ static inline void d_oct_level_boxes(const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up, int li,
-                                                        int4 *__restrict__ pinfo) {
+                                                        int4 *__restrict__ pinfo, int2 *__restrict__ l1) {
     const int j = blockIdx.x * (BS / OCT) + (threadIdx.x >> 3);
     const bool live = li < meta->nl && j < meta->cnt[li];
     if (__ballot(live) == 0ull) return;
-    oct_node_box(*meta, child, boxes, up, li, j, live, threadIdx.x & 7, pinfo);
+    oct_node_box(*meta, child, boxes, up, li, j, live, threadIdx.x & 7, pinfo, l1);
 }
 // remaining (small) levels in ONE workgroup of 1024 threads = 128 octets, level by level
 __device__ static inline void d_oct_upper_boxes(const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up, int first_li) {
@@ -721,14 +729,14 @@ __device__ static inline void d_oct_upper_boxes(const OctMeta *__restrict__ meta
 #define OCT_BATCH PCR_MAX_BATCH
 struct OctBuildDesc {
     const uint64_t *keys; const int *n; signed char *ls; int *rows; OctMeta *meta; int *child; int *leaf_of;
-    const float4 *pts; float4 *nodes; int4 *up; int4 *pinfo; OctGeom g; int n_tiles, node_cap;
+    const float4 *pts; float4 *nodes; int4 *up; int4 *pinfo; int2 *l1; OctGeom g; int n_tiles, node_cap;
 };
 struct OctBuildBatch { OctBuildDesc a[OCT_BATCH]; };
 __device__ static inline void dd_oct_lstar(const OctBuildDesc &d) { if ((int)blockIdx.x >= d.n_tiles) return; d_oct_lstar(d.keys, d.n, d.ls, d.rows); }
 __device__ static inline void dd_oct_meta(const OctBuildDesc &d) { d_oct_meta(d.n, d.rows, d.n_tiles, d.node_cap, d.meta, d.child, d.g); }
 __device__ static inline void dd_oct_apply(const OctBuildDesc &d) { if ((int)blockIdx.x >= d.n_tiles) return; d_oct_apply(d.ls, d.meta, d.rows, d.child, d.leaf_of); }
 __device__ static inline void dd_oct_leaf(const OctBuildDesc &d) { d_oct_leaf_boxes(d.pts, d.meta, d.child, d.nodes, d.up, d.pinfo); }
-__device__ static inline void dd_oct_level1(const OctBuildDesc &d) { d_oct_level_boxes(d.meta, d.child, d.nodes, d.up, 1, d.pinfo); }
+__device__ static inline void dd_oct_level1(const OctBuildDesc &d) { d_oct_level_boxes(d.meta, d.child, d.nodes, d.up, 1, d.pinfo, d.l1); }
 __device__ static inline void dd_oct_upper(const OctBuildDesc &d) { d_oct_upper_boxes(d.meta, d.child, d.nodes, d.up, 2); }
 __global__ void __launch_bounds__(BS) k_oct_lstar(OctBuildBatch b) { dd_oct_lstar(b.a[blockIdx.y]); }
 __global__ void __launch_bounds__(256) k_oct_meta(OctBuildBatch b) { dd_oct_meta(b.a[blockIdx.y]); }
@@ -759,7 +767,7 @@ int pcr_dev_build_bvh_batch(pcr_context *ctx, DevCloud *const *cs, int count) {
         d.ls = arena<signed char>(ctx, c->cap); d.rows = arena<int>(ctx, (size_t)d.n_tiles * OCT_ROW);
         if (!d.ls || !d.rows) return PCR_ENOMEM;
         d.keys = c->keys; d.n = c->n; d.meta = c->oct_meta; d.child = c->oct_child; d.leaf_of = c->leaf_of;
-        d.pts = c->pts; d.nodes = c->oct_nodes; d.up = c->oct_up; d.pinfo = c->pinfo;
+        d.pts = c->pts; d.nodes = c->oct_nodes; d.up = c->oct_up; d.pinfo = c->pinfo; d.l1 = c->oct_l1;
         for (int a = 0; a < 3; a++) { d.g.org[a] = c->key_org[a]; d.g.unit[a] = c->key_unit[a]; }
         d.g.leaf_div = div;
         const int nbl = (int)((((size_t)c->cap / 2 + 1) * OCT + BS - 1) / BS);       // <= n/2 leaves (or 1), one octet each
@@ -779,7 +787,7 @@ int pcr_dev_build_bvh_batch(pcr_context *ctx, DevCloud *const *cs, int count) {
 int pcr_dev_build_bvh(pcr_context *ctx, DevCloud *c) { return pcr_dev_build_bvh_batch(ctx, &c, 1); }
 
 static inline OctView oct_view(const DevCloud *c) {
-    OctView v; v.pts = c->pts; v.nodes = c->oct_nodes; v.up = c->oct_up; v.meta = c->oct_meta; v.leaf_of = c->leaf_of; v.keys = c->keys; v.pinfo = c->pinfo;
+    OctView v; v.pts = c->pts; v.nodes = c->oct_nodes; v.up = c->oct_up; v.meta = c->oct_meta; v.leaf_of = c->leaf_of; v.keys = c->keys; v.pinfo = c->pinfo; v.l1rng = c->oct_l1;
     return v;
 }
 
@@ -943,11 +951,13 @@ struct KnnArgs {
     const float4 *prior; float4 *normals; float *cov6;   // normals
     int32_t *dbg_idx; float *dbg_d2; int32_t *dbg_cnt;   // debug (rows unsorted)
     int dbg_visits;                                      // debug: dbg_cnt <- traversal counters
-    int32_t *list_idx; float *list_d2;                   // SOR: optional k-best lists, 32 slots per query (octet layout)
+    int32_t *list_idx; int list_pitch;                   // k-best lists: rows of list_pitch int32 per query (-1: empty slot).  SOR: optional output (32);
+                                                         //   wavefront kernel (pcr_knn_wave.h): required, its working rows (scratch in the other modes)
     const uint8_t *todo;                                 // optional: only queries with todo[q] != 0 are processed
     unsigned long long *stamps;                          // diagnostics (PCR_KNN_STAMPS): 24 words per wavefront
     int seed_span;                                       // Morton-index half-width of the seed range (-1: k)
     int *zero_a, *zero_b;                                // optional counters of LATER kernels, zeroed here (saves two memset launches)
+    uint8_t *hard; int wave_budget;                      // wavefront kernel: optional, queries it gave up after wave_budget batches (1) or served (0)
     const uint8_t *keep; const int *pos;                 // optional: search only among points with keep[i] != 0; results and `todo`
                                                          //   are indexed by pos[i] (the compacted order) -- the cleaned cloud needs no tree of its own
 };
@@ -1068,7 +1078,7 @@ __device__ static inline void d_knn(const KnnArgs &a) {
         if (ol == 0) a.avg[qi] = c > 0 ? s / c : -1.0;
         if (a.list_idx && SLOTS == 4) {
 #pragma unroll
-            for (int j = 0; j < SLOTS; j++) { a.list_idx[(size_t)qi * 32 + ol + OCT * j] = tk.si[j]; a.list_d2[(size_t)qi * 32 + ol + OCT * j] = tk.sd[j]; }
+            for (int j = 0; j < SLOTS; j++) a.list_idx[(size_t)qi * 32 + ol + OCT * j] = tk.si[j];
         }
     } else if (MODE == KNN_MODE_NORMALS) {
         double cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, c = 0;
@@ -1128,6 +1138,91 @@ template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn(K
 template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn_batch(KnnBatch b) { d_knn<MODE, SLOTS>(b.a[blockIdx.y]); }
 template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn_batchp(const KnnArgs *a) { d_knn<MODE, SLOTS>(a[blockIdx.y]); }
 
+#include "pcr_knn_wave.h"
+
+// Two exact k-NN kernels.  The OCTET kernel (8 lanes per query) is the default; the WAVEFRONT kernel (one query per lane, pcr_knn_wave.h,
+// k <= 64, no sparse `todo` searches) needs a third fewer VALU instructions (440 against 660 per query at k = 30) but takes the same
+// time: both run at the chip's VALU issue rate, the wavefront kernel at 4 wavefronts per SIMD (128 VGPRs) with a long tail of
+// wavefronts whose 64 queries lie far apart (handed to the octet kernel after a budget), the octet kernel at 7 with no tail to speak
+// of.  Measured round 3 (tools/knn_sat.py, 1.4 M queries, k = 30, outlier-filter mode): 1.8 + 0.1 ms against 2.0 ms; in the bench
+// 397-403 against 417 pairs/s.  PCR_KNN_WAVE=1 selects the wavefront kernel (per call: tests/test_gpu_stages.py runs every search
+// through both and compares them -- two independent exact searches).
+static bool knn_wave_enabled() { const char *e = getenv("PCR_KNN_WAVE"); return e && atoi(e) != 0; }
+static int knn_wave_seed() { static const int v = getenv("PCR_KNNW_SEED") ? atoi(getenv("PCR_KNNW_SEED")) : -1; return v; }
+static bool knn_wave_fits(const KnnArgs &a) { return a.k >= 1 && a.k <= 64 && !a.todo && !a.stamps && !a.dbg_visits; }
+// the wavefront kernel appends every query's k-best to a row in global memory: the caller's list (SOR) or scratch from the arena
+template <int MODE>
+static int knn_wave_rows(pcr_context *ctx, KnnArgs &a, int cap) {
+    if (MODE == KNN_MODE_DEBUG || (a.list_idx && a.list_pitch >= a.k)) return PCR_OK;
+    a.list_pitch = a.k;
+    a.list_idx = arena<int32_t>(ctx, (size_t)(cap > 0 ? cap : 1) * (size_t)a.k);
+    return a.list_idx ? PCR_OK : PCR_ENOMEM;
+}
+template <int MODE> static int launch_knn_wave_only(pcr_context *ctx, KnnArgs *a, int count, int mc, int kmax);
+static int knn_wave_budget() { const char *e = getenv("PCR_KNNW_BUDGET"); return e ? atoi(e) : 40; }      // batches of 64 candidates in pass 1 (mean 17, p99 43 at k = 30)
+template <int MODE> static int launch_knn_octet_batch(pcr_context *ctx, KnnArgs *a, const int *caps, int count);
+template <int MODE>
+static int launch_knn_wave_batch(pcr_context *ctx, KnnArgs *a, const int *caps, int count, int mc, int kmax) {
+    for (int k = 0; k < count; k++) PCR_TRY(knn_wave_rows<MODE>(ctx, a[k], caps[k]));
+    // the queries of the wavefronts that give up (budget, log) go to the octet kernel in a second launch (k <= 32: its batched form)
+    const int budget = knn_wave_budget();
+    const bool handover = MODE != KNN_MODE_DEBUG && kmax <= 32 && budget > 0;
+    if (handover) for (int k = 0; k < count; k++) {
+        a[k].hard = arena<uint8_t>(ctx, (size_t)(caps[k] > 0 ? caps[k] : 1)); a[k].wave_budget = budget;
+        if (!a[k].hard) return PCR_ENOMEM;
+    }
+    PCR_TRY(launch_knn_wave_only<MODE>(ctx, a, count, mc, kmax));
+    if (!handover) return PCR_OK;
+    std::vector<KnnArgs> o(a, a + count);
+    for (int k = 0; k < count; k++) { o[k].todo = a[k].hard; o[k].hard = nullptr; o[k].zero_a = nullptr; o[k].zero_b = nullptr; o[k].seed_span = -1; }
+    return launch_knn_octet_batch<MODE>(ctx, o.data(), caps, count);
+}
+template <int MODE>
+static int launch_knn_wave_only(pcr_context *ctx, KnnArgs *a, int count, int mc, int kmax) {
+    const dim3 grid((unsigned)(((size_t)mc + KW_BS - 1) / KW_BS), count), block(KW_BS);
+    if (kmax <= 20) return PCR_BATCH_LAUNCH(ctx, KnnBatch, (k_knn_wave_batch<MODE, 20>), (k_knn_wave_batchp<MODE, 20>), a, count, grid, block);
+    if (kmax <= 30) return PCR_BATCH_LAUNCH(ctx, KnnBatch, (k_knn_wave_batch<MODE, 30>), (k_knn_wave_batchp<MODE, 30>), a, count, grid, block);
+    return PCR_BATCH_LAUNCH(ctx, KnnBatch, (k_knn_wave_batch<MODE, 64>), (k_knn_wave_batchp<MODE, 64>), a, count, grid, block);
+}
+template <int MODE>
+static int launch_knn_wave(pcr_context *ctx, int cap, KnnArgs a) {
+    PCR_TRY(knn_wave_rows<MODE>(ctx, a, cap));
+    const dim3 grid((unsigned)(((size_t)cap + KW_BS - 1) / KW_BS)), block(KW_BS);
+    if (const char *path = MODE == KNN_MODE_DEBUG ? getenv("PCR_KNNW_STATS") : nullptr) {      // diagnostics: per-wavefront counters of the two passes, appended to a file
+        const size_t words = (size_t)grid.x * (KW_BS / 64) * 24;
+        unsigned long long *dev = nullptr;
+        if (hipMalloc(&dev, words * 8) != hipSuccess) return PCR_ENOMEM;
+        (void)hipMemsetAsync(dev, 0, words * 8, ctx->stream);
+        a.stamps = dev;
+        if (a.k <= 20) PCR_LAUNCH(ctx, (k_knn_wave_stats<MODE, 20>), grid, block, 0, ctx->stream, a);
+        else if (a.k <= 30) PCR_LAUNCH(ctx, (k_knn_wave_stats<MODE, 30>), grid, block, 0, ctx->stream, a);
+        else PCR_LAUNCH(ctx, (k_knn_wave_stats<MODE, 64>), grid, block, 0, ctx->stream, a);
+        (void)hipStreamSynchronize(ctx->stream);
+        std::vector<unsigned long long> h(words);
+        (void)hipMemcpy(h.data(), dev, words * 8, hipMemcpyDeviceToHost);
+        if (FILE *f = fopen(path, "ab")) { const unsigned long long hdr[4] = {0x4b57535441ull, (unsigned long long)a.k, (unsigned long long)cap, words / 24}; fwrite(hdr, 8, 4, f); fwrite(h.data(), 8, words, f); fclose(f); }
+        (void)hipFree(dev);
+        return PCR_OK;
+    }
+    const int budget = knn_wave_budget();
+    const bool handover = MODE != KNN_MODE_DEBUG && budget > 0;
+    if (handover) {
+        a.hard = arena<uint8_t>(ctx, (size_t)(cap > 0 ? cap : 1)); a.wave_budget = budget;
+        if (!a.hard) return PCR_ENOMEM;
+    }
+    if (a.k <= 20) PCR_LAUNCH(ctx, (k_knn_wave<MODE, 20>), grid, block, 0, ctx->stream, a);
+    else if (a.k <= 30) PCR_LAUNCH(ctx, (k_knn_wave<MODE, 30>), grid, block, 0, ctx->stream, a);
+    else PCR_LAUNCH(ctx, (k_knn_wave<MODE, 64>), grid, block, 0, ctx->stream, a);
+    if (handover) {                                  // the queries of the wavefronts that gave up: octet kernel, 8 per wavefront
+        KnnArgs o = a;
+        o.todo = a.hard; o.hard = nullptr; o.zero_a = nullptr; o.zero_b = nullptr; o.seed_span = -1;
+        const dim3 og((unsigned)(((size_t)cap * OCT + KNN_BS - 1) / KNN_BS));
+        if (o.k <= 32) PCR_LAUNCH(ctx, (k_knn<MODE, 4>), og, dim3(KNN_BS), 0, ctx->stream, o);
+        else PCR_LAUNCH(ctx, (k_knn<MODE, 8>), og, dim3(KNN_BS), 0, ctx->stream, o);
+    }
+    return PCR_OK;
+}
+
 // `count` searches in ONE launch (blockIdx.y picks the problem; k <= 32): the SOR / normals searches of all scales of a cloud
 template <int MODE> static int launch_knn_cap(pcr_context *ctx, int cap, KnnArgs a);
 template <int MODE>
@@ -1136,6 +1231,18 @@ static int launch_knn_batch(pcr_context *ctx, KnnArgs *a, const int *caps, int c
         for (int k = 0; k < count; k++) PCR_TRY(launch_knn_cap<MODE>(ctx, caps[k], a[k]));
         return PCR_OK;
     }
+    if (knn_wave_enabled()) {
+        bool fits = true; int kmax = 0, mcw = 0;
+        for (int k = 0; k < count; k++) { fits = fits && knn_wave_fits(a[k]); kmax = a[k].k > kmax ? a[k].k : kmax; mcw = caps[k] > mcw ? caps[k] : mcw; }
+        if (fits && mcw > 0) {
+            for (int k = 0; k < count; k++) a[k].seed_span = knn_wave_seed();
+            return launch_knn_wave_batch<MODE>(ctx, a, caps, count, mcw, kmax);
+        }
+    }
+    return launch_knn_octet_batch<MODE>(ctx, a, caps, count);
+}
+template <int MODE>
+static int launch_knn_octet_batch(pcr_context *ctx, KnnArgs *a, const int *caps, int count) {
     int mc = 0;
     for (int k = 0; k < count; k++) {
         if (a[k].k < 1 || a[k].k > 32) { ctx->err = "batched k-NN: k must be in 1..32"; return PCR_EINVAL; }
@@ -1174,6 +1281,7 @@ static int launch_knn_cap(pcr_context *ctx, int cap, KnnArgs a) {
         }
     } dump{ctx, stamp_path, a.stamps, stamp_words, MODE, a.k};
     { static const int ss = getenv("PCR_KNN_SEED") ? atoi(getenv("PCR_KNN_SEED")) : -1; a.seed_span = ss; }
+    if (knn_wave_enabled() && knn_wave_fits(a)) { a.seed_span = knn_wave_seed(); return launch_knn_wave<MODE>(ctx, cap, a); }
     if (a.k <= 32) PCR_LAUNCH(ctx, k_knn<MODE, 4>, grid, block, 0, ctx->stream, a);
     else if (a.k <= 64) PCR_LAUNCH(ctx, k_knn<MODE, 8>, grid, block, 0, ctx->stream, a);
     else PCR_LAUNCH(ctx, k_knn<MODE, 25>, grid, block, 0, ctx->stream, a);
@@ -1266,7 +1374,7 @@ __global__ void __launch_bounds__(KNN_BS) k_radius_moments(RadArgs a) {
 // then no second search is needed.  The (rare) other points are flagged `todo` and searched over the cleaned tree.
 struct NflArgs {
     const float4 *pts; const int *n_ptr;             // un-cleaned (voxel) cloud
-    const int32_t *lidx; const float *ld2;           // 32 slots per point
+    const int32_t *lidx;                             // rows of 32 int32 per point (-1: empty slot); distances are recomputed here
     const uint8_t *keep; const int *pos;             // filter result, old -> new index
     int k_list, k_nrm;
     const float4 *prior; float4 *normals;            // cleaned order
@@ -1287,13 +1395,15 @@ __device__ static inline void d_normals_from_lists(const NflArgs &a) {
     for (int r = 0; r < OCT; r++) {
         const int i = base + oct_id * OCT + r;
         const bool act = i < n && a.keep[i];
-        int id[4]; float d[4]; bool ok[4];
+        int id[4]; float d[4]; bool ok[4]; float4 pn[4];
         int lc = 0, vc = 0;
+        const float4 qp = a.pts[act ? i : 0];
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const int slot = ol + OCT * s;
             id[s] = (act && slot < a.k_list) ? a.lidx[(size_t)i * 32 + slot] : -1;
-            d[s] = id[s] >= 0 ? a.ld2[(size_t)i * 32 + slot] : -1.0f;
+            pn[s] = a.pts[id[s] >= 0 ? id[s] : 0];
+            d[s] = id[s] >= 0 ? pcr_d2(pn[s].x - qp.x, pn[s].y - qp.y, pn[s].z - qp.z) : -1.0f;      // the search's own float32 distance
             ok[s] = id[s] >= 0 && a.keep[id[s]];
             lc += id[s] >= 0 ? 1 : 0; vc += ok[s] ? 1 : 0;
         }
@@ -1321,7 +1431,7 @@ __device__ static inline void d_normals_from_lists(const NflArgs &a) {
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             if (exact && ok[s]) {
-                const float4 p = a.pts[id[s]];
+                const float4 p = pn[s];
                 const double x = p.x, y = p.y, z = p.z;
                 cu[0] += x; cu[1] += y; cu[2] += z;
                 cu[3] += x * x; cu[4] += x * y; cu[5] += x * z; cu[6] += y * y; cu[7] += y * z; cu[8] += z * z;
@@ -1460,11 +1570,11 @@ static int sor_batch(pcr_context *ctx, SorProblem *pr, int count, int nb_neighbo
         if (!avg || !stats3 || !stat_partials || !stat_ticket || !flags || !pos) return PCR_ENOMEM;
         // normals of the cleaned cloud straight from this pass's lists when they can be exact (see k_normals_from_lists)
         const bool fuse = normal_k > 0 && q.todo_out && nb_neighbors <= 32 && normal_k <= nb_neighbors;
-        int32_t *lidx = fuse ? arena<int32_t>(ctx, (size_t)in->cap * 32) : nullptr;
-        float *ld2 = fuse ? arena<float>(ctx, (size_t)in->cap * 32) : nullptr;
-        if (fuse && (!lidx || !ld2)) return PCR_ENOMEM;
+        const int pitch = nb_neighbors <= 32 ? 32 : 64;           // k-best rows: input of k_normals_from_lists (pitch 32) and the working rows of the wavefront search
+        int32_t *lidx = (fuse || nb_neighbors <= 64) ? arena<int32_t>(ctx, (size_t)in->cap * pitch) : nullptr;
+        if ((fuse || nb_neighbors <= 64) && !lidx) return PCR_ENOMEM;
         KnnArgs &a = kb.a[m];
-        a.t = oct_view(in); a.n_ptr = in->n; a.k = nb_neighbors; a.avg = avg; a.list_idx = lidx; a.list_d2 = ld2;
+        a.t = oct_view(in); a.n_ptr = in->n; a.k = nb_neighbors; a.avg = avg; a.list_idx = lidx; a.list_pitch = pitch;
         a.zero_a = (int *)stat_ticket; a.zero_b = (fuse && q.todo_out) ? q.todo_count : nullptr;      // zeroed by the search kernel for the kernels after it
         a.seed_span = -1;
         knn_radius(a, PCR_SEARCH_KNN, 0);
@@ -1475,7 +1585,7 @@ static int sor_batch(pcr_context *ctx, SorProblem *pr, int count, int nb_neighbo
             any_todo = true;
             if (fuse) {
                 NflArgs &f = nb_.a[m];
-                f.pts = in->pts; f.n_ptr = in->n; f.lidx = lidx; f.ld2 = ld2; f.keep = flags; f.pos = pos; f.k_list = nb_neighbors; f.k_nrm = normal_k;
+                f.pts = in->pts; f.n_ptr = in->n; f.lidx = lidx; f.keep = flags; f.pos = pos; f.k_list = nb_neighbors; f.k_nrm = normal_k;
                 f.prior = q.prior_out; f.normals = out->nrm_final; f.todo = q.todo_out; f.todo_count = q.todo_count;
             } else {
                 fuse_all = false;
@@ -1572,6 +1682,7 @@ int pcr_dev_normals(pcr_context *ctx, DevCloud *c, int search_kind, int knn, dou
 
 size_t pcr_scratch_bytes_for(int64_t n) {
     // voxel/sort temporaries (2x u64 keys, 2x u32 vals, flags, pos, sort temp) + clouds + boxes, with slack
-    return (size_t)(n > 0 ? n : 1) * 320 + pcr_sort_temp_bytes((size_t)(n > 0 ? n : 1)) + (4u << 20);
+    // (+ 256 B per point: the k-best rows of a search with k <= 64, pcr_knn_wave.h)
+    return (size_t)(n > 0 ? n : 1) * 576 + pcr_sort_temp_bytes((size_t)(n > 0 ? n : 1)) + (4u << 20);
 }
 

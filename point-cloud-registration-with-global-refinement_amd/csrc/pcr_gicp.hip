@@ -774,7 +774,7 @@ static void fill_args(IcpArgs &a, const DevCloud *src, const DevCloud *tgt, doub
     a.src_pts = src->pts; a.src_nrm = src->nrm; a.ns_ptr = src->n;
     a.src_cov6 = src->cov6; a.tgt_cov6 = tgt->cov6;
     a.tgt_pts = tgt->pts; a.tgt_nrm = tgt->nrm; a.nt_ptr = tgt->n;
-    a.tgt.pts = tgt->pts; a.tgt.nodes = tgt->oct_nodes; a.tgt.up = tgt->oct_up; a.tgt.meta = tgt->oct_meta; a.tgt.leaf_of = tgt->leaf_of; a.tgt.keys = tgt->keys; a.tgt.pinfo = tgt->pinfo;
+    a.tgt.pts = tgt->pts; a.tgt.nodes = tgt->oct_nodes; a.tgt.up = tgt->oct_up; a.tgt.meta = tgt->oct_meta; a.tgt.leaf_of = tgt->leaf_of; a.tgt.keys = tgt->keys; a.tgt.pinfo = tgt->pinfo; a.tgt.l1rng = tgt->oct_l1;
     a.match = match; a.src_cap = src->cap > 0 ? src->cap : 1; a.state = st; a.partials = partials;
     a.max_dist2 = max_dist * max_dist;
     // The float32 search works on float32-rounded query positions (ulp 8e-6 m at 100 m), the radius itself is tested in

@@ -136,6 +136,7 @@ struct DevCloud {
     struct OctMeta *oct_meta = nullptr;
     int *leaf_of = nullptr;
     int4 *pinfo = nullptr;       //   point -> (leaf, first point of the leaf, point count)
+    int2 *oct_l1 = nullptr;      //   level-1 node -> (first point, point count): the "fat leaf" as a point range
     float key_org[3] = {0, 0, 0};   // lattice of the Morton keys: coordinate i <-> [org + i*unit, org + (i+1)*unit)
     float key_unit[3] = {1, 1, 1};
 };

@@ -47,6 +47,7 @@ struct OctView {             // what a kernel needs to walk a tree
     const uint64_t *keys;
     const int4 *pinfo;       // point -> (node, its first point, its point count, level): the level-1 node holding the point
                              // (the leaf when the tree has one level) -- the "fat leaf" a warm-started search scans first
+    const int2 *l1rng;       // level-1 node -> (first point, point count)
 };
 
 __host__ __device__ static inline uint32_t pcr_compact21(uint64_t x) {

@@ -54,7 +54,7 @@ def test_bounds(P, small_pair):
     assert np.array_equal(pc.get_max_bound(), src.max(0).astype(np.float64))
 
 
-@pytest.mark.parametrize("k", [1, 20, 30])
+@pytest.mark.parametrize("k", [1, 20, 30, 33, 64])
 def test_knn_index_is_exact(P, oracle, small_pair, k):
     import ctypes as C
     import torch
@@ -78,6 +78,65 @@ def test_knn_index_is_exact(P, oracle, small_pair, k):
     for i, j in bad:
         assert abs(rd2[i, j] - ((pts[i] - pts[idx[i, j]]).astype(np.float64) ** 2).sum()) <= 4e-6 * max(rd2[i, j], 1e-12)
     assert same.mean() > 0.9999
+
+
+def _debug_knn(P, pts, k, radius=0.0):
+    import ctypes as C
+    import torch
+    n = len(pts)
+    ctx = P._lib.Context.current()
+    d = torch.from_numpy(np.ascontiguousarray(pts, dtype=np.float32)).cuda()
+    idx = torch.empty((n, k), dtype=torch.int32, device="cuda"); d2 = torch.empty((n, k), dtype=torch.float32, device="cuda")
+    cnt = torch.empty(n, dtype=torch.int32, device="cuda")
+    ctx.check(ctx.lib.pcr_debug_knn(ctx.handle, C.c_void_p(d.data_ptr()), C.c_int64(n), C.c_int(k), C.c_double(radius),
+                                    C.c_void_p(idx.data_ptr()), C.c_void_p(d2.data_ptr()), C.c_void_p(cnt.data_ptr())), "debug_knn")
+    return idx.cpu().numpy(), d2.cpu().numpy(), cnt.cpu().numpy()
+
+
+@pytest.mark.parametrize("k,radius,n", [(30, 0.0, None), (20, 0.25, 9000), (64, 0.0, 5000), (7, 0.0, 100), (30, 0.0, 11), (20, 0.0, 65), (30, 0.0, 1)])
+def test_knn_wave_equals_octet(P, small_pair, monkeypatch, k, radius, n):
+    """The one-query-per-lane search (pcr_knn_wave.h, PCR_KNN_WAVE=1) against the octet kernel (the default): two independent exact
+    searches must return the same distances row for row, and the same indices wherever distances do not tie -- also on clouds
+    smaller than k, smaller than a wavefront, and under a radius cap (Open3D SearchHybrid)."""
+    pts = P.PointCloud(small_pair["source"]).voxel_down_sample(0.2).points.astype(np.float32) if radius == 0.0 else small_pair["source"].astype(np.float32)
+    if n is not None:
+        pts = pts[:n].copy()
+    monkeypatch.setenv("PCR_KNN_WAVE", "1")
+    wi, wd, wc = _debug_knn(P, pts, k, radius)
+    monkeypatch.setenv("PCR_KNN_WAVE", "0")
+    oi, od, oc = _debug_knn(P, pts, k, radius)
+    assert np.array_equal(wc, oc)
+    assert (wc == np.minimum(k, len(pts))).all() or radius > 0
+    ow = np.lexsort((wi, wd), axis=1); oo = np.lexsort((oi, od), axis=1)
+    wi, wd = np.take_along_axis(wi, ow, 1), np.take_along_axis(wd, ow, 1)
+    oi, od = np.take_along_axis(oi, oo, 1), np.take_along_axis(od, oo, 1)
+    assert np.array_equal(wd, od)                                  # same float32 distances, slot for slot (inf = empty)
+    differ = wi != oi
+    if differ.any():                                               # only inside runs of equal distances
+        r, c = np.nonzero(differ)
+        for i, j in zip(r, c):
+            assert (wd[i] == wd[i, j]).sum() > 1
+        assert differ.mean() < 1e-3
+    for row_i, row_d in zip(wi[:50], wd[:50]):                     # no index twice
+        v = row_i[np.isfinite(row_d)]
+        assert len(set(v.tolist())) == len(v)
+
+
+def test_knn_wave_hands_hard_wavefronts_to_the_octet_kernel(P, oracle, small_pair, monkeypatch):
+    """A wavefront of the one-query-per-lane search gives up after PCR_KNNW_BUDGET candidate batches and leaves its 64 queries to the octet
+    kernel (default 40 batches: ~1 % of the wavefronts).  With a budget of 3 most wavefronts give up, with 8 about half: the outlier
+    mask must stay the oracle's bit for bit and the normals the same either way."""
+    pc = P.PointCloud(small_pair["source"]).voxel_down_sample(0.2)
+    pts = pc.points
+    keep, avg, mu, sd = oracle.remove_statistical_outlier(pts, 30, 1.0)
+    ref_n = oracle.estimate_normals(pts, oracle.SEARCH_KNN, 20)
+    monkeypatch.setenv("PCR_KNN_WAVE", "1")
+    for budget in ("3", "8", "40"):
+        monkeypatch.setenv("PCR_KNNW_BUDGET", budget)
+        clean, index = pc.remove_statistical_outlier(30, 1.0)
+        assert np.array_equal(np.asarray(index), np.nonzero(keep)[0])
+        pc2 = P.PointCloud(pts); pc2.estimate_normals(P.KDTreeSearchParamKNN(knn=20))
+        assert ((pc2.normals * ref_n).sum(1) > 1 - 1e-5).mean() > 0.999
 
 
 def test_knn_hybrid_radius(P, oracle, small_pair):
@@ -117,11 +176,13 @@ def test_sor_mask_is_exact(P, oracle, small_pair):
     assert np.array_equal(np.asarray(i2), np.nonzero(k2)[0])
 
 
-def test_normals_knn_match_oracle(P, oracle, small_pair):
+@pytest.mark.parametrize("knn", [20, 64])
+def test_normals_knn_match_oracle(P, oracle, small_pair, knn):
+    """knn = 20: the reference's own setting (ALL_FUNCTIONS.py:301-302); knn = 64: BASELINE config 5."""
     pc = P.PointCloud(small_pair["source"]).voxel_down_sample(0.2)
     pts = pc.points
-    pc.estimate_normals(P.KDTreeSearchParamKNN(knn=20))
-    ref = oracle.estimate_normals(pts, oracle.SEARCH_KNN, 20)
+    pc.estimate_normals(P.KDTreeSearchParamKNN(knn=knn))
+    ref = oracle.estimate_normals(pts, oracle.SEARCH_KNN, knn)
     dev = pc.normals
     dots = (dev * ref).sum(1)
     # same analytic solver on (almost) the same float64 covariance: sign included
@@ -129,7 +190,7 @@ def test_normals_knn_match_oracle(P, oracle, small_pair):
     assert (np.abs(dots) > 1 - 1e-3).mean() > 0.9999
     # prior orientation
     pc2 = P.PointCloud(pts); pc2.normals = -ref
-    pc2.estimate_normals(P.KDTreeSearchParamKNN(knn=20))
+    pc2.estimate_normals(P.KDTreeSearchParamKNN(knn=knn))
     assert ((pc2.normals * ref).sum(1) < -1 + 1e-5).mean() > 0.999
 
 

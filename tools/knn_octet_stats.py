@@ -1,0 +1,19 @@
+import importlib, os, sys, ctypes as C
+sys.path.insert(0, "/root/repo")
+import numpy as np
+OUT="/tmp/knn_stamps.bin"
+os.environ["PCR_KNN_STAMPS"]=OUT; os.environ["PCR_KNN_WAVE"]="0"
+import torch
+P = importlib.import_module("point-cloud-registration-with-global-refinement_amd")
+syn = importlib.import_module("point-cloud-registration-with-global-refinement_amd.synthetic")
+pair = syn.make_pair(200000, index=0)
+pc = P.PointCloud(pair.source).voxel_down_sample(0.1)
+if os.path.exists(OUT): os.remove(OUT)
+pc.remove_statistical_outlier(30, 1.0); torch.cuda.synchronize()
+raw=np.fromfile(OUT,dtype=np.uint64); pos=0
+while pos < len(raw):
+    mode,k,nw=int(raw[pos+1]),int(raw[pos+2]),int(raw[pos+3]); w=raw[pos+4:pos+4+24*nw].reshape(nw,24); pos+=4+24*nw
+    w=w[w[:,0]!=0]
+    scan=(w[:,4]>>np.uint64(32)).astype(float); rounds=(w[:,4]&np.uint64(0xffffffff)).astype(float); nvis=(w[:,7]&np.uint64(0x3ff)).astype(float); leaves=((w[:,7]>>np.uint64(20))).astype(float); climbs=((w[:,7]>>np.uint64(10))&np.uint64(0x3ff)).astype(float)
+    cyc=w[:,2].astype(float)
+    print(f"mode {mode} k {k} waves {len(w)}: scan steps {scan.mean():.1f} (p99 {np.percentile(scan,99):.0f}) rounds {rounds.mean():.1f} (p99 {np.percentile(rounds,99):.0f}) pops {nvis.mean():.1f} leaf visits {leaves.mean():.1f} climbs {climbs.mean():.1f} cycles {cyc.mean():.0f}")
