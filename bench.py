@@ -63,7 +63,7 @@ def parse_args(argv=None):
                     "(the reference's L1-IRLS trajectory is chaotic: 41-89 iterations for the same pair), for A/B runs of kernel variants; the metric is quoted on l1")
     ap.add_argument("--pairs", type=int, default=0, help="distinct pairs cycled through a step (default: --pairs-per-step, i.e. every pair of a batch is a "
                     "different pair in different buffers)")
-    ap.add_argument("--base-pairs", type=int, default=2, help="independently generated scenes samples (20 s each unless cached); the distinct pairs are these, "
+    ap.add_argument("--base-pairs", type=int, default=8, help="independently generated scenes samples (20 s each unless cached); the distinct pairs are these, "
                     "re-posed by a rigid motion of both clouds and re-ordered")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
@@ -104,6 +104,21 @@ def launch_ranks(args) -> int:
     return rc
 
 
+def tables_identical(gathered, world, device=None) -> bool:
+    """Every rank must hold the SAME ordered pose table after the one all-gather: all-gather a digest of each rank's table."""
+    if world <= 1:
+        return True
+    import hashlib
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    h = hashlib.sha256(np.ascontiguousarray(gathered, dtype=np.float64).tobytes()).digest()
+    mine = torch.tensor(list(h[:16]), dtype=torch.int64, device=device or "cpu")
+    out = torch.empty((world, 16), dtype=torch.int64, device=mine.device)
+    dist.all_gather_into_tensor(out, mine.reshape(1, 16))
+    return bool((out == out[0]).all().item())
+
+
 # ------------------------------------------------------------------------------------------------ dry run (launcher / gather plumbing on CPU)
 def dry_run(args, rank, world) -> int:
     """PCR_BENCH_DRYRUN=1: no GPU work at all; every rank fabricates its pose records, the gloo all-gather, barrier and MAX-reduce
@@ -120,6 +135,7 @@ def dry_run(args, rank, world) -> int:
     recs = np.zeros((n_done, shard.RECORD_DOUBLES)); recs[:, 0] = recs[:, 5] = recs[:, 10] = recs[:, 15] = 1.0
     recs[:, 21] = rank * n_done + np.arange(n_done)
     gathered = shard.gather_records(recs, world * n_done) if world > 1 else recs
+    same = tables_identical(gathered, world)
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -133,8 +149,8 @@ def dry_run(args, rank, world) -> int:
         print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "pairs/s", "n_gpus": world, "n_ranks_seen": seen, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
                           "data": "dry run: no registration was computed", "dry_run": True,
-                          "config": {"workload": "launcher / gather plumbing only", "gathered_records": int(len(gathered))}}))
-    return 0
+                          "config": {"workload": "launcher / gather plumbing only", "gathered_records": int(len(gathered)), "tables_identical": same}}))
+    return 0 if same else 4
 
 
 # ------------------------------------------------------------------------------------------------ the measured run of one rank
@@ -146,6 +162,9 @@ def main(argv=None) -> int:
         return launch_ranks(args)
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("PCR_BENCH_TEST_FAIL_RANK") == str(rank):
+        # test hook (tests/test_sharding.py): this rank fails before it joins the process group; the job must end non-zero, and nothing re-execs
+        raise SystemExit(3)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if os.environ.get("PCR_BENCH_DRYRUN") == "1":
@@ -208,7 +227,7 @@ def main(argv=None) -> int:
         batch = [(clouds[i % len(pairs)][0], clouds[i % len(pairs)][1], pairs[i % len(pairs)].T_init) for i in range(n)]
         p0 = pairs[0]
         return reg.register_pairs_plan(batch, "fgr+gicp" if variant == "fgr" else "gicp", p0.voxel_sizes, p0.max_distances_script, est, crit, 30, 1.0, knn,
-                                       inflight=inflight, with_correspondences=False, fgr_voxel_size=0.1, fgr_use_absolute_scale=True, fgr_seed=20241008,
+                                       inflight=inflight, with_correspondences=True, fgr_voxel_size=0.1, fgr_use_absolute_scale=True, fgr_seed=20241008,
                                        radius_rule="af" if rule == "af" else "given", prior_from_fgr=(variant == "fgr"), group=group)
 
     def barrier():
@@ -235,6 +254,7 @@ def main(argv=None) -> int:
         rec_rows += [shard.pack_record(rank * n_done + k * B + i, r) for i, r in enumerate(results)]    # pose records only; the rest is dropped
     recs = np.stack(rec_rows)
     gathered = shard.gather_records(recs, world * n_done, device=None if rehearse else torch.device("cuda", local_rank)) if world > 1 else recs
+    same_tables = tables_identical(gathered, world, None if rehearse else torch.device("cuda", local_rank))
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -266,28 +286,43 @@ def main(argv=None) -> int:
         us_event = 1e3 * ev_ms / ev_launches if ev_launches else None              # HIP events over fully-live chunks
         us_kernel = ik_us / live if live else None                                 # kernels' own s_memrealtime stamps
         achieved = bytes_per_launch / (us_event * 1e-6) / 1e9 if ev_launches else 0.0
+        # tracked rocprofv3 --pmc results of the same kernels (profiles/README.md): a bench run cannot read PMC counters itself.  The newest
+        # round's files are quoted with the commit they were taken at (profiles/MANIFEST.json) -- static evidence, not this run.
+        manifest = {}
+        try:
+            manifest = json.load(open(os.path.join(ROOT, "profiles", "MANIFEST.json")))
+        except Exception:       # noqa: BLE001
+            manifest = {}
+
+        def tracked(suffix):
+            for tag in ("r03", "r02"):
+                f = os.path.join(ROOT, "profiles", f"{tag}_{suffix}")
+                if os.path.exists(f):
+                    return f, f"profiles/{tag}_{suffix}", manifest.get(f"{tag}_{suffix}", {}).get("commit")
+            return None, None, None
         traffic_file = None
         valu_file = None
-        vcsv = os.path.join(ROOT, "profiles", "r02_pmc_valu_per_pair.csv")         # what the PATH is bound by (the iteration kernel itself is latency-bound)
-        if os.path.exists(vcsv):
+        vcsv, vname, vcommit = tracked("pmc_valu_per_pair.csv")                   # what the PATH is bound by (the iteration kernel itself is latency-bound)
+        if vcsv:
             try:
                 import csv as _csv
                 rows = list(_csv.DictReader(open(vcsv)))
                 tot = [r for r in rows if r["kernel"] == "TOTAL"][0]
                 minst = float(tot["valu_wave_instructions_per_pair_M"])
-                valu_file = {"file": "profiles/r02_pmc_valu_per_pair.csv", "valu_wave_instructions_per_pair_M": minst,
+                valu_file = {"file": vname, "taken_at_commit": vcommit, "valu_wave_instructions_per_pair_M": minst,
                              "ms_per_pair_at_peak_issue": minst / 614.4, "largest": {"kernel": rows[0]["kernel"], "share": float(rows[0]["share_of_valu_instructions"])},
                              "note": "tracked rocprofv3 --pmc SQ_INSTS_VALU result, one pair at a time, not this run: the pairs/s of the path are bound by VALU issue "
                                      "(1024 SIMDs x 1 wave64 instruction per 4 cycles at 2.4 GHz = 614.4 k instructions per us)"}
             except Exception:       # noqa: BLE001 -- a tracked file must never cost the line
                 valu_file = None
-        for name in ("r02_traffic.json", "r02_traffic.json"):                      # rocprofv3 --pmc passes (profiles/README.md); NOT measured in this run
-            tj = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(tj):
+        tj, tname, tcommit = tracked("traffic.json")
+        if tj:
+            try:
                 t = json.load(open(tj))
-                traffic_file = {"file": "profiles/" + name, "hbm_bytes_per_launch": t.get("k_icp_fused", {}).get("hbm_bytes_per_launch"),
+                traffic_file = {"file": tname, "taken_at_commit": tcommit, "hbm_bytes_per_launch": t.get("k_icp_fused", {}).get("hbm_bytes_per_launch"),
                                 "note": "tracked rocprofv3 --pmc result (FETCH_SIZE x2 + WRITE_SIZE), a previous run of the same kernel, not this run"}
-                break
+            except Exception:       # noqa: BLE001
+                traffic_file = None
         rule_txt = "radius_from_cloud_pair * 2^-i per pair (ALL_FUNCTIONS.py:277-278)" if args.radius_rule == "af" else "radii " + "/".join(f"{d:g}" for d in pairs[0].max_distances_script) + " m"
         workload_txt = (f"step = batch of {B} independent pairs ({n_distinct} distinct), each {len(pairs[0].source)}-pt synthetic NCLT-shaped clouds, "
                         + ("registro_FGR (voxel 0.1) + " if args.variant == "fgr" else "") + f"{n_scales}-scale GICP (voxels " + "/".join(f"{v:g}" for v in pairs[0].voxel_sizes)
@@ -296,7 +331,7 @@ def main(argv=None) -> int:
             "metric": METRIC,
             "value": world * n_done / dt, "unit": "pairs/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 points+search, f64 normal equations", "data": "synthetic",
+            "dtype": "f32 points+search, f64 normal equations (SURVEY 8a fp column)", "data": "synthetic",
             "config": {"workload": workload_txt, "variant": args.variant, "radius_rule": args.radius_rule,
                        "points_per_cloud": int(len(pairs[0].source)), "pairs_per_step": B, "distinct_pairs": n_distinct,
                        "distinct_how": f"{min(args.base_pairs, n_distinct)} independently sampled scene pairs, each re-posed by a rigid motion of both clouds and re-ordered (synthetic.derive_pair); every pair has its own buffers",
@@ -307,7 +342,7 @@ def main(argv=None) -> int:
                        "iterations_per_pair_mean": float(np.mean([sum(s["iterations"] for s in r.scales) for r in results])),
                        "err_vs_planted": pose_err(res, pairs[(B - 1) % len(pairs)]),
                        "err_vs_planted_max_over_last_step": {k: float(max(pose_err(r, pairs[i % len(pairs)])[k] for i, r in enumerate(results))) for k in ("rad", "m")},
-                       "gathered_records": int(len(gathered))},
+                       "gathered_records": int(len(gathered)), "tables_identical": same_tables},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_from_profiles": traffic_file, "valu_from_profiles": valu_file,
                          "kernel": "k_icp_fused (one GICP iteration; the first launch of a scale is k_icp_nn + k_icp_iter)",
@@ -325,7 +360,7 @@ def main(argv=None) -> int:
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
-    return 0
+    return 0 if same_tables else 4
 
 
 def fgr_roofline(prof):
@@ -337,9 +372,12 @@ def fgr_roofline(prof):
             "kernel": "k_feature_nn_screen (33-D nearest feature: f16 hi/lo split MFMA screen over the (query wavefront, 64-row tile) pairs whose "
                       "boxes in principal coordinates are close enough, ~20 % of them; survivors re-checked in float64)",
             "flops_per_launch": flops / launches if launches else 0.0, "ms_per_launch_hip_events": ms / launches if launches else None,
-            "peak_note": "algorithmic flops of the all-pairs search over the dense f16 MFMA peak.  The screen spends 3 f16 products per float32-accurate "
-                         "product (128 of K per 33 dimensions) but, with tile pruning, only on a fifth of the pairs; the float64 MFMA path it replaces "
-                         "peaks at 78.6 TFLOP/s"}
+            "executed_over_algorithmic": 0.2 * 128.0 / 33.0,
+            "executed_mfma_utilisation": tf * (0.2 * 128.0 / 33.0) / F16_MFMA_PEAK_TFLOPS,
+            "peak_note": "achieved = ALGORITHMIC flops of the all-pairs search (2 x 33 x Ns x Nt per direction) over the dense f16 MFMA peak.  The screen spends K = 128 "
+                         "per 33 dimensions (hi/lo split: 3 f16 products per float32-accurate product, padded) but, with tile pruning, only on ~0.2 of the (wavefront, "
+                         "tile) pairs (profiles/README.md): executed MFMA flops = 0.2 x 128/33 = 0.78 x algorithmic, so executed_mfma_utilisation is what the f16 pipe "
+                         "actually sustains; the float64 MFMA path it replaces peaks at 78.6 TFLOP/s"}
 
 
 def extras(args, P, syn, reg, est, crit, pairs, clouds, run_batch, pool_prof, pose_err, workload):
@@ -364,22 +402,51 @@ def extras(args, P, syn, reg, est, crit, pairs, clouds, run_batch, pool_prof, po
     out["gicp_af_radius_rule"] = {"pairs_per_s": pps, "pairs_timed": 2 * n, "max_distances_m": [s["max_dist"] for s in res[0].scales],
                                   "iterations": [s["iterations"] for s in res[0].scales], "err_vs_planted": pose_err(res[0], pairs[0]),
                                   "what": "same pairs, search radii radius_from_cloud_pair * 2^-i (ALL_FUNCTIONS.py:277-278): an effectively unbounded 1-NN"}
-    pool_prof(enable=1, reset=True)
     res, pps = timed("fgr", variant="fgr")
-    fp = pool_prof(enable=0, reset=True)
     out["fgr_plus_gicp"] = {"pairs_per_s": pps, "pairs_timed": 2 * n, "fgr_fitness": res[0].fgr.fitness, "fgr_inlier_rmse": res[0].fgr.inlier_rmse,
                             "err_vs_planted_fgr": pose_err(res[0].fgr, pairs[0]), "err_vs_planted": pose_err(res[0], pairs[0]),
                             "what": "config 2's FGR variant: registro_FGR (voxel 0.1, ALL_FUNCTIONS.py:178-203) + the same 3-scale GICP started from its pose; "
                                     "both inside the pair time"}
+    # the feature screen's roofline is measured like the GICP one: one pair at a time (HIP events stretched by other streams' kernels are not kernel time)
+    run_batch(1, variant="fgr", inflight=1, group=1)
+    pool_prof(enable=1, reset=True)
+    run_batch(2, variant="fgr", inflight=1, group=1)
+    torch.cuda.synchronize()
+    fp = pool_prof(enable=0, reset=True)
     if fp[10] > 0:
         out["fgr_plus_gicp"]["roofline"] = fgr_roofline(fp)
+        out["fgr_plus_gicp"]["roofline"]["measured_on"] = "2 pairs, one at a time, after the timed batch (solo, like the GICP roofline)"
+    # ---- BASELINE config 3's building block: NCLT-size pairs (20 000 points, script-2 five scales), the GICP stage and the FGR stage, in
+    # lockstep groups sized by the library (register_pairs_plan(group=None): 24 pairs per group at this size)
+    try:
+        import dataclasses
+        sub = np.random.default_rng(7).permutation(len(pairs[0].source))[:20_000]
+        small = [dataclasses.replace(p, source=p.source[sub], target=p.target[sub]) for p in pairs[:16]]
+        sc = [(P.PointCloud(p.source), P.PointCloud(p.target)) for p in small]
+        vox5 = [0.5, 0.4, 0.3, 0.2, 0.1]; dst5 = [1.5, 1.0, 0.6, 0.3, 0.1]
+        m = 96
+
+        def run_small(stage, group):
+            batch = [(sc[i % 16][0], sc[i % 16][1], small[i % 16].T_init) for i in range(m)]
+            return reg.register_pairs_plan(batch, stage, vox5, dst5, est, crit, 30, 1.0, 20, inflight=args.inflight, with_correspondences=True, fgr_voxel_size=0.1,
+                                           fgr_use_absolute_scale=False, fgr_seed=20241008, group=group)
+        nc = {}
+        for stage, group in (("gicp", None), ("fgr", None)):
+            run_small(stage, group); torch.cuda.synchronize(); t0 = time.perf_counter()
+            r = run_small(stage, group); torch.cuda.synchronize()
+            nc[stage] = {"pairs_per_s": m / (time.perf_counter() - t0), "pairs_timed": m, "err_vs_planted": pose_err(r[0], small[0])}
+        out["nclt_size_20k_points"] = {"gicp_stage_5_scales": nc["gicp"], "fgr_stage": nc["fgr"], "points_per_cloud": 20_000, "groups": "register_pairs_plan(group=None)",
+                                       "what": "BASELINE config 3's per-GPU building block on NCLT-size clouds (a 20 000-point subset of the 200k pairs): script-2 five-scale GICP "
+                                               "stage (2_MGICP...py:187-214) and the script-1 FGR stage (1_FGR...py:134-147), 96 pairs per call"}
+    except Exception as e:      # noqa: BLE001 -- an extra must never cost the main line
+        out["nclt_size_20k_points"] = {"error": repr(e)}
     try:
         p5, c5 = workload(2, config5=True)
         n5, fl5 = 12, 4
 
         def run5(m, inflight):
             batch = [(c5[i % 2][0], c5[i % 2][1], p5[i % 2].T_init) for i in range(m)]
-            return reg.register_pairs_plan(batch, "gicp", p5[0].voxel_sizes, p5[0].max_distances_script, est, crit, 30, 1.0, 64, inflight=inflight, with_correspondences=False)
+            return reg.register_pairs_plan(batch, "gicp", p5[0].voxel_sizes, p5[0].max_distances_script, est, crit, 30, 1.0, 64, inflight=inflight, with_correspondences=True)
         run5(fl5, fl5)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         r5 = run5(n5, fl5)

@@ -106,6 +106,7 @@ def l1_spread(run, chunks=(64, 1024, 4096)):
     of the sums, so this spread -- not a hand-picked constant -- is what bounds a device-vs-oracle comparison on L1."""
     base = run()
     ang = dt = 0.0
+    base.extra["variant_poses"] = []           # end poses of the other chunkings: more samples of the same scatter (tests/conftest.py)
     for c in chunks:
         old = set_sum_chunk(c)
         try:
@@ -113,6 +114,7 @@ def l1_spread(run, chunks=(64, 1024, 4096)):
         finally:
             set_sum_chunk(old)
         A, B = base.transformation, r.transformation
+        base.extra["variant_poses"].append(B.copy())
         ang = max(ang, float(2.0 * np.arcsin(min(1.0, np.linalg.norm(A[:3, :3] - B[:3, :3]) / (2.0 * np.sqrt(2.0))))))
         dt = max(dt, float(np.linalg.norm(A[:3, 3] - B[:3, 3])))
     return base, ang, dt

@@ -505,9 +505,8 @@ int pcr_dev_sort_cloud(pcr_context *ctx, const float *xyz, int64_t n, const doub
     float s[3];
     double emax = 0.0;
     for (int d = 0; d < 3; d++) emax = b6[3 + d] - b6[d] > emax ? b6[3 + d] - b6[d] : emax;
-    static const bool iso = !(getenv("PCR_RAW_ISO") && atoi(getenv("PCR_RAW_ISO")) == 0);
     for (int d = 0; d < 3; d++) {
-        const double e = iso ? emax : b6[3 + d] - b6[d];
+        const double e = emax;
         s[d] = e > 0 ? (float)(65535.0 / e) : 0.0f;
         out->key_org[d] = (float)b6[d]; out->key_unit[d] = e > 0 ? (float)(e / 65535.0) : 1.0f;
     }
@@ -1148,7 +1147,6 @@ template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn_b
 // 397-403 against 417 pairs/s.  PCR_KNN_WAVE=1 selects the wavefront kernel (per call: tests/test_gpu_stages.py runs every search
 // through both and compares them -- two independent exact searches).
 static bool knn_wave_enabled() { const char *e = getenv("PCR_KNN_WAVE"); return e && atoi(e) != 0; }
-static int knn_wave_seed() { static const int v = getenv("PCR_KNNW_SEED") ? atoi(getenv("PCR_KNNW_SEED")) : -1; return v; }
 static bool knn_wave_fits(const KnnArgs &a) { return a.k >= 1 && a.k <= 64 && !a.todo && !a.stamps && !a.dbg_visits; }
 // the wavefront kernel appends every query's k-best to a row in global memory: the caller's list (SOR) or scratch from the arena
 template <int MODE>
@@ -1235,7 +1233,7 @@ static int launch_knn_batch(pcr_context *ctx, KnnArgs *a, const int *caps, int c
         bool fits = true; int kmax = 0, mcw = 0;
         for (int k = 0; k < count; k++) { fits = fits && knn_wave_fits(a[k]); kmax = a[k].k > kmax ? a[k].k : kmax; mcw = caps[k] > mcw ? caps[k] : mcw; }
         if (fits && mcw > 0) {
-            for (int k = 0; k < count; k++) a[k].seed_span = knn_wave_seed();
+            for (int k = 0; k < count; k++) a[k].seed_span = -1;
             return launch_knn_wave_batch<MODE>(ctx, a, caps, count, mcw, kmax);
         }
     }
@@ -1246,7 +1244,7 @@ static int launch_knn_octet_batch(pcr_context *ctx, KnnArgs *a, const int *caps,
     int mc = 0;
     for (int k = 0; k < count; k++) {
         if (a[k].k < 1 || a[k].k > 32) { ctx->err = "batched k-NN: k must be in 1..32"; return PCR_EINVAL; }
-        { static const int ss = getenv("PCR_KNN_SEED") ? atoi(getenv("PCR_KNN_SEED")) : -1; a[k].seed_span = ss; }
+        a[k].seed_span = -1;
         mc = caps[k] > mc ? caps[k] : mc;
     }
     if (mc <= 0) return PCR_OK;
@@ -1280,8 +1278,8 @@ static int launch_knn_cap(pcr_context *ctx, int cap, KnnArgs a) {
             free(h); (void)hipFree(dev);
         }
     } dump{ctx, stamp_path, a.stamps, stamp_words, MODE, a.k};
-    { static const int ss = getenv("PCR_KNN_SEED") ? atoi(getenv("PCR_KNN_SEED")) : -1; a.seed_span = ss; }
-    if (knn_wave_enabled() && knn_wave_fits(a)) { a.seed_span = knn_wave_seed(); return launch_knn_wave<MODE>(ctx, cap, a); }
+    a.seed_span = -1;
+    if (knn_wave_enabled() && knn_wave_fits(a)) { a.seed_span = -1; return launch_knn_wave<MODE>(ctx, cap, a); }
     if (a.k <= 32) PCR_LAUNCH(ctx, k_knn<MODE, 4>, grid, block, 0, ctx->stream, a);
     else if (a.k <= 64) PCR_LAUNCH(ctx, k_knn<MODE, 8>, grid, block, 0, ctx->stream, a);
     else PCR_LAUNCH(ctx, k_knn<MODE, 25>, grid, block, 0, ctx->stream, a);

@@ -338,7 +338,6 @@ struct FnnArgs {
     const _Float16 *dbA; const float *db_nlo; int n_db_pad;        // database rows (A-form) and (1 - c)|x|^2
     const _Float16 *qB; const float *q_nrm; int n_q, n_q_pad;      // query rows (B-form) and |x|^2 (sign bit set: all-zero feature row)
     const int *db_first_zero;                                      // first all-zero row of the database (INT_MAX: none)
-    int variant;                                                   // diagnostics (PCR_FEATNN_VARIANT, timing only, results wrong): 1 no candidate path
     int step0, steps_per_split, step_end;                          // 64-row steps [step0 + split * sps, +sps) clipped to step_end
     // tile pruning (null L: every step of the range is processed)
     const float *L; int L_stride; int n_qt;                        // L[query tile][database tile]: lower bound of the squared distance between their boxes
@@ -500,7 +499,7 @@ __global__ void __launch_bounds__(FN_WG) k_feature_nn_screen(FnnArgs a) {
         }
         // ---- candidate path: blocks in which some lane saw a value under its threshold are recomputed from the LDS image
         unsigned long long any = BOUND_ONLY ? 0ull : __ballot(hits != 0u);
-        if (any != 0ull && !(a.variant & 1) && !dead) {
+        if (any != 0ull && !dead) {
             unsigned wave_hits = hits;                    // union over the wavefront, by a 6-step or-butterfly
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) wave_hits |= (unsigned)__shfl_xor((int)wave_hits, o, 64);
@@ -776,7 +775,6 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         int splits = rest > 0 ? (2048 + groups - 1) / groups : 1;
         if (prune && rest > 0) splits = (4608 + groups - 1) / groups;                // lists hold ~1/5 of their range and differ in length: more, shorter
                                                                                      //   ranges balance better (200k x 200k: 13.4 / 12.6 / 12.1 / 12.3 ms for 4 / 8 / 12 / 16)
-        { static const int se = getenv("PCR_FEATNN_SPLITS") ? atoi(getenv("PCR_FEATNN_SPLITS")) : 0; if (se > 0) splits = se; }
         if (splits > 256) splits = 256;
         if (splits < (rest + FN_LIST_CAP - 1) / FN_LIST_CAP) splits = (rest + FN_LIST_CAP - 1) / FN_LIST_CAP;
         if (splits > rest) splits = rest > 0 ? rest : 1;
@@ -807,7 +805,6 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         a.dbA = A[dc]; a.db_nlo = nlo[dc]; a.n_db_pad = np[dc]; a.qB = B[qc]; a.q_nrm = nrm[qc]; a.n_q = nq; a.n_q_pad = nqp;
         a.db_first_zero = first_zero + dc; a.Ug = Ug;
         a.pool_used = pool_used; a.pool_cap = pool_cap; a.chunk_fill = chunk_fill; a.rec_q = rec_q; a.rec_row = rec_row; a.rec_w = rec_w; a.flags = flags;
-        a.variant = getenv("PCR_FEATNN_VARIANT") ? atoi(getenv("PCR_FEATNN_VARIANT")) : 0;
         a.L = nullptr; a.L_stride = 0; a.n_qt = 0; a.prelist = nullptr; a.pre_mode = 0; a.n_bound = 0; a.stats = nullptr;
         unsigned long long *stats = nullptr;
         if (check) { stats = arena<unsigned long long>(ctx, 4); if (!stats) return PCR_ENOMEM; PCR_HIP_CHECK(ctx, hipMemsetAsync(stats, 0, 32, ctx->stream)); a.stats = stats; }
@@ -822,7 +819,7 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
             a.L = L; a.L_stride = nbt; a.n_qt = nqt; a.prelist = prelist;
             // (i) bounds only over the 16 nearest tiles (in a sorted database the running minimum improves row after row: with records
             // that is a record per improvement), (ii) the 48 nearest tiles with records under that bound, (iii) everything else that survives
-            static const int n_bound = getenv("PCR_FEATNN_NBOUND") ? atoi(getenv("PCR_FEATNN_NBOUND")) : 16;
+            const int n_bound = 16;
             a.step0 = 0; a.steps_per_split = 0; a.step_end = steps; a.pre_mode = 1; a.n_bound = n_bound < FN_NPRE ? n_bound : FN_NPRE;
             if (a.n_bound > 0) PCR_LAUNCH(ctx, k_feature_nn_screen<true>, dim3(groups, 1), dim3(FN_WG), 0, ctx->stream, a);
             PCR_LAUNCH(ctx, k_feature_nn_screen<false>, dim3(groups, 1), dim3(FN_WG), 0, ctx->stream, a);
@@ -833,21 +830,12 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
             // can be split over many workgroups -- the bounds meet in Ug by atomicMin -- where a pre-pass WITH records had to be one
             // workgroup per 512 queries walking its 64 steps one after the other (200 us per direction when the grid is small: 20k rows are
             // 40 workgroups).  The pass with records then covers every step, under those bounds.
-            static const int pre_bound = getenv("PCR_FEATNN_PREBOUND") ? atoi(getenv("PCR_FEATNN_PREBOUND")) : 2;
-            if (pre_bound == 2) {
+            {
                 const int pre_b = steps < 64 ? steps : 64, pb_splits = pre_b < 8 ? pre_b : 8, pb_sps = (pre_b + pb_splits - 1) / pb_splits;
                 a.step0 = 0; a.steps_per_split = pb_sps; a.step_end = pre_b;
                 PCR_LAUNCH(ctx, k_feature_nn_screen<true>, dim3(groups, pb_splits), dim3(FN_WG), 0, ctx->stream, a);
                 a.step0 = 0; a.steps_per_split = sps_all; a.step_end = steps;
                 PCR_LAUNCH(ctx, k_feature_nn_screen<false>, dim3(groups, splits_all), dim3(FN_WG), 0, ctx->stream, a);
-            } else {
-                a.step0 = 0; a.steps_per_split = pre; a.step_end = pre;
-                if (pre_bound == 1) PCR_LAUNCH(ctx, k_feature_nn_screen<true>, dim3(groups, 1), dim3(FN_WG), 0, ctx->stream, a);
-                PCR_LAUNCH(ctx, k_feature_nn_screen<false>, dim3(groups, 1), dim3(FN_WG), 0, ctx->stream, a);
-                if (rest > 0) {
-                    a.step0 = pre; a.steps_per_split = sps; a.step_end = steps;
-                    PCR_LAUNCH(ctx, k_feature_nn_screen<false>, dim3(groups, splits), dim3(FN_WG), 0, ctx->stream, a);
-                }
             }
         }
         FnxArgs x;

@@ -47,8 +47,10 @@ def _clouds_of(pairs, n_clouds):
 
 def _gather(results, n_pairs):
     import torch
+    import torch.distributed as dist
     recs = np.stack([sharding.pack_record(i, r) for i, r, _ in results]) if results else np.zeros((0, sharding.RECORD_DOUBLES))
-    dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+    on_gpu = torch.cuda.is_available() and not (dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo")
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else None          # RCCL gathers device tensors, gloo (tests, rehearsals) host ones
     table = sharding.gather_records(recs, n_pairs, device=dev)
     return [sharding.unpack_record(r) for r in table]
 
@@ -156,8 +158,11 @@ def main(argv=None) -> int:
     if args.stage in ("stage1", "stage2") and "RANK" in os.environ:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
+        # PCR_REHEARSE=1: every rank on device 0 and the gather over gloo -- the N > 1 path on a one-GPU box (tests/test_drivers.py)
+        rehearse = os.environ.get("PCR_REHEARSE") == "1"
+        torch.cuda.set_device(0 if rehearse else int(os.environ.get("LOCAL_RANK", "0")))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if rehearse else "nccl")
     if args.stage == "stage1":
         stage1_fgr(args.clouds, args.out, args.n, args.voxel, inflight=args.inflight, seed=args.seed)
     elif args.stage == "stage2":
@@ -165,4 +170,12 @@ def main(argv=None) -> int:
     else:
         r = stage3_refine(args.relative, args.n, args.out, args.groundtruth)
         print("closure error [R | t]:\n", r["closure"])
+    if args.stage in ("stage1", "stage2") and "RANK" in os.environ:
+        import torch.distributed as dist
+        dist.destroy_process_group()
     return 0
+
+
+if __name__ == "__main__":
+    import sys
+    sys.exit(main())

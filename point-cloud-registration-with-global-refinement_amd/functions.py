@@ -4,12 +4,11 @@ module's top level) and as the private copies pasted into scripts 1 and 2 (``scr
 namespaces below).  SURVEY.md §8b lists the surface; App. C lists the quirks preserved here.
 
 Everything heavy runs in ``libpcr_hip.so`` on the MI355X.  The multiscale loop body is ONE C-ABI call
-(``pcr_multiscale_gicp``) so that the clouds stay resident in HBM across all scales; ``stepwise=True``
-replays the reference's call-by-call sequence through the PointCloud stand-ins instead (used by tests).
+(``pcr_multiscale_gicp``) so that the clouds stay resident in HBM across all scales.  The reference's
+call-by-call sequences are replayed through the PointCloud stand-ins by the tests (tests/test_gpu_fgr.py,
+tests/test_gpu_gicp.py), not here: this module is signatures, constants and one library call each.
 """
 from __future__ import annotations
-
-import copy
 
 import numpy as np
 
@@ -22,29 +21,11 @@ KNN_NORMAIS = 20         # ALL_FUNCTIONS.py:301, 2_MGICP...py:152
 
 
 # ------------------------------------------------------------------------------- ALL_FUNCTIONS.py variants
-def registro_FGR(source, target, voxel_size, _use_absolute_scale=True, seed=None, stepwise=False):
-    """ALL_FUNCTIONS.py:178-203.  Mutates ``source``/``target`` (adds normals), like the reference.  One library call
-    (``pcr_registro_fgr``: each cloud is sorted and indexed once); ``stepwise=True`` replays the reference's five Open3D
-    calls through the stand-ins instead (tests compare the two)."""
-    if not stepwise:
-        return _r.registro_fgr(source, target, voxel_size, _use_absolute_scale, seed)
-    n_pontos = int((len(source.points) + len(target.points)) / 2)
-    kd_tree_normais = _g.KDTreeSearchParamHybrid(radius=2 * voxel_size, max_nn=20)
-    source.estimate_normals(kd_tree_normais)
-    target.estimate_normals(kd_tree_normais)
-    kd_tree_descritores = _g.KDTreeSearchParamHybrid(radius=10 * voxel_size, max_nn=200)
-    source_fpfh = _r.compute_fpfh_feature(source, kd_tree_descritores)
-    target_fpfh = _r.compute_fpfh_feature(target, kd_tree_descritores)
-    FGR_coarse = _r.FastGlobalRegistrationOption(
-        division_factor=1.4,
-        use_absolute_scale=_use_absolute_scale,
-        decrease_mu=True,
-        maximum_correspondence_distance=2 * voxel_size,
-        iteration_number=300,
-        tuple_scale=0.95,
-        maximum_tuple_count=int(n_pontos * 0.2),
-        seed=seed)
-    return _r.registration_fgr_based_on_feature_matching(source, target, source_fpfh, target_fpfh, FGR_coarse)
+def registro_FGR(source, target, voxel_size, _use_absolute_scale=True, seed=None):
+    """ALL_FUNCTIONS.py:178-203: normals Hybrid(2v, 20), FPFH Hybrid(10v, 200), FGR option (1.4, absolute scale, decrease_mu, 2v, 300,
+    0.95, int(0.2 * n_pontos)), feature-matching FGR.  Mutates ``source``/``target`` (adds normals), like the reference.  One library
+    call (``pcr_registro_fgr``: each cloud is sorted and indexed once)."""
+    return _r.registro_fgr(source, target, voxel_size, _use_absolute_scale, seed)
 
 
 def GICP_robusto(source, target, max_corres_dist, initial_T, iterations):
@@ -99,35 +80,21 @@ def radius_from_cloud_pair(source, target):
     return (rad_1 + rad_2) / 2
 
 
-def _multiscale(source, target, voxel_sizes, distances, itera_escala, T_ini, stepwise):
-    loss = _r.L1Loss()
-    est = _r.TransformationEstimationForGeneralizedICP(loss)
+def _multiscale(source, target, voxel_sizes, distances, itera_escala, T_ini):
+    """The loop body of ALL_FUNCTIONS.py:286-312 / 2_MGICP...py:140-163 for all scales in one library call: per scale voxel grid ->
+    outlier filter (30, 1.0) -> 20-NN normals -> GICP with L1Loss and criteria (1e-6, 1e-6, itera_escala), poses chained."""
+    est = _r.TransformationEstimationForGeneralizedICP(_r.L1Loss())
     crit = _r.ICPConvergenceCriteria(relative_fitness=1e-6, relative_rmse=1e-6, max_iteration=itera_escala)
-    if not stepwise:
-        return _r.multiscale_gicp(source, target, voxel_sizes, distances, T_ini, est, crit, KNN_FILTRO, STD_FILTRO, KNN_NORMAIS)
-    current_transformation = T_ini
-    result_icp = None
-    for i in range(len(voxel_sizes)):
-        source_temp = copy.deepcopy(source)
-        target_temp = copy.deepcopy(target)
-        source_down = source_temp.voxel_down_sample(voxel_sizes[i])
-        target_down = target_temp.voxel_down_sample(voxel_sizes[i])
-        source_clean, _ = source_down.remove_statistical_outlier(KNN_FILTRO, STD_FILTRO)
-        target_clean, _ = target_down.remove_statistical_outlier(KNN_FILTRO, STD_FILTRO)
-        source_clean.estimate_normals(_g.KDTreeSearchParamKNN(knn=KNN_NORMAIS))
-        target_clean.estimate_normals(_g.KDTreeSearchParamKNN(knn=KNN_NORMAIS))
-        result_icp = _r.registration_generalized_icp(source_clean, target_clean, distances[i], current_transformation, est, crit)
-        current_transformation = result_icp.transformation
-    return result_icp
+    return _r.multiscale_gicp(source, target, voxel_sizes, distances, T_ini, est, crit, KNN_FILTRO, STD_FILTRO, KNN_NORMAIS)
 
 
-def Multiscale_GICP(source, target, n_scales, itera_escala, T_ini, stepwise=False):
+def Multiscale_GICP(source, target, n_scales, itera_escala, T_ini):
     """ALL_FUNCTIONS.py:272-313: voxels 0.1*2^k coarse-to-fine, search radius = AABB radius * 2^-i."""
     voxel_sizes = create_scales(n_scales)
     voxel_sizes.reverse()
     max_correspondence_distance = radius_from_cloud_pair(source, target)
     max_correspondence_distances = [max_correspondence_distance * (2 ** (-i)) for i in range(n_scales)]
-    return _multiscale(source, target, voxel_sizes, max_correspondence_distances, itera_escala, T_ini, stepwise)
+    return _multiscale(source, target, voxel_sizes, max_correspondence_distances, itera_escala, T_ini)
 
 
 def Coarse_to_fine_FGR_M_GICP(source, target, voxel_size, seed=None):
@@ -167,9 +134,9 @@ class script1:
     """Private copies in 1_FGR_pairwise_registration_in_NCLT_dataset.py."""
 
     @staticmethod
-    def registro_FGR(source, target, voxel_size, seed=None, stepwise=False):
+    def registro_FGR(source, target, voxel_size, seed=None):
         """Script 1:41-66: identical to the library version except ``use_absolute_scale=False`` (:54)."""
-        return registro_FGR(source, target, voxel_size, _use_absolute_scale=False, seed=seed, stepwise=stepwise)
+        return registro_FGR(source, target, voxel_size, _use_absolute_scale=False, seed=seed)
 
 
 class script2:
@@ -197,8 +164,8 @@ class script2:
         raise UnboundLocalError("local variable 'max_correspondence_distances' referenced before assignment")
 
     @staticmethod
-    def Multiscale_GICP(source, target, n_scales, itera_escala, T_ini, stepwise=False):
+    def Multiscale_GICP(source, target, n_scales, itera_escala, T_ini):
         """Script 2:128-164."""
         voxel_sizes = script2.create_scales(n_scales)
         search_distances = script2.max_correspondence_distances(voxel_sizes)
-        return _multiscale(source, target, voxel_sizes, search_distances, itera_escala, T_ini, stepwise)
+        return _multiscale(source, target, voxel_sizes, search_distances, itera_escala, T_ini)

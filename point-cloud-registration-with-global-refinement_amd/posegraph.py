@@ -271,4 +271,7 @@ def full_registration(lista_nuvens, voxel_size, k, verbose=False) -> PoseGraph:
             ok += 1 if res.fitness > 0.40 else 0
             if verbose:
                 print(f"Registering cloud {s} in cloud {t}: {'Sucesso' if res.fitness > 0.40 else 'Falhou'}")
+    # the reference only PRINTS its success count (fitness > 0.40, `AF:369,385,393`); kept on the graph object for callers and tests
+    g.successes = ok
+    g.attempted = len(g.edges)
     return g

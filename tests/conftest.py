@@ -82,3 +82,58 @@ def l1_tolerance(oracle, run, chunks=(16, 32, 64, 128, 512, 1024, 4096), factor=
     tol_rad, tol_m, (spread_rad, spread_m)) with tol = max(north-star tolerance, factor x spread)."""
     base, a, d = oracle.l1_spread(run, chunks)
     return base, max(TOL_RAD, factor * a), max(TOL_M, factor * d), (a, d)
+
+
+def reference_next_step(oracle, src_xyz, tgt_xyz, voxel, max_dist, T, src_prior=None, tgt_prior=None, sor_k=30, sor_std=1.0, normal_k=20):
+    """What the REFERENCE iteration does next when it is handed the pose T at one scale: the oracle prepares the scale exactly as
+    `Multiscale_GICP` does (voxel grid, outlier filter, normals; float64), evaluates fitness / RMSE at T, takes ONE L1 Gauss-Newton
+    step of Open3D's GICP from T and evaluates again.  Returns dict(dfit, drmse, step_rad, step_m, n_src, fitness, rmse).
+
+    This is the chaos-proof form of an L1 comparison.  The END POSE of the L1-IRLS loop scatters by 1e-4 ... 1e-3 rad under a change
+    of the summation order alone (conftest.l1_tolerance measures that), so device-vs-oracle pose distances prove little on such
+    inputs; but wherever the loop stops, it stops because one more step no longer changes fitness and RMSE -- the reference's own
+    criteria, 2_MGICP_refinement_in_NCLT_dataset.py:159-162 -- and THAT is a smooth function of the pose: evaluated with the
+    oracle's own float64 arithmetic at the device's end pose it must hold as it holds at the oracle's own end pose, whatever the
+    summation order did to the trajectory."""
+    def prep(xyz, prior):
+        if prior is not None:
+            pts, nrm = oracle.voxel_down_sample(xyz, voxel, normals=prior)
+        else:
+            pts, nrm = oracle.voxel_down_sample(xyz, voxel), None
+        keep = oracle.remove_statistical_outlier(pts, sor_k, sor_std)[0]
+        pts = pts[keep]
+        return pts, oracle.estimate_normals(pts, oracle.SEARCH_KNN, normal_k, prior=nrm[keep] if nrm is not None else None)
+    sp, sn = prep(src_xyz, src_prior)
+    tp, tn = prep(tgt_xyz, tgt_prior)
+    T = np.asarray(T, float)
+    r = oracle.registration_gicp(sp, tp, max_dist, T, src_normals=sn, tgt_normals=tn, loss=oracle.LOSS_L1, rel_fitness=0.0, rel_rmse=0.0,
+                                 max_it=1, want_trace=True)
+    tr = r.extra["trace"]
+    step = r.transformation @ np.linalg.inv(T)
+    ang, dt = pose_error(step, np.eye(4))
+    return dict(dfit=abs(tr[1, 0] - tr[0, 0]), drmse=abs(tr[1, 1] - tr[0, 1]), step_rad=ang, step_m=dt, n_src=len(sp), fitness=tr[0, 0], rmse=tr[0, 1])
+
+
+def assert_reference_fixed_point(oracle, src_xyz, tgt_xyz, voxel, max_dist, T_device, T_oracle, what="", **kw):
+    """The device's end pose of an L1 scale is a fixed point of the reference iteration as much as the oracle's own end pose is: one
+    more reference step from it changes fitness by at most a few correspondences (the device decides on float32 points, the oracle
+    on float64 ones: a point on the rim of max_dist may count for one and not for the other) and RMSE by ~1e-6, and the step itself
+    is far inside the north-star tolerance.  Bounds are absolute (the reference's own 1e-6 criteria with that slack) AND relative to
+    what the oracle's own end pose shows on this input."""
+    d = reference_next_step(oracle, src_xyz, tgt_xyz, voxel, max_dist, T_device, **kw)
+    # T_oracle: one pose, or several end poses of the oracle under different summation chunkings (l1_tolerance leaves them in
+    # ref.extra["variant_poses"]): the loop stops where two consecutive evaluations HAPPEN to agree to 1e-6, so how quiet an end pose
+    # is scatters too -- the device is held to the least quiet of the oracle's own samples
+    poses = [T_oracle] if np.asarray(T_oracle).ndim == 2 else list(T_oracle)
+    os_ = [reference_next_step(oracle, src_xyz, tgt_xyz, voxel, max_dist, T, **kw) for T in poses]
+    o = {k: max(x[k] for x in os_) for k in ("dfit", "drmse", "step_rad", "step_m")}
+    print(f"fixed point {what}: device end pose -> next reference step {d['step_rad']:.1e} rad {d['step_m']:.1e} m, dfit {d['dfit']:.1e} drmse {d['drmse']:.1e};"
+          f" oracle end pose(s, {len(poses)}) -> {o['step_rad']:.1e} rad {o['step_m']:.1e} m, dfit {o['dfit']:.1e} drmse {o['drmse']:.1e}  (n {d['n_src']})")
+    slack_fit = 3.0 / max(d["n_src"], 1)
+    assert d["dfit"] <= max(1e-6 + slack_fit, 3.0 * o["dfit"]), (what, d, o)
+    # a correspondence entering or leaving at the rim (d = max_dist) moves the RMSE by (max_dist^2 - rmse^2) / (2 rmse n_corr): that much per flip is not motion
+    flips = round(d["dfit"] * d["n_src"])
+    per_flip = max_dist * max_dist / (2.0 * max(d["rmse"], 1e-9) * max(d["fitness"] * d["n_src"], 1.0))
+    assert d["drmse"] <= max(5e-6 + flips * per_flip, 3.0 * o["drmse"]), (what, d, o, flips, per_flip)
+    assert d["step_rad"] <= max(TOL_RAD / 4, 3.0 * o["step_rad"]) and d["step_m"] <= max(TOL_M / 4, 3.0 * o["step_m"]), (what, d, o)
+    return d, o

@@ -61,3 +61,40 @@ def test_stage1_stage2_on_a_two_cloud_circuit(tmp_path):
     assert sorted(os.listdir(tmp_path / "abs")) == ["pose0.txt", "pose1.txt"]
     back = pcr_amd.io.load_relative_poses(str(tmp_path / "gicp"), 2)
     np.testing.assert_allclose(np.stack(back), np.stack(rel), atol=1e-15)
+
+
+@pytest.mark.gpu
+def test_stage2_two_ranks_equal_one_rank_on_the_facade_circuit(tmp_path):
+    """the shipped Facade circuit (7 clouds, 7 pairs incl. the loop closure) through `drivers stage2` as ONE
+    process and as TWO ranks (contiguous blocks of 3 and 4 pairs, one all-gather of the pose records; both ranks on this box's one
+    device, gloo): the pose files rank 0 writes must be the same bits.  PCR_ICP_TILE pins the iteration kernel's tile so that
+    lockstep groups of different sizes sum in the same order (tests/test_gpu_groups.py)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    g = np.load(os.path.join(GOLDEN, "facade_loop.npz"))
+    n = 7
+    clouds = tmp_path / "clouds"; clouds.mkdir(); init = tmp_path / "init"; init.mkdir()
+    for i in range(n):
+        pcr_amd.io.write_pcd_xyz(str(clouds / f"s{i}.pcd"), g[f"s{i}"])
+        pcr_amd.io.write_pose(str(init / pcr_amd.io.relative_pose_name(i, n)), g["T_fgr"][i])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PCR_ICP_TILE="512", PCR_REHEARSE="1", PYTHONPATH=ROOT)
+    script = tmp_path / "run_stage.py"          # (the package name has hyphens: importlib, not `-m`)
+    # (and torchrun's own argument parser trips over `--n`: the stage arguments travel in the environment)
+    script.write_text("import importlib, json, os, sys\nsys.exit(importlib.import_module('point-cloud-registration-with-global-refinement_amd.drivers').main(json.loads(os.environ['PCR_STAGE_ARGS'])))\n")
+    common = ["stage2", "--clouds", str(clouds), "--init", str(init), "--n", str(n), "--scales", "3", "--iterations", "30", "--inflight", "2"]
+    import json
+    one = subprocess.run([sys.executable, str(script)], cwd=ROOT, env=dict(env, PCR_STAGE_ARGS=json.dumps(common + ["--out", str(tmp_path / "one")])),
+                         capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                          str(script)], cwd=ROOT, env=dict(env, PCR_STAGE_ARGS=json.dumps(common + ["--out", str(tmp_path / "two")])),
+                         capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a = pcr_amd.io.load_relative_poses(str(tmp_path / "one"), n); b = pcr_amd.io.load_relative_poses(str(tmp_path / "two"), n)
+    assert np.array_equal(np.stack(a), np.stack(b))                                        # every pair, every bit
+    assert sorted(os.listdir(tmp_path / "one")) == sorted(os.listdir(tmp_path / "two"))
+    for i in range(n):                                                                      # and they are registrations, not garbage: near the shipped GICP poses
+        ang, dt = pose_error(a[i], g["T_gicp"][i])
+        assert ang < 2e-2 and dt < 0.2, (i, ang, dt)

@@ -37,6 +37,31 @@ def test_fpfh_matches_oracle(P, oracle, fgr_inputs):
         close = np.abs(dev - ref) <= 1e-3 * (1.0 + np.abs(ref))
         assert close.mean() > 0.999, close.mean()
         assert (np.abs(dev - ref).max(axis=1) < 5.0).mean() > 0.9999
+        # ... and that is ALL the mismatching entries are: inside each of the three 11-bin histograms of a point the difference
+        # device - oracle carries no mass (the votes are the same votes) and moves it only between ADJACENT bins.  For a vote of weight
+        # w cast one bin over, the difference is (+w, -w) in neighbouring bins: its running sum is w in one bin, so
+        # L1(running sum) = L1(difference) / 2; a vote that landed g bins away would give g times that.
+        diff = (dev - ref).reshape(-1, 3, 11)
+        bad = ~close.reshape(-1, 3, 11).all(axis=2)                       # (point, histogram) pairs with a mismatching entry
+        print(f"FPFH: {int((~close).sum())} of {close.size} entries differ by more than 1e-3 relative; {int(bad.sum())} histograms affected")
+        assert bad.mean() < 0.02, bad.mean()                                 # (on the golden pairs there are none at all)
+        if not bad.any():
+            continue
+        d = diff[bad]
+        l1 = np.abs(d).sum(1)
+        assert (np.abs(d.sum(1)) <= 1e-3 * (1.0 + l1)).all()                # mass conserved inside the histogram
+        run = np.abs(np.cumsum(d, axis=1)).sum(1)
+        # f0 is an ANGLE (atan2 in [-pi, pi], histogram 0): its first and last bin are neighbours too -- a pair feature at +-pi is on an edge
+        wrap = d.copy()
+        is_f0 = np.nonzero(bad)[1] == 0
+        wrap[is_f0] = np.roll(d[is_f0], 5, axis=1)                          # bins 0 and 10 become 5 and 4
+        run_w = np.abs(np.cumsum(wrap, axis=1)).sum(1)
+        run = np.where(is_f0, np.minimum(run, run_w), run)
+        for k in range(min(3, len(d))):
+            print("   mismatching histogram", int(np.nonzero(bad)[1][k]), "bins", np.nonzero(np.abs(d[k]) > 1e-3 * (1 + np.abs(d[k]).max()))[0], "values", d[k][np.abs(d[k]) > 1e-6].round(4))
+        adjacent = run <= 0.5 * l1 * (1.0 + 1e-3) + 1e-3
+        assert adjacent.mean() > 0.98, adjacent.mean()                      # adjacent bins only ...
+        assert (run <= l1 * (1.0 + 1e-3) + 1e-3).all(), float((run / np.maximum(l1, 1e-12)).max())     # ... but for two chained edge votes in one histogram
 
 
 def test_fpfh_errors(P, small_pair):
@@ -152,7 +177,7 @@ def test_multiscale_gicp_af_semantics_match_oracle(P, oracle, pair0, small_pair,
     0.4/0.2/0.1 and search radii `radius_from_cloud_pair * [1, 1/2, 1/4]` (44.7 / 22.4 / 11.2 m on s1 -> s0).  The oracle gets
     the same pose, normals and radii: stage counts and matched counts exact, L2 pose within 1e-5 rad / 1e-4 m, L1 (the reference's
     loss) within the tolerance derived from the oracle's own summation-order spread on this input."""
-    from conftest import TOL_M, TOL_RAD, l1_tolerance
+    from conftest import TOL_M, TOL_RAD, assert_reference_fixed_point, l1_tolerance
     g = pair0 if pair_name == "pair0" else small_pair
     src, tgt = P.PointCloud(g["source"]), P.PointCloud(g["target"])
     fgr = P.registro_FGR(src, tgt, 0.1, seed=7)                       # ALL_FUNCTIONS variant: absolute scale; leaves normals
@@ -178,6 +203,11 @@ def test_multiscale_gicp_af_semantics_match_oracle(P, oracle, pair0, small_pair,
         a, d = pose_error(res.transformation, ref.transformation)
         print(f"a16 {pair_name} {type(loss).__name__}: device vs oracle {a:.2e} rad {d:.2e} m (bound {tr:.2e} rad {tm:.2e} m)")
         assert a <= tr and d <= tm, (pair_name, type(loss).__name__, a, d, tr, tm)
+        if oloss == oracle.LOSS_L1:
+            # the derived bound above is wide on this input; the chaos-proof statement is not: the device's end pose is as stationary
+            # for the reference iteration (oracle arithmetic, same normals as orientation prior, same radius) as the oracle's own
+            assert_reference_fixed_point(oracle, g["source"], g["target"], vox[-1], dists[-1], res.transformation, [ref.transformation] + ref.extra["variant_poses"], f"a16 {pair_name}",
+                                         src_prior=sn, tgt_prior=tn)
         # with radii of 45 / 22 / 11 m every source point is matched at every scale and the L1 end pose of the ORACLE ITSELF scatters
         # by up to 3e-3 rad / 3 cm on s1 -> s0 when only its summation chunking changes: the derived bound is that wide, not tighter
         assert tr <= 2e-2 and tm <= 0.2
@@ -187,6 +217,20 @@ def test_multiscale_gicp_af_semantics_match_oracle(P, oracle, pair0, small_pair,
     assert [s["max_dist"] for s in af.scales] == dists
 
 
+def _registro_fgr_five_calls(P, source, target, voxel_size, use_absolute_scale, seed):
+    """The reference's own call sequence (ALL_FUNCTIONS.py:178-203 / 1_FGR...py:41-66) through the stand-ins: two estimate_normals,
+    two compute_fpfh_feature, the option object, registration_fgr_based_on_feature_matching."""
+    n_pontos = int((len(source.points) + len(target.points)) / 2)
+    normals = P.KDTreeSearchParamHybrid(radius=2 * voxel_size, max_nn=20)
+    source.estimate_normals(normals); target.estimate_normals(normals)
+    feats = P.KDTreeSearchParamHybrid(radius=10 * voxel_size, max_nn=200)
+    fs = P.registration.compute_fpfh_feature(source, feats); ft = P.registration.compute_fpfh_feature(target, feats)
+    opt = P.registration.FastGlobalRegistrationOption(division_factor=1.4, use_absolute_scale=use_absolute_scale, decrease_mu=True,
+                                                      maximum_correspondence_distance=2 * voxel_size, iteration_number=300, tuple_scale=0.95,
+                                                      maximum_tuple_count=int(n_pontos * 0.2), seed=seed)
+    return P.registration.registration_fgr_based_on_feature_matching(source, target, fs, ft, opt)
+
+
 def test_registro_fgr_fused_call_equals_the_five_calls(P, small_pair):
     """`registro_FGR` as one library call (pcr_registro_fgr: every cloud sorted and indexed once) against the reference's own call
     sequence through the stand-ins (estimate_normals x2, compute_fpfh_feature x2, registration_fgr...): same normals, same pose."""
@@ -194,7 +238,7 @@ def test_registro_fgr_fused_call_equals_the_five_calls(P, small_pair):
         a_s, a_t = P.PointCloud(small_pair["source"]), P.PointCloud(small_pair["target"])
         b_s, b_t = P.PointCloud(small_pair["source"]), P.PointCloud(small_pair["target"])
         fused = fn(a_s, a_t, 0.1, seed=5)
-        steps = fn(b_s, b_t, 0.1, seed=5, stepwise=True)
+        steps = _registro_fgr_five_calls(P, b_s, b_t, 0.1, abs_scale, 5)
         assert np.array_equal(a_s.normals, b_s.normals) and np.array_equal(a_t.normals, b_t.normals)
         assert np.array_equal(fused.transformation, steps.transformation), abs_scale
         assert fused.fitness == steps.fitness and fused.inlier_rmse == steps.inlier_rmse

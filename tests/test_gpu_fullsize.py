@@ -38,7 +38,7 @@ def test_config2_reference_parameters_l1(P, oracle, pair200k):
     """The benchmark configuration itself (L1, 1e-6/1e-6/100) against the oracle.  The bound is DERIVED in the test: the oracle is
     re-run on this very pair with other float64 summation chunkings (conftest.l1_tolerance); the device must agree with the oracle
     within max(north-star tolerance 1e-4 rad / 1e-3 m, twice that measured spread), and both must recover the planted motion."""
-    from conftest import TOL_M, TOL_RAD, l1_tolerance
+    from conftest import TOL_M, TOL_RAD, assert_reference_fixed_point, l1_tolerance
     p = pair200k
     est = P.registration.TransformationEstimationForGeneralizedICP(P.registration.L1Loss())
     crit = P.registration.ICPConvergenceCriteria(1e-6, 1e-6, 100)
@@ -51,6 +51,8 @@ def test_config2_reference_parameters_l1(P, oracle, pair200k):
     assert tol_rad <= 1e-3 and tol_m <= 1e-2, spread       # the derived bound itself must stay meaningful
     for a, b in zip(res.scales, ref.extra["scales"]):
         assert a["n_voxel"] == tuple(b["n_voxel"]) and a["n_clean"] == tuple(b["n_clean"])
+    # chaos-proof: the device's end pose is as stationary for the REFERENCE iteration (oracle arithmetic) as the oracle's own
+    assert_reference_fixed_point(oracle, p.source, p.target, p.voxel_sizes[-1], p.max_distances_script[-1], res.transformation, [ref.transformation] + ref.extra["variant_poses"], "config 2")
     for T in (res.transformation, ref.transformation):
         ang, dt = pose_error(T, p.T_true)
         assert ang < 2e-3 and dt < 2e-2, (ang, dt)
@@ -78,6 +80,51 @@ def test_config2_af_radius_rule_matches_oracle(P, oracle, pair200k):
     assert ang < 1e-5 and dt < 1e-4, (ang, dt)
     plan = P.registration.register_pairs_plan([(src, tgt, p.T_init)], "gicp", p.voxel_sizes, None, est, crit, radius_rule="af", inflight=1)[0]
     assert np.array_equal(plan.transformation, res.transformation) and [s["max_dist"] for s in plan.scales] == dists
+
+
+@pytest.mark.parametrize("which", ["golden500", "pair200k"])
+def test_config5_parameters_match_oracle(P, oracle, pair200k, which):
+    """BASELINE config 5's PARAMETERS (script-2 table of 5 scales, outlier filter (30, 1.0), 64-NN normals) against the oracle at sizes it
+    finishes in seconds: golden pair 500 (NCLT) and the 200 000-point pair.  Stage counts exact, L2 pose 1e-5 rad / 1e-4 m; L1 (the
+    reference loss) inside the bound derived from the oracle's own summation-order spread AND as stationary for the reference
+    iteration as the oracle's end pose.  The 2M-point run below is the same code path, checked by the planted motion."""
+    import os
+    from conftest import GOLDEN, SCRIPT2_DISTS, SCRIPT2_VOXELS, assert_reference_fixed_point, l1_tolerance
+    if which == "golden500":
+        g = np.load(os.path.join(GOLDEN, "nclt_pair_500.npz")); src, tgt, T0 = g["source"], g["target"], g["T_fgr"]
+    else:
+        src, tgt, T0 = pair200k.source, pair200k.target, pair200k.T_init
+    crit = P.registration.ICPConvergenceCriteria(1e-6, 1e-6, 100)
+    for loss, oloss in ((P.registration.L2Loss(), oracle.LOSS_L2), (P.registration.L1Loss(), oracle.LOSS_L1)):
+        if which == "pair200k" and oloss == oracle.LOSS_L1:
+            continue                                                   # (the L1 spread runs at this size take minutes on the CPU; config 2's own L1 test covers the size)
+        est = P.registration.TransformationEstimationForGeneralizedICP(loss)
+        res = P.registration.multiscale_gicp(P.PointCloud(src), P.PointCloud(tgt), SCRIPT2_VOXELS, SCRIPT2_DISTS, T0, est, crit, nb_neighbors=30, std_ratio=1.0, normal_knn=64)
+        run = lambda: oracle.multiscale_gicp(src, tgt, SCRIPT2_VOXELS, SCRIPT2_DISTS, T0, sor_k=30, sor_std=1.0, normal_k=64, loss=oloss)      # noqa: E731
+        if oloss == oracle.LOSS_L2:
+            ref, tr, tm = run(), 1e-5, 1e-4
+        else:
+            ref, tr, tm, spread = l1_tolerance(oracle, run, chunks=(64, 512, 4096))
+        for a, b in zip(res.scales, ref.extra["scales"]):
+            assert a["n_voxel"] == tuple(b["n_voxel"]) and a["n_clean"] == tuple(b["n_clean"]), (which, a, b)
+        # scale by scale while the ORACLE's loop converges: a scale that runs into max_iteration without settling (64-NN normals at 0.1 m
+        # voxels on an NCLT pair: the matches at 0.1 m keep switching, fitness 0.3) ends at a pose that is chaotic in the last bits
+        # whatever the loss, and everything after it inherits that
+        settled = True
+        for k, (a, b) in enumerate(zip(res.scales, ref.extra["scales"])):
+            settled = settled and bool(b["converged"])
+            ang, dt = pose_error(a["T"], b["T"])
+            print(f"config-5 parameters on {which}, {type(loss).__name__}, scale {k}: iterations {a['iterations']} / {b['iterations']}, device vs oracle {ang:.2e} rad {dt:.2e} m"
+                  f"{'' if settled else '   (oracle loop not converged: not compared)'}")
+            if settled:
+                assert ang <= tr and dt <= tm, (which, type(loss).__name__, k, ang, dt, tr, tm)      # (iteration counts are never compared: SURVEY App. B.3)
+                if oloss == oracle.LOSS_L2:
+                    assert abs(a["n_corr"] - b["n_corr"]) <= 2 + 1e-4 * b["n_corr"]        # (a stop one or two iterations apart moves a few rim matches)
+        assert which != "pair200k" or settled                             # the benchmark-shaped pair settles on every scale
+        if oloss == oracle.LOSS_L1:
+            assert tr <= 2e-3 and tm <= 2e-2                             # (golden pair 500 with 64-NN normals: the oracle's own chunkings end 3.4 mm apart)
+        if oloss == oracle.LOSS_L1 and settled:                           # (no fixed point to speak of where the reference loop itself ran out of iterations)
+            assert_reference_fixed_point(oracle, src, tgt, SCRIPT2_VOXELS[-1], SCRIPT2_DISTS[-1], res.transformation, [ref.transformation] + ref.extra["variant_poses"], f"config-5 parameters {which}", normal_k=64)
 
 
 def test_config5_two_million_points_recovers_planted_motion(P, pair200k):

@@ -143,10 +143,13 @@ def test_multiscale_gicp_reproduces_shipped_pose(P, oracle, golden_pair):
     with a tight L1 attractor the device lands on the shipped pose inside the north-star tolerance.  Pairs 0 and 899 scatter by
     more than that under a mere change of the float64 summation order (tests/test_oracle_golden.py measures it): there the device
     must sit inside the oracle's own measured spread (conftest.l1_tolerance), i.e. be one more sample of the same scatter."""
-    from conftest import l1_tolerance
+    from conftest import assert_reference_fixed_point, l1_tolerance
     g = golden_pair
     res = P.script2.Multiscale_GICP(P.PointCloud(g["source"]), P.PointCloud(g["target"]), 5, 100, g["T_fgr"])
     ang, dt = pose_error(res.transformation, g["T_gicp"])
+    # chaos-proof (every pair): one more step of the reference iteration (oracle, float64) from the device's end pose moves as little as
+    # one from the pose the REFERENCE ITSELF shipped for this pair
+    assert_reference_fixed_point(oracle, g["source"], g["target"], SCRIPT2_VOXELS[-1], SCRIPT2_DISTS[-1], res.transformation, g["T_gicp"], f"pair {int(g['pair'])}")
     if int(g["pair"]) not in (0, 899):
         assert ang <= TOL_RAD and dt <= TOL_M, (int(g["pair"]), ang, dt)
         return

@@ -9,7 +9,7 @@ pose graph, 3_Global_Optimizations_in_NCLT_dataset.py:292-364) on the device's r
 import numpy as np
 import pytest
 
-from conftest import TOL_M, TOL_RAD, l1_tolerance, pkg, pose_error
+from conftest import assert_reference_fixed_point, TOL_M, TOL_RAD, l1_tolerance, pkg, pose_error
 from test_gpu_gicp import _facade_loop
 
 pytestmark = pytest.mark.gpu
@@ -54,6 +54,8 @@ def test_facade_loop_stage2_on_device_and_global_refinement_on_host(P, oracle):
             ang, dt = pose_error(res[i].transformation, ref.transformation)
             assert ang <= tr and dt <= tm, (name, i, ang, dt, tr, tm)
             assert tr <= 1e-3 and tm <= 1e-2
+            if name == "l1" and i in (0, 3, 6):       # chaos-proof form of the L1 comparison (conftest.assert_reference_fixed_point)
+                assert_reference_fixed_point(oracle, clouds[s], clouds[t], vox[-1], dst[-1], res[i].transformation, [ref.transformation] + ref.extra["variant_poses"], f"facade pair {i}")
             ref_rel.append(ref.transformation)
         rel[name] = ([r.transformation for r in res], ref_rel)
     dev, ref = rel["l1"]

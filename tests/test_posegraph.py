@@ -115,3 +115,60 @@ def test_script3_graph_builder_conventions():
     assert [e.uncertain for e in g.edges] == [False] * 6 + [True]
     np.testing.assert_allclose(g.edges[2].transformation, rf.Transformar_de_volta(rel[2]))
     np.testing.assert_allclose(g.nodes[0].pose, np.eye(4)); np.testing.assert_allclose(g.nodes[3].pose, ab[2])     # the script's off-by-one
+
+
+def test_full_registration_builds_the_reference_graph(monkeypatch):
+    """`full_registration` (ALL_FUNCTIONS.py:342-394) with the pairwise registration replaced by a stub: which pairs are registered
+    (every cloud onto its next k), which edges are odometry (`uncertain=False`, consecutive clouds) and which loop closures, what the
+    nodes hold (inverse of the accumulated odometry, `AF:357-360`), and the fitness > 0.40 success count the reference prints."""
+    from types import SimpleNamespace
+    from pcr_amd import functions
+    rng = np.random.default_rng(3)
+    n, k = 6, 2
+    T = {}
+    calls = []
+
+    def fake(source, target, voxel_size):
+        s, t = source, target                                    # the "clouds" are just their indices here
+        calls.append((s, t, voxel_size))
+        T[(s, t)] = _T(_rot(rng.normal(size=3), 0.1), rng.normal(size=3))
+        fit = 0.40 if (s, t) == (0, 1) else (0.41 if t == s + 1 else 0.39)          # exactly 0.40 is NOT a success (strict >)
+        return SimpleNamespace(transformation=T[(s, t)], fitness=fit), np.eye(6) * (10 * s + t)
+    monkeypatch.setattr(functions, "Coarse_to_fine_FGR_M_GICP", fake)
+    g = pg.full_registration(list(range(n)), 0.1, k)
+    want = [(s, t) for s in range(n) for t in range(s + 1, n) if t - s <= k]
+    assert [(c[0], c[1]) for c in calls] == want and all(c[2] == 0.1 for c in calls)
+    assert len(g.edges) == k * (n - k) + (k * k - k) // 2 == len(want)               # the count the reference prints (AF:343)
+    for e, (s, t) in zip(g.edges, want):
+        assert (e.source_node_id, e.target_node_id) == (s, t) and e.uncertain == (t != s + 1)
+        assert np.array_equal(e.transformation, T[(s, t)]) and e.information[0, 0] == 10 * s + t
+    assert len(g.nodes) == n and np.array_equal(g.nodes[0].pose, np.eye(4))
+    odo = np.eye(4)
+    for i in range(n - 1):
+        odo = T[(i, i + 1)] @ odo
+        assert np.allclose(g.nodes[i + 1].pose, np.linalg.inv(odo), atol=1e-12)
+    assert g.attempted == len(want) and g.successes == n - 2                        # consecutive pairs but (0, 1): fitness 0.41 > 0.40
+
+
+@pytest.mark.gpu
+def test_full_registration_on_three_facade_scans():
+    """The same function on real clouds (three consecutive scans of the shipped Facade loop, k = 2): three registrations through
+    `Coarse_to_fine_FGR_M_GICP` on the device, two odometry edges and one loop closure, node poses consistent with the edges, and a
+    graph the optimiser accepts."""
+    import os
+    from conftest import GOLDEN
+    f = np.load(os.path.join(GOLDEN, "facade_loop.npz"))
+    clouds = [pcr_amd.PointCloud(f[f"s{i}"]) for i in range(3)]
+    g = pg.full_registration(clouds, 0.1, 2)
+    assert [(e.source_node_id, e.target_node_id, e.uncertain) for e in g.edges] == [(0, 1, False), (0, 2, True), (1, 2, False)]
+    assert g.attempted == 3 and 0 <= g.successes <= 3
+    assert np.allclose(g.nodes[1].pose, np.linalg.inv(g.edges[0].transformation), atol=1e-12)
+    assert np.allclose(g.nodes[2].pose, np.linalg.inv(g.edges[2].transformation @ g.edges[0].transformation), atol=1e-12)
+    # the loop-closure edge (0 -> 2) agrees with the composition of the odometry edges within the registration accuracy on these scans
+    ang, dt = pose_error(g.edges[1].transformation, g.edges[2].transformation @ g.edges[0].transformation)
+    assert ang < 3e-2 and dt < 0.3, (ang, dt)
+    for e in g.edges:
+        assert e.information.shape == (6, 6) and e.information[5, 5] > 100           # number of correspondences within voxel_size
+    pg.global_optimization(g, pg.GlobalOptimizationLevenbergMarquardt(), pg.GlobalOptimizationConvergenceCriteria(),
+                           pg.GlobalOptimizationOption(max_correspondence_distance=0.2, edge_prune_threshold=0.25, reference_node=0))
+    assert np.allclose(g.nodes[0].pose, np.eye(4), atol=1e-9)

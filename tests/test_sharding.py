@@ -96,3 +96,38 @@ def test_bench_gpus_2_launches_two_ranks_itself():
     env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], cwd=ROOT, env=env2, capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
+
+
+def _clean_env():
+    return {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+
+
+def test_bench_gpus_8_rehearsal_on_cpu():
+    """The driver's N = 8 command line, rehearsed without a GPU (a one-GPU box admits at most 6 processes on its card, so the eight
+    ranks cannot meet there): `python bench.py --gpus 8` starts eight ranks itself, each packs steps x B pose records, ONE gloo
+    all-gather leaves 8 x steps x B ordered records on every rank, and every rank holds the same table (digest all-gather)."""
+    import json
+    import subprocess
+    env = _clean_env(); env["PCR_BENCH_DRYRUN"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--pairs-per-step", "4"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]                     # rank 0 alone prints, once
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["n_ranks_seen"] == 8 and d["scaling"] == "weak"
+    assert d["config"]["gathered_records"] == 8 * 3 * 4 and d["config"]["tables_identical"] is True
+
+
+def test_bench_rank_that_fails_before_init_ends_the_job_nonzero():
+    """A rank that dies before it joins the process group (device missing, bad environment) must take the job down with a non-zero
+    exit code -- no hang, no re-exec of a surviving rank, no result line."""
+    import subprocess
+    import time
+    env = _clean_env(); env["PCR_BENCH_DRYRUN"] = "1"; env["PCR_BENCH_TEST_FAIL_RANK"] = "2"
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1", "--pairs-per-step", "2"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert time.time() - t0 < 300

@@ -1,0 +1,17 @@
+import importlib, os, sys
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import numpy as np
+from conftest import SCRIPT2_DISTS, SCRIPT2_VOXELS, pose_error
+P = importlib.import_module("point-cloud-registration-with-global-refinement_amd")
+from oracle import oracle as orc
+orc.build()
+g = np.load("/root/repo/tests/golden/nclt_pair_500.npz"); src, tgt, T0 = g["source"], g["target"], g["T_fgr"]
+est = P.registration.TransformationEstimationForGeneralizedICP(P.registration.L2Loss())
+crit = P.registration.ICPConvergenceCriteria(1e-6, 1e-6, 100)
+nk = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+vox, dst = SCRIPT2_VOXELS, SCRIPT2_DISTS
+res = P.registration.multiscale_gicp(P.PointCloud(src), P.PointCloud(tgt), vox, dst, T0, est, crit, nb_neighbors=30, std_ratio=1.0, normal_knn=nk)
+ref = orc.multiscale_gicp(src, tgt, vox, dst, T0, sor_k=30, sor_std=1.0, normal_k=nk, loss=orc.LOSS_L2)
+for a, b in zip(res.scales, ref.extra["scales"]):
+    print("   scale", a["voxel"] if "voxel" in a else "", "iters", a["iterations"], b["iterations"], "fitness", round(a["fitness"], 6), round(b["fitness"], 6), "n_corr", a["n_corr"], b["n_corr"], "pose", pose_error(a["T"], b["T"]) if "T" in a else "")
+print("normal_k", nk, "env", {k: v for k, v in os.environ.items() if k.startswith("PCR_")}, "counts", res.scales[-1]["n_clean"], ref.extra["scales"][-1]["n_clean"], "iters", res.scales[-1]["iterations"], ref.extra["scales"][-1]["iterations"], "pose err", pose_error(res.transformation, ref.transformation))
