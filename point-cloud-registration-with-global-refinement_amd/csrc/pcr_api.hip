@@ -440,6 +440,7 @@ static int prep_scale(pcr_context *ctx, const float *xyz, const float *nrm, int6
         tmp.nrm_final = clean->nrm;                              // normals of the cleaned cloud, straight from the SOR lists
         PCR_TRY(pcr_dev_sor(ctx, &v, sor_k, sor_std, &tmp, nullptr, nullptr, normal_k, prior, todo, nv_keep + 1, cnt_voxel_out, cnt_clean_out, !need_tree));
         for (int d = 0; d < 3; d++) { clean->key_org[d] = tmp.key_org[d]; clean->key_unit[d] = tmp.key_unit[d]; }
+        clean->voxel_lattice = tmp.voxel_lattice;
     }
     if (need_tree) {     // a GICP target: its tree serves the correspondence search and the few incomplete normal lists
         PCR_TRY(pcr_dev_build_bvh(ctx, clean));
@@ -504,7 +505,7 @@ static int multiscale_batched(pcr_context *ctx, const float *src_xyz, const floa
         for (int s = 0; s < n_scales; s++) vp[s] = &vox[s];
         PCR_TRY(pcr_dev_build_bvh_batch(ctx, vp, n_scales));
         PCR_TRY(pcr_dev_sor_batch(ctx, ins, outs, n_scales, sor_k, sor_std, normal_k, priors, todos, todo_counts, cnt_in, cnt_kept, !need_tree));
-        for (int s = 0; s < n_scales; s++) for (int d = 0; d < 3; d++) { clean[which][s].key_org[d] = tmp[s].key_org[d]; clean[which][s].key_unit[d] = tmp[s].key_unit[d]; }
+        for (int s = 0; s < n_scales; s++) { for (int d = 0; d < 3; d++) { clean[which][s].key_org[d] = tmp[s].key_org[d]; clean[which][s].key_unit[d] = tmp[s].key_unit[d]; } clean[which][s].voxel_lattice = tmp[s].voxel_lattice; }
         if (need_tree) {
             PCR_TRY(pcr_dev_build_bvh_batch(ctx, trees, n_scales));
             PCR_TRY(pcr_dev_normals_knn_batch(ctx, trees, n_scales, normal_k, priors, nouts, todos));
@@ -616,7 +617,7 @@ static int multiscale_group(pcr_context *ctx, pcr_pair_ex *const *px, int G, con
             }
         PCR_TRY(pcr_dev_sor_batch(ctx, ins.data(), outs.data(), (int)ins.size(), sor_k, sor_std, normal_k, pr.data(), td.data(), tc.data(), ci.data(), ck.data(), which == 0));
     }
-    for (size_t k = 0; k < clean.size(); k++) for (int d = 0; d < 3; d++) { clean[k].key_org[d] = tmp[k].key_org[d]; clean[k].key_unit[d] = tmp[k].key_unit[d]; }
+    for (size_t k = 0; k < clean.size(); k++) { for (int d = 0; d < 3; d++) { clean[k].key_org[d] = tmp[k].key_org[d]; clean[k].key_unit[d] = tmp[k].key_unit[d]; } clean[k].voxel_lattice = tmp[k].voxel_lattice; }
     {
         std::vector<DevCloud *> trees; std::vector<const float4 *> pr; std::vector<float4 *> no; std::vector<const uint8_t *> td;
         for (int g = 0; g < G; g++)

@@ -293,7 +293,7 @@ int pcr_dev_voxel(pcr_context *ctx, const float *xyz, const float *nrm_in, int64
     }
     const int end_bit = 3 * bits_for(mx);
     out->key_org[0] = (float)ox; out->key_org[1] = (float)oy; out->key_org[2] = (float)oz;
-    out->key_unit[0] = out->key_unit[1] = out->key_unit[2] = (float)voxel;
+    out->key_unit[0] = out->key_unit[1] = out->key_unit[2] = (float)voxel; out->voxel_lattice = true;
     ArenaMark mark(ctx);
     const int ni = (int)n;
     uint64_t *k0 = arena<uint64_t>(ctx, n), *k1 = arena<uint64_t>(ctx, n);
@@ -398,7 +398,7 @@ static int voxel_multi_batch(pcr_context *ctx, int count, const float *const *xy
             if (3 * bits_for(mx) > shift) shift = 3 * bits_for(mx);
             DevCloud &o = outs[c * n_scales + s];
             o.key_org[0] = (float)a.g.ox[s]; o.key_org[1] = (float)a.g.oy[s]; o.key_org[2] = (float)a.g.oz[s];
-            o.key_unit[0] = o.key_unit[1] = o.key_unit[2] = (float)voxel;
+            o.key_unit[0] = o.key_unit[1] = o.key_unit[2] = (float)voxel; o.voxel_lattice = true;
             a.o.pts[s] = o.pts; a.o.nrm[s] = o.nrm; a.o.keys[s] = o.keys; a.o.n[s] = o.n;
         }
         if (shift < 1) shift = 1;
@@ -784,6 +784,63 @@ int pcr_dev_build_bvh_batch(pcr_context *ctx, DevCloud *const *cs, int count) {
     return PCR_OK;
 }
 int pcr_dev_build_bvh(pcr_context *ctx, DevCloud *c) { return pcr_dev_build_bvh_batch(ctx, &c, 1); }
+
+// ====================================================================== cell hash of a voxel-lattice cloud (pcr_octree.h GridView)
+// One thread per point: the first point of a level-L Morton cell counts the cell's points (<= 8^L: the lattice holds one point per
+// voxel) and inserts (code -> first, count) by linear probing.  blockIdx.y picks the cloud.
+struct GridBuildDesc { const uint64_t *keys; const int *n; GridEntry *tab; unsigned mask; int shift; };
+__global__ void __launch_bounds__(BS) k_grid_build(const GridBuildDesc *descs) {
+    const GridBuildDesc d = descs[blockIdx.y];
+    const int n = *d.n, i = blockIdx.x * BS + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long code = d.keys[i] >> d.shift;
+    if (i > 0 && (d.keys[i - 1] >> d.shift) == code) return;
+    int j = i + 1;
+    while (j < n && (d.keys[j] >> d.shift) == code) j++;
+    unsigned h = pcr_grid_hash(code, d.mask);
+    for (;;) {
+        const unsigned long long old = atomicCAS(&d.tab[h].code, PCR_GRID_EMPTY, code);
+        if (old == PCR_GRID_EMPTY) { d.tab[h].first = i; d.tab[h].count = j - i; return; }
+        h = (h + 1) & d.mask;                              // (a cell has one first point: `old == code` cannot happen)
+    }
+}
+// level whose cell edge covers the radius with 0.2 % to spare (rounding of the query's cell against the points' exact voxel indices), or -1:
+// only for voxel-lattice clouds and cells of at most 4 voxels (27 cells = at most a few hundred candidates on a surface)
+int pcr_grid_level_for(const DevCloud *c, double search_radius) {
+    if (!c->voxel_lattice || !(search_radius > 0.0) || !(c->key_unit[0] > 0.0f)) return -1;
+    int L = 0;
+    while (L <= 2 && (double)c->key_unit[0] * (double)(1 << L) * 0.998 < search_radius) L++;
+    return L <= 2 ? L : -1;
+}
+int pcr_dev_build_grid_batch(pcr_context *ctx, const DevCloud *const *cs, const int *levels, int count, GridView *views) {
+    std::vector<GridBuildDesc> d; int max_cap = 0;
+    size_t total_slots = 0;
+    auto slots_of = [](const DevCloud *c) { unsigned s = 64; while (s < (unsigned)c->cap * 2u && s < (1u << 30)) s <<= 1; return s; };      // load factor <= 0.5
+    for (int k = 0; k < count; k++) {
+        std::memset(&views[k], 0, sizeof(GridView)); views[k].L = -1;
+        if (levels[k] < 0 || cs[k]->cap <= 0 || !cs[k]->voxel_lattice) continue;
+        total_slots += slots_of(cs[k]);
+    }
+    if (total_slots == 0) return PCR_OK;
+    GridEntry *tab = arena<GridEntry>(ctx, total_slots);
+    if (!tab) return PCR_ENOMEM;
+    PCR_HIP_CHECK(ctx, hipMemsetAsync(tab, 0xff, total_slots * sizeof(GridEntry), ctx->stream));
+    size_t off = 0;
+    for (int k = 0; k < count; k++) {
+        const DevCloud *c = cs[k];
+        if (levels[k] < 0 || c->cap <= 0 || !c->voxel_lattice) continue;
+        const unsigned slots = slots_of(c);
+        GridView &g = views[k];
+        g.tab = tab + off; g.mask = slots - 1; g.L = levels[k];
+        for (int a = 0; a < 3; a++) { g.org[a] = c->key_org[a]; g.inv_unit[a] = 1.0f / c->key_unit[a]; g.cell[a] = c->key_unit[a] * (float)(1 << levels[k]); }
+        d.push_back(GridBuildDesc{c->keys, c->n, tab + off, slots - 1, 3 * levels[k]});
+        off += slots; max_cap = c->cap > max_cap ? c->cap : max_cap;
+    }
+    const GridBuildDesc *dd = pcr_desc_upload(ctx, d.data(), (int)d.size());
+    if (!dd) return PCR_ENOMEM;
+    PCR_LAUNCH(ctx, k_grid_build, dim3((unsigned)((max_cap + BS - 1) / BS), (unsigned)d.size()), dim3(BS), 0, ctx->stream, dd);
+    return PCR_OK;
+}
 
 static inline OctView oct_view(const DevCloud *c) {
     OctView v; v.pts = c->pts; v.nodes = c->oct_nodes; v.up = c->oct_up; v.meta = c->oct_meta; v.leaf_of = c->leaf_of; v.keys = c->keys; v.pinfo = c->pinfo; v.l1rng = c->oct_l1;
@@ -1558,6 +1615,7 @@ static int sor_batch(pcr_context *ctx, SorProblem *pr, int count, int nb_neighbo
         SorProblem &q = pr[k];
         const DevCloud *in = q.in; DevCloud *out = q.out;
         for (int d = 0; d < 3; d++) { out->key_org[d] = in->key_org[d]; out->key_unit[d] = in->key_unit[d]; }
+        out->voxel_lattice = in->voxel_lattice;
         if (in->cap <= 0) { PCR_HIP_CHECK(ctx, hipMemsetAsync(out->n, 0, sizeof(int), ctx->stream)); continue; }
         double *avg = q.avg_sorted ? q.avg_sorted : arena<double>(ctx, in->cap);
         double *stats3 = arena<double>(ctx, 4);

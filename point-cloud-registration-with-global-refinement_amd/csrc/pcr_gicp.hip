@@ -42,6 +42,7 @@ struct IcpArgs {
     const float4 *src_pts, *src_nrm; const int *ns_ptr;
     const float *src_cov6, *tgt_cov6;            // optional raw covariances (xx,xy,xz,yy,yz,zz), Morton order
     const float4 *tgt_pts, *tgt_nrm; OctView tgt; const int *nt_ptr;
+    GridView grid;                               // cell hash of the target (grid.tab == nullptr: search the octree)
     int32_t *match; int src_cap;
     float4 *ref; int32_t *rbest;                 // per source point: position and margin / nearest point of its last search (skip certificate)
     float r2s, rs_minus_r;                       // search cap (r + g)^2 of the certificate mode and g = the unmatched margin
@@ -53,6 +54,7 @@ struct IcpArgs {
     double rel_fit, rel_rmse; int max_it;
     int single;                                  // 1: linearise once, never update (debug / evaluate)
     int dbg_visits;                              // diagnostics: store node/leaf visit counts instead of matches
+    int dbg_phase;                               // diagnostics (PCR_ICP_PHASE = 1 / 2): t_dbg[1] <- slowest workgroup's end of phase A / B of the fused kernel
     unsigned long long *stamps_nn, *stamps_it;   // diagnostics (PCR_ICP_STAMPS): per-wavefront clocks of the first 16 launches
 };
 #define ICP_STAMP_LAUNCHES 16
@@ -263,6 +265,7 @@ __device__ static bool icp_ldlt6_pivoted(const double *S, const double *b6, doub
 
 // ---- kernel 1 of an iteration: exact 1-NN of every transformed source point, ONE query per octet (32 per
 // workgroup).  Latency-bound pointer chasing, so it runs at full occupancy (few registers, many wavefronts).
+template <bool GRID>
 __device__ static inline void d_icp_nn(const IcpArgs &a) {
     IcpState *st = a.state;
     constexpr int OPB = ICP_BS / OCT;
@@ -330,7 +333,9 @@ __device__ static inline void d_icp_nn(const IcpArgs &a) {
     int qi = 0;
     if (live) { const float4 r = rec_q[ob]; qx = r.x; qy = r.y; qz = r.z; hint = __float_as_int(r.w); qi = rec_i[ob]; }
     int visits = 0, start_pt = 0; float d1 = 0, d2 = 0;
-    const int best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.ref ? a.r2s : a.r2f, hint, ol, oct, ob, &start_pt, a.dbg_visits ? &visits : nullptr, &d1, &d2);
+    int best;
+    if (GRID) { best = grid_nn_query(a.grid, a.tgt_pts, live, qx, qy, qz, a.ref ? a.r2s : a.r2f, ol, &d1, &d2); start_pt = hint >= 0 ? hint : 0; }
+    else best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.ref ? a.r2s : a.r2f, hint, ol, oct, ob, &start_pt, a.dbg_visits ? &visits : nullptr, &d1, &d2);
     if (a.verify && ol == 0 && live && rec_c[ob] != -2) {
         const int claim = rec_c[ob];
         const bool bad = claim >= 0 ? best != claim : (best >= 0 && d1 < a.r2f);
@@ -353,9 +358,11 @@ __device__ static inline void d_icp_nn(const IcpArgs &a) {
     }
 }
 
-__global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_icp_nn(IcpArgs a) { d_icp_nn(a); }
+// GRID: the correspondence search goes through the target's cell hash (a.grid) instead of its octree -- a compile-time choice, so that
+// neither form carries the other's registers (both in one kernel: 52 VGPRs spilled here, 150 VGPRs = one workgroup per CU in the fused kernel)
+template <bool GRID> __global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_icp_nn(IcpArgs a) { d_icp_nn<GRID>(a); }
 // group form (lockstep group of pairs, blockIdx.y = pair; arguments in device memory)
-__global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_icp_nn_g(const IcpArgs *a) { d_icp_nn(a[blockIdx.y]); }
+template <bool GRID> __global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_icp_nn_g(const IcpArgs *a) { d_icp_nn<GRID>(a[blockIdx.y]); }
 
 // ---- one correspondence in float64: accumulates its 30 sums into acc[]; `cand` = candidate target point (or < 0)
 template <int MODE>
@@ -466,7 +473,7 @@ __device__ static inline void icp_point(const IcpArgs &a, const double *T, int i
 // ---- workgroup reduction of acc[], write-through partial row + ticket, and -- in the last-arriving workgroup -- the end of
 // the iteration: gather the rows, fixed-order sums, convergence test, 6x6 solve, pose update.  BS = workgroup size.
 template <int MODE, int BS>
-__device__ static inline void icp_finish(const IcpArgs &a, IcpState *st, const double *T, double *acc, int nb, int ns, int launches, unsigned long long t_entry, int row) {
+__device__ static inline void icp_finish(const IcpArgs &a, IcpState *st, const double *T, double *acc, int nb, int ns, int launches, unsigned long long t_entry, int row, unsigned long long t_phase = 0) {
     __shared__ double red[BS / 16][NVP];           // one row per 16-lane DPP row
     __shared__ double fin[16][NVP];
     __shared__ int is_last;
@@ -489,7 +496,7 @@ __device__ static inline void icp_finish(const IcpArgs &a, IcpState *st, const d
     }
     if (threadIdx.x == 63) {   // diagnostics in the two padding columns: ticks to end-of-search / end-of-reduction
         __hip_atomic_store(&a.partials[(size_t)row * NVP + 30], (double)t_search, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&a.partials[(size_t)row * NVP + 31], (double)(wall_clock64() - t_entry), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.partials[(size_t)row * NVP + 31], (double)(a.dbg_phase ? t_phase : wall_clock64() - t_entry), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its stores ...
     const unsigned long long t_drain = wall_clock64();
@@ -628,13 +635,14 @@ template <int MODE> __global__ void __launch_bounds__(LIN_BS) k_icp_iter_g(const
 // launches of the loop (the in-flight throughput is bound by the dispatch rate of small dependent kernels, ~90k/s
 // system-wide) and removes the match[] round trip between the two kernels.
 #define FUSED_BS 512
+#define PCR_GRID_LANE_SEARCH 0     // 1: one pending query per LANE through the cell hash (measured: divergent per-lane scans, 47 us against 27 us per launch at the coarsest scale)
 // PPL = source points per lane (PCR_ICP_PPL, default 1).  The kernel is latency-bound (dependent loads, publish -> ticket -> gather), so
 // its wavefronts mostly wait, and at one point per lane a 160k-point launch is 312 workgroups of 8 wavefronts at 122 VGPRs -- 61 % of
 // the chip's wavefront slots for ONE pair's iteration.  Two / four points per lane (half / a quarter of the wavefronts, partial rows
 // and tickets; a lane's certificate tests and float64 linearisations back to back) were measured: 4 pairs in flight 327 / 318 / 293
 // pairs/s for PPL 1 / 2 / 4, 8 in flight 314 / 334 / 313, one pair alone 178 / 158 / 125 -- the wavefront slots are not what bounds the
 // pairs in flight ("what bounds the throughput"), and alone the longer lanes cost what they cost.  Kept as a switch.
-template <int TILE_PTS>
+template <int TILE_PTS, bool GRID>
 __device__ static inline void d_icp_fused(const IcpArgs &a) {
     IcpState *st = a.state;
     constexpr int OPB = FUSED_BS / OCT;
@@ -705,8 +713,24 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
         if (mine) cand_l[p * FUSED_BS + tid] = cand;
     }
     __syncthreads();
-    // ---- phase B: the 64 octets work through the pending list
+    const unsigned long long t_a = wall_clock64() - t_entry;
+    // ---- phase B: the pending list.  Cell hash: one query per LANE, the whole list in ceil(npend / 512) rounds; octree: one query per
+    // octet, 64 per round
     const int npend = n_rec;
+    if (GRID && PCR_GRID_LANE_SEARCH) {
+        for (int e = tid; e < npend; e += FUSED_BS) {
+            const float4 r = rec_q[e]; const int l = rec_l[e];
+            float d1 = 0, d2 = 0;
+            const int best = grid_nn_lane(a.grid, a.tgt_pts, r.x, r.y, r.z, a.r2s, &d1, &d2);
+            const int qi = tile0 + l, hint = __float_as_int(r.w);
+            const float slack = 2e-5f + 1e-6f * (fabsf(r.x) + fabsf(r.y) + fabsf(r.z));
+            const float margin = best >= 0 ? 0.5f * (sqrtf(d2) - sqrtf(d1)) - slack : a.rs_minus_r - slack;
+            a.ref[qi] = make_float4(r.x, r.y, r.z, margin > 0.0f ? margin : 0.0f);
+            a.rbest[qi] = best;
+            if (best < 0) a.match[qi] = -((hint >= 0 ? hint : 0) + 2);       // (the hint only matters to the octree search)
+            cand_l[l] = best;
+        }
+    } else
     for (int e0 = 0; e0 < npend; e0 += OPB) {
         const int e = e0 + ob;
         const bool live = e < npend;
@@ -714,7 +738,9 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
         float qx = 0, qy = 0, qz = 0; int hint = -1, l = 0;
         if (live) { const float4 r = rec_q[e]; qx = r.x; qy = r.y; qz = r.z; hint = __float_as_int(r.w); l = rec_l[e]; }
         int start_pt = 0; float d1 = 0, d2 = 0;
-        const int best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.r2s, hint, ol, oct, ob, &start_pt, nullptr, &d1, &d2);
+        int best;
+        if (GRID) { best = grid_nn_query(a.grid, a.tgt_pts, live, qx, qy, qz, a.r2s, ol, &d1, &d2); start_pt = hint >= 0 ? hint : 0; }
+        else best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.r2s, hint, ol, oct, ob, &start_pt, nullptr, &d1, &d2);
         if (ol == 0 && live) {
             const int qi = tile0 + l;
             const float slack = 2e-5f + 1e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz));
@@ -726,6 +752,7 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
         }
     }
     __syncthreads();
+    const unsigned long long t_b = wall_clock64() - t_entry;
     // ---- phase C: the lane's correspondences one after the other (icp_point stores the match, or the hint when the radius test fails)
     double acc[NV];
 #pragma unroll
@@ -739,10 +766,10 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
             icp_point<ICP_MODE_GICP>(a, T, i, ns, c, acc);
         }
     }
-    icp_finish<ICP_MODE_GICP, FUSED_BS>(a, st, T, acc, nb, ns, launches, t_entry, bid);
+    icp_finish<ICP_MODE_GICP, FUSED_BS>(a, st, T, acc, nb, ns, launches, t_entry, bid, a.dbg_phase == 1 ? t_a : t_b);
 }
-template <int TILE_PTS> __global__ void __launch_bounds__(FUSED_BS) k_icp_fused(IcpArgs a) { d_icp_fused<TILE_PTS>(a); }
-template <int TILE_PTS> __global__ void __launch_bounds__(FUSED_BS) k_icp_fused_g(const IcpArgs *a) { d_icp_fused<TILE_PTS>(a[blockIdx.y]); }
+template <int TILE_PTS, bool GRID> __global__ void __launch_bounds__(FUSED_BS) k_icp_fused(IcpArgs a) { d_icp_fused<TILE_PTS, GRID>(a); }
+template <int TILE_PTS, bool GRID> __global__ void __launch_bounds__(FUSED_BS) k_icp_fused_g(const IcpArgs *a) { d_icp_fused<TILE_PTS, GRID>(a[blockIdx.y]); }
 
 // Source points per workgroup of the fused kernel (PCR_ICP_TILE = 128 ... 2048; PCR_ICP_PPL = 1 / 2 / 4 is the older spelling of
 // 512 / 1024 / 2048).  The workgroup's 64 octets serve its pending queries 64 at a time, so a 512-point tile whose certificates do not
@@ -758,17 +785,21 @@ static int fused_tile_points(int cap, int G) {
     }
     return t >= 2048 ? 2048 : (t >= 1024 ? 1024 : (t >= 512 ? 512 : (t >= 256 ? 256 : 128)));
 }
-#define PCR_FUSED_LAUNCH(ctx, KERNEL, tile, grid, arg)                                                                 \
+#define PCR_FUSED_LAUNCH_(ctx, KERNEL, GRID, tile, grid, arg)                                                          \
     do {                                                                                                               \
         switch (tile) {                                                                                                \
-            case 128: PCR_LAUNCH(ctx, KERNEL<128>, grid, dim3(FUSED_BS), 0, (ctx)->stream, arg); break;                \
-            case 256: PCR_LAUNCH(ctx, KERNEL<256>, grid, dim3(FUSED_BS), 0, (ctx)->stream, arg); break;                \
-            case 1024: PCR_LAUNCH(ctx, KERNEL<1024>, grid, dim3(FUSED_BS), 0, (ctx)->stream, arg); break;              \
-            case 2048: PCR_LAUNCH(ctx, KERNEL<2048>, grid, dim3(FUSED_BS), 0, (ctx)->stream, arg); break;              \
-            default: PCR_LAUNCH(ctx, KERNEL<512>, grid, dim3(FUSED_BS), 0, (ctx)->stream, arg); break;                 \
+            case 128: PCR_LAUNCH(ctx, (KERNEL<128, GRID>), grid, dim3(FUSED_BS), 0, (ctx)->stream, arg); break;        \
+            case 256: PCR_LAUNCH(ctx, (KERNEL<256, GRID>), grid, dim3(FUSED_BS), 0, (ctx)->stream, arg); break;        \
+            case 1024: PCR_LAUNCH(ctx, (KERNEL<1024, GRID>), grid, dim3(FUSED_BS), 0, (ctx)->stream, arg); break;      \
+            case 2048: PCR_LAUNCH(ctx, (KERNEL<2048, GRID>), grid, dim3(FUSED_BS), 0, (ctx)->stream, arg); break;      \
+            default: PCR_LAUNCH(ctx, (KERNEL<512, GRID>), grid, dim3(FUSED_BS), 0, (ctx)->stream, arg); break;         \
         }                                                                                                              \
     } while (0)
+#define PCR_FUSED_LAUNCH(ctx, KERNEL, use_grid, tile, grid, arg)                                                       \
+    do { if (use_grid) PCR_FUSED_LAUNCH_(ctx, KERNEL, true, tile, grid, arg); else PCR_FUSED_LAUNCH_(ctx, KERNEL, false, tile, grid, arg); } while (0)
 
+// PCR_ICP_GRID=0: every correspondence search over the octree (the independent check of tests/test_gpu_gicp.py::test_switches_do_not_change_the_result)
+static bool icp_use_grid() { static const bool on = !(getenv("PCR_ICP_GRID") && atoi(getenv("PCR_ICP_GRID")) == 0); return on; }
 static void fill_args(IcpArgs &a, const DevCloud *src, const DevCloud *tgt, double max_dist, const pcr_gicp_params *p,
                       int32_t *match, IcpState *st, double *partials, int single) {
     a.src_pts = src->pts; a.src_nrm = src->nrm; a.ns_ptr = src->n;
@@ -787,8 +818,10 @@ static void fill_args(IcpArgs &a, const DevCloud *src, const DevCloud *tgt, doub
     a.rel_fit = p ? p->relative_fitness : 1e-6; a.rel_rmse = p ? p->relative_rmse : 1e-6; a.max_it = p ? p->max_iteration : 30;
     a.single = single;
     a.dbg_visits = (single && getenv("PCR_DEBUG_VISITS")) ? 1 : 0;
+    a.dbg_phase = getenv("PCR_ICP_PHASE") ? atoi(getenv("PCR_ICP_PHASE")) : 0;
     a.stamps_nn = nullptr; a.stamps_it = nullptr;
     a.ref = nullptr; a.rbest = nullptr;
+    memset(&a.grid, 0, sizeof a.grid); a.grid.L = -1;
 }
 
 static int read_state(pcr_context *ctx, const IcpState *st_dev, IcpState *host) {
@@ -832,6 +865,11 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
         a.r2s = (float)(rs * rs * (1.0 + 1e-6)); a.rs_minus_r = (float)g;
         a.verify = getenv("PCR_ICP_VERIFY") ? 1 : 0;
     }
+    if (icp_use_grid() && !use_cov) {       // cell hash of the target for radii of a few voxels (pcr_octree.h GridView); the octree serves the others
+        const int L = pcr_grid_level_for(tgt, std::sqrt((double)(a.ref ? a.r2s : a.r2f)));
+        PCR_TRY(pcr_dev_build_grid_batch(ctx, &tgt, &L, 1, &a.grid));
+    }
+    const bool grid = a.grid.tab != nullptr;
     IcpInit in; memcpy(in.T, T0, sizeof in.T);
     PCR_LAUNCH(ctx, k_icp_init, dim3(1), dim3(64), 0, ctx->stream, st, in);
     const char *stamp_path = getenv("PCR_ICP_STAMPS");          // diagnostics only
@@ -854,10 +892,11 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     const bool fused = use_fused && a.ref && !use_cov && !stamp_path && nbf <= 4096;
     auto enqueue = [&](int launch_index) {
         if (fused && launch_index > 0) {
-            PCR_FUSED_LAUNCH(ctx, k_icp_fused, tile_pts, dim3(nbf), a);
+            PCR_FUSED_LAUNCH(ctx, k_icp_fused, grid, tile_pts, dim3(nbf), a);
             return;
         }
-        PCR_LAUNCH(ctx, k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
+        if (grid) PCR_LAUNCH(ctx, k_icp_nn<true>, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
+        else PCR_LAUNCH(ctx, k_icp_nn<false>, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
         if (use_cov) PCR_LAUNCH(ctx, k_icp_iter<ICP_MODE_GICP_COV>, dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
         else PCR_LAUNCH(ctx, k_icp_iter<ICP_MODE_GICP>, dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
     };
@@ -865,7 +904,7 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     if (use_graph && !stamp_path) {
         for (int which = 0; which < 2; which++) {
             std::string key((const char *)&a, sizeof a);
-            const int extra[6] = {nbnn, nbmax, use_cov ? 1 : 0, CHUNK, fused ? nbf + (tile_pts << 16) : 0, which};
+            const int extra[7] = {nbnn, nbmax, use_cov ? 1 : 0, CHUNK, fused ? nbf + (tile_pts << 16) : 0, which, grid ? 1 : 0};
             key.append((const char *)extra, sizeof extra);
             for (auto &g : ctx->icp_graphs) if (g.first == key) { chunk_exec[which] = g.second; break; }
             if (!chunk_exec[which]) {
@@ -985,6 +1024,18 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
         a.r2s = (float)(rs * rs * (1.0 + 1e-6)); a.rs_minus_r = (float)gg;
         memcpy(inits[g].T, T0 + 16 * g, sizeof inits[g].T);
     }
+    bool grid = false, grid_ok = false; (void)grid_ok;
+    if (icp_use_grid()) {
+        std::vector<int> levels((size_t)G); std::vector<GridView> views((size_t)G);
+        for (int g = 0; g < G; g++) levels[g] = pcr_grid_level_for(tgt[g], std::sqrt((double)args[g].r2s));
+        bool all = true;
+        for (int g = 0; g < G; g++) all = all && levels[g] >= 0 && tgt[g]->cap > 0;
+        if (all) {                          // one kernel form per launch: the grid form only when every target of the group has a cell hash
+            PCR_TRY(pcr_dev_build_grid_batch(ctx, tgt, levels.data(), G, views.data()));
+            for (int g = 0; g < G; g++) { args[g].grid = views[g]; grid = grid_ok = true; }
+            for (int g = 0; g < G; g++) grid = grid && views[g].tab != nullptr;
+        }
+    }
     if (nbf > 4096) { ctx->err = "GICP group: cloud too large for the fused iteration kernel"; return PCR_EINVAL; }
     // arguments and start poses live in a per-context device buffer at a FIXED address (the captured graph reads them there)
     const size_t args_bytes = sizeof(IcpArgs) * 32 + sizeof(IcpInit) * 32;
@@ -1003,18 +1054,20 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
     const int max_it = p ? p->max_iteration : 30;
     const int total = max_it + 1, CHUNK = chunk_env < 1 ? 1 : (chunk_env > 32 ? 32 : chunk_env);
     static const bool use_graph = !(getenv("PCR_ICP_GRAPH") && atoi(getenv("PCR_ICP_GRAPH")) == 0);
+    static const bool use_fused_g = !(getenv("PCR_ICP_FUSED") && atoi(getenv("PCR_ICP_FUSED")) == 0);
     auto enqueue = [&](int launch_index) {
-        if (launch_index > 0) {
-            PCR_FUSED_LAUNCH(ctx, k_icp_fused_g, tile_pts, dim3(nbf, G), dargs);
+        if (launch_index > 0 && use_fused_g) {
+            PCR_FUSED_LAUNCH(ctx, k_icp_fused_g, grid, tile_pts, dim3(nbf, G), dargs);
             return;
         }
-        PCR_LAUNCH(ctx, k_icp_nn_g, dim3(nbnn, G), dim3(ICP_BS), 0, ctx->stream, dargs);
+        if (grid) PCR_LAUNCH(ctx, k_icp_nn_g<true>, dim3(nbnn, G), dim3(ICP_BS), 0, ctx->stream, dargs);
+        else PCR_LAUNCH(ctx, k_icp_nn_g<false>, dim3(nbnn, G), dim3(ICP_BS), 0, ctx->stream, dargs);
         PCR_LAUNCH(ctx, k_icp_iter_g<ICP_MODE_GICP>, dim3(nbmax, G), dim3(LIN_BS), 0, ctx->stream, dargs);
     };
     hipGraphExec_t chunk_exec[2] = {nullptr, nullptr};
     if (use_graph) {
         for (int which = 0; which < 2; which++) {
-            const long long kv[8] = {0x47525550ll /* "GRUP" */, G, nbnn, nbmax, nbf, tile_pts, CHUNK, which};
+            const long long kv[8] = {0x47525550ll /* "GRUP" */, G + (grid ? 1000 : 0) + (use_fused_g ? 0 : 2000), nbnn, nbmax, nbf, tile_pts, CHUNK, which};
             std::string key((const char *)kv, sizeof kv);
             key.append((const char *)&dargs, sizeof dargs);
             for (auto &gr : ctx->icp_graphs) if (gr.first == key) { chunk_exec[which] = gr.second; break; }
@@ -1106,7 +1159,7 @@ int pcr_dev_linearize_once(pcr_context *ctx, const DevCloud *src, const DevCloud
     IcpArgs a; memset(&a, 0, sizeof a); fill_args(a, src, tgt, max_dist, p, match, st, partials, 1);
     IcpInit in; memcpy(in.T, T, sizeof in.T);
     PCR_LAUNCH(ctx, k_icp_init, dim3(1), dim3(64), 0, ctx->stream, st, in);
-    PCR_LAUNCH(ctx, k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
+    PCR_LAUNCH(ctx, k_icp_nn<false>, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
     PCR_LAUNCH(ctx, k_icp_iter<ICP_MODE_GICP>, dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
     IcpState h;
     PCR_TRY(read_state(ctx, st, &h));
@@ -1131,7 +1184,7 @@ int pcr_dev_evaluate(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt,
     IcpArgs a; memset(&a, 0, sizeof a); fill_args(a, src, tgt, max_dist, nullptr, match, st, partials, 1);
     IcpInit in; memcpy(in.T, T, sizeof in.T);
     PCR_LAUNCH(ctx, k_icp_init, dim3(1), dim3(64), 0, ctx->stream, st, in);
-    PCR_LAUNCH(ctx, k_icp_nn, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
+    PCR_LAUNCH(ctx, k_icp_nn<false>, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
     PCR_LAUNCH(ctx, k_icp_iter<ICP_MODE_EVAL>, dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
     IcpState h;
     PCR_TRY(read_state(ctx, st, &h));

@@ -139,6 +139,7 @@ struct DevCloud {
     int2 *oct_l1 = nullptr;      //   level-1 node -> (first point, point count): the "fat leaf" as a point range
     float key_org[3] = {0, 0, 0};   // lattice of the Morton keys: coordinate i <-> [org + i*unit, org + (i+1)*unit)
     float key_unit[3] = {1, 1, 1};
+    bool voxel_lattice = false;     // the keys are voxel indices of a voxel grid (at most one point per lattice cell): cell hashes make sense
 };
 
 static inline size_t oct_node_capacity(int cap_points) { return (size_t)cap_points + 256; }   // entries of child[] / box pairs
@@ -169,6 +170,10 @@ int pcr_dev_sort_cloud(pcr_context *ctx, const float *xyz, int64_t n, const doub
                        uint32_t *perm);
 int pcr_dev_build_bvh(pcr_context *ctx, DevCloud *c);
 int pcr_dev_build_bvh_batch(pcr_context *ctx, DevCloud *const *cs, int count);     // up to 8 trees per launch (blockIdx.y)
+// cell hash of level L over a voxel-lattice cloud (the GICP correspondence search with a radius of a few voxels); tables from the arena
+struct GridView;
+int pcr_dev_build_grid_batch(pcr_context *ctx, const DevCloud *const *cs, const int *levels, int count, GridView *views /* count; codes == nullptr: none */);
+int pcr_grid_level_for(const DevCloud *c, double search_radius);      // -1: no grid for this radius on this cloud
 // SOR: keep flags + compaction into `out` (out.cap >= in.cap); returns nothing to the host
 int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double std_ratio, DevCloud *out,
                 uint8_t *keep_sorted /*optional device, in.cap*/, double *avg_sorted /*optional*/,
