@@ -71,10 +71,10 @@ def parse_args(argv=None):
                     help="independent pairs (or lockstep groups, see --group) in flight per GPU (one library worker thread + context + streams each)")
     ap.add_argument("--group", type=int, default=int(os.environ.get("PCR_BENCH_GROUP", "0")),
                     help="pairs per lockstep group (pcr_pairs_plan.group): that many consecutive pairs of a batch go through the same launches; "
-                         "0 = by cloud size as registration.register_pairs_plan(group=None) does (about 400k points per group: 2 at 200k points)")
+                         "0 = by cloud size as registration.register_pairs_plan(group=None) does (registration.default_group: 6 at 200k points)")
     args = ap.parse_args(argv)
     if args.group <= 0:
-        args.group = int(min(16, max(1, round(400_000 / max(args.points * (10 if args.config5 else 1), 1)))))
+        args.group = -1          # resolved by registration.default_group once the package is imported (main)
     return args
 
 
@@ -192,6 +192,8 @@ def main(argv=None) -> int:
     syn = importlib.import_module(PKG + ".synthetic")
     shard = importlib.import_module(PKG + ".sharding")
     reg = P.registration
+    if args.group <= 0:
+        args.group = reg.default_group(args.points * (10 if args.config5 else 1))
     ctypes = __import__("ctypes")
     lib = P._lib.load()
 

@@ -56,7 +56,7 @@ extern "C" int pcr_destroy(pcr_context *ctx) {
     for (int i = 0; i < 2; i++) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < 2; i++) if (ctx->fence_ev[i]) (void)hipEventDestroy(ctx->fence_ev[i]);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
-    for (auto &g : ctx->icp_graphs) (void)hipGraphExecDestroy(g.second);
+    for (auto &g : ctx->icp_graphs) { (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
     if (ctx->side_stream2) { (void)hipStreamSynchronize(ctx->side_stream2); (void)hipStreamDestroy(ctx->side_stream2); }

@@ -362,7 +362,7 @@ __device__ static inline void d_icp_nn(const IcpArgs &a) {
 // neither form carries the other's registers (both in one kernel: 52 VGPRs spilled here, 150 VGPRs = one workgroup per CU in the fused kernel)
 template <bool GRID> __global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_icp_nn(IcpArgs a) { d_icp_nn<GRID>(a); }
 // group form (lockstep group of pairs, blockIdx.y = pair; arguments in device memory)
-template <bool GRID> __global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_icp_nn_g(const IcpArgs *a) { d_icp_nn<GRID>(a[blockIdx.y]); }
+template <bool GRID> __global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_icp_nn_g(const IcpArgs *__restrict__ a) { d_icp_nn<GRID>(a[blockIdx.y]); }
 
 // ---- one correspondence in float64: accumulates its 30 sums into acc[]; `cand` = candidate target point (or < 0)
 template <int MODE>
@@ -627,7 +627,7 @@ __device__ static inline void d_icp_iter(const IcpArgs &a) {
     icp_finish<MODE, LIN_BS>(a, st, T, acc, nb, ns, launches, t_entry, (int)blockIdx.x);
 }
 template <int MODE> __global__ void __launch_bounds__(LIN_BS) k_icp_iter(IcpArgs a) { d_icp_iter<MODE>(a); }
-template <int MODE> __global__ void __launch_bounds__(LIN_BS) k_icp_iter_g(const IcpArgs *a) { d_icp_iter<MODE>(a[blockIdx.y]); }
+template <int MODE> __global__ void __launch_bounds__(LIN_BS) k_icp_iter_g(const IcpArgs *__restrict__ a) { d_icp_iter<MODE>(a[blockIdx.y]); }
 
 // ---- ONE kernel per iteration (launches after the first of a scale): workgroup b owns source points [512 b, 512 b + 512):
 // certificates per lane -> its pending queries compacted into LDS -> the workgroup's 64 octets search them -> barrier ->
@@ -769,7 +769,14 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
     icp_finish<ICP_MODE_GICP, FUSED_BS>(a, st, T, acc, nb, ns, launches, t_entry, bid, a.dbg_phase == 1 ? t_a : t_b);
 }
 template <int TILE_PTS, bool GRID> __global__ void __launch_bounds__(FUSED_BS) k_icp_fused(IcpArgs a) { d_icp_fused<TILE_PTS, GRID>(a); }
-template <int TILE_PTS, bool GRID> __global__ void __launch_bounds__(FUSED_BS) k_icp_fused_g(const IcpArgs *a) { d_icp_fused<TILE_PTS, GRID>(a[blockIdx.y]); }
+// (the problem's arguments are copied out of the device buffer ONCE, by scalar loads, like by-value kernel arguments: read through the
+// pointer wherever they are used they sat in VGPRs -- 146-162 instead of 122, one workgroup per CU instead of two)
+template <int TILE_PTS, bool GRID> __global__ void __launch_bounds__(FUSED_BS) k_icp_fused_g(const IcpArgs *__restrict__ a) { d_icp_fused<TILE_PTS, GRID>(a[blockIdx.y]); }
+// groups of up to ICP_BYVAL problems: the argument structs travel BY VALUE in the kernel arguments (scalar loads on demand, 123 VGPRs = two
+// workgroups per CU; read through a device pointer the fields sit in VGPRs: 147-150, one workgroup per CU)
+#define ICP_BYVAL 8
+struct IcpArgsB { IcpArgs a[ICP_BYVAL]; };
+template <int TILE_PTS, bool GRID> __global__ void __launch_bounds__(FUSED_BS) k_icp_fused_b(IcpArgsB b) { d_icp_fused<TILE_PTS, GRID>(b.a[blockIdx.y]); }
 
 // Source points per workgroup of the fused kernel (PCR_ICP_TILE = 128 ... 2048; PCR_ICP_PPL = 1 / 2 / 4 is the older spelling of
 // 512 / 1024 / 2048).  The workgroup's 64 octets serve its pending queries 64 at a time, so a 512-point tile whose certificates do not
@@ -906,7 +913,7 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
             std::string key((const char *)&a, sizeof a);
             const int extra[7] = {nbnn, nbmax, use_cov ? 1 : 0, CHUNK, fused ? nbf + (tile_pts << 16) : 0, which, grid ? 1 : 0};
             key.append((const char *)extra, sizeof extra);
-            for (auto &g : ctx->icp_graphs) if (g.first == key) { chunk_exec[which] = g.second; break; }
+            for (auto &g : ctx->icp_graphs) if (g.key == key) { chunk_exec[which] = g.exec; break; }
             if (!chunk_exec[which]) {
                 hipGraph_t graph = nullptr;
                 PCR_HIP_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
@@ -916,10 +923,14 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
                 (void)hipGraphDestroy(graph);
                 if (ctx->icp_graphs.size() >= 32) {           // evict the oldest entry this call does not use itself
                     size_t victim = 0;
-                    while (victim < ctx->icp_graphs.size() && ctx->icp_graphs[victim].second == chunk_exec[0]) victim++;
-                    if (victim < ctx->icp_graphs.size()) { (void)hipGraphExecDestroy(ctx->icp_graphs[victim].second); ctx->icp_graphs.erase(ctx->icp_graphs.begin() + victim); }
+                    while (victim < ctx->icp_graphs.size() && ctx->icp_graphs[victim].exec == chunk_exec[0]) victim++;
+                    if (victim < ctx->icp_graphs.size()) {
+                        (void)hipGraphExecDestroy(ctx->icp_graphs[victim].exec);
+                        if (ctx->icp_graphs[victim].graph) (void)hipGraphDestroy(ctx->icp_graphs[victim].graph);
+                        ctx->icp_graphs.erase(ctx->icp_graphs.begin() + victim);
+                    }
                 }
-                ctx->icp_graphs.emplace_back(std::move(key), chunk_exec[which]);
+                { IcpGraph e; e.key = std::move(key); e.exec = chunk_exec[which]; ctx->icp_graphs.push_back(std::move(e)); }
             }
         }
     }
@@ -1055,36 +1066,84 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
     const int total = max_it + 1, CHUNK = chunk_env < 1 ? 1 : (chunk_env > 32 ? 32 : chunk_env);
     static const bool use_graph = !(getenv("PCR_ICP_GRAPH") && atoi(getenv("PCR_ICP_GRAPH")) == 0);
     static const bool use_fused_g = !(getenv("PCR_ICP_FUSED") && atoi(getenv("PCR_ICP_FUSED")) == 0);
+    static const bool byval_env = !(getenv("PCR_ICP_BYVAL") && atoi(getenv("PCR_ICP_BYVAL")) == 0);
+    const bool byval = byval_env && G <= ICP_BYVAL;
+    IcpArgsB hb; memset(&hb, 0, sizeof hb);
+    for (int g = 0; g < G && g < ICP_BYVAL; g++) hb.a[g] = args[g];
     auto enqueue = [&](int launch_index) {
         if (launch_index > 0 && use_fused_g) {
-            PCR_FUSED_LAUNCH(ctx, k_icp_fused_g, grid, tile_pts, dim3(nbf, G), dargs);
+            if (byval) PCR_FUSED_LAUNCH(ctx, k_icp_fused_b, grid, tile_pts, dim3(nbf, G), hb);
+            else PCR_FUSED_LAUNCH(ctx, k_icp_fused_g, grid, tile_pts, dim3(nbf, G), dargs);
             return;
         }
         if (grid) PCR_LAUNCH(ctx, k_icp_nn_g<true>, dim3(nbnn, G), dim3(ICP_BS), 0, ctx->stream, dargs);
         else PCR_LAUNCH(ctx, k_icp_nn_g<false>, dim3(nbnn, G), dim3(ICP_BS), 0, ctx->stream, dargs);
         PCR_LAUNCH(ctx, k_icp_iter_g<ICP_MODE_GICP>, dim3(nbmax, G), dim3(LIN_BS), 0, ctx->stream, dargs);
     };
+    // One captured chunk per launch FORM (group size, kernel forms, tile, chunk length): what differs from call to call -- the
+    // grid widths and, for the by-value kernels, the argument batch -- is patched into the instantiated graph's kernel nodes
+    // (hipGraphExecKernelNodeSetParams), so circuits whose clouds differ in size do not pay a capture + instantiate per call.
     hipGraphExec_t chunk_exec[2] = {nullptr, nullptr};
     if (use_graph) {
+        const void *dargs_v = dargs;
+        std::string now;
+        { const int w[3] = {nbnn, nbmax, nbf}; now.assign((const char *)w, sizeof w); if (byval) now.append((const char *)&hb, sizeof hb); }
         for (int which = 0; which < 2; which++) {
-            const long long kv[8] = {0x47525550ll /* "GRUP" */, G + (grid ? 1000 : 0) + (use_fused_g ? 0 : 2000), nbnn, nbmax, nbf, tile_pts, CHUNK, which};
+            const long long kv[6] = {0x47525550ll /* "GRUP" */, G + (grid ? 1000 : 0) + (use_fused_g ? 0 : 2000) + (byval ? 4000 : 0), tile_pts, CHUNK, which, (long long)(uintptr_t)dargs_v};
             std::string key((const char *)kv, sizeof kv);
-            key.append((const char *)&dargs, sizeof dargs);
-            for (auto &gr : ctx->icp_graphs) if (gr.first == key) { chunk_exec[which] = gr.second; break; }
-            if (!chunk_exec[which]) {
-                hipGraph_t graph = nullptr;
+            IcpGraph *hit = nullptr;
+            for (auto &gr : ctx->icp_graphs) if (gr.key == key) { hit = &gr; break; }
+            if (!hit) {
+                IcpGraph e; e.key = key;
                 PCR_HIP_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
                 for (int k = 0; k < CHUNK; k++) enqueue(which == 0 ? k : CHUNK + k);
-                PCR_HIP_CHECK(ctx, hipStreamEndCapture(ctx->stream, &graph));
-                PCR_HIP_CHECK(ctx, hipGraphInstantiate(&chunk_exec[which], graph, nullptr, nullptr, 0));
-                (void)hipGraphDestroy(graph);
+                PCR_HIP_CHECK(ctx, hipStreamEndCapture(ctx->stream, &e.graph));
+                PCR_HIP_CHECK(ctx, hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
+                // the captured chunk is a chain: walk it from its root so that nodes[] is in launch order
+                size_t nr = 1; hipGraphNode_t node = nullptr;
+                PCR_HIP_CHECK(ctx, hipGraphGetRootNodes(e.graph, &node, &nr));
+                while (node) {
+                    e.nodes.push_back(node);
+                    size_t nd = 0;
+                    PCR_HIP_CHECK(ctx, hipGraphNodeGetDependentNodes(node, nullptr, &nd));
+                    if (nd == 0) break;
+                    if (nd != 1) { ctx->err = "GICP group: captured chunk is not a chain"; return PCR_EHIP; }
+                    hipGraphNode_t next = nullptr;
+                    PCR_HIP_CHECK(ctx, hipGraphNodeGetDependentNodes(node, &next, &nd));
+                    node = next;
+                }
+                e.baked = now;
                 if (ctx->icp_graphs.size() >= 32) {
                     size_t victim = 0;
-                    while (victim < ctx->icp_graphs.size() && ctx->icp_graphs[victim].second == chunk_exec[0]) victim++;
-                    if (victim < ctx->icp_graphs.size()) { (void)hipGraphExecDestroy(ctx->icp_graphs[victim].second); ctx->icp_graphs.erase(ctx->icp_graphs.begin() + victim); }
+                    while (victim < ctx->icp_graphs.size() && ctx->icp_graphs[victim].exec == chunk_exec[0]) victim++;
+                    if (victim < ctx->icp_graphs.size()) {
+                        (void)hipGraphExecDestroy(ctx->icp_graphs[victim].exec);
+                        if (ctx->icp_graphs[victim].graph) (void)hipGraphDestroy(ctx->icp_graphs[victim].graph);
+                        ctx->icp_graphs.erase(ctx->icp_graphs.begin() + victim);
+                    }
                 }
-                ctx->icp_graphs.emplace_back(std::move(key), chunk_exec[which]);
+                ctx->icp_graphs.push_back(std::move(e));
+                hit = &ctx->icp_graphs.back();
+            } else if (hit->baked != now) {
+                // launch order of a chunk (enqueue above): launch 0 is search + iteration, every later launch one fused kernel
+                size_t i = 0;
+                for (int k = 0; k < CHUNK; k++) {
+                    const int launch_index = which == 0 ? k : CHUNK + k;
+                    const bool one = launch_index > 0 && use_fused_g;
+                    for (int part = 0; part < (one ? 1 : 2); part++, i++) {
+                        if (i >= hit->nodes.size()) { ctx->err = "GICP group: captured chunk shorter than its launch list"; return PCR_EHIP; }
+                        hipKernelNodeParams np;
+                        PCR_HIP_CHECK(ctx, hipGraphKernelNodeGetParams(hit->nodes[i], &np));
+                        void *kp[1];
+                        if (one) { np.gridDim = dim3(nbf, G); kp[0] = byval ? (void *)&hb : (void *)&dargs_v; }
+                        else { np.gridDim = part == 0 ? dim3(nbnn, G) : dim3(nbmax, G); kp[0] = (void *)&dargs_v; }
+                        np.kernelParams = kp; np.extra = nullptr;
+                        PCR_HIP_CHECK(ctx, hipGraphExecKernelNodeSetParams(hit->exec, hit->nodes[i], &np));
+                    }
+                }
+                hit->baked = now;
             }
+            chunk_exec[which] = hit->exec;
         }
     }
     // two read-back slots of G states each in the pinned window

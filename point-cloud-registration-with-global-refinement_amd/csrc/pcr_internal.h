@@ -8,6 +8,16 @@
 #include "../../include/pcr_hip.h"
 
 
+// One captured chunk of GICP launches.  Solo calls key it by everything the launches bake in; lockstep groups key it by the launch
+// form only and patch grid widths / by-value arguments into `exec` through `nodes` (kept in launch order, owned by `graph`).
+struct IcpGraph {
+    std::string key;
+    hipGraphExec_t exec = nullptr;
+    hipGraph_t graph = nullptr;
+    std::vector<hipGraphNode_t> nodes;
+    std::string baked;
+};
+
 struct pcr_context {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -29,7 +39,7 @@ struct pcr_context {
     int profiling = 0;             // bench instrumentation (pcr_profile_*)
     double prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [0..7] GICP loop (pcr_hip.h), [8..10] feature matching: ms, flops, launches
     std::vector<hipEvent_t> prof_events;
-    std::vector<std::pair<std::string, hipGraphExec_t>> icp_graphs;   // captured launch chunks of the GICP loop, keyed by their arguments
+    std::vector<IcpGraph> icp_graphs;   // captured launch chunks of the GICP loop
     std::string err;
     // The caller's stream is the legacy default stream (pcr_set_stream(ctx, NULL), torch's default stream): the work runs on the
     // context's own stream (graph capture is not allowed on the legacy stream) and every call is fenced against the

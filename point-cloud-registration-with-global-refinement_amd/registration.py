@@ -239,6 +239,15 @@ def registro_fgr(source: PointCloud, target: PointCloud, voxel_size: float, use_
     return _result(res, corr)
 
 
+def default_group(points_per_cloud: float) -> int:
+    """Pairs per lockstep GICP group for clouds of this size: about 1.2M points per group, at most 8 (the by-value argument batch
+    of ``k_icp_fused_b``), 16 for clouds small enough that launch count decides.  Measured on one MI355X, 4 groups in flight, 3-scale
+    GICP stage, pair by pair -> groups: 200k-point pairs 340 -> 530 pairs/s (groups of 6), 100k 440 -> 850 (8), 50k 540 -> 1360 (8),
+    20k 680 -> 2590 (16; 2460 with 8)."""
+    g = int(round(1_200_000 / max(float(points_per_cloud), 1.0)))
+    return 16 if g > 32 else max(1, min(8, g))
+
+
 def register_pairs_plan(pairs, stage: str = "gicp", voxel_sizes=None, max_correspondence_distances=None, estimation_method=None, criteria=None,
                         nb_neighbors: int = 30, std_ratio: float = 1.0, normal_knn: int = 20, inflight: int = 3, with_correspondences: bool = True,
                         fgr_voxel_size: float = 0.1, fgr_use_absolute_scale: bool = True, fgr_seed=None, radius_rule: str = "given",
@@ -253,9 +262,7 @@ def register_pairs_plan(pairs, stage: str = "gicp", voxel_sizes=None, max_corres
     ``group`` > 1 (stages "gicp" and "fgr+gicp"): that many consecutive pairs run in LOCKSTEP through the same GICP launches (preprocessing
     batched over clouds and scales, one GICP loop per scale for the whole group; same per-pair arithmetic; with "fgr+gicp" the worker runs
     registro_FGR pair by pair first); ``inflight`` counts groups.
-    ``group=None`` picks by cloud size, about 400k points per group (measured on one MI355X with 4 groups in flight, pair by pair ->
-    groups: 20k-point pairs 680 -> 2190 pairs/s with groups of 12-16, 50k 540 -> 1080 with 6-8, 100k 440 -> 635 with 4, 200k 340 -> 410
-    with 2).
+    ``group=None`` picks by cloud size (``default_group``).
     The library keeps ``inflight`` pairs in flight on the current device.  Returns RegistrationResults in input order (for
     stages with FGR the FGR result is attached as ``.fgr``; ``.information`` when ``info_max_dist > 0``)."""
     estimation = estimation_method or TransformationEstimationForGeneralizedICP()
@@ -276,7 +283,7 @@ def register_pairs_plan(pairs, stage: str = "gicp", voxel_sizes=None, max_corres
         return []
     if group is None:
         mean_pts = float(np.mean([len(s_) + len(t_) for s_, t_, _ in pairs])) / 2
-        group = int(min(16, max(1, round(400_000 / max(mean_pts, 1.0)))))
+        group = default_group(mean_pts)
     if stage == "fgr+gicp" and group > 1 and n > 1:
         # Two passes over the batch instead of FGR -> GICP pair by pair: registro_FGR is a chain of ~150 small launches with a few host
         # waits and wants MANY pairs in flight (20k-point pairs: 230 / 590 / 700 pairs/s with 1 / 4 / 8), the GICP wants lockstep groups.

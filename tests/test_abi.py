@@ -71,3 +71,11 @@ def test_io_roundtrip(tmp_path):
         pio.write_pose(q, T, fmt)
         assert np.allclose(pio.read_pose(q), T)
     assert pio.relative_pose_name(900, 901) == "pose_0_900.txt" and pio.relative_pose_name(900, 901, False) == "pose_901_900.txt"
+
+
+def test_default_group_rule():
+    """``register_pairs_plan(group=None)``: about 1.2M points per lockstep group, at most 8 pairs (the by-value argument batch of the fused
+    iteration kernel holds 8), 16 for clouds so small that the launch count decides, pair by pair from 2M-point clouds (config 5) up."""
+    g = pkg().registration.default_group
+    assert [g(n) for n in (20_000, 50_000, 100_000, 200_000, 400_000, 2_000_000)] == [16, 8, 8, 6, 3, 1]
+    assert g(0) == 16 and g(1e9) == 1

@@ -88,7 +88,7 @@ def test_a_bad_pair_in_a_group_fails_alone():
 
 
 def test_group_none_sizes_groups_by_the_clouds(golden_pair_list):
-    """``group=None`` (what the stage-2 driver passes) picks about 400k points per group: on NCLT-size pairs one group holds all of them;
+    """``group=None`` (what the stage-2 driver passes) picks ``registration.default_group`` pairs per group: on NCLT-size pairs one group holds all of them;
     smooth loss: the poses agree with pair by pair to rounding."""
     P = pkg(); reg = P.registration
     vox = P.script2.create_scales(3); dst = P.script2.max_correspondence_distances(vox)
