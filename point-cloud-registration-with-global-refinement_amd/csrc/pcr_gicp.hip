@@ -790,7 +790,10 @@ static int fused_tile_points(int cap, int G) {
     if (t <= 0) {
         t = G > 1 ? 1024 : (cap >= 40000 ? 256 : 512);
     }
-    return t >= 2048 ? 2048 : (t >= 1024 ? 1024 : (t >= 512 ? 512 : (t >= 256 ? 256 : 128)));
+    t = t >= 2048 ? 2048 : (t >= 1024 ? 1024 : (t >= 512 ? 512 : (t >= 256 ? 256 : 128)));
+    // the last workgroup of the fused kernel gathers one partial row per tile: at most 4096 of them (2M-point clouds of config 5: tiles of 512)
+    while (t < 2048 && (cap + t - 1) / t > 4088) t *= 2;
+    return t;
 }
 #define PCR_FUSED_LAUNCH_(ctx, KERNEL, GRID, tile, grid, arg)                                                          \
     do {                                                                                                               \

@@ -3,8 +3,9 @@
 #   profiles/rNN_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the DEFAULT bench command
 #   profiles/rNN_pmc_hbm_traffic.csv      per-kernel HBM traffic from separate --pmc passes (FETCH_SIZE, WRITE_SIZE, TCC hit/miss)
 #   profiles/rNN_traffic.json             the same numbers keyed by kernel (bench.py reads it for roofline.traffic)
-# usage: tools/make_profiles.sh r02
-TAG=${1:-r02}
+#   profiles/rNN_config5_kernel_stats.csv / rNN_nclt_kernel_stats.csv: the same summary for config 5 (2M points, 5 scales) and NCLT-size pairs
+# usage: tools/make_profiles.sh r03
+TAG=${1:-r03}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/profiles_$TAG
@@ -22,6 +23,14 @@ grep '^{"metric' "$OUT/bench_fgr.log" | tail -1 > "$ROOT/profiles/${TAG}_bench_l
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/solo" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 1 --warmup 1 --pairs-per-step 8 --inflight 1 --group 1 > "$OUT/bench_solo.log" 2> "$OUT/bench_solo.err" || exit 1
 python3 "$ROOT/tools/icp_gap_hist.py" "$OUT/solo" "$ROOT/profiles/${TAG}_icp_gaps_solo.txt" > /dev/null
 cp "$(find "$OUT/solo" -name '*kernel_stats.csv' | head -1)" "$ROOT/profiles/${TAG}_solo_kernel_stats.csv"
+# config 5 (2M-point clouds, 5 scales, 64-NN normals) and NCLT-size pairs (20k points, the default group rule): kernel summaries of the commands
+# whose bench lines are stored next to them
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c5" -o run -- python3 "$ROOT/bench.py" --config5 --pairs-per-step 8 --base-pairs 2 --steps 2 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/bench_c5.log" 2> "$OUT/bench_c5.err" || exit 1
+cp "$(find "$OUT/c5" -name '*kernel_stats.csv' | head -1)" "$ROOT/profiles/${TAG}_config5_kernel_stats.csv"
+grep '^{"metric' "$OUT/bench_c5.log" | tail -1 > "$ROOT/profiles/${TAG}_bench_line_config5_under_rocprof.json"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/nclt" -o run -- python3 "$ROOT/bench.py" --points 20000 --pairs-per-step 192 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > "$OUT/bench_nclt.log" 2> "$OUT/bench_nclt.err" || exit 1
+cp "$(find "$OUT/nclt" -name '*kernel_stats.csv' | head -1)" "$ROOT/profiles/${TAG}_nclt_kernel_stats.csv"
+grep '^{"metric' "$OUT/bench_nclt.log" | tail -1 > "$ROOT/profiles/${TAG}_bench_line_nclt_under_rocprof.json"
 for pass in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   d=$OUT/pmc_$(echo $pass | tr ' ' '_')
   rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$d" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 1 --warmup 1 --pairs-per-step 4 --inflight 1 --group 1 > "$d.log" 2> "$d.err" || exit 1
@@ -30,20 +39,23 @@ done
 python3 - "$OUT" "$ROOT/profiles/${TAG}" <<'PY'
 import csv, glob, json, sys, collections
 out, dst = sys.argv[1], sys.argv[2]
+def norm(name):                      # whatever the tile, the search form and the argument form
+    if "k_icp_fused" in name: return "k_icp_fused"
+    if name.startswith("void k_icp_nn<") or name.startswith("k_icp_nn("): return "k_icp_nn"
+    return {"void k_icp_iter<0>(IcpArgs)": "k_icp_iter<GICP>", "void k_knn_batch<0, 4>(KnnBatch)": "k_knn_batch<SOR,4>", "void k_knn_batch<1, 4>(KnnBatch)": "k_knn_batch<NORMALS,4>",
+            "k_normals_from_lists_batch(NflBatch)": "k_normals_from_lists_batch", "k_grid_build(GridBuildDesc const*)": "k_grid_build"}.get(name, name.split("(")[0])
 def load(pat):
     f = glob.glob(f"{out}/{pat}/**/*counter_collection.csv", recursive=True)[0]
     d = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-        name = r["Kernel_Name"]
-        if name.startswith("void k_icp_fused<") and name.endswith("(IcpArgs)"): name = "void k_icp_fused<512>(IcpArgs)"      # whatever the tile
+        name = norm(r["Kernel_Name"])
         d[name][r["Counter_Name"]].append((float(r["Counter_Value"]), dur))
     return d
 fetch, write, tcc = load("pmc_FETCH_SIZE"), load("pmc_WRITE_SIZE"), load("pmc_TCC_HIT_sum_TCC_MISS_sum")
-short = {"void k_icp_fused<512>(IcpArgs)": "k_icp_fused", "k_icp_nn(IcpArgs)": "k_icp_nn", "void k_icp_iter<0>(IcpArgs)": "k_icp_iter<GICP>", "void k_knn_batch<0, 4>(KnnBatch)": "k_knn_batch<SOR,4>",
-         "void k_knn_batch<1, 4>(KnnBatch)": "k_knn_batch<NORMALS,4>", "k_normals_from_lists_batch(NflBatch)": "k_normals_from_lists_batch", "k_rs_scatter(unsigned long const*, unsigned int const*, int, int, int const*, unsigned long*, unsigned int*)": "k_rs_scatter"}
 rows, js = [], {}
-for full, name in short.items():
+for name in ["k_icp_fused", "k_icp_nn", "k_icp_iter<GICP>", "k_knn_batch<SOR,4>", "k_knn_batch<NORMALS,4>", "k_normals_from_lists_batch", "k_grid_build", "k_rs_scatter"]:
+    full = name
     live = lambda lst: [v for v, dur in lst if dur > 6.0]            # launches after 'done' return at once: not live
     f = live(fetch[full]["FETCH_SIZE"]); w = live(write[full]["WRITE_SIZE"])
     h = live(tcc[full]["TCC_HIT_sum"]); m = live(tcc[full]["TCC_MISS_sum"])
@@ -80,7 +92,7 @@ with open(dst + "_pmc_valu_per_pair.csv", "w", newline="") as fo:
         w.writerow([k[:60], round(n / npairs, 1), round(dur / 1e3 / npairs, 3), round(insts / 1e6 / npairs, 1), round(insts / tot, 3), int(insts / dur), round(insts / dur / PEAK, 3)])
     w.writerow(["TOTAL", "", round(sum(r[3] for r in rows) / 1e3 / npairs, 3), round(tot / 1e6 / npairs, 1), 1.0, "", ""])
 PY
-grep '^{"metric' "$OUT/bench_stats.log" | tail -1 > "$ROOT/gpurun_out/bench_under_rocprof_$TAG.json"
+grep '^{"metric' "$OUT/bench_stats.log" | tail -1 > "$ROOT/profiles/${TAG}_bench_line_under_rocprof.json"
 # gpurun only merges gpurun_out/ back: export the files to commit there as well
 cp "$ROOT"/profiles/${TAG}_* "$ROOT/gpurun_out/profiles_export/"
 head -12 "$ROOT/profiles/${TAG}_bench_kernel_stats.csv" | cut -c1-150
