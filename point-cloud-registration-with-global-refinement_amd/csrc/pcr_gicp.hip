@@ -334,7 +334,7 @@ __device__ static inline void d_icp_nn(const IcpArgs &a) {
     if (live) { const float4 r = rec_q[ob]; qx = r.x; qy = r.y; qz = r.z; hint = __float_as_int(r.w); qi = rec_i[ob]; }
     int visits = 0, start_pt = 0; float d1 = 0, d2 = 0;
     int best;
-    if (GRID) { best = grid_nn_query(a.grid, a.tgt_pts, live, qx, qy, qz, a.ref ? a.r2s : a.r2f, ol, &d1, &d2); start_pt = hint >= 0 ? hint : 0; }
+    if (GRID) { best = grid_nn_search(a.grid, a.tgt_pts, live, qx, qy, qz, a.ref ? a.r2s : a.r2f, ol, &d1, &d2); start_pt = hint >= 0 ? hint : 0; }
     else best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.ref ? a.r2s : a.r2f, hint, ol, oct, ob, &start_pt, a.dbg_visits ? &visits : nullptr, &d1, &d2);
     if (a.verify && ol == 0 && live && rec_c[ob] != -2) {
         const int claim = rec_c[ob];
@@ -363,6 +363,86 @@ __device__ static inline void d_icp_nn(const IcpArgs &a) {
 template <bool GRID> __global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_icp_nn(IcpArgs a) { d_icp_nn<GRID>(a); }
 // group form (lockstep group of pairs, blockIdx.y = pair; arguments in device memory)
 template <bool GRID> __global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_icp_nn_g(const IcpArgs *__restrict__ a) { d_icp_nn<GRID>(a[blockIdx.y]); }
+
+// ---- large clouds (icp_stream_min() points and more): the iteration as TWO streaming kernels.  k_icp_ab = phases A and B of the fused
+// kernel below without its float64 part: one source point per LANE for the certificate test (the cold kernel above spends an octet on
+// it), the workgroup's pending queries compacted in LDS, its 32 octets search them; 64 VGPRs = 8 wavefronts per SIMD where the fused
+// kernel's 122 leave 4, and k_icp_iter follows with one 512-point tile per workgroup.  At 0.5-1.6M source points a launch of the fused
+// kernel is 2-3 rounds of workgroups that mostly wait on dependent loads; the two kernel boundaries cost less than that.
+template <bool GRID>
+__device__ static inline void d_icp_ab(const IcpArgs &a) {
+    IcpState *st = a.state;
+    constexpr int OPB = ICP_BS / OCT;
+    __shared__ OctMeta m;
+    __shared__ OctStack<OPB> stk;
+    __shared__ float4 rec_q[ICP_BS];
+    __shared__ int rec_i[ICP_BS];
+    __shared__ int n_rec;
+    const int done = st->done;
+    const int ns = *a.ns_ptr, nt = *a.nt_ptr;
+    const int tid = threadIdx.x, lane = tid & 63, oct = lane >> 3, ol = lane & 7, ob = tid >> 3;
+    const int i = blockIdx.x * ICP_BS + tid;
+    const int ic = i < a.src_cap ? i : 0;
+    const float4 pf = a.src_pts[ic];
+    const int mraw = a.match[ic];
+    const float4 refv = a.ref[ic];
+    const int rb = a.rbest[ic];
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = st->T[k];
+    int mword = 0;
+    if (tid < (int)(sizeof(OctMeta) / 4)) mword = ((const int *)a.tgt.meta)[tid];
+    if (done) return;
+    if ((int)blockIdx.x * ICP_BS >= ns) return;
+    if (blockIdx.x == 0 && tid == 0) st->t_start = wall_clock64();
+    if (tid < (int)(sizeof(OctMeta) / 4)) ((int *)&m)[tid] = mword;
+    if (tid == 0) n_rec = 0;
+    __syncthreads();
+    {
+        bool need = false;
+        float qx = 0, qy = 0, qz = 0; int hint = -1;
+        if (i < ns) {
+            const double px = pf.x, py = pf.y, pz = pf.z;
+            qx = (float)(T[0] * px + T[1] * py + T[2] * pz + T[3]);
+            qy = (float)(T[4] * px + T[5] * py + T[6] * pz + T[7]);
+            qz = (float)(T[8] * px + T[9] * py + T[10] * pz + T[11]);
+            hint = mraw >= 0 ? mraw : (mraw <= -2 ? -(mraw + 2) : -1);
+            const float ex = qx - refv.x, ey = qy - refv.y, ez = qz - refv.z;
+            const bool certified = refv.w > 0.0f && pcr_d2(ex, ey, ez) < refv.w * refv.w;
+            need = nt > 0 && !certified;
+            if (certified && rb >= 0 && mraw != rb) a.match[i] = rb;     // k_icp_iter may have turned it into a hint (beyond max_dist)
+        }
+        const unsigned long long nbm = __ballot(need);
+        int base = 0;
+        if (lane == 0 && nbm != 0ull) base = atomicAdd(&n_rec, __builtin_popcountll(nbm));
+        base = __shfl(base, 0, 64);
+        if (need) {
+            const int slot = base + __builtin_popcountll(nbm & ((1ull << lane) - 1ull));
+            rec_q[slot] = make_float4(qx, qy, qz, __int_as_float(hint)); rec_i[slot] = i;
+        }
+    }
+    __syncthreads();
+    const int npend = n_rec;
+    for (int e0 = 0; e0 < npend; e0 += OPB) {
+        const int e = e0 + ob;
+        const bool live = e < npend;
+        if (__ballot(live) == 0ull) continue;
+        float qx = 0, qy = 0, qz = 0; int hint = -1, qi = 0;
+        if (live) { const float4 r = rec_q[e]; qx = r.x; qy = r.y; qz = r.z; hint = __float_as_int(r.w); qi = rec_i[e]; }
+        int start_pt = 0; float d1 = 0, d2 = 0;
+        int best;
+        if (GRID) { best = grid_nn_search(a.grid, a.tgt_pts, live, qx, qy, qz, a.r2s, ol, &d1, &d2); start_pt = hint >= 0 ? hint : 0; }
+        else best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.r2s, hint, ol, oct, ob, &start_pt, nullptr, &d1, &d2);
+        if (ol == 0 && live) {
+            const float slack = 2e-5f + 1e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz));
+            const float margin = best >= 0 ? 0.5f * (sqrtf(d2) - sqrtf(d1)) - slack : a.rs_minus_r - slack;
+            a.ref[qi] = make_float4(qx, qy, qz, margin > 0.0f ? margin : 0.0f);
+            a.rbest[qi] = best;
+            a.match[qi] = best >= 0 ? best : -(start_pt + 2);
+        }
+    }
+}
+template <bool GRID> __global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_icp_ab(IcpArgs a) { d_icp_ab<GRID>(a); }
 
 // ---- one correspondence in float64: accumulates its 30 sums into acc[]; `cand` = candidate target point (or < 0)
 template <int MODE>
@@ -627,6 +707,28 @@ __device__ static inline void d_icp_iter(const IcpArgs &a) {
     icp_finish<MODE, LIN_BS>(a, st, T, acc, nb, ns, launches, t_entry, (int)blockIdx.x);
 }
 template <int MODE> __global__ void __launch_bounds__(LIN_BS) k_icp_iter(IcpArgs a) { d_icp_iter<MODE>(a); }
+// streaming form behind k_icp_ab: workgroup b owns the 512-point tile b (the partial rows and their order are those of k_icp_fused<512>),
+// held at 128 VGPRs = two workgroups per CU (the strided loop of k_icp_iter takes 218)
+__global__ void __launch_bounds__(LIN_BS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_icp_lin(IcpArgs a) {
+    IcpState *st = a.state;
+    const int done = st->done, launches = st->launches;
+    const int ns = *a.ns_ptr;
+    const int i = blockIdx.x * LIN_BS + threadIdx.x;
+    const int mi = a.match[i < a.src_cap ? i : 0];
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = st->T[k];
+    if (done) return;
+    int nb = (ns + LIN_BS - 1) / LIN_BS;
+    if (nb < 1) nb = 1;
+    if ((int)blockIdx.x >= nb) return;
+    const unsigned long long t_entry = wall_clock64();
+    double acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) acc[k] = 0.0;
+    if (i < ns) icp_point<ICP_MODE_GICP>(a, T, i, ns, mi, acc);
+    icp_finish<ICP_MODE_GICP, LIN_BS>(a, st, T, acc, nb, ns, launches, t_entry, (int)blockIdx.x);
+}
 template <int MODE> __global__ void __launch_bounds__(LIN_BS) k_icp_iter_g(const IcpArgs *__restrict__ a) { d_icp_iter<MODE>(a[blockIdx.y]); }
 
 // ---- ONE kernel per iteration (launches after the first of a scale): workgroup b owns source points [512 b, 512 b + 512):
@@ -739,7 +841,7 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
         if (live) { const float4 r = rec_q[e]; qx = r.x; qy = r.y; qz = r.z; hint = __float_as_int(r.w); l = rec_l[e]; }
         int start_pt = 0; float d1 = 0, d2 = 0;
         int best;
-        if (GRID) { best = grid_nn_query(a.grid, a.tgt_pts, live, qx, qy, qz, a.r2s, ol, &d1, &d2); start_pt = hint >= 0 ? hint : 0; }
+        if (GRID) { best = grid_nn_search(a.grid, a.tgt_pts, live, qx, qy, qz, a.r2s, ol, &d1, &d2); start_pt = hint >= 0 ? hint : 0; }
         else best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.r2s, hint, ol, oct, ob, &start_pt, nullptr, &d1, &d2);
         if (ol == 0 && live) {
             const int qi = tile0 + l;
@@ -854,16 +956,21 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     if (!use_cov && (!src->nrm || !tgt->nrm)) { ctx->err = "GICP needs normals (or covariances) on both clouds"; return PCR_EINVAL; }
     ArenaMark mark(ctx);
     const int cap = src->cap > 0 ? src->cap : 1;
-    const int nbmax = (cap + LIN_BS - 1) / LIN_BS < LIN_MAX_BLOCKS ? (cap + LIN_BS - 1) / LIN_BS : LIN_MAX_BLOCKS;
-    const int nbnn = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT);
+    static const bool use_skip = !(getenv("PCR_ICP_SKIP") && atoi(getenv("PCR_ICP_SKIP")) == 0);
+    // PCR_ICP_STREAM_MIN: source points from which an iteration is k_icp_ab + k_icp_iter instead of the fused kernel (0 = never)
+    static const int stream_min = getenv("PCR_ICP_STREAM_MIN") ? atoi(getenv("PCR_ICP_STREAM_MIN")) : 400000;
+    const int nblin = (cap + LIN_BS - 1) / LIN_BS;                  // k_icp_lin: one tile per workgroup
+    const bool stream = stream_min > 0 && cap >= stream_min && nblin <= 8192 && use_skip && max_dist < 1e15 && !use_cov && !getenv("PCR_ICP_STAMPS");
+    const int nbmax = nblin < LIN_MAX_BLOCKS ? nblin : LIN_MAX_BLOCKS;
+    const int nbnn = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT), nbab = (cap + ICP_BS - 1) / ICP_BS;
     const int tile_pts = fused_tile_points(cap, 1);
     const int nbf = ((cap + tile_pts - 1) / tile_pts + 7) & ~7;      // workgroups of the fused kernel: one per tile of source points, a multiple of 8 (XCD order)
     IcpState *st = arena<IcpState>(ctx, 1);
-    double *partials = arena<double>(ctx, (size_t)(nbmax > nbf ? nbmax : nbf) * NVP);
+    const int rows = stream ? nblin : (nbmax > nbf ? nbmax : nbf);
+    double *partials = arena<double>(ctx, (size_t)rows * NVP);
     int32_t *match = match_dev ? match_dev : arena<int32_t>(ctx, cap);
     if (!st || !partials || !match) return PCR_ENOMEM;
     IcpArgs a; memset(&a, 0, sizeof a); fill_args(a, src, tgt, max_dist, p, match, st, partials, 0);
-    static const bool use_skip = !(getenv("PCR_ICP_SKIP") && atoi(getenv("PCR_ICP_SKIP")) == 0);
     if (use_skip && max_dist < 1e15) {
         a.ref = arena<float4>(ctx, cap); a.rbest = arena<int32_t>(ctx, cap);
         if (!a.ref || !a.rbest) return PCR_ENOMEM;
@@ -886,7 +993,7 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     const size_t sw_nn = (size_t)ICP_STAMP_LAUNCHES * nbnn * (ICP_BS / 64) * 2, sw_it = (size_t)ICP_STAMP_LAUNCHES * nbmax * (LIN_BS / 64) * 12;
     if (stamp_path) {
         if (hipMalloc(&a.stamps_nn, sw_nn * 8) != hipSuccess || hipMalloc(&a.stamps_it, sw_it * 8) != hipSuccess) return PCR_ENOMEM;
-        hipMemsetAsync(a.stamps_nn, 0, sw_nn * 8, ctx->stream); hipMemsetAsync(a.stamps_it, 0, sw_it * 8, ctx->stream);
+        PCR_HIP_CHECK(ctx, hipMemsetAsync(a.stamps_nn, 0, sw_nn * 8, ctx->stream)); PCR_HIP_CHECK(ctx, hipMemsetAsync(a.stamps_it, 0, sw_it * 8, ctx->stream));
     }
 
     // Launch in chunks; the state of chunk c is copied back while chunk c+1 is already queued, so the GPU never
@@ -899,8 +1006,14 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     static const bool use_graph = !(getenv("PCR_ICP_GRAPH") && atoi(getenv("PCR_ICP_GRAPH")) == 0);
     static const bool use_fused = !(getenv("PCR_ICP_FUSED") && atoi(getenv("PCR_ICP_FUSED")) == 0);
     // launch 0 of a scale searches every query (cold): two kernels at full occupancy; later launches: the fused kernel
-    const bool fused = use_fused && a.ref && !use_cov && !stamp_path && nbf <= 4096;
+    const bool fused = use_fused && a.ref && !use_cov && !stamp_path && nbf <= 4096 && !stream;
     auto enqueue = [&](int launch_index) {
+        if (launch_index > 0 && stream) {
+            if (grid) PCR_LAUNCH(ctx, k_icp_ab<true>, dim3(nbab), dim3(ICP_BS), 0, ctx->stream, a);
+            else PCR_LAUNCH(ctx, k_icp_ab<false>, dim3(nbab), dim3(ICP_BS), 0, ctx->stream, a);
+            PCR_LAUNCH(ctx, k_icp_lin, dim3(nblin), dim3(LIN_BS), 0, ctx->stream, a);
+            return;
+        }
         if (fused && launch_index > 0) {
             PCR_FUSED_LAUNCH(ctx, k_icp_fused, grid, tile_pts, dim3(nbf), a);
             return;
@@ -914,7 +1027,7 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     if (use_graph && !stamp_path) {
         for (int which = 0; which < 2; which++) {
             std::string key((const char *)&a, sizeof a);
-            const int extra[7] = {nbnn, nbmax, use_cov ? 1 : 0, CHUNK, fused ? nbf + (tile_pts << 16) : 0, which, grid ? 1 : 0};
+            const int extra[7] = {nbnn, nbmax, use_cov ? 1 : 0, CHUNK, fused ? nbf + (tile_pts << 16) : (stream ? -nblin : 0), which, grid ? 1 : 0};
             key.append((const char *)extra, sizeof extra);
             for (auto &g : ctx->icp_graphs) if (g.key == key) { chunk_exec[which] = g.exec; break; }
             if (!chunk_exec[which]) {
@@ -986,12 +1099,12 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     }
     if (stamp_path) {
         unsigned long long *h = (unsigned long long *)malloc((sw_nn + sw_it) * 8);
-        hipMemcpy(h, a.stamps_nn, sw_nn * 8, hipMemcpyDeviceToHost); hipMemcpy(h + sw_nn, a.stamps_it, sw_it * 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(h, a.stamps_nn, sw_nn * 8, hipMemcpyDeviceToHost); (void)hipMemcpy(h + sw_nn, a.stamps_it, sw_it * 8, hipMemcpyDeviceToHost);
         if (FILE *f = fopen(stamp_path, "ab")) {
             const unsigned long long hdr[6] = {0x49435053ull, (unsigned long long)nbnn * (ICP_BS / 64), (unsigned long long)nbmax * (LIN_BS / 64), ICP_STAMP_LAUNCHES, (unsigned long long)fin.launches, (unsigned long long)fin.ns};
             fwrite(hdr, 8, 6, f); fwrite(h, 8, sw_nn + sw_it, f); fclose(f);
         }
-        free(h); hipFree(a.stamps_nn); hipFree(a.stamps_it);
+        free(h); (void)hipFree(a.stamps_nn); (void)hipFree(a.stamps_it);
     }
     state_to_result(fin, out);
     for (int k = 0; k < 16; k++) if (!std::isfinite(fin.T[k])) { ctx->err = "non-finite pose"; return PCR_ENUMERIC; }
