@@ -351,6 +351,7 @@ def main(argv=None) -> int:
                          "bytes_per_launch": bytes_per_launch, "us_per_launch_hip_events": us_event,
                          "us_per_launch_in_kernel_clock": us_kernel, "us_per_launch_in_flight": us_in_flight,
                          "us_slowest_workgroup_search_phase": (solo[6] / live) if live else None, "us_until_partial_sums_gathered": (solo[7] / live) if live else None,
+                         "fraction_of_queries_searched_again": (solo[11] / (alg_bytes / 48.0)) if alg_bytes else None,
                          "measured_on": "up to 4 extra single-pair steps after the timed region (same process, HIP events on the launch stream)",
                          "live_launches": live, "launches_issued_timed_region": issued},
         }

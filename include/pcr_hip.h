@@ -242,7 +242,8 @@ int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, const float *sr
  *           [2] us of in-kernel time summed over live launches, [3] live launches,
  *           [4] algorithmic bytes of the live launches (48 B x source points), [5] launches issued, [6], [7] diagnostics,
  *           [8] ms of HIP-event time over the feature-matching kernels of registro_FGR, [9] their algorithmic flops
- *           (2 * 33 * Ns * Nt per direction), [10] launches, rest 0 } */
+ *           (2 * 33 * Ns * Nt per direction), [10] launches, [11] GICP queries whose skip certificate did not hold (searched again),
+ *           summed over the launches after the first of every scale, rest 0 } */
 int pcr_profile_enable(pcr_context *ctx, int on);
 int pcr_profile_read(pcr_context *ctx, double *out16, int reset);
 

@@ -1205,14 +1205,17 @@ template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn_b
 
 #include "pcr_knn_wave.h"
 
-// Two exact k-NN kernels.  The OCTET kernel (8 lanes per query) is the default; the WAVEFRONT kernel (one query per lane, pcr_knn_wave.h,
-// k <= 64, no sparse `todo` searches) needs a third fewer VALU instructions (440 against 660 per query at k = 30) but takes the same
-// time: both run at the chip's VALU issue rate, the wavefront kernel at 4 wavefronts per SIMD (128 VGPRs) with a long tail of
-// wavefronts whose 64 queries lie far apart (handed to the octet kernel after a budget), the octet kernel at 7 with no tail to speak
-// of.  Measured round 3 (tools/knn_sat.py, 1.4 M queries, k = 30, outlier-filter mode): 1.8 + 0.1 ms against 2.0 ms; in the bench
-// 397-403 against 417 pairs/s.  PCR_KNN_WAVE=1 selects the wavefront kernel (per call: tests/test_gpu_stages.py runs every search
-// through both and compares them -- two independent exact searches).
-static bool knn_wave_enabled() { const char *e = getenv("PCR_KNN_WAVE"); return e && atoi(e) != 0; }
+// Two exact k-NN kernels: the OCTET kernel (8 lanes per query) and the WAVEFRONT kernel (one query per lane, pcr_knn_wave.h, k <= 64, no
+// sparse `todo` searches).  The wavefront kernel needs a third fewer VALU instructions (440 against 660 per query at k = 30); ALONE it
+// takes the same time or longer -- both run at the chip's VALU issue rate, the wavefront kernel at 4 wavefronts per SIMD (128 VGPRs)
+// with a long tail of wavefronts whose 64 queries lie far apart (handed to the octet kernel after a budget), the octet kernel at 7 with
+// no tail to speak of (tools/knn_sat.py, 1.4 M queries, k = 30, outlier-filter mode: 1.8 + 0.1 ms against 2.0 ms; one pair at a time
+// 182 against 200 pairs/s) -- but in the batched searches of a lockstep group (2 G clouds x S scales per launch, other groups' kernels
+// alongside) the tail hides and the instruction count decides: 200k-point pairs 569 -> 602 pairs/s, 100k 913 -> 977, 20k 2736 -> 2880.
+// So: the wavefront kernel for batches of at least KNN_WAVE_MIN_BATCH searches, the octet kernel otherwise.  PCR_KNN_WAVE=0 / 1 forces
+// one of them (per call: tests/test_gpu_stages.py runs every search through both and compares them -- two independent exact searches).
+#define KNN_WAVE_MIN_BATCH 6
+static bool knn_wave_enabled(int batch) { const char *e = getenv("PCR_KNN_WAVE"); return e ? atoi(e) != 0 : batch >= KNN_WAVE_MIN_BATCH; }
 static bool knn_wave_fits(const KnnArgs &a) { return a.k >= 1 && a.k <= 64 && !a.todo && !a.stamps && !a.dbg_visits; }
 // the wavefront kernel appends every query's k-best to a row in global memory: the caller's list (SOR) or scratch from the arena
 template <int MODE>
@@ -1223,7 +1226,7 @@ static int knn_wave_rows(pcr_context *ctx, KnnArgs &a, int cap) {
     return a.list_idx ? PCR_OK : PCR_ENOMEM;
 }
 template <int MODE> static int launch_knn_wave_only(pcr_context *ctx, KnnArgs *a, int count, int mc, int kmax);
-static int knn_wave_budget() { const char *e = getenv("PCR_KNNW_BUDGET"); return e ? atoi(e) : 40; }      // batches of 64 candidates in pass 1 (mean 17, p99 43 at k = 30)
+static int knn_wave_budget() { const char *e = getenv("PCR_KNNW_BUDGET"); return e ? atoi(e) : 80; }      // batches of 64 candidates in pass 1 (mean 17, p99 43 at k = 30)
 template <int MODE> static int launch_knn_octet_batch(pcr_context *ctx, KnnArgs *a, const int *caps, int count);
 template <int MODE>
 static int launch_knn_wave_batch(pcr_context *ctx, KnnArgs *a, const int *caps, int count, int mc, int kmax) {
@@ -1295,7 +1298,7 @@ static int launch_knn_batch(pcr_context *ctx, KnnArgs *a, const int *caps, int c
         for (int k = 0; k < count; k++) PCR_TRY(launch_knn_cap<MODE>(ctx, caps[k], a[k]));
         return PCR_OK;
     }
-    if (knn_wave_enabled()) {
+    if (knn_wave_enabled(count)) {
         bool fits = true; int kmax = 0, mcw = 0;
         for (int k = 0; k < count; k++) { fits = fits && knn_wave_fits(a[k]); kmax = a[k].k > kmax ? a[k].k : kmax; mcw = caps[k] > mcw ? caps[k] : mcw; }
         if (fits && mcw > 0) {
@@ -1345,7 +1348,7 @@ static int launch_knn_cap(pcr_context *ctx, int cap, KnnArgs a) {
         }
     } dump{ctx, stamp_path, a.stamps, stamp_words, MODE, a.k};
     a.seed_span = -1;
-    if (knn_wave_enabled() && knn_wave_fits(a)) { a.seed_span = -1; return launch_knn_wave<MODE>(ctx, cap, a); }
+    if (knn_wave_enabled(1) && knn_wave_fits(a)) { a.seed_span = -1; return launch_knn_wave<MODE>(ctx, cap, a); }
     if (a.k <= 32) PCR_LAUNCH(ctx, k_knn<MODE, 4>, grid, block, 0, ctx->stream, a);
     else if (a.k <= 64) PCR_LAUNCH(ctx, k_knn<MODE, 8>, grid, block, 0, ctx->stream, a);
     else PCR_LAUNCH(ctx, k_knn<MODE, 25>, grid, block, 0, ctx->stream, a);

@@ -36,6 +36,7 @@ struct IcpState {
     unsigned long long t_start; // s_memrealtime (100 MHz) stamp of workgroup 0 at kernel entry
     unsigned long long t_live;  // sum over live launches of (last workgroup's exit stamp - t_start)
     unsigned long long t_dbg[4]; // diagnostic stamps (sum): wg0 after search, wg0 after reduce, last wg entering tail, last wg after partial sums
+    unsigned long long searched; // queries whose certificate did not hold, summed over the launches after the cold one (bench: fraction searched)
 };
 
 struct IcpArgs {
@@ -63,7 +64,7 @@ struct IcpInit { double T[16]; };
 __device__ static inline void d_icp_init(IcpState *st, const IcpInit &in) {
     if (threadIdx.x == 0) {
         for (int k = 0; k < 16; k++) st->T[k] = in.T[k];
-        st->fitness = 0; st->rmse = 0; st->count = 0; st->iter = 0; st->launches = 0; st->done = 0; st->converged = 0; st->ticket = 0; st->ns = 0; st->t_start = 0; st->t_live = 0; for (int k = 0; k < 4; k++) st->t_dbg[k] = 0;
+        st->fitness = 0; st->rmse = 0; st->count = 0; st->iter = 0; st->launches = 0; st->done = 0; st->converged = 0; st->ticket = 0; st->ns = 0; st->t_start = 0; st->t_live = 0; st->searched = 0; for (int k = 0; k < 4; k++) st->t_dbg[k] = 0;
         for (int k = 0; k < NVP; k++) st->sums[k] = 0;
     }
 }
@@ -423,6 +424,7 @@ __device__ static inline void d_icp_ab(const IcpArgs &a) {
     }
     __syncthreads();
     const int npend = n_rec;
+    if (tid == 0 && npend > 0) atomicAdd(&st->searched, (unsigned long long)npend);
     for (int e0 = 0; e0 < npend; e0 += OPB) {
         const int e = e0 + ob;
         const bool live = e < npend;
@@ -819,6 +821,7 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
     // ---- phase B: the pending list.  Cell hash: one query per LANE, the whole list in ceil(npend / 512) rounds; octree: one query per
     // octet, 64 per round
     const int npend = n_rec;
+    if (tid == 0 && npend > 0) atomicAdd(&st->searched, (unsigned long long)npend);
     if (GRID && PCR_GRID_LANE_SEARCH) {
         for (int e = tid; e < npend; e += FUSED_BS) {
             const float4 r = rec_q[e]; const int l = rec_l[e];
@@ -1095,6 +1098,7 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
         ctx->prof[4] += 48.0 * (double)fin.ns * (double)fin.launches;   // 48 B per source point per launch
         ctx->prof[5] += launched;
         ctx->prof[6] += (double)fin.t_dbg[0] * 0.01; ctx->prof[7] += (double)fin.t_dbg[3] * 0.01;
+        ctx->prof[11] += (double)fin.searched;
         if (getenv("PCR_DEBUG_STAMPS")) fprintf(stderr, "icp stamps (us/launch): slowest-wg search %.1f slowest-wg reduce %.1f (unused %.1f) sums-done %.1f end %.1f (launches %d ns %d)\n", fin.t_dbg[0] * 0.01 / fin.launches, fin.t_dbg[1] * 0.01 / fin.launches, fin.t_dbg[2] * 0.01 / fin.launches, fin.t_dbg[3] * 0.01 / fin.launches, fin.t_live * 0.01 / fin.launches, fin.launches, fin.ns);
     }
     if (stamp_path) {
@@ -1310,6 +1314,7 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
         for (int g = 0; g < G; g++) {
             ctx->prof[2] += (double)fin[g].t_live * 0.01; ctx->prof[3] += fin[g].launches;
             ctx->prof[4] += 48.0 * (double)fin[g].ns * (double)fin[g].launches;
+            ctx->prof[11] += (double)fin[g].searched;
         }
         ctx->prof[5] += launched;
     }

@@ -37,7 +37,7 @@ struct pcr_context {
     size_t pinned_cap = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
     int profiling = 0;             // bench instrumentation (pcr_profile_*)
-    double prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [0..7] GICP loop (pcr_hip.h), [8..10] feature matching: ms, flops, launches
+    double prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [0..7] GICP loop (pcr_hip.h), [8..10] feature matching: ms, flops, launches, [11] GICP queries searched again
     std::vector<hipEvent_t> prof_events;
     std::vector<IcpGraph> icp_graphs;   // captured launch chunks of the GICP loop
     std::string err;

@@ -25,9 +25,10 @@ def _helper(env):
 @pytest.mark.parametrize("rule", ["given", "af"])
 def test_groups_are_bit_identical_at_equal_summation_grouping(rule):
     """Groups of 1, 2, 3 and 8 over 5 pairs of different sizes (ragged last group, group larger than the batch): poses, iteration
-    counts, cloud counts, radii and correspondence sets are the same bits when the iteration kernel's tile is the same (PCR_ICP_PPL)."""
-    for ppl in ("1", "2"):
-        groups, _ = _helper({"PCR_ICP_PPL": ppl, "GROUP_POSE_RULE": rule})
+    counts, cloud counts, radii and correspondence sets are the same bits when the iteration kernel's tile (PCR_ICP_PPL) and the k-NN kernel
+    (PCR_KNN_WAVE) are the same."""
+    for ppl, wave in (("1", "0"), ("2", "1")):          # (one search kernel for all batch sizes: by default batches of 6 searches and more take the wavefront k-NN kernel)
+        groups, _ = _helper({"PCR_ICP_PPL": ppl, "GROUP_POSE_RULE": rule, "PCR_KNN_WAVE": wave})
         assert len(groups) == 4
         assert all(g == groups[0] for g in groups), (ppl, groups)
 
@@ -36,13 +37,14 @@ def test_fgr_plus_gicp_groups_are_bit_identical():
     """Stage FGR + GICP (Coarse_to_fine / full_registration, ALL_FUNCTIONS.py:317-332, 349-392) with lockstep groups: registro_FGR runs
     pair by pair, the GICP of the group in lockstep from the FGR poses with the FGR normals as orientation prior and the AF radius rule,
     then the information matrices -- the same bits as pair by pair when the iteration kernel's tile is the same."""
-    groups, _ = _helper({"PCR_ICP_TILE": "512", "GROUP_POSE_STAGE": "fgr+gicp", "GROUP_POSE_RULE": "af"})
+    groups, _ = _helper({"PCR_ICP_TILE": "512", "GROUP_POSE_STAGE": "fgr+gicp", "GROUP_POSE_RULE": "af", "PCR_KNN_WAVE": "0"})
     assert len(groups) == 4
     assert all(g == groups[0] for g in groups), groups
 
 
 def test_default_groups_agree_with_pair_by_pair():
-    """Default policy (two source points per lane inside groups, one outside) only regroups the float64 sums: smooth loss, 1e-7."""
+    """Default policy (two source points per lane and the wavefront k-NN kernel inside groups, one point per lane and the octet kernel
+    outside) only regroups float64 sums: smooth loss, 1e-7."""
     _, poses = _helper({"GROUP_POSE_LOSS": "l2"})
     for a, b in zip(poses["POSES1"], poses["POSES3"]):
         ang, d = pose_error(a, b)
