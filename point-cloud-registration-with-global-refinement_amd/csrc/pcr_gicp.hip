@@ -709,9 +709,10 @@ __device__ static inline void d_icp_iter(const IcpArgs &a) {
     icp_finish<MODE, LIN_BS>(a, st, T, acc, nb, ns, launches, t_entry, (int)blockIdx.x);
 }
 template <int MODE> __global__ void __launch_bounds__(LIN_BS) k_icp_iter(IcpArgs a) { d_icp_iter<MODE>(a); }
-// streaming form behind k_icp_ab: workgroup b owns the 512-point tile b (the partial rows and their order are those of k_icp_fused<512>),
-// held at 128 VGPRs = two workgroups per CU (the strided loop of k_icp_iter takes 218)
-__global__ void __launch_bounds__(LIN_BS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_icp_lin(IcpArgs a) {
+// tile form (every GICP linearisation that is not fused into k_icp_fused): workgroup b owns the 512-point tile b, so the partial rows and
+// their order are those of k_icp_fused<512>; held at 128 VGPRs = two workgroups per CU (the strided loop of k_icp_iter takes 218 and is
+// capped at 128 workgroups: a cold launch over 1.6M points took 0.8-3 ms)
+__device__ static inline void d_icp_lin(const IcpArgs &a) {
     IcpState *st = a.state;
     const int done = st->done, launches = st->launches;
     const int ns = *a.ns_ptr;
@@ -731,7 +732,8 @@ __global__ void __launch_bounds__(LIN_BS) __attribute__((amdgpu_waves_per_eu(4, 
     if (i < ns) icp_point<ICP_MODE_GICP>(a, T, i, ns, mi, acc);
     icp_finish<ICP_MODE_GICP, LIN_BS>(a, st, T, acc, nb, ns, launches, t_entry, (int)blockIdx.x);
 }
-template <int MODE> __global__ void __launch_bounds__(LIN_BS) k_icp_iter_g(const IcpArgs *__restrict__ a) { d_icp_iter<MODE>(a[blockIdx.y]); }
+__global__ void __launch_bounds__(LIN_BS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_icp_lin(IcpArgs a) { d_icp_lin(a); }
+__global__ void __launch_bounds__(LIN_BS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_icp_lin_g(const IcpArgs *__restrict__ a) { d_icp_lin(a[blockIdx.y]); }
 
 // ---- ONE kernel per iteration (launches after the first of a scale): workgroup b owns source points [512 b, 512 b + 512):
 // certificates per lane -> its pending queries compacted into LDS -> the workgroup's 64 octets search them -> barrier ->
@@ -963,13 +965,13 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     // PCR_ICP_STREAM_MIN: source points from which an iteration is k_icp_ab + k_icp_iter instead of the fused kernel (0 = never)
     static const int stream_min = getenv("PCR_ICP_STREAM_MIN") ? atoi(getenv("PCR_ICP_STREAM_MIN")) : 400000;
     const int nblin = (cap + LIN_BS - 1) / LIN_BS;                  // k_icp_lin: one tile per workgroup
-    const bool stream = stream_min > 0 && cap >= stream_min && nblin <= 8192 && use_skip && max_dist < 1e15 && !use_cov && !getenv("PCR_ICP_STAMPS");
+    const bool stream = stream_min > 0 && cap >= stream_min && use_skip && max_dist < 1e15 && !use_cov && !getenv("PCR_ICP_STAMPS");
     const int nbmax = nblin < LIN_MAX_BLOCKS ? nblin : LIN_MAX_BLOCKS;
     const int nbnn = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT), nbab = (cap + ICP_BS - 1) / ICP_BS;
     const int tile_pts = fused_tile_points(cap, 1);
     const int nbf = ((cap + tile_pts - 1) / tile_pts + 7) & ~7;      // workgroups of the fused kernel: one per tile of source points, a multiple of 8 (XCD order)
     IcpState *st = arena<IcpState>(ctx, 1);
-    const int rows = stream ? nblin : (nbmax > nbf ? nbmax : nbf);
+    const int rows = nblin > nbf ? nblin : nbf;
     double *partials = arena<double>(ctx, (size_t)rows * NVP);
     int32_t *match = match_dev ? match_dev : arena<int32_t>(ctx, cap);
     if (!st || !partials || !match) return PCR_ENOMEM;
@@ -1024,7 +1026,8 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
         if (grid) PCR_LAUNCH(ctx, k_icp_nn<true>, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
         else PCR_LAUNCH(ctx, k_icp_nn<false>, dim3(nbnn), dim3(ICP_BS), 0, ctx->stream, a);
         if (use_cov) PCR_LAUNCH(ctx, k_icp_iter<ICP_MODE_GICP_COV>, dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
-        else PCR_LAUNCH(ctx, k_icp_iter<ICP_MODE_GICP>, dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
+        else if (stamp_path) PCR_LAUNCH(ctx, k_icp_iter<ICP_MODE_GICP>, dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
+        else PCR_LAUNCH(ctx, k_icp_lin, dim3(nblin), dim3(LIN_BS), 0, ctx->stream, a);
     };
     hipGraphExec_t chunk_exec[2] = {nullptr, nullptr};          // [0]: the chunk that starts with launch 0, [1]: every later chunk
     if (use_graph && !stamp_path) {
@@ -1139,7 +1142,7 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
     static const double gfrac = getenv("PCR_ICP_GAP") ? atof(getenv("PCR_ICP_GAP")) : 0.25;
     for (int g = 0; g < G; g++) {
         const int cap = src[g]->cap > 0 ? src[g]->cap : 1;
-        const int m_ = (cap + LIN_BS - 1) / LIN_BS < LIN_MAX_BLOCKS ? (cap + LIN_BS - 1) / LIN_BS : LIN_MAX_BLOCKS;
+        const int m_ = (cap + LIN_BS - 1) / LIN_BS;                      // k_icp_lin_g: one 512-point tile per workgroup
         const int n_ = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT), f_ = ((cap + tile_pts - 1) / tile_pts + 7) & ~7;
         nbmax = m_ > nbmax ? m_ : nbmax; nbnn = n_ > nbnn ? n_ : nbnn; nbf = f_ > nbf ? f_ : nbf;
         double *partials = arena<double>(ctx, (size_t)(m_ > f_ ? m_ : f_) * NVP);
@@ -1198,7 +1201,7 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
         }
         if (grid) PCR_LAUNCH(ctx, k_icp_nn_g<true>, dim3(nbnn, G), dim3(ICP_BS), 0, ctx->stream, dargs);
         else PCR_LAUNCH(ctx, k_icp_nn_g<false>, dim3(nbnn, G), dim3(ICP_BS), 0, ctx->stream, dargs);
-        PCR_LAUNCH(ctx, k_icp_iter_g<ICP_MODE_GICP>, dim3(nbmax, G), dim3(LIN_BS), 0, ctx->stream, dargs);
+        PCR_LAUNCH(ctx, k_icp_lin_g, dim3(nbmax, G), dim3(LIN_BS), 0, ctx->stream, dargs);
     };
     // One captured chunk per launch FORM (group size, kernel forms, tile, chunk length): what differs from call to call -- the
     // grid widths and, for the by-value kernels, the argument batch -- is patched into the instantiated graph's kernel nodes
