@@ -42,6 +42,15 @@ def test_fgr_plus_gicp_groups_are_bit_identical():
     assert all(g == groups[0] for g in groups), groups
 
 
+def test_argument_forms_of_a_group_are_bit_identical():
+    """Groups of up to 8 pairs hand their argument structs to the fused kernel BY VALUE (k_icp_fused_b), larger groups and
+    PCR_ICP_BYVAL=0 through a device pointer (k_icp_fused_g); the cached graphs are patched with the new arguments from call to call:
+    same bits either way."""
+    a, _ = _helper({"PCR_ICP_PPL": "2"})
+    b, _ = _helper({"PCR_ICP_PPL": "2", "PCR_ICP_BYVAL": "0"})
+    assert a == b
+
+
 def test_default_groups_agree_with_pair_by_pair():
     """Default policy (two source points per lane and the wavefront k-NN kernel inside groups, one point per lane and the octet kernel
     outside) only regroups float64 sums: smooth loss, 1e-7."""
