@@ -1023,8 +1023,6 @@ struct KnnArgs {
     int seed_span;                                       // Morton-index half-width of the seed range (-1: k)
     int *zero_a, *zero_b;                                // optional counters of LATER kernels, zeroed here (saves two memset launches)
     uint8_t *hard; int wave_budget;                      // wavefront kernel: optional, queries it gave up after wave_budget batches (1) or served (0)
-    const GridEntry *l1tab; unsigned l1mask;             // wavefront kernel, BLOCK mode: hash of the tree's level-1 nodes (cell code -> node)
-    const GridEntry *l2tab; unsigned l2mask;             //   and of its level-2 nodes
     const uint8_t *keep; const int *pos;                 // optional: search only among points with keep[i] != 0; results and `todo`
                                                          //   are indexed by pos[i] (the compacted order) -- the cleaned cloud needs no tree of its own
 };
@@ -1230,52 +1228,6 @@ static int knn_wave_rows(pcr_context *ctx, KnnArgs &a, int cap) {
 template <int MODE> static int launch_knn_wave_only(pcr_context *ctx, KnnArgs *a, int count, int mc, int kmax);
 static int knn_wave_budget() { const char *e = getenv("PCR_KNNW_BUDGET"); return e ? atoi(e) : 80; }      // batches of 64 candidates in pass 1 (mean 17, p99 43 at k = 30)
 template <int MODE> static int launch_knn_octet_batch(pcr_context *ctx, KnnArgs *a, const int *caps, int count);
-// hash of the level-1 nodes of `count` trees (Morton code of the cell -> node index), for the BLOCK mode of the wavefront kernel: the
-// leaf level holds at most n / PCR_OCT_DIV cells (>= 4: checked by the caller), so n / 2 slots keep the load under a half
-struct L1HashDesc { const OctMeta *meta; const uint64_t *keys; const int2 *l1rng; const float4 *nodes; GridEntry *tab[2]; unsigned mask[2]; };
-__global__ void __launch_bounds__(BS) k_l1hash_build(const L1HashDesc *descs) {
-    const L1HashDesc d = descs[blockIdx.y];
-    const OctMeta *m = d.meta;
-    const int lv = 1 + (int)blockIdx.z;                       // level 1 or 2
-    if (m->nl < lv + 1) return;
-    const int j = blockIdx.x * BS + threadIdx.x;
-    if (j >= m->cnt[lv]) return;
-    const int c1 = lv == 1 ? j : __float_as_int(d.nodes[2 * (size_t)(m->off[2] + j)].w);      // a level-1 node under it: its first child
-    const unsigned long long code = d.keys[d.l1rng[c1].x] >> (3 * (m->l0 + lv));
-    GridEntry *tab = d.tab[lv - 1]; const unsigned mask = d.mask[lv - 1];
-    unsigned h = pcr_grid_hash(code, mask);
-    for (;;) {
-        const unsigned long long old = atomicCAS(&tab[h].code, PCR_GRID_EMPTY, code);
-        if (old == PCR_GRID_EMPTY) { tab[h].first = j; tab[h].count = 0; return; }
-        h = (h + 1) & mask;
-    }
-}
-// PCR_KNNW_BLOCK=0: the wavefront kernel walks the tree in batched searches too (read per call)
-static bool knn_wave_block_enabled() {
-    static const bool div_ok = !(getenv("PCR_OCT_DIV") && atoi(getenv("PCR_OCT_DIV")) < 4);
-    const char *e = getenv("PCR_KNNW_BLOCK");
-    return div_ok && !(e && atoi(e) == 0);
-}
-static int knn_wave_build_l1hash(pcr_context *ctx, KnnArgs *a, const int *caps, int count) {
-    auto slots_of = [](int cap, int lv) { unsigned s = 64; while (s < (unsigned)(cap > 0 ? cap : 1) / (lv == 1 ? 2u : 4u) + 1u) s <<= 1; return s; };
-    size_t total = 0; int mc = 0;
-    for (int k = 0; k < count; k++) { total += slots_of(caps[k], 1) + slots_of(caps[k], 2); mc = caps[k] > mc ? caps[k] : mc; }
-    GridEntry *tab = arena<GridEntry>(ctx, total);
-    if (!tab) return PCR_ENOMEM;
-    PCR_HIP_CHECK(ctx, hipMemsetAsync(tab, 0xff, total * sizeof(GridEntry), ctx->stream));
-    std::vector<L1HashDesc> d((size_t)count);
-    size_t off = 0;
-    for (int k = 0; k < count; k++) {
-        const unsigned s1 = slots_of(caps[k], 1), s2 = slots_of(caps[k], 2);
-        d[k] = L1HashDesc{a[k].t.meta, a[k].t.keys, a[k].t.l1rng, a[k].t.nodes, {tab + off, tab + off + s1}, {s1 - 1, s2 - 1}};
-        a[k].l1tab = tab + off; a[k].l1mask = s1 - 1; a[k].l2tab = tab + off + s1; a[k].l2mask = s2 - 1;
-        off += s1 + s2;
-    }
-    const L1HashDesc *dd = pcr_desc_upload(ctx, d.data(), count);
-    if (!dd) return PCR_ENOMEM;
-    PCR_LAUNCH(ctx, k_l1hash_build, dim3((unsigned)((mc / 4 + BS) / BS), (unsigned)count, 2), dim3(BS), 0, ctx->stream, dd);
-    return PCR_OK;
-}
 template <int MODE>
 static int launch_knn_wave_batch(pcr_context *ctx, KnnArgs *a, const int *caps, int count, int mc, int kmax) {
     for (int k = 0; k < count; k++) PCR_TRY(knn_wave_rows<MODE>(ctx, a[k], caps[k]));
@@ -1286,23 +1238,7 @@ static int launch_knn_wave_batch(pcr_context *ctx, KnnArgs *a, const int *caps, 
         a[k].hard = arena<uint8_t>(ctx, (size_t)(caps[k] > 0 ? caps[k] : 1)); a[k].wave_budget = budget;
         if (!a[k].hard) return PCR_ENOMEM;
     }
-    if (handover && kmax <= 30 && knn_wave_block_enabled()) {     // BLOCK mode (pcr_knn_wave.h kw_pass_block): neighbour leaves through a hash, no walk
-        PCR_TRY(knn_wave_build_l1hash(ctx, a, caps, count));
-        const dim3 grid((unsigned)(((size_t)mc + KW_BS - 1) / KW_BS), count), block(KW_BS);
-        if (kmax <= 20) PCR_TRY((PCR_BATCH_LAUNCH(ctx, KnnBatch, (k_knn_wave_blk_batch<MODE, 20>), (k_knn_wave_blk_batchp<MODE, 20>), a, count, grid, block)));
-        else PCR_TRY((PCR_BATCH_LAUNCH(ctx, KnnBatch, (k_knn_wave_blk_batch<MODE, 30>), (k_knn_wave_blk_batchp<MODE, 30>), a, count, grid, block)));
-    } else
     PCR_TRY(launch_knn_wave_only<MODE>(ctx, a, count, mc, kmax));
-    if (handover && getenv("PCR_KNNW_HARDSTAT")) {            // diagnostics: share of the queries handed to the octet kernel, per problem
-        (void)hipStreamSynchronize(ctx->stream);
-        for (int k = 0; k < count; k++) {
-            std::vector<uint8_t> h((size_t)(caps[k] > 0 ? caps[k] : 1)); int n = 0;
-            (void)hipMemcpy(h.data(), a[k].hard, h.size(), hipMemcpyDeviceToHost); (void)hipMemcpy(&n, a[k].n_ptr, sizeof n, hipMemcpyDeviceToHost);
-            long hard = 0, why[5] = {0, 0, 0, 0, 0}; for (int i = 0; i < n && i < (int)h.size(); i++) { hard += h[i] != 0; why[h[i] < 5 ? h[i] : 0]++; }
-            fprintf(stderr, "knn wave: problem %d k %d n %d handed over %ld (%.1f %%): budget/list %ld, log %ld, seeds %ld, outside block %ld\n", k, a[k].k, n, hard, n ? 100.0 * hard / n : 0.0,
-                    why[1], why[2], why[3], why[4]);
-        }
-    }
     if (!handover) return PCR_OK;
     std::vector<KnnArgs> o(a, a + count);
     for (int k = 0; k < count; k++) { o[k].todo = a[k].hard; o[k].hard = nullptr; o[k].zero_a = nullptr; o[k].zero_b = nullptr; o[k].seed_span = -1; }

@@ -26,7 +26,6 @@
 // every lane's k-best): it replays the log.  Results are exact (ties aside), as before: tests/test_gpu_stages.py::
 // test_knn_index_is_exact, test_knn_wave_equals_octet, test_sor_mask_is_exact.
 #pragma once
-#include <type_traits>
 
 #define KW_BS 128                       // 2 wavefronts per workgroup (LDS: ~6 KB per wavefront at K <= 32, ~9 KB above)
 
@@ -48,19 +47,12 @@ struct KwStack {                        // per wavefront (LDS)
     unsigned cd2[OCT_MAXL][OCT];        // per child: smallest conservative box distance over the subgroups (float bits): pop order
     float4 leafbox[OCT][2];             // boxes of the fat-leaf (level-1) list tested last (such a list is consumed before the next one is tested)
 };
-// BLOCK mode (below): the fat leaves around the wavefront's own one or two, faces first, then edges, then corners
-#define KW_NBR 64                       // listed neighbour leaves (more: the wavefront is handed over; 4 adjacent cells rarely have 40 occupied neighbours)
-struct KwBlock {
-    int sc[6];                          // low corners (level-1 cell coordinates) of the one or two level-2 cells holding the seed leaves
-    int first[KW_NBR], count[KW_NBR];
-    float4 box[KW_NBR][2];
-};
-template <int K, bool BLOCK = false>
+template <int K>
 struct KwShared {
     static constexpr int LOG = K <= 32 ? 768 : 1536;   // pass-1 log capacity (events per wavefront at k = 30: mean 260, p99 580)
     KwStage stage;                      // candidate batch
     int log[LOG];                       // indices of the candidates that beat the bound of some lane in pass 1
-    typename std::conditional<BLOCK, KwBlock, KwStack>::type stk;
+    KwStack stk;
 };
 
 __device__ static inline float kw_octet_fmin(float v) {
@@ -284,134 +276,20 @@ __device__ static inline bool kw_pass(const OctView &t, const OctMeta &m, KwStac
     }
 }
 
-// BLOCK mode of pass 1: no tree walk.  The level-1 cells (fat leaves, ~25 points on a surface) are a uniform grid of edge E = unit 2^(l0+1),
-// and the ball of a query's k-th distance almost never leaves the 3 x 3 x 3 block of cells around the query's own (measured: 0.2 % of
-// the queries of the bench clouds).  The wavefront's 64 Morton-consecutive queries lie in 2-5 consecutive fat leaves (the seed range),
-// which are children of ONE level-2 cell or of two consecutive ones; the blocks of all of them lie inside the 4 x 4 x 4 cells made of
-// that parent's 2 x 2 x 2 children and a rim of one cell -- 64 cells, one per LANE.  So, after the seed range, lane l looks cell l of the
-// first parent's 4 x 4 x 4 up in a hash of the level-1 nodes (`tab`: cell code -> node; ONE round trip for all of them, one more for
-// their point ranges and tight boxes; a second round for the second parent's cells outside the first's), the found leaves are listed
-// in LDS, and every listed leaf whose box meets the ball of some lane is staged whole, as the walk did.  Afterwards a lane whose ball
-// left its block (sparse regions), or a wavefront spanning more than two parents, flags its queries `hard` for the octet kernel
-// (d_knn_wave).  The walk cost ~9 000 of the ~37 000 VALU instructions of a wavefront at k = 30 (18 sibling tests of ~190, 38 pops of
-// ~100); this costs ~1 000.
-template <bool STATS, class WorstFn, class ScanFn>
-__device__ static inline bool kw_pass_block(const OctView &t, const OctMeta &m, KwBlock &blk, const GridEntry *__restrict__ tab, unsigned tmask, float qx, float qy, float qz,
-                                            int plo, int phi, int u /* unit level of the block: 1 or 2 */, int ja, int jb /* seed nodes of level u */,
-                                            int parents /* 1, 2; 0: give up (blk.sc: their low corners in level-u cells) */,
-                                            const uint8_t *keep, KwStage &stage, int budget, WorstFn worst, ScanFn scan, KwStats &st) {
-    const int lane = threadIdx.x & 63;
-    int r0f = plo, r0c = phi - plo + 1;
-    int nlist = -1, nk = 0;
-    int nb = 0, bidx = 0;
-    int pre_n = 0; float4 pre = make_float4(0, 0, 0, 0);
-    for (;;) {
-        bool done = false;
-        for (;;) {
-            if (r0c > 0 && nb < 64) {
-                const int take = r0c < 64 - nb ? r0c : 64 - nb;
-                if (lane >= nb && lane < nb + take) bidx = r0f + (lane - nb);
-                nb += take; r0f += take; r0c -= take;
-            }
-            if (r0c > 0 || nb >= 48) break;                     // a batch is ready
-            if (nlist < 0) {
-                if (nb > 0) break;                              // the seeds are scanned before the first neighbour is tested (tight bounds)
-                if (m.nl < 2 || parents == 0) { nlist = 0; continue; }      // one level: the seed range was the whole cloud; too long a seed range: the caller gives up
-                const int sh1 = m.l0 + u;
-                const int lim = sh1 < 21 ? (1 << (21 - sh1)) : 1;
-                const int ox = blk.sc[0] - 1, oy = blk.sc[1] - 1, oz = blk.sc[2] - 1;
-                int base = 0;
-                if (u == 2) {
-                    // the seed nodes of level 2 hold more than the seed range (the fat leaves of the queries themselves): the rest of the first
-                    // and of the last one comes first in the list (boxes: the nodes' own, conservative)
-                    const size_t sa = (size_t)(m.off[2] + ja), sb = (size_t)(m.off[2] + jb);
-                    const float4 alo = t.nodes[2 * sa], ahi = t.nodes[2 * sa + 1], blo = t.nodes[2 * sb], bhi = t.nodes[2 * sb + 1];
-                    const int fa = t.l1rng[__float_as_int(alo.w)].x;
-                    const int2 rb = t.l1rng[__float_as_int(blo.w) + __float_as_int(bhi.w) - 1];
-                    const int eb = rb.x + rb.y;
-                    if (lane == 0) {
-                        blk.first[0] = fa; blk.count[0] = plo - fa; blk.box[0][0] = alo; blk.box[0][1] = ahi;
-                        blk.first[1] = phi + 1; blk.count[1] = eb - (phi + 1); blk.box[1][0] = blo; blk.box[1][1] = bhi;
-                    }
-                    base = 2;
-                }
-                for (int r = 0; r < parents; r++) {
-                    const int cx = blk.sc[3 * r] - 1 + (lane & 3), cy = blk.sc[3 * r + 1] - 1 + ((lane >> 2) & 3), cz = blk.sc[3 * r + 2] - 1 + (lane >> 4);
-                    bool want = cx >= 0 && cy >= 0 && cz >= 0 && cx < lim && cy < lim && cz < lim;
-                    if (r > 0) want = want && !((unsigned)(cx - ox) < 4u && (unsigned)(cy - oy) < 4u && (unsigned)(cz - oz) < 4u);      // the first round had it
-                    int node = -1;
-                    if (want) {
-                        const unsigned long long code = pcr_morton3((uint32_t)cx, (uint32_t)cy, (uint32_t)cz);
-                        unsigned h = pcr_grid_hash(code, tmask);
-                        for (int probe = 0; probe < 64; probe++) {
-                            const int4 e = *(const int4 *)&tab[h];
-                            const unsigned long long c = ((unsigned long long)(unsigned)e.y << 32) | (unsigned)e.x;
-                            if (c == code) { node = e.z; break; }
-                            if (c == PCR_GRID_EMPTY) break;
-                            h = (h + 1) & tmask;
-                        }
-                    }
-                    if (node >= ja && node <= jb) node = -1;    // a seed node: scanned already / listed above
-                    int f = 0, c = 0; float4 lo = make_float4(0, 0, 0, 0), hi = lo;
-                    if (node >= 0) {
-                        const size_t j = (size_t)(m.off[u] + node);
-                        lo = t.nodes[2 * j]; hi = t.nodes[2 * j + 1];
-                        if (u == 1) { const int2 rg = t.l1rng[node]; f = rg.x; c = rg.y; }
-                        else { const int c0 = __float_as_int(lo.w), cn = __float_as_int(hi.w); f = t.l1rng[c0].x; const int2 rl = t.l1rng[c0 + cn - 1]; c = rl.x + rl.y - f; }
-                    }
-                    const unsigned long long b = __ballot(node >= 0);
-                    const int pos = base + __builtin_popcountll(b & ((1ull << lane) - 1ull));
-                    if (node >= 0 && pos < KW_NBR) { blk.first[pos] = f; blk.count[pos] = c; blk.box[pos][0] = lo; blk.box[pos][1] = hi; }
-                    base += __builtin_popcountll(b);
-                }
-                __builtin_amdgcn_wave_barrier();
-                nlist = __builtin_amdgcn_readfirstlane(base);
-                if (nlist > KW_NBR) return false;               // (the list kept its first KW_NBR entries only)
-                continue;
-            }
-            if (nk >= nlist) { done = true; break; }
-            const float4 lo = blk.box[nk][0], hi = blk.box[nk][1];
-            const int nf = __builtin_amdgcn_readfirstlane(blk.first[nk]), nc = __builtin_amdgcn_readfirstlane(blk.count[nk]);
-            nk++;
-            if (STATS) st.pops++;
-            if (__ballot(pcr_box_d2(lo, hi, qx, qy, qz) < worst()) != 0ull) { r0f = nf; r0c = nc; if (STATS) st.leaf_hits++; }
-        }
-        if (nb > 0) {
-            if (STATS) { st.batches++; st.cands += nb; }
-            if (--budget < 0) return false;
-            const float inf = __builtin_inff();
-            float4 p = make_float4(inf, inf, inf, 0.0f);        // empty slots and points outside `keep` are staged at infinity
-            if (lane < nb && (!keep || keep[bidx])) { p = lane < pre_n ? pre : t.pts[bidx]; p.w = __int_as_float(bidx); }
-            int nx = 0, nidx = 0;                               // the pending range goes on: its next batch is gathered while this one is scanned
-            if (r0c > 0) {
-                nx = r0c < 64 ? r0c : 64;
-                if (lane < nx) { nidx = r0f + lane; pre = t.pts[nidx]; }
-                r0f += nx; r0c -= nx;
-            }
-            __builtin_amdgcn_wave_barrier();
-            stage.x[lane] = p.x; stage.y[lane] = p.y; stage.z[lane] = p.z; stage.i[lane] = __float_as_int(p.w);
-            __builtin_amdgcn_wave_barrier();
-            scan(nb);
-            nb = nx; pre_n = nx; bidx = nidx;
-        }
-        if (done && nb == 0) return true;
-    }
-}
-
 // PK: packed float32 distance math (v_pk_add / v_pk_mul / v_pk_fma, two candidates per instruction): 10 % fewer VALU instructions, but 7 % MORE
 // wave-cycles and 1-3 % fewer pairs/s (measured, interleaved A/B) -- packed float32 issues at half rate here.  Off.
-template <int MODE, int K, bool STATS = false, bool PK = false, bool BLOCK = false>
+template <int MODE, int K, bool STATS = false, bool PK = false>
 __device__ static inline void d_knn_wave(const KnnArgs &a) {
     constexpr int WPB = KW_BS / 64;
     __shared__ OctMeta m;
-    __shared__ KwShared<K, BLOCK> shw[WPB];
+    __shared__ KwShared<K> shw[WPB];
     if (threadIdx.x == 0) m = *a.t.meta;
     if (blockIdx.x == 0 && threadIdx.x == 0) { if (a.zero_a) *a.zero_a = 0; if (a.zero_b) *a.zero_b = 0; }
     __syncthreads();
     const int n = __builtin_amdgcn_readfirstlane(m.n);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    KwShared<K, BLOCK> &sh = shw[wv];
+    KwShared<K> &sh = shw[wv];
     const int g0 = (blockIdx.x * WPB + wv) * 64;
     if (g0 >= n) return;
     const int qi = g0 + lane;
@@ -435,38 +313,10 @@ __device__ static inline void d_knn_wave(const KnnArgs &a) {
     const int glast = g0 + 63 < n - 1 ? g0 + 63 : n - 1;
     // seed range: the fat leaves of the first and the last query and what lies between them in Morton order (one or two leaves, rarely
     // three); scanned first, skipped by the walk.  A tree of one level is scanned whole.
-    int plo = 0, phi = n - 1, start_node = 0, last_node = 0;
+    int plo = 0, phi = n - 1, start_node = 0;
     if (m.nl >= 2) {
         const int4 pa = a.t.pinfo[g0], pb = a.t.pinfo[glast];
         plo = __builtin_amdgcn_readfirstlane(pa.y); phi = __builtin_amdgcn_readfirstlane(pb.y + pb.z - 1); start_node = __builtin_amdgcn_readfirstlane(pa.x);
-        last_node = __builtin_amdgcn_readfirstlane(pb.x);
-    }
-    // BLOCK: level-1 cell of this lane's query, and the level-2 parents of the first and the last seed leaf (consecutive seeds have
-    // consecutive parents: when those two are the same or neighbours in the node order, every seed is a child of one of them)
-    int cq[3] = {0, 0, 0};
-    int parents = 0, unit_lv = 1, seed_a = start_node, seed_b = last_node;
-    if (BLOCK && m.nl >= 2) {
-        const uint64_t code_q = a.t.keys[qi < n ? qi : g0] >> (3 * (m.l0 + 1));
-        cq[0] = (int)pcr_compact21(code_q); cq[1] = (int)pcr_compact21(code_q >> 1); cq[2] = (int)pcr_compact21(code_q >> 2);
-        if constexpr (BLOCK) {
-            if (m.nl >= 3) {
-                const int pa = __builtin_amdgcn_readfirstlane(a.t.up[m.off[1] + start_node].x), pb = __builtin_amdgcn_readfirstlane(a.t.up[m.off[1] + last_node].x);
-                parents = pb == pa ? 1 : (pb - pa == 1 ? 2 : 0);
-                if (parents == 0 && a.l2tab) {
-                    // a sparse stretch of the curve (the 64 queries under three level-2 cells or more): the same one level up -- level-2 cells
-                    // as the unit, their level-3 parents' 4 x 4 x 4 as the block
-                    unit_lv = 2; seed_a = pa; seed_b = pb;
-                    if (m.nl >= 4) {
-                        const int ga = __builtin_amdgcn_readfirstlane(a.t.up[m.off[2] + pa].x), gb = __builtin_amdgcn_readfirstlane(a.t.up[m.off[2] + pb].x);
-                        parents = gb == ga ? 1 : (gb - ga == 1 ? 2 : 0);
-                    } else parents = 1;
-                }
-            } else parents = 1;                                  // two levels: the root is the one parent
-            const int us = unit_lv - 1;                          // level-1 cell -> level-u cell
-            if (lane == 0) { sh.stk.sc[0] = (cq[0] >> us) & ~1; sh.stk.sc[1] = (cq[1] >> us) & ~1; sh.stk.sc[2] = (cq[2] >> us) & ~1; }
-            if (lane == glast - g0) { sh.stk.sc[3] = (cq[0] >> us) & ~1; sh.stk.sc[4] = (cq[1] >> us) & ~1; sh.stk.sc[5] = (cq[2] >> us) & ~1; }
-            __builtin_amdgcn_wave_barrier();
-        }
     }
     // pass 1: distances only; every candidate that beats the bound of some lane is logged for pass 2
     int nlog = 0;
@@ -493,7 +343,7 @@ __device__ static inline void d_knn_wave(const KnnArgs &a) {
             const float d2 = d4[u];
             if (__ballot(d2 < sd[0]) != 0ull) {
                 if (STATS) st1.events++;
-                sh.log[nlog < KwShared<K, BLOCK>::LOG ? nlog : KwShared<K, BLOCK>::LOG - 1] = i4[u];      // all lanes, one address, one value
+                sh.log[nlog < KwShared<K>::LOG ? nlog : KwShared<K>::LOG - 1] = i4[u];      // all lanes, one address, one value
                 nlog = __builtin_amdgcn_readfirstlane(nlog + 1);
                 // x replaces the largest entry when it is smaller, else the chain leaves the list as it is; entries are >= 0 or -1, so
                 // they order like their bit patterns (integer min / max: no NaN canonicalisation)
@@ -515,33 +365,11 @@ __device__ static inline void d_knn_wave(const KnnArgs &a) {
     // A wavefront whose 64 queries lie far apart (sparse regions, a jump of the Morton curve inside the group) would drag all its lanes
     // through the neighbourhoods of each: ~1 % of the wavefronts took 3-6x the mean and set the length of the launch.  They stop after
     // a.wave_budget batches (or when the log is full) and flag their queries in a.hard for the octet kernel, which serves 8 per wavefront.
-    bool finished;
-    if constexpr (BLOCK) finished = kw_pass_block<STATS>(a.t, m, sh.stk, unit_lv == 2 ? a.l2tab : a.l1tab, unit_lv == 2 ? a.l2mask : a.l1mask, q.x, q.y, q.z, plo, phi, unit_lv, seed_a, seed_b, parents,
-                                                         a.keep, sh.stage, a.wave_budget, [&]() { return sd[0]; }, scan1, st1);
-    else finished = kw_pass<false, STATS>(a.t, m, sh.stk, live, start_node, g0, q.x, q.y, q.z, plo, phi, a.keep, sh.stage, a.hard ? a.wave_budget : 0x7fffffff, [&]() { return sd[0]; }, scan1, st1);
-    bool served = live;                 // this lane's query is answered here (not handed to the octet kernel)
+    const bool finished = kw_pass<false, STATS>(a.t, m, sh.stk, live, start_node, g0, q.x, q.y, q.z, plo, phi, a.keep, sh.stage, a.hard ? a.wave_budget : 0x7fffffff, [&]() { return sd[0]; }, scan1, st1);
     if (a.hard) {
-        bool give_up = !finished || nlog > KwShared<K, BLOCK>::LOG;
-        if (BLOCK && m.nl >= 2) {
-            // the block around the lane's own cell holds every point within the distance from the query to the block's surface: the k-best
-            // of the lane are final if its bound lies inside that (a little spare for the rounding of org + i * unit)
-            give_up = give_up || parents == 0;
-            const float qq[3] = {q.x, q.y, q.z};
-            float dmin = 3.0e38f;
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                const float E = m.unit[d] * (float)(1 << (m.l0 + unit_lv));
-                const float lo = m.org[d] + (float)((cq[d] >> (unit_lv - 1)) - 1) * E;
-                dmin = fminf(dmin, fminf(qq[d] - lo, lo + 3.0f * E - qq[d]) - 2e-3f * E);
-            }
-            const bool inside = sd[0] < 3.0e38f && dmin > 0.0f && sd[0] * 1.00002f < dmin * dmin;
-            served = live && inside;
-        }
-        // (the value is the reason, for PCR_KNNW_HARDSTAT: 1 budget / list overflow, 2 log overflow, 3 seed leaves under more than two level-2 cells, 4 ball outside the block)
-        const int why = !finished ? 1 : (nlog > KwShared<K, BLOCK>::LOG ? 2 : ((BLOCK && parents == 0) ? 3 : 4));
-        if (give_up) served = false;
-        if (live) a.hard[oq] = served ? 0 : (uint8_t)why;
-        if (__ballot(served) == 0ull) return;
+        const bool give_up = !finished || nlog > KwShared<K>::LOG;
+        if (qi < n) a.hard[oq] = (give_up && live) ? 1 : 0;
+        if (give_up) return;
     }
     const unsigned long long c_mid = STATS ? __builtin_readcyclecounter() : 0ull;
 
@@ -552,7 +380,6 @@ __device__ static inline void d_knn_wave(const KnnArgs &a) {
 #pragma unroll
     for (int j = 0; j < K; j++) ties += (sd[j] == bound) ? 1 : 0;
     if (!live || bound == a.r2cap_f) ties = 0;
-    const int k_out = served ? k : 0;                      // lanes handed over take nothing
     int cnt = 0, tcnt = 0;
     auto scan2 = [&](int nb) {
         float4 nX = *(const float4 *)&sh.stage.x[0], nY = *(const float4 *)&sh.stage.y[0], nZ = *(const float4 *)&sh.stage.z[0];
@@ -578,14 +405,14 @@ __device__ static inline void d_knn_wave(const KnnArgs &a) {
             if (__ballot(le) != 0ull) {
                 if (STATS) st2.events++;
                 const bool eq = d2 == bound;
-                const bool take = le && (!eq || tcnt < ties) && cnt < k_out;
+                const bool take = le && (!eq || tcnt < ties) && cnt < k;
                 if (take) row[cnt] = i4[u];
                 cnt += take ? 1 : 0; tcnt += (take && eq) ? 1 : 0;
             }
             }
         }
     };
-    if (nlog <= KwShared<K, BLOCK>::LOG) {
+    if (nlog <= KwShared<K>::LOG) {
         // every member of a lane's k-best beat that lane's bound when pass 1 saw it, so the log holds them all: replay it, the gather of
         // the next 64 entries in flight while the current ones are scanned
         const float inf = __builtin_inff();
@@ -602,7 +429,7 @@ __device__ static inline void d_knn_wave(const KnnArgs &a) {
             if (STATS) { st2.batches++; st2.cands += nb; }
             scan2(nb);
         }
-    } else if constexpr (!BLOCK) kw_pass<true, STATS>(a.t, m, sh.stk, live, start_node, g0, q.x, q.y, q.z, plo, phi, a.keep, sh.stage, 0x7fffffff, [&]() { return bound; }, scan2, st2);
+    } else kw_pass<true, STATS>(a.t, m, sh.stk, live, start_node, g0, q.x, q.y, q.z, plo, phi, a.keep, sh.stage, 0x7fffffff, [&]() { return bound; }, scan2, st2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the rows this wavefront has just stored are read back below
     if (STATS && a.stamps && lane == 0) {                       // diagnostics (PCR_KNNW_STATS): 24 words per wavefront
         unsigned long long *w = a.stamps + 24 * (size_t)(g0 / 64);
@@ -629,7 +456,7 @@ __device__ static inline void d_knn_wave(const KnnArgs &a) {
                 if (d2 < a.r2cap) { s += sqrt(d2); c += 1.0; }
             }
         }
-        if (served) {
+        if (live) {
             a.avg[qi] = c > 0 ? s / c : -1.0;
             for (int j = cnt; j < a.list_pitch; j++) row[j] = -1;              // empty slots of the caller's list
         }
@@ -647,7 +474,7 @@ __device__ static inline void d_knn_wave(const KnnArgs &a) {
                 }
             }
         }
-        if (served) {
+        if (live) {
             double C6[6];
             if (c >= 3.0) {
                 for (int t = 0; t < 9; t++) cu[t] = cu[t] / c;       // cumulants /= n, as Open3D
@@ -667,7 +494,7 @@ __device__ static inline void d_knn_wave(const KnnArgs &a) {
             }
         }
     } else {
-        if (served) {
+        if (live) {
             for (int j = 0; j < a.k; j++) {
                 float d2 = __builtin_inff();
                 if (j < cnt) { const float4 p = a.t.pts[row[j]]; d2 = pcr_d2(p.x - q.x, p.y - q.y, p.z - q.z); }
@@ -685,8 +512,3 @@ template <int MODE, int K> __global__ void __launch_bounds__(KW_BS) KW_OCC(K) k_
 template <int MODE, int K> __global__ void __launch_bounds__(KW_BS) KW_OCC(K) k_knn_wave_stats(KnnArgs a) { d_knn_wave<MODE, K, true>(a); }
 template <int MODE, int K> __global__ void __launch_bounds__(KW_BS) KW_OCC(K) k_knn_wave_batch(KnnBatch b) { d_knn_wave<MODE, K>(b.a[blockIdx.y]); }
 template <int MODE, int K> __global__ void __launch_bounds__(KW_BS) KW_OCC(K) k_knn_wave_batchp(const KnnArgs *a) { d_knn_wave<MODE, K>(a[blockIdx.y]); }
-// BLOCK mode (kw_pass_block): needs a.l1tab and a.hard
-// (93 VGPRs without the walk's state: 5 wavefronts per SIMD)
-#define KW_OCC_BLK __attribute__((amdgpu_waves_per_eu(5, 5)))
-template <int MODE, int K> __global__ void __launch_bounds__(KW_BS) KW_OCC_BLK k_knn_wave_blk_batch(KnnBatch b) { d_knn_wave<MODE, K, false, false, true>(b.a[blockIdx.y]); }
-template <int MODE, int K> __global__ void __launch_bounds__(KW_BS) KW_OCC_BLK k_knn_wave_blk_batchp(const KnnArgs *a) { d_knn_wave<MODE, K, false, false, true>(a[blockIdx.y]); }

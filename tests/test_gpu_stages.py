@@ -122,18 +122,6 @@ def test_knn_wave_equals_octet(P, small_pair, monkeypatch, k, radius, n):
         assert len(set(v.tolist())) == len(v)
 
 
-@pytest.mark.parametrize("voxel", [0.1, 0.4, 1.5])
-def test_knn_wave_block_mode_keeps_the_outlier_mask(P, oracle, small_pair, monkeypatch, voxel):
-    """Batched searches of the wavefront kernel take the neighbour leaves from a hash of the level-1 cells instead of walking the tree
-    (kw_pass_block) and hand every query whose k-th distance leaves its 3 x 3 x 3 block of cells to the octet kernel: dense (0.1 m),
-    medium and sparse (1.5 m voxels: most balls leave their block) clouds, outlier mask = the oracle's bit for bit."""
-    pc = P.PointCloud(small_pair["source"]).voxel_down_sample(voxel)
-    keep = oracle.remove_statistical_outlier(pc.points, 30, 1.0)[0]
-    monkeypatch.setenv("PCR_KNN_WAVE", "1")
-    clean, index = pc.remove_statistical_outlier(30, 1.0)
-    assert np.array_equal(np.asarray(index), np.nonzero(keep)[0])
-
-
 def test_knn_wave_hands_hard_wavefronts_to_the_octet_kernel(P, oracle, small_pair, monkeypatch):
     """A wavefront of the one-query-per-lane search gives up after PCR_KNNW_BUDGET candidate batches and leaves its 64 queries to the octet
     kernel (default 40 batches: ~1 % of the wavefronts).  With a budget of 3 most wavefronts give up, with 8 about half: the outlier
