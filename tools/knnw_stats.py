@@ -8,7 +8,7 @@ syn = importlib.import_module("point-cloud-registration-with-global-refinement_a
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 path = "/tmp/knnw_stats.bin"
 if os.path.exists(path): os.remove(path)
-os.environ["PCR_KNNW_STATS"] = path
+os.environ["PCR_KNNW_STATS"] = path; os.environ["PCR_KNN_WAVE"] = "1"
 pair = syn.make_pair(200000, index=0)
 ctx = P._lib.Context.current()
 copies = int(sys.argv[2]) if len(sys.argv) > 2 else 1
