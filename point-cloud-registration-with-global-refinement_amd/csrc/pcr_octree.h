@@ -300,10 +300,13 @@ __device__ static inline int grid_nn_query(const GridView &g, const float4 *__re
 // ONE QUERY PER OCTET over cells of edge c >= 2.04 r (PCR_GRID8, pcr_grid_level_for): the ball around q then meets, per axis, only q's own
 // cell and the neighbour on the NEARER side, i.e. the 2 x 2 x 2 block of cells around q: lane b of the octet looks up the cell whose
 // offset bits are b (bit set = the neighbour along that axis; lane 0 = q's own cell) -- one lookup per lane, one round trip for the
-// block -- and then the octet scans the cells TOGETHER, own cell first, face / edge / corner neighbours after it, 16 consecutive points
-// per step (two coalesced loads per lane); a cell is skipped when the ball of the octet's second-nearest distance so far does not
+// block -- and then the octet scans the cells TOGETHER, own cell first, face / edge / corner neighbours after it, 8 PCR_GRID8_PPS consecutive
+// points per step (that many coalesced loads per lane in flight); a cell is skipped when the ball of the octet's second-nearest distance so far does not
 // reach its cube.  Against the 27-cell form above (4 lookups and up to 8 scattered point loads per lane and step, most lanes without
 // work): a third of the load instructions and of the VALU work per query.  Same answers (ties -> lower index).
+#ifndef PCR_GRID8_PPS
+#define PCR_GRID8_PPS 8      // points per lane and step of a cell scan (loads in flight)
+#endif
 template <int K> __device__ static inline int pcr_octet_bcast(int v, int ol) {       // value of octet lane K in all 8 lanes
     const int q = pcr_dpp_i<(K & 3) * 0x55>(v);                                     // quad_perm [K&3 x 4]
     const int h = pcr_dpp_i<PCR_DPP_HMIRROR>(q);
@@ -345,17 +348,18 @@ __device__ static inline int grid_nn_query8(const GridView &g, const float4 *__r
         if (!(g2k < bound)) r = 0;
         const int cnt = (int)((unsigned)r >> 22), first = r & 0x3fffff;
         if (__ballot(cnt > 0) == 0ull) continue;
-        for (int j0 = 0; __ballot(j0 < cnt) != 0ull; j0 += 2 * OCT) {
-            const int ja = j0 + ol, jb = j0 + OCT + ol;
-            const float4 pa = pts[first + (ja < cnt ? ja : 0)], pb = pts[first + (jb < cnt ? jb : 0)];
-            const float da = pcr_d2(pa.x - qx, pa.y - qy, pa.z - qz), db = pcr_d2(pb.x - qx, pb.y - qy, pb.z - qz);
-            if (ja < cnt) {
-                if (da < d || (da == d && first + ja < id)) { dd = d; d = da; id = first + ja; }
-                else dd = fminf(dd, da);
-            }
-            if (jb < cnt) {
-                if (db < d || (db == d && first + jb < id)) { dd = d; d = db; id = first + jb; }
-                else dd = fminf(dd, db);
+        for (int j0 = 0; __ballot(j0 < cnt) != 0ull; j0 += PCR_GRID8_PPS * OCT) {
+            float4 pp[PCR_GRID8_PPS];
+#pragma unroll
+            for (int u = 0; u < PCR_GRID8_PPS; u++) { const int j = j0 + u * OCT + ol; pp[u] = pts[first + (j < cnt ? j : 0)]; }
+#pragma unroll
+            for (int u = 0; u < PCR_GRID8_PPS; u++) {
+                const int j = j0 + u * OCT + ol;
+                const float du = pcr_d2(pp[u].x - qx, pp[u].y - qy, pp[u].z - qz);
+                if (j < cnt) {
+                    if (du < d || (du == d && first + j < id)) { dd = d; d = du; id = first + j; }
+                    else dd = fminf(dd, du);
+                }
             }
         }
         // octet-wide second-nearest so far: the winner lane's runner-up or another lane's best
