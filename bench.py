@@ -304,7 +304,9 @@ def main(argv=None) -> int:
             return None, None, None
         traffic_file = None
         valu_file = None
-        vcsv, vname, vcommit = tracked("pmc_valu_per_pair.csv")                   # what the PATH is bound by (the iteration kernel itself is latency-bound)
+        vcsv, vname, vcommit = tracked("pmc_valu_per_pair_groups.csv")            # what the PATH is bound by (the iteration kernel itself is latency-bound):
+        if not vcsv:                                                              # the table of the default run (lockstep groups), else the one-pair-at-a-time table
+            vcsv, vname, vcommit = tracked("pmc_valu_per_pair.csv")
         if vcsv:
             try:
                 import csv as _csv
@@ -313,10 +315,13 @@ def main(argv=None) -> int:
                 minst = float(tot["valu_wave_instructions_per_pair_M"])
                 valu_file = {"file": vname, "taken_at_commit": vcommit, "valu_wave_instructions_per_pair_M": minst,
                              "ms_per_pair_at_peak_issue": minst / 614.4, "largest": {"kernel": rows[0]["kernel"], "share": float(rows[0]["share_of_valu_instructions"])},
-                             "note": "tracked rocprofv3 --pmc SQ_INSTS_VALU result, one pair at a time, not this run: the pairs/s of the path are bound by VALU issue "
+                             "note": "tracked rocprofv3 --pmc SQ_INSTS_VALU result (kernels serialised by the counter collection), not this run: the pairs/s of the path are bound by VALU issue "
                                      "(1024 SIMDs x 1 wave64 instruction per 4 cycles at 2.4 GHz = 614.4 k instructions per us)"}
             except Exception:       # noqa: BLE001 -- a tracked file must never cost the line
                 valu_file = None
+        if valu_file and "groups" in (vname or "") and args.variant == "gicp" and not args.config5 and args.points == 200_000:
+            # the path's own roof: share of the chip's VALU issue slots this run's pairs/s amount to (per GPU)
+            valu_file["valu_issue_utilisation_at_this_runs_rate"] = valu_file["ms_per_pair_at_peak_issue"] * 1e-3 * (n_done / dt)
         tj, tname, tcommit = tracked("traffic.json")
         if tj:
             try:

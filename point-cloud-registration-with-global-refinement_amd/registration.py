@@ -248,6 +248,17 @@ def default_group(points_per_cloud: float) -> int:
     return 16 if g > 32 else max(1, min(8, g))
 
 
+def balanced_group(group: int, n_pairs: int, inflight: int) -> int:
+    """Group size near ``group`` for which the groups of a batch of ``n_pairs`` fill whole rounds of ``inflight`` workers: 96 pairs in
+    groups of 16 are 6 groups -- a round of 4 and a round of 2 -- in groups of 12 they are two full rounds (NCLT-size pairs, 5-scale
+    GICP stage: 1930 -> 2400 pairs/s)."""
+    if group <= 1 or inflight <= 1 or n_pairs <= group * inflight:
+        return max(1, group)
+    n_groups = -(-n_pairs // group)
+    n_groups = -(-n_groups // inflight) * inflight
+    return max(1, -(-n_pairs // n_groups))
+
+
 def register_pairs_plan(pairs, stage: str = "gicp", voxel_sizes=None, max_correspondence_distances=None, estimation_method=None, criteria=None,
                         nb_neighbors: int = 30, std_ratio: float = 1.0, normal_knn: int = 20, inflight: int = 3, with_correspondences: bool = True,
                         fgr_voxel_size: float = 0.1, fgr_use_absolute_scale: bool = True, fgr_seed=None, radius_rule: str = "given",
@@ -283,7 +294,7 @@ def register_pairs_plan(pairs, stage: str = "gicp", voxel_sizes=None, max_corres
         return []
     if group is None:
         mean_pts = float(np.mean([len(s_) + len(t_) for s_, t_, _ in pairs])) / 2
-        group = default_group(mean_pts)
+        group = balanced_group(default_group(mean_pts), n, int(inflight))
     if stage == "fgr+gicp" and group > 1 and n > 1:
         # Two passes over the batch instead of FGR -> GICP pair by pair: registro_FGR is a chain of ~150 small launches with a few host
         # waits and wants MANY pairs in flight (20k-point pairs: 230 / 590 / 700 pairs/s with 1 / 4 / 8), the GICP wants lockstep groups.

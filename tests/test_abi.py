@@ -79,3 +79,6 @@ def test_default_group_rule():
     g = pkg().registration.default_group
     assert [g(n) for n in (20_000, 50_000, 100_000, 200_000, 400_000, 2_000_000)] == [16, 8, 8, 6, 3, 1]
     assert g(0) == 16 and g(1e9) == 1
+    # ... rounded so that the groups of a batch fill whole rounds of the workers in flight
+    b = pkg().registration.balanced_group
+    assert [b(16, 96, 4), b(6, 48, 4), b(16, 192, 4), b(16, 20, 4), b(1, 100, 4), b(6, 48, 1)] == [12, 6, 16, 16, 1, 6]

@@ -92,6 +92,29 @@ with open(dst + "_pmc_valu_per_pair.csv", "w", newline="") as fo:
         w.writerow([k[:60], round(n / npairs, 1), round(dur / 1e3 / npairs, 3), round(insts / 1e6 / npairs, 1), round(insts / tot, 3), int(insts / dur), round(insts / dur / PEAK, 3)])
     w.writerow(["TOTAL", "", round(sum(r[3] for r in rows) / 1e3 / npairs, 3), round(tot / 1e6 / npairs, 1), 1.0, "", ""])
 PY
+# the same table for the DEFAULT bench (lockstep groups: wavefront k-NN kernel, by-value fused kernel) -- what the headline number runs
+d=$OUT/pmc_valu_groups
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU --output-format csv -d "$d" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 1 --warmup 1 > "$d.log" 2> "$d.err" || exit 1
+python3 - "$OUT" "$ROOT/profiles/${TAG}" <<'PY'
+import csv, glob, sys, collections, json
+out, dst = sys.argv[1], sys.argv[2]
+f = glob.glob(f"{out}/pmc_valu_groups/**/*counter_collection.csv", recursive=True)[0]
+d = collections.defaultdict(lambda: [0.0, 0, 0.0])
+for r in csv.DictReader(open(f)):
+    if r["Counter_Name"] != "SQ_INSTS_VALU": continue
+    e = d[r["Kernel_Name"].split("(")[0]]; e[0] += float(r["Counter_Value"]); e[1] += 1; e[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+line = json.loads([l for l in open(f"{out}/pmc_valu_groups.log") if l.startswith('{"metric')][-1])
+pps = line["config"]["pairs_per_step"]
+npairs = float(pps * (line["steps"] + max(line["warmup"], 1)) + 5)          # timed + warm-up steps + the single-pair steps of the roofline measurement
+tot = sum(e[0] for e in d.values())
+PEAK = 256 * 4 * 2400 / 4.0
+with open(dst + "_pmc_valu_per_pair_groups.csv", "w", newline="") as fo:
+    w = csv.writer(fo)
+    w.writerow(["kernel", "launches", "valu_wave_instructions_per_pair_M", "share_of_valu_instructions", "valu_instructions_per_us_serialised", "share_of_peak_issue_614k_per_us"])
+    for k, e in sorted(d.items(), key=lambda x: -x[1][0])[:20]:
+        w.writerow([k[:60], e[1], round(e[0] / 1e6 / npairs, 1), round(e[0] / tot, 3), int(e[0] / e[2]), round(e[0] / e[2] / PEAK, 3)])
+    w.writerow(["TOTAL", "pairs counted: %d" % npairs, round(tot / 1e6 / npairs, 1), 1.0, "", ""])
+PY
 grep '^{"metric' "$OUT/bench_stats.log" | tail -1 > "$ROOT/profiles/${TAG}_bench_line_under_rocprof.json"
 # gpurun only merges gpurun_out/ back: export the files to commit there as well
 cp "$ROOT"/profiles/${TAG}_* "$ROOT/gpurun_out/profiles_export/"
