@@ -92,7 +92,7 @@ __device__ static inline float kw_boxbox_d2(const float4 lo, const float4 hi, co
 //   AT the k-th distance).  scan(nb) consumes the nb candidates staged in LDS (stage[j] = xyz + index bits, slots beyond nb at infinity).
 // The gather of a batch is issued one batch AHEAD whenever the pending point range continues (seed ranges and fat leaves are longer than
 // a batch more often than not): the scan of the current batch then hides the load latency of the next.
-struct KwStats { int tests, exact_inner, pops, leaf_hits, climbs, batches, cands, events; unsigned long long t_walk, t_stage, t_scan; };
+struct KwStats { int tests, exact_inner, pops, leaf_hits, climbs, batches, cands, events; unsigned long long t_walk, t_stage, t_scan; int culled; };
 // Returns false when the pass was given up after `budget` batches (a wavefront whose queries lie far apart: the caller hands them over).
 template <bool INCL, bool STATS, class WorstFn, class ScanFn>
 __device__ static inline bool kw_pass(const OctView &t, const OctMeta &m, KwStack &stk, bool live, int start_node, int start_point, float qx, float qy, float qz,
@@ -263,12 +263,20 @@ __device__ static inline bool kw_pass(const OctView &t, const OctMeta &m, KwStac
                 r0f += nx; r0c -= nx;
                 if (r0c == 0) { r0f = r1f; r0c = r1c; r1c = 0; }
             }
+            // CULL at staging time, one candidate per lane: a point farther from the BOX of the wavefront's queries than the largest bound of
+            // any lane beats nobody's bound (fat leaves are staged whole and straddle the balls: half of their points go here, at ~25
+            // instructions per batch instead of 8 per candidate); the survivors are compacted to the front, infinity behind them
+            const float wmax = kw_wave_fmax(worst());
+            const bool in = p.x < inf && beats(pcr_box_d2(make_float4(glo[0], glo[1], glo[2], 0.0f), make_float4(ghi[0], ghi[1], ghi[2], 0.0f), p.x, p.y, p.z), wmax);
+            const unsigned long long km = __ballot(in);
+            const int nkeep = __builtin_popcountll(km), below = __builtin_popcountll(km & ((1ull << lane) - 1ull));
+            const int slot = in ? below : nkeep + (lane - below);
             __builtin_amdgcn_wave_barrier();
-            stage.x[lane] = p.x; stage.y[lane] = p.y; stage.z[lane] = p.z; stage.i[lane] = __float_as_int(p.w);
+            stage.x[slot] = in ? p.x : inf; stage.y[slot] = in ? p.y : inf; stage.z[slot] = in ? p.z : inf; stage.i[slot] = __float_as_int(p.w);
             __builtin_amdgcn_wave_barrier();
             unsigned long long ts0 = 0;
-            if (STATS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ts0 = __builtin_readcyclecounter(); st.t_stage += ts0 - tw1; }
-            scan(nb);
+            if (STATS) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ts0 = __builtin_readcyclecounter(); st.t_stage += ts0 - tw1; st.culled += nb - nkeep; }
+            if (nkeep > 0) scan(nkeep);
             if (STATS) st.t_scan += __builtin_readcyclecounter() - ts0;
             nb = nx; pre_n = nx; bidx = nidx;
         }
@@ -302,7 +310,7 @@ __device__ static inline void d_knn_wave(const KnnArgs &a) {
     // the query's k-best row: MODE_SOR / MODE_NORMALS -> a.list_idx with a.list_pitch entries per row (indexed like the outputs), MODE_DEBUG -> dbg_idx
     int32_t *const row = MODE == KNN_MODE_DEBUG ? a.dbg_idx + (size_t)qi * a.k : a.list_idx + (size_t)(MODE == KNN_MODE_SOR ? qi : oq) * a.list_pitch;
 
-    KwStats st1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st2 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    KwStats st1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st2 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long c_begin = STATS ? __builtin_readcyclecounter() : 0ull;
     // ---- the lane's k smallest squared distances, DESCENDING (sd[0] = the bound); slots beyond k and lanes without a query hold -1
     float sd[K];
@@ -434,7 +442,7 @@ __device__ static inline void d_knn_wave(const KnnArgs &a) {
     if (STATS && a.stamps && lane == 0) {                       // diagnostics (PCR_KNNW_STATS): 24 words per wavefront
         unsigned long long *w = a.stamps + 24 * (size_t)(g0 / 64);
         const unsigned long long c_end = __builtin_readcyclecounter();
-        w[0] = c_mid - c_begin; w[1] = c_end - c_mid; w[2] = wall_clock64();
+        w[0] = c_mid - c_begin; w[1] = c_end - c_mid; w[2] = wall_clock64(); w[3] = (unsigned long long)st1.culled;
         const KwStats *ss[2] = {&st1, &st2};
         for (int h = 0; h < 2; h++) {
             w[4 + 8 * h] = ss[h]->tests; w[5 + 8 * h] = ss[h]->exact_inner; w[6 + 8 * h] = ss[h]->pops; w[7 + 8 * h] = ss[h]->leaf_hits;

@@ -29,4 +29,5 @@ while off < len(raw):
         cyc = w[:, h]
         print(f"  {nm}: cycles mean {cyc.mean():.0f} p50 {np.median(cyc):.0f} p90 {np.percentile(cyc, 90):.0f} p99 {np.percentile(cyc, 99):.0f} max {cyc.max():.0f}")
         print("     " + "  ".join(f"{names[j]} {w[:, 4 + 8 * h + j].mean():.1f}/{np.percentile(w[:, 4 + 8 * h + j], 99):.0f}" for j in range(8)) + "   (mean/p99 per wavefront)")
+    print(f"  pass 1: candidates culled at staging time (farther from the wavefront's query box than any bound): {w[:, 3].mean():.1f} of {w[:, 4 + 6].mean():.1f} per wavefront")
     print(f"  pass 1 cycles by part: walk {w[:, 20].mean():.0f}  staging (gather wait) {w[:, 21].mean():.0f}  scan {w[:, 22].mean():.0f}")
