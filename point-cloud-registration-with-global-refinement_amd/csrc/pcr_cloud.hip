@@ -1212,10 +1212,14 @@ template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn_b
 // no tail to speak of (tools/knn_sat.py, 1.4 M queries, k = 30, outlier-filter mode: 1.8 + 0.1 ms against 2.0 ms; one pair at a time
 // 182 against 200 pairs/s) -- but in the batched searches of a lockstep group (2 G clouds x S scales per launch, other groups' kernels
 // alongside) the tail hides and the instruction count decides: 200k-point pairs 569 -> 602 pairs/s, 100k 913 -> 977, 20k 2736 -> 2880.
-// So: the wavefront kernel for batches of at least KNN_WAVE_MIN_BATCH searches, the octet kernel otherwise.  PCR_KNN_WAVE=0 / 1 forces
+// So: the wavefront kernel for batches of at least KNN_WAVE_MIN_BATCH searches or KNN_WAVE_MIN_POINTS queries, the octet kernel otherwise.  PCR_KNN_WAVE=0 / 1 forces
 // one of them (per call: tests/test_gpu_stages.py runs every search through both and compares them -- two independent exact searches).
 #define KNN_WAVE_MIN_BATCH 6
-static bool knn_wave_enabled(int batch) { const char *e = getenv("PCR_KNN_WAVE"); return e ? atoi(e) != 0 : batch >= KNN_WAVE_MIN_BATCH; }
+#define KNN_WAVE_MIN_POINTS 1500000       // ... or of that much query CAPACITY in all (the scales of config 5, 2M each: 21.7 -> 22.6 pairs/s; a lone 200k-point pair, 3 x 200k in a batch, is faster with the octet kernel: 208 against 183 pairs/s)
+static bool knn_wave_enabled(int batch, long long points) {
+    const char *e = getenv("PCR_KNN_WAVE");
+    return e ? atoi(e) != 0 : (batch >= KNN_WAVE_MIN_BATCH || points >= KNN_WAVE_MIN_POINTS);
+}
 static bool knn_wave_fits(const KnnArgs &a) { return a.k >= 1 && a.k <= 64 && !a.todo && !a.stamps && !a.dbg_visits; }
 // the wavefront kernel appends every query's k-best to a row in global memory: the caller's list (SOR) or scratch from the arena
 template <int MODE>
@@ -1298,7 +1302,9 @@ static int launch_knn_batch(pcr_context *ctx, KnnArgs *a, const int *caps, int c
         for (int k = 0; k < count; k++) PCR_TRY(launch_knn_cap<MODE>(ctx, caps[k], a[k]));
         return PCR_OK;
     }
-    if (knn_wave_enabled(count)) {
+    long long total_pts = 0;
+    for (int k = 0; k < count; k++) total_pts += caps[k];
+    if (knn_wave_enabled(count, total_pts)) {
         bool fits = true; int kmax = 0, mcw = 0;
         for (int k = 0; k < count; k++) { fits = fits && knn_wave_fits(a[k]); kmax = a[k].k > kmax ? a[k].k : kmax; mcw = caps[k] > mcw ? caps[k] : mcw; }
         if (fits && mcw > 0) {
@@ -1348,7 +1354,7 @@ static int launch_knn_cap(pcr_context *ctx, int cap, KnnArgs a) {
         }
     } dump{ctx, stamp_path, a.stamps, stamp_words, MODE, a.k};
     a.seed_span = -1;
-    if (knn_wave_enabled(1) && knn_wave_fits(a)) { a.seed_span = -1; return launch_knn_wave<MODE>(ctx, cap, a); }
+    if (knn_wave_enabled(1, cap) && knn_wave_fits(a)) { a.seed_span = -1; return launch_knn_wave<MODE>(ctx, cap, a); }
     if (a.k <= 32) PCR_LAUNCH(ctx, k_knn<MODE, 4>, grid, block, 0, ctx->stream, a);
     else if (a.k <= 64) PCR_LAUNCH(ctx, k_knn<MODE, 8>, grid, block, 0, ctx->stream, a);
     else PCR_LAUNCH(ctx, k_knn<MODE, 25>, grid, block, 0, ctx->stream, a);
