@@ -287,6 +287,7 @@ def test_switches_do_not_change_the_result():
                 {"PCR_ICP_GRID": "0"}, {"PCR_ICP_GRID": "0", "PCR_ICP_FUSED": "0"},      # correspondence search over the octree instead of the cell hash
                 {"PCR_ICP_STREAM_MIN": "1000"},                                          # the two streaming kernels of large clouds (k_icp_ab + k_icp_lin) instead of the fused one
                 {"PCR_ICP_STREAM_MIN": "1000", "PCR_ICP_GRID": "0"},
+                {"PCR_ICP_STREAM_MIN": "1000", "PCR_ICP_COMPACT": "0"},                  # ... with per-workgroup pending lists (k_icp_ab) instead of one list for the cloud
                 {"PCR_PIPELINE": "1", "PCR_LANES": "1"}, {"PCR_VOXEL_MERGED": "0", "PCR_ICP_FUSED": "0", "PCR_ICP_GRAPH": "0", "PCR_PIPELINE": "2"}]
     lines = []
     for env in variants:
