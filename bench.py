@@ -352,7 +352,7 @@ def main(argv=None) -> int:
                        "gathered_records": int(len(gathered)), "tables_identical": same_tables},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_from_profiles": traffic_file, "valu_from_profiles": valu_file,
-                         "kernel": ("k_icp_ab + k_icp_lin (one GICP iteration as two streaming kernels: clouds from 400k points)" if args.config5 else "k_icp_fused (one GICP iteration)") + "; the first launch of a scale is k_icp_nn + k_icp_lin",
+                         "kernel": ("k_icp_cert + k_icp_search + k_icp_lin (one GICP iteration as streaming kernels: clouds from 400k points)" if args.config5 else "k_icp_fused (one GICP iteration)") + "; the first launch of a scale is k_icp_nn + k_icp_lin",
                          "bytes_per_launch": bytes_per_launch, "us_per_launch_hip_events": us_event,
                          "us_per_launch_in_kernel_clock": us_kernel, "us_per_launch_in_flight": us_in_flight,
                          "us_slowest_workgroup_search_phase": (solo[6] / live) if live else None, "us_until_partial_sums_gathered": (solo[7] / live) if live else None,
@@ -471,7 +471,7 @@ def extras(args, P, syn, reg, est, crit, pairs, clouds, run_batch, pool_prof, po
             "pairs_per_s": n5 / dt, "pairs_timed": n5, "points_per_cloud": int(len(p5[0].source)), "pairs_in_flight": fl5,
             "scales": [dict(voxel=s["voxel"], n_clean=s["n_clean"], iterations=s["iterations"]) for s in r5[0].scales],
             "err_vs_planted": pose_err(r5[0], p5[0]),
-            "roofline": {"bound": "hbm", "kernel": "k_icp_ab + k_icp_lin (one GICP iteration as two streaming kernels: clouds from 400k points)", "bytes_per_launch": bpl, "us_per_launch_hip_events": us,
+            "roofline": {"bound": "hbm", "kernel": "k_icp_cert + k_icp_search + k_icp_lin (one GICP iteration as streaming kernels: clouds from 400k points)", "bytes_per_launch": bpl, "us_per_launch_hip_events": us,
                          "measured_on": "2 pairs, one at a time, after the timed batch",
                          "achieved": (bpl / (us * 1e-6) / 1e9) if us else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (bpl / (us * 1e-6) / 1e9 / HBM_PEAK_GBS) if us else 0.0},
