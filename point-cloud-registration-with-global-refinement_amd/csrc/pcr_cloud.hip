@@ -804,22 +804,16 @@ __global__ void __launch_bounds__(BS) k_grid_build(const GridBuildDesc *descs) {
         h = (h + 1) & d.mask;                              // (a cell has one first point: `old == code` cannot happen)
     }
 }
-// level whose cell edge covers the radius with 0.2 % to spare (rounding of the query's cell against the points' exact voxel indices), or -1:
-// only for voxel-lattice clouds and cells of at most 4 voxels (27 cells = at most a few hundred candidates on a surface)
+// level whose cell edge covers twice the radius with 2 % to spare (rounding of the query's cell against the points' exact voxel indices), or -1:
+// only for voxel-lattice clouds
 int pcr_grid_level_for(const DevCloud *c, double search_radius) {
     if (!c->voxel_lattice || !(search_radius > 0.0) || !(c->key_unit[0] > 0.0f)) return -1;
-#if PCR_GRID8
     // grid_nn_query8: cell edge >= 2.04 r (the ball meets only the 2 x 2 x 2 block of cells on q's side), cells of at most 8 voxels
     // (<= 512 points: the packed range of a cell holds 10 bits of count and 22 of index)
     if (c->cap >= (1 << 22)) return -1;
     int L = 0;
     while (L <= 3 && (double)c->key_unit[0] * (double)(1 << L) * 0.49 < search_radius) L++;
     return L <= 3 ? L : -1;
-#else
-    int L = 0;
-    while (L <= 2 && (double)c->key_unit[0] * (double)(1 << L) * 0.998 < search_radius) L++;
-    return L <= 2 ? L : -1;
-#endif
 }
 int pcr_dev_build_grid_batch(pcr_context *ctx, const DevCloud *const *cs, const int *levels, int count, GridView *views) {
     std::vector<GridBuildDesc> d; int max_cap = 0;

@@ -336,7 +336,7 @@ __device__ static inline void d_icp_nn(const IcpArgs &a) {
     if (live) { const float4 r = rec_q[ob]; qx = r.x; qy = r.y; qz = r.z; hint = __float_as_int(r.w); qi = rec_i[ob]; }
     int visits = 0, start_pt = 0; float d1 = 0, d2 = 0;
     int best;
-    if (GRID) { best = grid_nn_search(a.grid, a.tgt_pts, live, qx, qy, qz, a.ref ? a.r2s : a.r2f, ol, &d1, &d2); start_pt = hint >= 0 ? hint : 0; }
+    if (GRID) { best = grid_nn_query8(a.grid, a.tgt_pts, live, qx, qy, qz, a.ref ? a.r2s : a.r2f, ol, &d1, &d2); start_pt = hint >= 0 ? hint : 0; }
     else best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.ref ? a.r2s : a.r2f, hint, ol, oct, ob, &start_pt, a.dbg_visits ? &visits : nullptr, &d1, &d2);
     if (a.verify && ol == 0 && live && rec_c[ob] != -2) {
         const int claim = rec_c[ob];
@@ -434,7 +434,7 @@ __device__ static inline void d_icp_ab(const IcpArgs &a) {
         if (live) { const float4 r = rec_q[e]; qx = r.x; qy = r.y; qz = r.z; hint = __float_as_int(r.w); qi = rec_i[e]; }
         int start_pt = 0; float d1 = 0, d2 = 0;
         int best;
-        if (GRID) { best = grid_nn_search(a.grid, a.tgt_pts, live, qx, qy, qz, a.r2s, ol, &d1, &d2); start_pt = hint >= 0 ? hint : 0; }
+        if (GRID) { best = grid_nn_query8(a.grid, a.tgt_pts, live, qx, qy, qz, a.r2s, ol, &d1, &d2); start_pt = hint >= 0 ? hint : 0; }
         else best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.r2s, hint, ol, oct, ob, &start_pt, nullptr, &d1, &d2);
         if (ol == 0 && live) {
             const float slack = 2e-5f + 1e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz));
@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 
         if (live) { const float4 r = a.pend_q[e]; qx = r.x; qy = r.y; qz = r.z; hint = __float_as_int(r.w); qi = a.pend_i[e]; }
         int start_pt = 0; float d1 = 0, d2 = 0;
         int best;
-        if (GRID) { best = grid_nn_search(a.grid, a.tgt_pts, live, qx, qy, qz, a.r2s, ol, &d1, &d2); start_pt = hint >= 0 ? hint : 0; }
+        if (GRID) { best = grid_nn_query8(a.grid, a.tgt_pts, live, qx, qy, qz, a.r2s, ol, &d1, &d2); start_pt = hint >= 0 ? hint : 0; }
         else best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.r2s, hint, ol, oct, ob, &start_pt, nullptr, &d1, &d2);
         if (ol == 0 && live) {
             const float slack = 2e-5f + 1e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz));
@@ -831,7 +831,6 @@ __global__ void __launch_bounds__(LIN_BS) __attribute__((amdgpu_waves_per_eu(4, 
 // launches of the loop (the in-flight throughput is bound by the dispatch rate of small dependent kernels, ~90k/s
 // system-wide) and removes the match[] round trip between the two kernels.
 #define FUSED_BS 512
-#define PCR_GRID_LANE_SEARCH 0     // 1: one pending query per LANE through the cell hash (measured: divergent per-lane scans, 47 us against 27 us per launch at the coarsest scale)
 // PPL = source points per lane (PCR_ICP_PPL, default 1).  The kernel is latency-bound (dependent loads, publish -> ticket -> gather), so
 // its wavefronts mostly wait, and at one point per lane a 160k-point launch is 312 workgroups of 8 wavefronts at 122 VGPRs -- 61 % of
 // the chip's wavefront slots for ONE pair's iteration.  Two / four points per lane (half / a quarter of the wavefronts, partial rows
@@ -910,24 +909,10 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
     }
     __syncthreads();
     const unsigned long long t_a = wall_clock64() - t_entry;
-    // ---- phase B: the pending list.  Cell hash: one query per LANE, the whole list in ceil(npend / 512) rounds; octree: one query per
-    // octet, 64 per round
+    // ---- phase B: the pending list, one query per octet, 64 per round (one query per LANE through the cell hash was measured: divergent
+    // per-lane scans, 47 us against 27 us per launch at the coarsest scale)
     const int npend = n_rec;
     if (tid == 0 && npend > 0) atomicAdd(&st->searched, (unsigned long long)npend);
-    if (GRID && PCR_GRID_LANE_SEARCH) {
-        for (int e = tid; e < npend; e += FUSED_BS) {
-            const float4 r = rec_q[e]; const int l = rec_l[e];
-            float d1 = 0, d2 = 0;
-            const int best = grid_nn_lane(a.grid, a.tgt_pts, r.x, r.y, r.z, a.r2s, &d1, &d2);
-            const int qi = tile0 + l, hint = __float_as_int(r.w);
-            const float slack = 2e-5f + 1e-6f * (fabsf(r.x) + fabsf(r.y) + fabsf(r.z));
-            const float margin = best >= 0 ? 0.5f * (sqrtf(d2) - sqrtf(d1)) - slack : a.rs_minus_r - slack;
-            a.ref[qi] = make_float4(r.x, r.y, r.z, margin > 0.0f ? margin : 0.0f);
-            a.rbest[qi] = best;
-            if (best < 0) a.match[qi] = -((hint >= 0 ? hint : 0) + 2);       // (the hint only matters to the octree search)
-            cand_l[l] = best;
-        }
-    } else
     for (int e0 = 0; e0 < npend; e0 += OPB) {
         const int e = e0 + ob;
         const bool live = e < npend;
@@ -936,7 +921,7 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
         if (live) { const float4 r = rec_q[e]; qx = r.x; qy = r.y; qz = r.z; hint = __float_as_int(r.w); l = rec_l[e]; }
         int start_pt = 0; float d1 = 0, d2 = 0;
         int best;
-        if (GRID) { best = grid_nn_search(a.grid, a.tgt_pts, live, qx, qy, qz, a.r2s, ol, &d1, &d2); start_pt = hint >= 0 ? hint : 0; }
+        if (GRID) { best = grid_nn_query8(a.grid, a.tgt_pts, live, qx, qy, qz, a.r2s, ol, &d1, &d2); start_pt = hint >= 0 ? hint : 0; }
         else best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.r2s, hint, ol, oct, ob, &start_pt, nullptr, &d1, &d2);
         if (ol == 0 && live) {
             const int qi = tile0 + l;

@@ -187,10 +187,12 @@ __device__ static inline void oct_search(const OctView &t, const OctMeta &m, Oct
 
 // ---------------------------------------------------------------------------------------------------------------
 // CELL HASH over a voxel-lattice cloud: the points of a Morton cell of level L (edge c = unit * 2^L) are a contiguous range of the
-// sorted cloud; `codes` / `rng` is an open-addressing hash from the cell's Morton code (key >> 3L) to that range.  A ball of radius
-// r <= 0.998 c around q meets only the 27 cells around q's cell, so the nearest point inside the ball comes out of 27 INDEPENDENT
-// lookups and then independent point loads -- two or three round trips where the bottom-up tree walk chains 6-20 dependent loads
-// (the GICP iteration kernel spent 26 of its 38 us in the slowest workgroup's walks).
+// sorted cloud; `tab` is an open-addressing hash from the cell's Morton code (key >> 3L) to that range.  A ball of radius r <= 0.49 c
+// around q meets only the 2 x 2 x 2 block of cells on q's side, so the nearest point inside the ball comes out of 8 INDEPENDENT lookups
+// (one per lane of the octet) and then coalesced point loads -- two or three round trips where the bottom-up tree walk chains 6-20
+// dependent loads (the GICP iteration kernel spent 26 of its 38 us in the slowest workgroup's walks).  (A table sized by the
+// cells -- a tenth to a fortieth of the points at the levels used, counted on the device -- instead of by the points was measured: no
+// gain at 200k or 2M points, the lookups are not what the searches wait for.)
 struct GridEntry { unsigned long long code; int first, count; };     // 16 B: one load per probe; code 0xffff... = empty slot
 struct GridView {
     const GridEntry *tab;
@@ -201,109 +203,29 @@ struct GridView {
 __host__ __device__ static inline unsigned pcr_grid_hash(unsigned long long code, unsigned mask) {
     return (unsigned)((code * 0x9E3779B97F4A7C15ull) >> 40) & mask;
 }
-__device__ static inline int2 pcr_grid_lookup(const GridView &g, int x, int y, int z) {
+__device__ static inline int2 pcr_grid_lookup(const GridView &g, unsigned mask, int x, int y, int z) {
     const int lim = (1 << 21) >> g.L;
     if (x < 0 || y < 0 || z < 0 || x >= lim || y >= lim || z >= lim) return make_int2(0, 0);
     const unsigned long long code = pcr_morton3((uint32_t)x, (uint32_t)y, (uint32_t)z);
-    unsigned h = pcr_grid_hash(code, g.mask);
+    unsigned h = pcr_grid_hash(code, mask);
     for (int probe = 0; probe < 64; probe++) {
         const int4 e = *(const int4 *)&g.tab[h];                                   // one 16-B load
         const unsigned long long c = ((unsigned long long)(unsigned)e.y << 32) | (unsigned)e.x;
         if (c == code) return make_int2(e.z, e.w);
         if (c == PCR_GRID_EMPTY) break;
-        h = (h + 1) & g.mask;
+        h = (h + 1) & mask;
     }
     return make_int2(0, 0);
 }
 
-// ONE QUERY PER OCTET: lane c of the octet looks up cells c, c + 8, c + 16, c + 24 of the 27 (all its lookups in flight together),
-// then scans their points two per cell at a time (up to 8 loads in flight); cells whose cube the ball of the lane's current
-// second-nearest distance does not reach are skipped.  All 64 lanes call it; live is octet-uniform.  Same answers as the tree search
-// (ties -> lower index).
-__device__ static inline int grid_nn_query(const GridView &g, const float4 *__restrict__ pts, bool live, float qx, float qy, float qz, float r2cap, int ol,
-                                           float *d1_out, float *d2_out) {
-    float d = r2cap, dd = r2cap; int id = -1;              // lane-local best / second
-    int first[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0}; float gap2[4] = {0, 0, 0, 0};
-    if (live) {
-        const float fx = (qx - g.org[0]) * g.inv_unit[0], fy = (qy - g.org[1]) * g.inv_unit[1], fz = (qz - g.org[2]) * g.inv_unit[2];
-        const int cx = (int)floorf(fx) >> g.L, cy = (int)floorf(fy) >> g.L, cz = (int)floorf(fz) >> g.L;
-        const float lox = qx - (g.org[0] + (float)cx * g.cell[0]), loy = qy - (g.org[1] + (float)cy * g.cell[1]), loz = qz - (g.org[2] + (float)cz * g.cell[2]);
-        const float slack = 2e-3f * g.cell[0];
-        // the FIRST probe of the lane's four cells goes out together (a lookup is one 16-B load; probing cell after cell chained four
-        // round trips); the rare collision chain is followed afterwards
-        unsigned long long code[4]; unsigned h[4]; int4 e[4]; bool want[4];
-        const int lim = (1 << 21) >> g.L;
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int c27 = ol + OCT * t;
-            const int dx = c27 % 3 - 1, dy = (c27 / 3) % 3 - 1, dz = c27 / 9 - 1;
-            const float ax = dx < 0 ? lox - slack : (dx > 0 ? g.cell[0] - lox - slack : 0.0f), ay = dy < 0 ? loy - slack : (dy > 0 ? g.cell[1] - loy - slack : 0.0f),
-                        az = dz < 0 ? loz - slack : (dz > 0 ? g.cell[2] - loz - slack : 0.0f);
-            gap2[t] = pcr_d2(fmaxf(ax, 0.0f), fmaxf(ay, 0.0f), fmaxf(az, 0.0f));
-            const int x = cx + dx, y = cy + dy, z = cz + dz;
-            want[t] = c27 < 27 && gap2[t] < r2cap && x >= 0 && y >= 0 && z >= 0 && x < lim && y < lim && z < lim;
-            code[t] = pcr_morton3((uint32_t)(want[t] ? x : 0), (uint32_t)(want[t] ? y : 0), (uint32_t)(want[t] ? z : 0));
-            h[t] = pcr_grid_hash(code[t], g.mask);
-            e[t] = *(const int4 *)&g.tab[h[t]];
-        }
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            if (!want[t]) continue;
-            for (int probe = 0; probe < 64; probe++) {
-                const unsigned long long c = ((unsigned long long)(unsigned)e[t].y << 32) | (unsigned)e[t].x;
-                if (c == code[t]) { first[t] = e[t].z; cnt[t] = e[t].w; break; }
-                if (c == PCR_GRID_EMPTY) break;
-                h[t] = (h[t] + 1) & g.mask;
-                e[t] = *(const int4 *)&g.tab[h[t]];
-            }
-        }
-    }
-    // every step: two points of each of the lane's cells (8 loads in flight), then the OCTET's second-nearest distance so far prunes
-    // the cells of all 8 lanes: after the first step (up to 64 candidates around the query) usually only the query's own few cells remain
-    int j0 = 0;
-    while (__ballot(max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3])) > j0) != 0ull) {
-        float4 p[4][2];
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int u = 0; u < 2; u++) { const int j = j0 + u < cnt[t] ? j0 + u : (cnt[t] > 0 ? cnt[t] - 1 : 0); p[t][u] = pts[first[t] + j]; }
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int idx = first[t] + j0 + u;
-                const float du = pcr_d2(p[t][u].x - qx, p[t][u].y - qy, p[t][u].z - qz);
-                if (j0 + u < cnt[t]) {
-                    if (du < d || (du == d && idx < id)) { dd = d; d = du; id = idx; }
-                    else dd = fminf(dd, du);
-                }
-            }
-        j0 += 2;
-        // octet-wide second-nearest so far: the winner lane's runner-up or another lane's best
-        const float m1 = pcr_octet_min(d);
-        const unsigned hold = (unsigned)(__ballot(d == m1) >> (threadIdx.x & 56)) & 0xffu;
-        const bool winner = ol == (int)__builtin_ctz(hold | 0x100u);
-        const float bound = pcr_octet_min(winner ? dd : d);
-#pragma unroll
-        for (int t = 0; t < 4; t++) if (!(gap2[t] < bound)) cnt[t] = 0;        // the ball no longer reaches this cell
-    }
-    // octet arg-min (ties -> lower index); the runner-up is the smallest of the winner lane's second and the other lanes' best
-    const float dmin = pcr_octet_min(d);
-    int cand = (d == dmin && id >= 0) ? id : 0x7fffffff;
-    cand = min(cand, pcr_dpp_i<PCR_DPP_XOR1>(cand)); cand = min(cand, pcr_dpp_i<PCR_DPP_XOR2>(cand)); cand = min(cand, pcr_dpp_i<PCR_DPP_HMIRROR>(cand));
-    const float sec = pcr_octet_min(id == cand ? dd : d);
-    if (cand == 0x7fffffff) { *d1_out = r2cap; *d2_out = r2cap; return -1; }
-    *d1_out = dmin; *d2_out = sec;
-    return cand;
-}
-
-// ONE QUERY PER OCTET over cells of edge c >= 2.04 r (PCR_GRID8, pcr_grid_level_for): the ball around q then meets, per axis, only q's own
+// ONE QUERY PER OCTET over cells of edge c >= 2.04 r (pcr_grid_level_for): the ball around q then meets, per axis, only q's own
 // cell and the neighbour on the NEARER side, i.e. the 2 x 2 x 2 block of cells around q: lane b of the octet looks up the cell whose
 // offset bits are b (bit set = the neighbour along that axis; lane 0 = q's own cell) -- one lookup per lane, one round trip for the
 // block -- and then the octet scans the cells TOGETHER, own cell first, face / edge / corner neighbours after it, 8 PCR_GRID8_PPS consecutive
 // points per step (that many coalesced loads per lane in flight); a cell is skipped when the ball of the octet's second-nearest distance so far does not
-// reach its cube.  Against the 27-cell form above (4 lookups and up to 8 scattered point loads per lane and step, most lanes without
-// work): a third of the load instructions and of the VALU work per query.  Same answers (ties -> lower index).
+// reach its cube.  Against the first form of this search (27 cells of edge >= r: 4 lookups and up to 8 scattered point loads per lane
+// and step, most lanes without work): a third of the load instructions and of the VALU work per query.  Same answers as the tree walk
+// (ties -> lower index).
 #ifndef PCR_GRID8_PPS
 #define PCR_GRID8_PPS 8      // points per lane and step of a cell scan (loads in flight)
 #endif
@@ -315,6 +237,7 @@ template <int K> __device__ static inline int pcr_octet_bcast(int v, int ol) {  
 __device__ static inline int grid_nn_query8(const GridView &g, const float4 *__restrict__ pts, bool live, float qx, float qy, float qz, float r2cap, int ol,
                                             float *d1_out, float *d2_out) {
     float d = r2cap, dd = r2cap; int id = -1;
+    const unsigned mask = g.mask;
     int rng = 0;                                    // the lane's cell: first point | count << 22 (0: absent, empty or out of reach)
     float gx2 = 0.0f, gy2 = 0.0f, gz2 = 0.0f;       // squared gap between q and the neighbour cell, per axis (the same in all lanes of the octet)
     if (live) {
@@ -330,7 +253,7 @@ __device__ static inline int grid_nn_query8(const GridView &g, const float4 *__r
         const float g2 = ((ol & 1) ? gx2 : 0.0f) + ((ol & 2) ? gy2 : 0.0f) + ((ol & 4) ? gz2 : 0.0f);
         const int lim = (1 << 21) >> g.L;
         if (g2 < r2cap && x >= 0 && y >= 0 && z >= 0 && x < lim && y < lim && z < lim) {
-            const int2 r = pcr_grid_lookup(g, x, y, z);
+            const int2 r = pcr_grid_lookup(g, mask, x, y, z);
             rng = r.y > 0 ? (r.x | (r.y << 22)) : 0;
         }
     }
@@ -375,66 +298,6 @@ __device__ static inline int grid_nn_query8(const GridView &g, const float4 *__r
     if (cand == 0x7fffffff) { *d1_out = r2cap; *d2_out = r2cap; return -1; }
     *d1_out = dmin; *d2_out = sec;
     return cand;
-}
-#ifndef PCR_GRID8
-#define PCR_GRID8 1
-#endif
-#if PCR_GRID8
-#define grid_nn_search grid_nn_query8
-#else
-#define grid_nn_search grid_nn_query
-#endif
-
-// ONE QUERY PER LANE: nearest and second-nearest squared distance (both capped at r2cap) among the points of the 27 cells around q;
-// returns the nearest point's index or -1.  Lanes are independent (no cross-lane traffic): a tile whose certificates all fail is
-// searched in ONE round by its 512 lanes, where one query per octet took tile / 64 rounds of ~7 us.  The slice of cells at the
-// query's own z level first (9 lookups in flight), the slices above and below only if the ball of the current second-nearest distance
-// reaches them; inside a slice a cell is scanned only if that ball reaches its cube.  Same answers as the tree search (ties -> lower
-// index).
-__device__ static inline int grid_nn_lane(const GridView &g, const float4 *__restrict__ pts, float qx, float qy, float qz, float r2cap, float *d1_out, float *d2_out) {
-    float d = r2cap, dd = r2cap; int id = -1;
-    const float fx = (qx - g.org[0]) * g.inv_unit[0], fy = (qy - g.org[1]) * g.inv_unit[1], fz = (qz - g.org[2]) * g.inv_unit[2];
-    const int cx = (int)floorf(fx) >> g.L, cy = (int)floorf(fy) >> g.L, cz = (int)floorf(fz) >> g.L;
-    // distance of q to the lower / upper faces of its own cell, per axis (>= 0; a little slack for the rounding of the cell index)
-    const float lox = qx - (g.org[0] + (float)cx * g.cell[0]), loy = qy - (g.org[1] + (float)cy * g.cell[1]), loz = qz - (g.org[2] + (float)cz * g.cell[2]);
-    const float slack = 2e-3f * g.cell[0];
-    const float gx[3] = {fmaxf(lox - slack, 0.0f), 0.0f, fmaxf(g.cell[0] - lox - slack, 0.0f)};      // gap to the cells at x-1, x, x+1
-    const float gy[3] = {fmaxf(loy - slack, 0.0f), 0.0f, fmaxf(g.cell[1] - loy - slack, 0.0f)};
-    const float gz[3] = {fmaxf(loz - slack, 0.0f), 0.0f, fmaxf(g.cell[2] - loz - slack, 0.0f)};
-#pragma unroll
-    for (int s = 0; s < 3; s++) {
-        const int dz = s == 0 ? 1 : (s == 1 ? 0 : 2);                 // own slice first
-        if (!(gz[dz] * gz[dz] < dd)) continue;
-        int2 r[9];
-#pragma unroll
-        for (int c = 0; c < 9; c++) {
-            const int dx = c % 3, dy = c / 3;
-            r[c] = make_int2(0, 0);
-            if (pcr_d2(gx[dx], gy[dy], gz[dz]) < dd) r[c] = pcr_grid_lookup(g, cx + dx - 1, cy + dy - 1, cz + dz - 1);
-        }
-#pragma unroll
-        for (int c = 0; c < 9; c++) {
-            const int dx = c % 3, dy = c / 3;
-            if (r[c].y > 0 && pcr_d2(gx[dx], gy[dy], gz[dz]) < dd) {
-                for (int j0 = 0; j0 < r[c].y; j0 += 4) {
-                    float4 p[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) p[u] = pts[r[c].x + (j0 + u < r[c].y ? j0 + u : r[c].y - 1)];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int idx = r[c].x + j0 + u;
-                        const float du = pcr_d2(p[u].x - qx, p[u].y - qy, p[u].z - qz);
-                        if (j0 + u < r[c].y) {
-                            if (du < d || (du == d && idx < id)) { dd = d; d = du; id = idx; }
-                            else dd = fminf(dd, du);
-                        }
-                    }
-                }
-            }
-        }
-    }
-    *d1_out = d; *d2_out = dd;
-    return id;
 }
 
 // greedy nearest-box descent from the root (cold start of a 1-NN query): returns a leaf id (octet-uniform)
