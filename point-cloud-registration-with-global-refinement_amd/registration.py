@@ -251,7 +251,7 @@ def default_group(points_per_cloud: float) -> int:
 def balanced_group(group: int, n_pairs: int, inflight: int) -> int:
     """Group size near ``group`` for which the groups of a batch of ``n_pairs`` fill whole rounds of ``inflight`` workers: 96 pairs in
     groups of 16 are 6 groups -- a round of 4 and a round of 2 -- in groups of 12 they are two full rounds (NCLT-size pairs, 5-scale
-    GICP stage: 1930 -> 2400 pairs/s)."""
+    GICP stage: 1930 -> 2138 pairs/s)."""
     if group <= 1 or inflight <= 1 or n_pairs <= group * inflight:
         return max(1, group)
     n_groups = -(-n_pairs // group)
