@@ -588,9 +588,13 @@ __device__ static inline void fgr_update(const double *S, double *trans /*16*/) 
 
 // ---- small correspondence sets (NCLT-size clouds): ALL iterations in ONE launch of one 1024-thread workgroup -- the
 // multi-workgroup version costs a kernel launch per iteration (300 of them), and launches are what bounds the throughput
+// NT threads: 1024, or 256 for up to FGR_SINGLE_SMALL correspondences (NCLT-size pairs have ~850: 4 wavefronts synchronise faster than 16
+// and their 16 partial rows are summed by one DPP row each -- 4.8 -> 3.x us per iteration of the 300)
 #define FSB 1024
-__global__ void __launch_bounds__(FSB) k_fgr_opt_single(FgrOptArgs a, int iterations) {
-    __shared__ double red[FSB / 16][FNVP];
+#define FGR_SINGLE_SMALL 2048
+template <int NT>
+__global__ void __launch_bounds__(NT) k_fgr_opt_single(FgrOptArgs a, int iterations) {
+    __shared__ double red[NT / 16][FNVP];
     __shared__ double S[FNVP];
     __shared__ double trans[16];
     __shared__ double par_s;
@@ -609,12 +613,21 @@ __global__ void __launch_bounds__(FSB) k_fgr_opt_single(FgrOptArgs a, int iterat
         double acc[FC];
 #pragma unroll
         for (int k = 0; k < FC; k++) acc[k] = 0.0;
-        fgr_accumulate_all(a, T, par, threadIdx.x, FSB, acc);
+        fgr_accumulate_all(a, T, par, threadIdx.x, NT, acc);
         const unsigned long long t1 = wall_clock64();
 #pragma unroll
         for (int k = 0; k < FC; k++) { const double s = pcr_row16_sum(acc[k]); if ((threadIdx.x & 15) == 0) red[threadIdx.x >> 4][k] = s; }
         __syncthreads();
-        if (threadIdx.x < FC) { double s = 0; for (int r = 0; r < FSB / 16; r++) s += red[r][threadIdx.x]; S[threadIdx.x] = s; }
+        // the NT / 16 partial rows: sum k is taken by the 16 lanes of DPP row k (lane r0 adds rows r0, r0 + 16, ..., then one row sum)
+        // instead of one thread walking all rows (64 dependent LDS reads: 2.4 us of the iteration)
+        if (threadIdx.x < 16 * FC) {
+            const int k = threadIdx.x >> 4, r0 = threadIdx.x & 15;
+            double s = 0;
+#pragma unroll
+            for (int r = r0; r < NT / 16; r += 16) s += red[r][k];
+            s = pcr_row16_sum(s);
+            if (r0 == 0) S[k] = s;
+        }
         __syncthreads();
         const unsigned long long t2 = wall_clock64();
         tA += t1 - t0; tB += t2 - t1;
@@ -918,7 +931,8 @@ static int fgr_pose(pcr_context *ctx, const float *src_xyz, const float *src_fea
             // PCR_FGR_MULTI_TIMEOUT: ticks of the 100 MHz wall clock a workgroup waits at the barrier (tests set 0 to force the fallback)
             static const unsigned long long fm_timeout = getenv("PCR_FGR_MULTI_TIMEOUT") ? strtoull(getenv("PCR_FGR_MULTI_TIMEOUT"), nullptr, 10) : 5000000ull;
             if (multi) PCR_LAUNCH(ctx, k_fgr_opt_multi, dim3(FMG), dim3(FMB), 0, ctx->stream, oa, (int)opt->iteration_number, rows, fm_timeout);
-            else if (ncorr <= single_max) PCR_LAUNCH(ctx, k_fgr_opt_single, dim3(1), dim3(FSB), 0, ctx->stream, oa, (int)opt->iteration_number);
+            else if (ncorr <= single_max && ncorr <= FGR_SINGLE_SMALL) PCR_LAUNCH(ctx, k_fgr_opt_single<256>, dim3(1), dim3(256), 0, ctx->stream, oa, (int)opt->iteration_number);
+            else if (ncorr <= single_max) PCR_LAUNCH(ctx, k_fgr_opt_single<FSB>, dim3(1), dim3(FSB), 0, ctx->stream, oa, (int)opt->iteration_number);
             else per_iteration();
             PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
             PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
