@@ -1456,7 +1456,7 @@ __device__ static inline void d_normals_from_lists(const NflArgs &a) {
     const int ol = threadIdx.x & 7, oct_id = (threadIdx.x & 63) >> 3;
     const int base = (blockIdx.x * (KNN_BS / 64) + (threadIdx.x >> 6)) * 64;
     if (base >= n) return;
-    double myC[6] = {1, 0, 0, 1, 0, 1};
+    double my_cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, my_c = 0;      // raw moments of the point this lane solves (the divisions wait until all 64 lanes have one)
     bool my_exact = false; int my_j = 0;
 #pragma unroll 1
     for (int r = 0; r < OCT; r++) {
@@ -1509,15 +1509,19 @@ __device__ static inline void d_normals_from_lists(const NflArgs &a) {
         for (int t = 0; t < 9; t++) cu[t] = octet_sum(cu[t]);
         c = octet_sum(c);
         if (ol == r) {                                  // this lane solves the point of round r
-            my_exact = exact; my_j = j;
-            if (c >= 3.0) {
-                for (int t = 0; t < 9; t++) cu[t] = cu[t] / c;
-                myC[0] = cu[3] - cu[0] * cu[0]; myC[1] = cu[4] - cu[0] * cu[1]; myC[2] = cu[5] - cu[0] * cu[2];
-                myC[3] = cu[6] - cu[1] * cu[1]; myC[4] = cu[7] - cu[1] * cu[2]; myC[5] = cu[8] - cu[2] * cu[2];
-            }
+            my_exact = exact; my_j = j; my_c = c;
+#pragma unroll
+            for (int t = 0; t < 9; t++) my_cu[t] = cu[t];
         }
     }
     if (!my_exact) return;
+    double myC[6] = {1, 0, 0, 1, 0, 1};
+    if (my_c >= 3.0) {                                  // (the nine float64 divisions once per wavefront, not once per round under a one-lane-in-eight branch)
+#pragma unroll
+        for (int t = 0; t < 9; t++) my_cu[t] = my_cu[t] / my_c;
+        myC[0] = my_cu[3] - my_cu[0] * my_cu[0]; myC[1] = my_cu[4] - my_cu[0] * my_cu[1]; myC[2] = my_cu[5] - my_cu[0] * my_cu[2];
+        myC[3] = my_cu[6] - my_cu[1] * my_cu[1]; myC[4] = my_cu[7] - my_cu[1] * my_cu[2]; myC[5] = my_cu[8] - my_cu[2] * my_cu[2];
+    }
     double nv[3];
     d_fast_eigen3x3(myC, nv);
     const double nn = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
