@@ -82,3 +82,18 @@ def test_default_group_rule():
     # ... rounded so that the groups of a batch fill whole rounds of the workers in flight
     b = pkg().registration.balanced_group
     assert [b(16, 96, 4), b(6, 48, 4), b(16, 192, 4), b(16, 20, 4), b(1, 100, 4), b(6, 48, 1)] == [12, 6, 16, 16, 1, 6]
+
+
+def test_profiles_manifest_lists_the_tracked_evidence():
+    """bench.py quotes tracked rocprof results with the commit they were taken at (profiles/MANIFEST.json): every file of the newest round
+    is listed there with a commit, and every listed file exists."""
+    import json
+    prof = os.path.join(ROOT, "profiles")
+    manifest = json.load(open(os.path.join(prof, "MANIFEST.json")))
+    newest = sorted({f[:3] for f in os.listdir(prof) if re.match(r"r\d\d_", f)})[-1]
+    files = [f for f in os.listdir(prof) if f.startswith(newest + "_")]
+    assert files, newest
+    for f in files:
+        assert f in manifest and re.fullmatch(r"[0-9a-f]{7,40}", manifest[f].get("commit", "")), f
+    for f in manifest:
+        assert os.path.exists(os.path.join(prof, f)), f
