@@ -514,7 +514,8 @@ __device__ static inline void d_knn_wave(const KnnArgs &a) {
     }
 }
 
-// 4 wavefronts per SIMD up to K = 32 (128 VGPRs, no spill; the compiler left alone takes 131 and gets 3; 5 would spill 45)
+// 4 wavefronts per SIMD up to K = 32 (128 VGPRs, 18 spilled; in the default bench, groups of 6 x 4 in flight: 3 wavefronts, 144 VGPRs and no
+// spill 617 pairs/s, 4 wavefronts 643, 5 wavefronts, 96 VGPRs and 64 spilled 588)
 #define KW_OCC(K) __attribute__((amdgpu_waves_per_eu(K <= 32 ? 4 : 2, K <= 32 ? 4 : 3)))
 template <int MODE, int K> __global__ void __launch_bounds__(KW_BS) KW_OCC(K) k_knn_wave(KnnArgs a) { d_knn_wave<MODE, K>(a); }
 template <int MODE, int K> __global__ void __launch_bounds__(KW_BS) KW_OCC(K) k_knn_wave_stats(KnnArgs a) { d_knn_wave<MODE, K, true>(a); }
