@@ -691,20 +691,21 @@ __device__ static inline void icp_finish(const IcpArgs &a, IcpState *st, const d
     // hand-written 8-load groups took three.
     {
         typedef unsigned int icp_u2 __attribute__((ext_vector_type(2)));
-        const int vcol = threadIdx.x & 31, chunk = threadIdx.x >> 5;      // 16 chunks x 32 columns; chunk c <- rows c, c+16, ...
+        constexpr int NCH = BS / 32;                                       // chunks of 32 columns; chunk c <- rows c, c + NCH, ...
+        const int vcol = threadIdx.x & 31, chunk = threadIdx.x >> 5;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)a.partials, 0, nb * NVP * 8, 0x00020000);
         double s = 0.0;
-        for (int b0 = 0; b0 < nb; b0 += 320) {
+        for (int b0 = 0; b0 < nb; b0 += NCH * 20) {
             double v[20];
 #pragma unroll
             for (int r = 0; r < 20; r++) {
-                const int row = b0 + chunk + 16 * r;
+                const int row = b0 + chunk + NCH * r;
                 union { icp_u2 u; double d; } x;
                 x.u = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (row < nb ? row : 0) * (NVP * 8) + vcol * 8, 0, 17 /* sc0 | sc1 */);
                 v[r] = x.d;
             }
 #pragma unroll
-            for (int r = 0; r < 20; r++) { const double x = b0 + chunk + 16 * r < nb ? v[r] : 0.0; s = vcol < NV ? s + x : fmax(s, x); }
+            for (int r = 0; r < 20; r++) { const double x = b0 + chunk + NCH * r < nb ? v[r] : 0.0; s = vcol < NV ? s + x : fmax(s, x); }
         }
         fin[chunk][vcol] = s;
     }
@@ -713,7 +714,7 @@ __device__ static inline void icp_finish(const IcpArgs &a, IcpState *st, const d
     if (threadIdx.x < NVP) {
         double s = 0;
 #pragma unroll
-        for (int c = 0; c < 16; c++) s = threadIdx.x < NV ? s + fin[c][threadIdx.x] : fmax(s, fin[c][threadIdx.x]);
+        for (int c = 0; c < BS / 32; c++) s = threadIdx.x < NV ? s + fin[c][threadIdx.x] : fmax(s, fin[c][threadIdx.x]);
         fin[0][threadIdx.x] = s;
         st->sums[threadIdx.x] = s;
     }
