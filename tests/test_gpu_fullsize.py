@@ -34,6 +34,27 @@ def test_config2_counts_exact_and_l2_pose_matches_oracle(P, oracle, pair200k):
     assert ang < 2e-3 and dt < 2e-2, (ang, dt)          # within 2e-3 rad / 2 cm of the planted motion
 
 
+def test_config2_default_group_path_matches_oracle(P, oracle, pair200k):
+    """The path bench.py measures -- register_pairs_plan with the default lockstep groups (six 200 000-point pairs per group: the
+    wavefront k-NN kernel, the by-value fused iteration kernel, the cell-hash search) -- against the oracle at full size: stage counts
+    exact, L2 pose 1e-5 rad / 1e-4 m, every pair of the group alike (re-posed copies of one pair are registered to the re-posed answer)."""
+    import importlib
+    syn = importlib.import_module("point-cloud-registration-with-global-refinement_amd.synthetic")
+    reg = P.registration
+    pairs = [syn.derive_pair(pair200k, k) for k in range(6)]
+    work = [(P.PointCloud(q.source), P.PointCloud(q.target), q.T_init) for q in pairs]
+    est = reg.TransformationEstimationForGeneralizedICP(reg.L2Loss()); crit = reg.ICPConvergenceCriteria(1e-6, 1e-6, 100)
+    res = reg.register_pairs_plan(work, "gicp", pair200k.voxel_sizes, pair200k.max_distances_script, est, crit, inflight=1, group=None)
+    ref = oracle.multiscale_gicp(pair200k.source, pair200k.target, pair200k.voxel_sizes, pair200k.max_distances_script, pair200k.T_init, loss=oracle.LOSS_L2)
+    for a, b in zip(res[0].scales, ref.extra["scales"]):
+        assert a["n_voxel"] == tuple(b["n_voxel"]) and a["n_clean"] == tuple(b["n_clean"])
+    ang, dt = pose_error(res[0].transformation, ref.transformation)
+    assert ang < 1e-5 and dt < 1e-4, (ang, dt)
+    for q, r in zip(pairs, res):
+        ang, dt = pose_error(r.transformation, q.T_true)
+        assert ang < 2e-3 and dt < 2e-2, (ang, dt)
+
+
 def test_config2_reference_parameters_l1(P, oracle, pair200k):
     """The benchmark configuration itself (L1, 1e-6/1e-6/100) against the oracle.  The bound is DERIVED in the test: the oracle is
     re-run on this very pair with other float64 summation chunkings (conftest.l1_tolerance); the device must agree with the oracle
