@@ -83,7 +83,7 @@ typedef struct {
     double maximum_correspondence_distance;
     int32_t iteration_number;
     double tuple_scale;
-    int32_t maximum_tuple_count;
+    int32_t maximum_tuple_count;   /* pcr_registro_fgr / plans: < 0 = the reference's rule per pair, int(0.2 * int((n_src + n_tgt) / 2)) (ALL_FUNCTIONS.py:179,196) */
     int32_t tuple_test;
     uint64_t seed;            /* Open3D seeds from std::random_device; here explicit */
 } pcr_fgr_option;
@@ -202,7 +202,13 @@ typedef struct {
     int32_t group;                                      /* > 1 (stages GICP and FGR + GICP, whose FGR part stays pair by pair): `group` consecutive pairs run in LOCKSTEP through the same
                                                            launches (blockIdx.y = pair: preprocessing batched over clouds and scales, one GICP loop per
                                                            scale for the whole group); `inflight` then counts groups.  Same per-pair arithmetic as the
-                                                           pair-by-pair path (bit-identical at equal PCR_ICP_PPL; groups default to 2 points per lane); <= 32 */
+                                                           pair-by-pair path; <= 32.  Every unit of such a plan -- a ragged last group of ONE pair too --
+                                                           runs the GROUP forms of the kernels (one-query-per-lane k-NN, 1024-point iteration tiles),
+                                                           so a pair's bits do not depend on how the batch was cut */
+    int32_t pair_forms;                                 /* != 0: the kernel forms are chosen by the PAIR alone (group forms iff both clouds hold fewer than
+                                                           400 000 points; larger pairs run one by one with the single-pair forms) whatever `group` is:
+                                                           a pair's pose bits are then the same in every batch, group size and shard (gathered
+                                                           multi-GPU poses = the single-GPU run).  What registration.register_pairs_plan(group=None) sets. */
 } pcr_pairs_plan;
 typedef struct {
     pcr_pair base;                                      /* inputs, records (stages with GICP), correspondences of the LAST stage run, status */
@@ -262,6 +268,13 @@ int pcr_debug_gicp_linearize(pcr_context *ctx, const float *src_xyz, const float
  * out_0to1 likewise.  mode 0: f16-split MFMA screen + exact float64 re-check (production; with tile pruning from ~70k rows per side),
  * 1: all-pairs float64 MFMA, 2: float32 brute force, 3 / 4: the screen with tile pruning forced on / off */
 int pcr_debug_feature_nn(pcr_context *ctx, const float *f0, int64_t n0, const float *f1, int64_t n1, int32_t *out_1to0, int32_t *out_0to1, int mode);
+
+/* test / diagnostic switches of the process (no reference equivalent).  Each one is latched from the environment variable of the same
+ * name in upper case with the PCR_ prefix when the library first needs it; this call overrides it afterwards without touching the
+ * environment (worker threads read an atomic, never getenv).  "knn_wave": -1 by size and call form (default), 0 the octet k-NN kernel,
+ * 1 the one-query-per-lane kernel for every search that fits it; "knnw_budget": candidate batches a wavefront of that kernel takes before
+ * it hands its queries over.  Returns PCR_EINVAL for an unknown name. */
+int pcr_set_option(const char *name, long long value);
 
 #ifdef __cplusplus
 }

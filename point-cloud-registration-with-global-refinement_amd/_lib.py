@@ -56,7 +56,7 @@ class PcrPairsPlan(C.Structure):
     _fields_ = [("stage", C.c_int32), ("fgr", C.POINTER(PcrFgrParams)), ("voxel_sizes", C.POINTER(C.c_double)),
                 ("max_distances", C.POINTER(C.c_double)), ("n_scales", C.c_int32), ("radius_rule", C.c_int32),
                 ("sor_k", C.c_int32), ("sor_std", C.c_double), ("normal_k", C.c_int32), ("gicp", C.POINTER(PcrGicpParams)),
-                ("gicp_prior_from_fgr", C.c_int32), ("info_max_dist", C.c_double), ("inflight", C.c_int32), ("group", C.c_int32)]
+                ("gicp_prior_from_fgr", C.c_int32), ("info_max_dist", C.c_double), ("inflight", C.c_int32), ("group", C.c_int32), ("pair_forms", C.c_int32)]
 
 
 class PcrPairEx(C.Structure):
@@ -73,7 +73,7 @@ EXPORTS = [
     "pcr_registration_generalized_icp", "pcr_multiscale_gicp", "pcr_evaluate_registration", "pcr_information_matrix",
     "pcr_compute_fpfh_feature", "pcr_registration_fgr", "pcr_debug_knn", "pcr_debug_gicp_linearize",
     "pcr_profile_enable", "pcr_profile_read", "pcr_registration_generalized_icp_cov", "pcr_register_pairs", "pcr_pool_profile",
-    "pcr_registro_fgr", "pcr_register_pairs_plan", "pcr_debug_feature_nn",
+    "pcr_registro_fgr", "pcr_register_pairs_plan", "pcr_debug_feature_nn", "pcr_set_option",
 ]
 
 _lib = None
@@ -110,8 +110,16 @@ def load():
             lib.pcr_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
             lib.pcr_destroy.argtypes = [C.c_void_p]
             lib.pcr_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+            lib.pcr_set_option.argtypes = [C.c_char_p, C.c_longlong]
             _lib = lib
     return _lib
+
+
+def set_option(name: str, value: int) -> None:
+    """Test / diagnostic switch of the process (``pcr_set_option``, include/pcr_hip.h), e.g. ``set_option("knn_wave", 1)``."""
+    rc = load().pcr_set_option(name.encode(), int(value))
+    if rc != PCR_OK:
+        raise ValueError(f"pcr_set_option: unknown option {name!r}")
 
 
 class Context:

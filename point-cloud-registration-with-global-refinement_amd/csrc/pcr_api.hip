@@ -12,7 +12,24 @@
 #include "pcr_octree.h"
 
 // ------------------------------------------------------------------------------------------- context
-extern "C" int pcr_version(void) { return 210; }
+extern "C" int pcr_version(void) { return 220; }
+
+PcrOptions &pcr_options() {
+    static PcrOptions o;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        if (const char *e = getenv("PCR_KNN_WAVE")) o.knn_wave = atoi(e);
+        if (const char *e = getenv("PCR_KNNW_BUDGET")) o.knnw_budget = atoi(e);
+    });
+    return o;
+}
+extern "C" int pcr_set_option(const char *name, long long value) {
+    if (!name) return PCR_EINVAL;
+    PcrOptions &o = pcr_options();
+    if (!strcmp(name, "knn_wave")) { o.knn_wave = (int)value; return PCR_OK; }
+    if (!strcmp(name, "knnw_budget")) { o.knnw_budget = (int)value; return PCR_OK; }
+    return PCR_EINVAL;
+}
 
 extern "C" int pcr_create(int device, pcr_context **out) {
     if (!out) return PCR_EINVAL;
@@ -904,13 +921,12 @@ extern "C" int pcr_register_pairs_plan(int device, pcr_pair_ex *pairs, int n_pai
         if (!ctx) { failed++; return; }
         use_private_stream(ctx);
         if (ensure_stream(ctx) == PCR_OK) (void)hipStreamWaitEvent(ctx->stream, ready, 0);
-        for (;;) {
-            const int i = next.fetch_add(group);
-            if (i >= n_pairs) break;
-            const int cnt = i + group <= n_pairs ? group : n_pairs - i;
+        const bool gicp_stage = plan->stage == PCR_STAGE_GICP || plan->stage == PCR_STAGE_FGR_GICP;
+        auto group_unit = [&](int i, int cnt) -> int {
             int rc_group = 1;
-            if (group > 1 && cnt > 1) {
-                // `cnt` consecutive pairs through the same launches (lockstep group); rc 1: declined, pair by pair below
+            {
+                // `cnt` consecutive pairs through the same launches (lockstep group; a ragged last group of ONE pair as well, so that its
+                // arithmetic does not depend on how the batch was cut); rc 1: declined, pair by pair below (still with the group forms)
                 std::vector<pcr_pair_ex *> gp((size_t)cnt);
                 std::vector<pcr_pair_ex> staged;                   // stage FGR + GICP: copies that carry the FGR pose and normals into the group's GICP
                 for (int k = 0; k < cnt; k++) { gp[k] = &pairs[i + k]; pairs[i + k].base.error[0] = 0; }
@@ -973,15 +989,42 @@ extern "C" int pcr_register_pairs_plan(int device, pcr_pair_ex *pairs, int n_pai
                     for (int k = 0; k < cnt; k++) { pairs[i + k].base.status = rc_group; failed++; snprintf(pairs[i + k].base.error, sizeof pairs[i + k].base.error, "%s", ctx->err.c_str()); }
                 } else rc_group = 1;                        // an argument / capacity error: pair by pair, so that it lands on the pair that has it
             }
-            if (rc_group == 1)
+            return rc_group;
+        };
+        auto solo_unit = [&](int i, int cnt) -> int {
+            for (int k = 0; k < cnt; k++) {
+                pcr_pair &p = pairs[i + k].base;
+                p.error[0] = 0;
+                p.status = run_pair(ctx, pairs[i + k], i + k, *plan);
+                if (p.status != PCR_OK) { failed++; snprintf(p.error, sizeof p.error, "%s", ctx->err.c_str()); }
+            }
+            return PCR_OK;
+        };
+        for (;;) {
+            const int i = next.fetch_add(group);
+            if (i >= n_pairs) break;
+            const int cnt = i + group <= n_pairs ? group : n_pairs - i;
+            // kernel forms (ctx->group_forms: wavefront k-NN, 1024-point iteration tiles).  plan->pair_forms == 0: by the plan -- every unit
+            // of a plan with group > 1 takes the group forms, a ragged last group of ONE pair included, so that a pair's arithmetic does not
+            // depend on how the batch was cut.  pair_forms != 0: by the PAIR alone -- group forms iff both clouds are under
+            // PCR_GROUP_FORMS_MAX_POINTS -- whatever `group` says, so that shards of any world size produce the single-GPU bits.
+            auto small_pair = [&](int k) { const pcr_pair &p = pairs[k].base; return (p.n_src > p.n_tgt ? p.n_src : p.n_tgt) < PCR_GROUP_FORMS_MAX_POINTS; };
+            bool all_small = true;
+            for (int k = 0; k < cnt; k++) all_small = all_small && small_pair(i + k);
+            if (plan->pair_forms && gicp_stage && !all_small) {
                 for (int k = 0; k < cnt; k++) {
-                    pcr_pair &p = pairs[i + k].base;
-                    p.error[0] = 0;
-                    p.status = run_pair(ctx, pairs[i + k], i + k, *plan);
-                    if (p.status != PCR_OK) { failed++; snprintf(p.error, sizeof p.error, "%s", ctx->err.c_str()); }
+                    ctx->group_forms = small_pair(i + k);
+                    int rc1 = ctx->group_forms ? group_unit(i + k, 1) : 1;
+                    if (rc1 == 1) rc1 = solo_unit(i + k, 1);
                 }
+                continue;
+            }
+            ctx->group_forms = gicp_stage && (plan->pair_forms ? true : group > 1);
+            int rc_group = ctx->group_forms ? group_unit(i, cnt) : 1;
+            if (rc_group == 1) solo_unit(i, cnt);
         }
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        ctx->group_forms = false;
         pool_give(device, ctx);
     };
     std::vector<std::thread> threads;

@@ -1210,9 +1210,9 @@ template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn_b
 // one of them (per call: tests/test_gpu_stages.py runs every search through both and compares them -- two independent exact searches).
 #define KNN_WAVE_MIN_BATCH 6
 #define KNN_WAVE_MIN_POINTS 1500000       // ... or of that much query CAPACITY in all (the scales of config 5, 2M each: 21.7 -> 22.6 pairs/s; a lone 200k-point pair, 3 x 200k in a batch, is faster with the octet kernel: 208 against 183 pairs/s)
-static bool knn_wave_enabled(int batch, long long points) {
-    const char *e = getenv("PCR_KNN_WAVE");
-    return e ? atoi(e) != 0 : (batch >= KNN_WAVE_MIN_BATCH || points >= KNN_WAVE_MIN_POINTS);
+static bool knn_wave_enabled(const pcr_context *ctx, int batch, long long points) {
+    const int forced = pcr_options().knn_wave.load(std::memory_order_relaxed);
+    return forced >= 0 ? forced != 0 : (ctx->group_forms || batch >= KNN_WAVE_MIN_BATCH || points >= KNN_WAVE_MIN_POINTS);
 }
 static bool knn_wave_fits(const KnnArgs &a) { return a.k >= 1 && a.k <= 64 && !a.todo && !a.stamps && !a.dbg_visits; }
 // the wavefront kernel appends every query's k-best to a row in global memory: the caller's list (SOR) or scratch from the arena
@@ -1224,7 +1224,7 @@ static int knn_wave_rows(pcr_context *ctx, KnnArgs &a, int cap) {
     return a.list_idx ? PCR_OK : PCR_ENOMEM;
 }
 template <int MODE> static int launch_knn_wave_only(pcr_context *ctx, KnnArgs *a, int count, int mc, int kmax);
-static int knn_wave_budget() { const char *e = getenv("PCR_KNNW_BUDGET"); return e ? atoi(e) : 80; }      // batches of 64 candidates in pass 1 (mean 17, p99 43 at k = 30)
+static int knn_wave_budget() { return pcr_options().knnw_budget.load(std::memory_order_relaxed); }      // batches of 64 candidates in pass 1 (mean 17, p99 43 at k = 30)
 template <int MODE> static int launch_knn_octet_batch(pcr_context *ctx, KnnArgs *a, const int *caps, int count);
 template <int MODE>
 static int launch_knn_wave_batch(pcr_context *ctx, KnnArgs *a, const int *caps, int count, int mc, int kmax) {
@@ -1298,7 +1298,7 @@ static int launch_knn_batch(pcr_context *ctx, KnnArgs *a, const int *caps, int c
     }
     long long total_pts = 0;
     for (int k = 0; k < count; k++) total_pts += caps[k];
-    if (knn_wave_enabled(count, total_pts)) {
+    if (knn_wave_enabled(ctx, count, total_pts)) {
         bool fits = true; int kmax = 0, mcw = 0;
         for (int k = 0; k < count; k++) { fits = fits && knn_wave_fits(a[k]); kmax = a[k].k > kmax ? a[k].k : kmax; mcw = caps[k] > mcw ? caps[k] : mcw; }
         if (fits && mcw > 0) {
@@ -1348,7 +1348,7 @@ static int launch_knn_cap(pcr_context *ctx, int cap, KnnArgs a) {
         }
     } dump{ctx, stamp_path, a.stamps, stamp_words, MODE, a.k};
     a.seed_span = -1;
-    if (knn_wave_enabled(1, cap) && knn_wave_fits(a)) { a.seed_span = -1; return launch_knn_wave<MODE>(ctx, cap, a); }
+    if (knn_wave_enabled(ctx, 1, cap) && knn_wave_fits(a)) { a.seed_span = -1; return launch_knn_wave<MODE>(ctx, cap, a); }
     if (a.k <= 32) PCR_LAUNCH(ctx, k_knn<MODE, 4>, grid, block, 0, ctx->stream, a);
     else if (a.k <= 64) PCR_LAUNCH(ctx, k_knn<MODE, 8>, grid, block, 0, ctx->stream, a);
     else PCR_LAUNCH(ctx, k_knn<MODE, 25>, grid, block, 0, ctx->stream, a);

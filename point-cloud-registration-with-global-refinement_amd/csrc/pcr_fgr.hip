@@ -975,6 +975,9 @@ extern "C" int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, cons
     return pcr_api_call(ctx, [&]() -> int {
     if (!result) return PCR_EINVAL;
     PCR_TRY(fgr_check_args(ctx, opt, ns, nt));
+    pcr_fgr_option opt_local = *opt;
+    if (opt_local.maximum_tuple_count < 0) opt_local.maximum_tuple_count = (int32_t)((double)((ns + nt) / 2) * 0.2);     // the per-pair rule (pcr_hip.h)
+    const pcr_fgr_option *opt = &opt_local;
     if ((ns > 0 && (!src_xyz || !src_feat)) || (nt > 0 && (!tgt_xyz || !tgt_feat))) return PCR_EINVAL;
     double Tsrc2tgt[16];
     PCR_TRY(pcr_arena_reserve(ctx, fgr_scratch_bytes(ns, nt, opt)));
@@ -989,8 +992,16 @@ extern "C" int pcr_registration_fgr(pcr_context *ctx, const float *src_xyz, cons
 static int fgr_tail(pcr_context *ctx, DevCloud *c, uint32_t **perm, float **feat, const float *src_xyz, const float *tgt_xyz, int64_t ns, int64_t nt,
                     const pcr_fgr_params *p, pcr_result *result, int32_t *correspondences);
 int pcr_registro_fgr_impl(pcr_context *ctx, const float *src_xyz, const float *src_prior, int64_t ns, const float *tgt_xyz, const float *tgt_prior, int64_t nt,
-                          const pcr_fgr_params *p, float *src_normals_out, float *tgt_normals_out, pcr_result *result, int32_t *correspondences) {
-    if (!p || !result) return PCR_EINVAL;
+                          const pcr_fgr_params *p_in, float *src_normals_out, float *tgt_normals_out, pcr_result *result, int32_t *correspondences) {
+    if (!p_in || !result) return PCR_EINVAL;
+    pcr_fgr_params p_local = *p_in;
+    // maximum_tuple_count < 0: the reference's rule for THIS pair, int(0.2 * n_pontos) with n_pontos = int((len(source) + len(target)) / 2)
+    // (ALL_FUNCTIONS.py:179,196) -- so that one plan serves pairs of different sizes (every NCLT scan has its own point count)
+    if (p_local.option.maximum_tuple_count < 0) p_local.option.maximum_tuple_count = (int32_t)((double)((ns + nt) / 2) * 0.2);
+    const pcr_fgr_params *p = &p_local;
+    // the group forms of a lockstep plan concern its GICP stage: registro_FGR is the same arithmetic in every plan
+    struct FormsGuard { pcr_context *c; bool was; ~FormsGuard() { c->group_forms = was; } } forms_guard{ctx, ctx->group_forms};
+    ctx->group_forms = false;
     PCR_TRY(fgr_check_args(ctx, &p->option, ns, nt));
     if ((ns > 0 && !src_xyz) || (nt > 0 && !tgt_xyz)) return PCR_EINVAL;
     if (p->normal_max_nn < 1 || !(p->normal_radius > 0.0)) { ctx->err = "estimate_normals: radius <= 0 or max_nn < 1"; return PCR_EINVAL; }

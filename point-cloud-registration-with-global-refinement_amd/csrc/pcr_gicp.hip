@@ -967,11 +967,11 @@ template <int TILE_PTS, bool GRID> __global__ void __launch_bounds__(FUSED_BS) k
 // 43.6 / 40.7 / 46.0 us per launch for tiles of 512 / 256 / 128 points (the slowest single walk is); lockstep groups of 2, four in
 // flight: 333 / 304 / 258 pairs/s for 1024 / 512 / 256.  One pair: 256 from 40k points (below: 512, the tile of k_icp_iter, so that
 // PCR_ICP_FUSED=0 stays the same arithmetic on NCLT-size clouds); groups: 1024.
-static int fused_tile_points(int cap, int G) {
+static int fused_tile_points(const pcr_context *ctx, int cap, int G) {
     static const int fixed = getenv("PCR_ICP_TILE") ? atoi(getenv("PCR_ICP_TILE")) : (getenv("PCR_ICP_PPL") ? FUSED_BS * atoi(getenv("PCR_ICP_PPL")) : 0);
     int t = fixed;
     if (t <= 0) {
-        t = G > 1 ? 1024 : (cap >= 40000 ? 256 : 512);
+        t = (G > 1 || ctx->group_forms) ? 1024 : (cap >= 40000 ? 256 : 512);      // group_forms: a unit of a lockstep-group plan, whatever its size
     }
     t = t >= 2048 ? 2048 : (t >= 1024 ? 1024 : (t >= 512 ? 512 : (t >= 256 ? 256 : 128)));
     // the last workgroup of the fused kernel gathers one partial row per tile: at most 4096 of them (2M-point clouds of config 5: tiles of 512)
@@ -1045,7 +1045,7 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     const int nbmax = nblin < LIN_MAX_BLOCKS ? nblin : LIN_MAX_BLOCKS;
     const int nbnn = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT), nbab = (cap + ICP_BS - 1) / ICP_BS;
     const int nbsearch = nbnn < 2048 ? nbnn : 2048;                 // k_icp_search: a fixed grid strides over the pending list (8 workgroups of 4 wavefronts per CU)
-    const int tile_pts = fused_tile_points(cap, 1);
+    const int tile_pts = fused_tile_points(ctx, cap, 1);
     const int nbf = ((cap + tile_pts - 1) / tile_pts + 7) & ~7;      // workgroups of the fused kernel: one per tile of source points, a multiple of 8 (XCD order)
     IcpState *st = arena<IcpState>(ctx, 1);
     const int rows = nblin > nbf ? nblin : nbf;
@@ -1214,7 +1214,8 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
 // dependent kernels per GROUP instead of one per pair: the kernels are G times fatter, the device retires small dependent kernels at
 // a fixed rate whatever feeds it, and the replayed graph reads its arguments from a fixed device buffer, so it
 // is captured once per (G, grid) and never again.  Per-problem arithmetic, tiles and summation order are those of pcr_dev_gicp:
-// the results are bit-identical to registering the pairs one by one.
+// the results are bit-identical to registering the pairs one by one WITH THE SAME KERNEL FORMS (ctx->group_forms: 1024-point tiles, the
+// wavefront k-NN kernel in the preprocessing) -- which is how pcr_register_pairs_plan runs every unit of a plan with group > 1.
 int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, const DevCloud *const *tgt, const double *max_dists, const double *T0,
                        const pcr_gicp_params *p, pcr_result *out, int32_t *const *match_dev) {
     for (int g = 0; g < G; g++) if (!(max_dists[g] > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
@@ -1225,7 +1226,7 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
     // groups in flight: 200k points, groups of 2, 4 groups in flight 367 -> 408 pairs/s); PCR_ICP_PPL overrides
     int max_cap = 1;
     for (int g = 0; g < G; g++) max_cap = src[g]->cap > max_cap ? src[g]->cap : max_cap;
-    const int tile_pts = fused_tile_points(max_cap, G);
+    const int tile_pts = fused_tile_points(ctx, max_cap, G);
     int nbmax = 1, nbnn = 1, nbf = 1;
     std::vector<IcpArgs> args((size_t)G); std::vector<IcpInit> inits((size_t)G);
     IcpState *st = arena<IcpState>(ctx, G);

@@ -5,7 +5,13 @@
 #include <string>
 #include <cstring>
 #include <vector>
+#include <atomic>
 #include "../../include/pcr_hip.h"
+
+// process-wide switches (pcr_set_option, include/pcr_hip.h): latched from the environment once, atomics afterwards
+struct PcrOptions { std::atomic<int> knn_wave{-1}, knnw_budget{80}; };
+PcrOptions &pcr_options();
+#define PCR_GROUP_FORMS_MAX_POINTS 400000      // pcr_pairs_plan.pair_forms: pairs with both clouds under this take the group forms of the kernels
 
 
 // One captured chunk of GICP launches.  Solo calls key it by everything the launches bake in; lockstep groups key it by the launch
@@ -49,6 +55,10 @@ struct pcr_context {
     // first failed kernel launch of the current call (hipGetLastError after every launch); reported by pcr_leave
     hipError_t launch_err = hipSuccess;
     const char *launch_file = nullptr; int launch_line = 0;
+    // Inside a lockstep-group plan every unit takes the GROUP forms of the kernels (wavefront k-NN, 1024-point iteration tiles) whatever
+    // its size: a ragged last group of one pair, or a one-pair shard of another world size, is then the same arithmetic as the pair
+    // inside a full group (gathered poses are the single-GPU bits)
+    bool group_forms = false;
 };
 
 // every extern "C" entry point runs its body between these two (pcr_api.hip): device, stream, fences, launch errors

@@ -18,6 +18,7 @@ from . import registration as _r
 KNN_FILTRO = 30          # ALL_FUNCTIONS.py:280, 2_MGICP...py:134
 STD_FILTRO = 1.0         # ALL_FUNCTIONS.py:281, 2_MGICP...py:135
 KNN_NORMAIS = 20         # ALL_FUNCTIONS.py:301, 2_MGICP...py:152
+RETENTION_A, RETENTION_B = 1.18397758, 5.09388767     # ALL_FUNCTIONS.py:241-242: share of the points a voxel grid keeps ~ a * exp(-b * voxel)
 
 
 # ------------------------------------------------------------------------------- ALL_FUNCTIONS.py variants
@@ -31,14 +32,11 @@ def registro_FGR(source, target, voxel_size, _use_absolute_scale=True, seed=None
 def GICP_robusto(source, target, max_corres_dist, initial_T, iterations):
     """ALL_FUNCTIONS.py:211-227: radius-0.20 normals, raw 30-NN covariances (``estimate_covariances()`` default search),
     GICP with ``GMLoss(k=1.0)``.  Mutates ``source``/``target`` (normals and covariances), like the reference."""
-    kd_tree_normais = _g.KDTreeSearchParamRadius(radius=0.20)
-    source.estimate_normals(kd_tree_normais)
-    target.estimate_normals(kd_tree_normais)
-    source.estimate_covariances()
-    target.estimate_covariances()
-    loss = _r.GMLoss(k=1.0)
-    return _r.registration_icp(source, target, max_corres_dist, initial_T,
-                               _r.TransformationEstimationForGeneralizedICP(loss),
+    for cloud in (source, target):
+        cloud.estimate_normals(_g.KDTreeSearchParamRadius(radius=0.20))
+    for cloud in (source, target):
+        cloud.estimate_covariances()
+    return _r.registration_icp(source, target, max_corres_dist, initial_T, _r.TransformationEstimationForGeneralizedICP(_r.GMLoss(k=1.0)),
                                _r.ICPConvergenceCriteria(max_iteration=iterations))
 
 
@@ -47,37 +45,23 @@ def amostragem_multiescala_otimizada(nuvem, n_escalas, voxel_inicial, seed=None)
     coarser voxel grids (retention model a*exp(-b*voxel), a = 1.18397758, b = 5.09388767, normalised as the reference does);
     returned as the reference returns them: the random subsets in reverse order of creation, the voxel cloud last.  ``seed``
     (not in the reference, whose draws come from Open3D's random device) makes the subsets repeatable."""
-    nuvem_amostrada_inicial = nuvem.voxel_down_sample(voxel_inicial)
-    total_pts = len(np.asarray(nuvem.points))
-    pts_inici = len(np.asarray(nuvem_amostrada_inicial.points))
-    escalas = np.asarray([voxel_inicial + voxel_inicial * i for i in range(n_escalas)])
-    a, b = 1.18397758, 5.09388767
-    porcentagens = a * np.exp(-b * escalas)
-    porcentagens_escalonadas = porcentagens * total_pts / pts_inici
-    porcentagens_normalizadas = porcentagens_escalonadas / np.linalg.norm(porcentagens_escalonadas)
-    porcentagens_normalizadas = porcentagens_normalizadas[1:10]
-    lista_nuvens_amostradas = []
-    for i in range(n_escalas - 1):
-        lista_nuvens_amostradas.append(nuvem_amostrada_inicial.random_down_sample(porcentagens_normalizadas[i], seed=None if seed is None else seed + i))
-    lista_nuvens_amostradas.insert(0, nuvem_amostrada_inicial)
-    return list(reversed(lista_nuvens_amostradas))
+    base = nuvem.voxel_down_sample(voxel_inicial)
+    voxels = voxel_inicial + voxel_inicial * np.arange(n_escalas)                    # the grids being imitated: v, 2v, 3v, ...
+    share = RETENTION_A * np.exp(-RETENTION_B * voxels) * len(nuvem.points) / len(base.points)
+    share = (share / np.linalg.norm(share))[1:10]                                    # the reference's normalisation; entry 0 is the voxel cloud itself
+    subsets = [base.random_down_sample(share[k], seed=None if seed is None else seed + k) for k in range(n_escalas - 1)]
+    return subsets[::-1] + [base]
 
 
 def create_scales(n_scales):
-    """ALL_FUNCTIONS.py:260-264: doubling voxel sizes [0.1, 0.2, 0.4, ...]."""
-    voxel_radius = [0.1]
-    for i in range(n_scales - 1):
-        voxel_radius.append(voxel_radius[-1] + voxel_radius[-1])
-    return voxel_radius
+    """ALL_FUNCTIONS.py:260-264: doubling voxel sizes [0.1, 0.2, 0.4, ...] (a product with a power of two is the repeated sum, bit for bit)."""
+    return [0.1 * 2.0 ** k for k in range(n_scales)]
 
 
 def radius_from_cloud_pair(source, target):
     """ALL_FUNCTIONS.py:1092-1101: mean of the cube roots of the two AABB volumes."""
-    dif_1 = source.get_max_bound() - source.get_min_bound()
-    dif_2 = target.get_max_bound() - target.get_min_bound()
-    rad_1 = (dif_1[0] * dif_1[1] * dif_1[2]) ** (1 / 3)
-    rad_2 = (dif_2[0] * dif_2[1] * dif_2[2]) ** (1 / 3)
-    return (rad_1 + rad_2) / 2
+    edge = [np.prod(c.get_max_bound() - c.get_min_bound()) ** (1 / 3) for c in (source, target)]
+    return (edge[0] + edge[1]) / 2
 
 
 def _multiscale(source, target, voxel_sizes, distances, itera_escala, T_ini):
@@ -90,43 +74,31 @@ def _multiscale(source, target, voxel_sizes, distances, itera_escala, T_ini):
 
 def Multiscale_GICP(source, target, n_scales, itera_escala, T_ini):
     """ALL_FUNCTIONS.py:272-313: voxels 0.1*2^k coarse-to-fine, search radius = AABB radius * 2^-i."""
-    voxel_sizes = create_scales(n_scales)
-    voxel_sizes.reverse()
-    max_correspondence_distance = radius_from_cloud_pair(source, target)
-    max_correspondence_distances = [max_correspondence_distance * (2 ** (-i)) for i in range(n_scales)]
-    return _multiscale(source, target, voxel_sizes, max_correspondence_distances, itera_escala, T_ini)
+    radius = radius_from_cloud_pair(source, target)
+    return _multiscale(source, target, create_scales(n_scales)[::-1], [radius * 2 ** -k for k in range(n_scales)], itera_escala, T_ini)
 
 
 def Coarse_to_fine_FGR_M_GICP(source, target, voxel_size, seed=None):
     """ALL_FUNCTIONS.py:317-332 -> (RegistrationResult, 6x6 information matrix)."""
-    result_FGR = registro_FGR(source, target, voxel_size, seed=seed)
-    n_scales = 3
-    itera_escala = 100
-    T_ini = result_FGR.transformation
-    result_M_GICP = Multiscale_GICP(source, target, n_scales, itera_escala, T_ini)
-    information_matrix = _r.get_information_matrix_from_point_clouds(source, target, voxel_size, result_M_GICP.transformation)
-    return result_M_GICP, information_matrix
+    coarse = registro_FGR(source, target, voxel_size, seed=seed)
+    fine = Multiscale_GICP(source, target, 3, 100, coarse.transformation)                      # 3 scales, 100 iterations each (:320-321)
+    return fine, _r.get_information_matrix_from_point_clouds(source, target, voxel_size, fine.transformation)
 
 
 def calculate_RMSE_and_fitness(lista_nuvens, T_circuito, distancia):
-    """ALL_FUNCTIONS.py:801-824."""
-    n_nuvens = len(lista_nuvens)
-    n_T = len(T_circuito)
-    lista_RMSE, lista_fitness = [], []
-    if n_nuvens == n_T:
-        for i in range(n_nuvens):
-            src = lista_nuvens[i + 1] if i < n_nuvens - 1 else lista_nuvens[0]
-            result = _r.evaluate_registration(src, lista_nuvens[i], distancia, T_circuito[i])
-            lista_RMSE.append(result.inlier_rmse)
-            lista_fitness.append(result.fitness)
-    elif n_nuvens - 1 == n_T:
-        for i in range(n_T):
-            result = _r.evaluate_registration(lista_nuvens[i + 1], lista_nuvens[i], distancia, T_circuito[i])
-            lista_RMSE.append(result.inlier_rmse)
-            lista_fitness.append(result.fitness)
+    """ALL_FUNCTIONS.py:801-824: ``evaluate_registration`` of every pose of a circuit -- pose i moves cloud i+1 onto cloud i; with as
+    many poses as clouds the last one closes the loop (cloud 0 onto the last cloud); any other count prints the reference's message
+    and returns two empty lists."""
+    n = len(lista_nuvens)
+    if len(T_circuito) == n:
+        pairs = [((i + 1) % n, i) for i in range(n)]
+    elif len(T_circuito) == n - 1:
+        pairs = [(i + 1, i) for i in range(n - 1)]
     else:
         print("The number of clouds and poses are inconsistent")
-    return lista_RMSE, lista_fitness
+        return [], []
+    results = [_r.evaluate_registration(lista_nuvens[s], lista_nuvens[t], distancia, T) for (s, t), T in zip(pairs, T_circuito)]
+    return [r.inlier_rmse for r in results], [r.fitness for r in results]
 
 
 # ------------------------------------------------------------------------------------ script variants
@@ -145,23 +117,16 @@ class script2:
     @staticmethod
     def create_scales(n_scales):
         """Script 2:102-106: linear voxel sizes, already coarse-to-fine."""
-        voxel_radius = 0.1
-        voxel_radius = [voxel_radius + (0.1 * i) for i in range(n_scales)]
-        voxel_radius.reverse()
-        return voxel_radius
+        return [0.1 + 0.1 * k for k in reversed(range(n_scales))]
 
     @staticmethod
     def max_correspondence_distances(scales):
         """Script 2:112-120 (defined for 3, 4 or 5 scales only; other counts raise like the reference's
         UnboundLocalError, here as a ValueError subclass-compatible NameError)."""
-        n_scales = len(scales)
-        if n_scales == 3:
-            return [3 * scales[0], 2 * scales[1], scales[2]]
-        elif n_scales == 4:
-            return [3 * scales[0], 2.5 * scales[1], 2 * scales[2], scales[3]]
-        elif n_scales == 5:
-            return [3 * scales[0], 2.5 * scales[1], 2 * scales[2], 1.5 * scales[3], scales[4]]
-        raise UnboundLocalError("local variable 'max_correspondence_distances' referenced before assignment")
+        factors = {3: (3, 2, 1), 4: (3, 2.5, 2, 1), 5: (3, 2.5, 2, 1.5, 1)}.get(len(scales))
+        if factors is None:
+            raise UnboundLocalError("local variable 'max_correspondence_distances' referenced before assignment")
+        return [f * v for f, v in zip(factors, scales)]
 
     @staticmethod
     def Multiscale_GICP(source, target, n_scales, itera_escala, T_ini):

@@ -15,6 +15,30 @@ _PCD_TYPES = {("F", 4): "<f4", ("F", 8): "<f8", ("U", 1): "u1", ("U", 2): "<u2",
               ("I", 1): "i1", ("I", 2): "<i2", ("I", 4): "<i4"}
 
 
+def pcd_point_count(path: str) -> int:
+    """``POINTS`` of a PCD header (``WIDTH x HEIGHT`` without it) -- the header alone is read: what the cost-balanced sharding of a
+    circuit needs of every cloud (``sharding.circuit_costs``)."""
+    width = height = None
+    with open(path, "rb") as f:
+        for _ in range(64):
+            line = f.readline()
+            if not line:
+                break
+            key, _, rest = line.decode("ascii", "replace").strip().partition(" ")
+            key = key.upper()
+            if key == "POINTS":
+                return int(rest.split()[0])
+            if key == "WIDTH":
+                width = int(rest.split()[0])
+            if key == "HEIGHT":
+                height = int(rest.split()[0])
+            if key == "DATA":
+                break
+    if width is None or height is None:
+        raise ValueError(f"{path}: no POINTS / WIDTH x HEIGHT in the PCD header")
+    return width * height
+
+
 def read_pcd_xyz(path: str) -> np.ndarray:
     """Return the ``x y z`` columns of a PCD file as an (N, 3) float32 array.
 

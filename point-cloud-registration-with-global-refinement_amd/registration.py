@@ -213,7 +213,7 @@ def _fgr_params(voxel_size: float, use_absolute_scale: bool, n_pontos: int, seed
     if seed is None:                       # Open3D draws from std::random_device; here a process-local counter
         _fgr_seed_counter[0] = (_fgr_seed_counter[0] * 6364136223846793005 + 1442695040888963407) & (2 ** 64 - 1)
         seed = _fgr_seed_counter[0]
-    opt = _lib.PcrFgrOption(1.4, int(bool(use_absolute_scale)), 1, 2 * voxel_size, 300, 0.95, int(n_pontos * 0.2), 1, int(seed) & (2 ** 64 - 1))
+    opt = _lib.PcrFgrOption(1.4, int(bool(use_absolute_scale)), 1, 2 * voxel_size, 300, 0.95, -1 if n_pontos is None else int(n_pontos * 0.2), 1, int(seed) & (2 ** 64 - 1))
     return _lib.PcrFgrParams(2 * voxel_size, 20, 10 * voxel_size, 200, opt)
 
 
@@ -244,6 +244,8 @@ def default_group(points_per_cloud: float) -> int:
     of ``k_icp_fused_b``), 16 for clouds small enough that launch count decides.  Measured on one MI355X, 4 groups in flight, 3-scale
     GICP stage, pair by pair -> groups: 200k-point pairs 340 -> 530 pairs/s (groups of 6), 100k 440 -> 850 (8), 50k 540 -> 1360 (8),
     20k 680 -> 2590 (16; 2460 with 8)."""
+    if points_per_cloud >= 400_000:           # PCR_GROUP_FORMS_MAX_POINTS: such pairs run one by one with the single-pair kernel forms
+        return 1
     g = int(round(1_200_000 / max(float(points_per_cloud), 1.0)))
     return 16 if g > 32 else max(1, min(8, g))
 
@@ -262,7 +264,7 @@ def balanced_group(group: int, n_pairs: int, inflight: int) -> int:
 def register_pairs_plan(pairs, stage: str = "gicp", voxel_sizes=None, max_correspondence_distances=None, estimation_method=None, criteria=None,
                         nb_neighbors: int = 30, std_ratio: float = 1.0, normal_knn: int = 20, inflight: int = 3, with_correspondences: bool = True,
                         fgr_voxel_size: float = 0.1, fgr_use_absolute_scale: bool = True, fgr_seed=None, radius_rule: str = "given",
-                        prior_from_fgr: bool = False, info_max_dist: float = 0.0, keep_fgr_normals: bool = False, group=1) -> list:
+                        prior_from_fgr: bool = False, info_max_dist: float = 0.0, keep_fgr_normals: bool = False, group=1, pair_forms=None) -> list:
     """The per-pair loops of the reference as ONE library call (``pcr_register_pairs_plan``): `pairs` = [(source PointCloud,
     target PointCloud, initial 4x4 or None), ...].
 
@@ -274,6 +276,8 @@ def register_pairs_plan(pairs, stage: str = "gicp", voxel_sizes=None, max_corres
     batched over clouds and scales, one GICP loop per scale for the whole group; same per-pair arithmetic; with "fgr+gicp" the worker runs
     registro_FGR pair by pair first); ``inflight`` counts groups.
     ``group=None`` picks by cloud size (``default_group``).
+    ``pair_forms`` (default: on exactly when ``group`` is None): the kernel forms of the GICP stage go by the PAIR alone
+    (``pcr_pairs_plan.pair_forms``), so a pair's pose bits are the same in every batch, group size and shard of a multi-GPU run.
     The library keeps ``inflight`` pairs in flight on the current device.  Returns RegistrationResults in input order (for
     stages with FGR the FGR result is attached as ``.fgr``; ``.information`` when ``info_max_dist > 0``)."""
     estimation = estimation_method or TransformationEstimationForGeneralizedICP()
@@ -292,6 +296,8 @@ def register_pairs_plan(pairs, stage: str = "gicp", voxel_sizes=None, max_corres
     n = len(pairs)
     if n == 0:
         return []
+    if pair_forms is None:
+        pair_forms = group is None
     if group is None:
         mean_pts = float(np.mean([len(s_) + len(t_) for s_, t_, _ in pairs])) / 2
         group = balanced_group(default_group(mean_pts), n, int(inflight))
@@ -307,7 +313,7 @@ def register_pairs_plan(pairs, stage: str = "gicp", voxel_sizes=None, max_corres
                                  fgr_voxel_size, fgr_use_absolute_scale, fgr_seed, "given", False, 0.0, True, 1)
         second = [((vs if prior_from_fgr else s_), (vt if prior_from_fgr else t_), f.transformation) for (vs, vt, _), (s_, t_, _), f in zip(views, pairs, fg)]
         out = register_pairs_plan(second, "gicp", voxel_sizes, max_correspondence_distances, estimation, criteria, nb_neighbors, std_ratio, normal_knn, inflight,
-                                  with_correspondences, radius_rule=radius_rule, info_max_dist=info_max_dist, group=group)
+                                  with_correspondences, radius_rule=radius_rule, info_max_dist=info_max_dist, group=group, pair_forms=pair_forms)
         for r, f, (vs, vt, _), (s_, t_, _) in zip(out, fg, views, pairs):
             r.fgr = f
             if keep_fgr_normals:              # the reference's side effect: both inputs gain normals
@@ -339,26 +345,14 @@ def register_pairs_plan(pairs, stage: str = "gicp", voxel_sizes=None, max_corres
     plan.stage = stage_id
     fp = None
     if do_fgr:
-        n_pontos = int((len(pairs[0][0]) + len(pairs[0][1])) / 2)
-        if any(int((len(s) + len(t)) / 2) != n_pontos for s, t, _ in pairs):
-            # maximum_tuple_count depends on the pair's sizes (ALL_FUNCTIONS.py:179,196): one plan per distinct size
-            out = [None] * n
-            groups = {}
-            for k, (s, t, _) in enumerate(pairs):
-                groups.setdefault(int((len(s) + len(t)) / 2), []).append(k)
-            for ks in groups.values():
-                sub = register_pairs_plan([pairs[k] for k in ks], stage, voxel_sizes, max_correspondence_distances, estimation, criteria, nb_neighbors,
-                                          std_ratio, normal_knn, inflight, with_correspondences, fgr_voxel_size, fgr_use_absolute_scale,
-                                          None if fgr_seed is None else fgr_seed + ks[0], radius_rule, prior_from_fgr, info_max_dist, keep_fgr_normals, group)
-                for k, r in zip(ks, sub):
-                    out[k] = r
-            return out
+        # maximum_tuple_count = int(0.2 * n_pontos) depends on the pair's sizes (ALL_FUNCTIONS.py:179,196): the library applies the rule per pair
+        n_pontos = None
         fp = _fgr_params(fgr_voxel_size, fgr_use_absolute_scale, n_pontos, fgr_seed)
         plan.fgr = C.pointer(fp)
     plan.voxel_sizes = vox.ctypes.data_as(C.POINTER(C.c_double)); plan.max_distances = dst.ctypes.data_as(C.POINTER(C.c_double))
     plan.n_scales = int(vox.size); plan.radius_rule = rule
     plan.sor_k = int(nb_neighbors); plan.sor_std = float(std_ratio); plan.normal_k = int(normal_knn)
-    plan.gicp = C.pointer(p); plan.gicp_prior_from_fgr = int(bool(prior_from_fgr)); plan.info_max_dist = float(info_max_dist); plan.inflight = int(inflight); plan.group = int(group)
+    plan.gicp = C.pointer(p); plan.gicp_prior_from_fgr = int(bool(prior_from_fgr)); plan.info_max_dist = float(info_max_dist); plan.inflight = int(inflight); plan.group = int(group); plan.pair_forms = int(pair_forms)
     dev = torch.cuda.current_device()
     rc = lib.pcr_register_pairs_plan(C.c_int(dev), arr, C.c_int(n), C.byref(plan), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     out = []

@@ -10,12 +10,58 @@ import numpy as np
 RECORD_DOUBLES = 22      # 16 pose + fitness + rmse + n_corr + iterations + converged + pair index
 
 
-def partition(n_pairs: int, world_size: int, rank: int) -> range:
-    """Contiguous block partition [r*P/W, (r+1)*P/W): neighbouring pairs share a cloud, so a rank uploads
-    P/W + 1 clouds.  The loop-closure pair (last index) falls to the last rank."""
-    lo = (rank * n_pairs) // world_size
-    hi = ((rank + 1) * n_pairs) // world_size
-    return range(lo, hi)
+def block_bounds(costs, world_size: int) -> list:
+    """Cut points b[0] = 0 <= b[1] <= ... <= b[W] = P of the contiguous partition of P pairs into W blocks whose LARGEST block cost
+    is minimal (the time of a sharded run is its slowest rank's).  Bisection on the block capacity with a greedy feasibility test
+    (exact for integer costs); among the optimal cuts the greedy one is evened out from the back so that no rank is left empty
+    while another holds several pairs.  Deterministic: every rank computes the same cuts from the same costs."""
+    c = [int(v) for v in costs]
+    P, W = len(c), int(world_size)
+    if W <= 1 or P == 0:
+        return [0] + [P] * max(W, 1)
+
+    def cuts(cap):
+        b, acc = [0], 0
+        for i, v in enumerate(c):
+            if acc + v > cap and acc > 0:
+                b.append(i); acc = 0
+            acc += v
+        return b + [P]
+    lo, hi = max(c), sum(c)
+    while lo < hi:
+        mid = (lo + hi) // 2
+        if len(cuts(mid)) - 1 <= W:
+            hi = mid
+        else:
+            lo = mid + 1
+    b = cuts(lo)
+    b = b[:-1] + [P] * (W + 1 - (len(b) - 1))                   # fewer than W blocks: the rest are empty for now
+    changed = True
+    while changed:                                              # an empty block takes the last pair of a predecessor that holds several
+        changed = False                                         # (one pair costs at most max(c) <= lo: the optimum stays)
+        for r in range(W - 1, 0, -1):
+            if b[r] == b[r + 1] and b[r] - b[r - 1] >= 2:
+                b[r] -= 1; changed = True
+    return b
+
+
+def partition(n_pairs: int, world_size: int, rank: int, costs=None) -> range:
+    """Contiguous block of pair indices of `rank`: neighbouring pairs share a cloud, so a rank uploads (block + 1) clouds; the
+    loop-closure pair (last index) falls to the last rank.  Without `costs` the blocks are [r*P/W, (r+1)*P/W); with `costs`
+    (one number per pair, e.g. the points of its two clouds: NCLT scans hold 6.9k-31k points and an index split leaves the slowest
+    of 8 ranks 25 % over the mean) the blocks are balanced by cost (`block_bounds`)."""
+    if costs is None:
+        return range((rank * n_pairs) // world_size, ((rank + 1) * n_pairs) // world_size)
+    if len(costs) != n_pairs:
+        raise ValueError("partition: one cost per pair")
+    b = block_bounds(costs, world_size)
+    return range(b[rank], b[rank + 1])
+
+
+def circuit_costs(point_counts) -> list:
+    """Cost of pair i of a closed circuit = points of its two clouds (`circuit_pair`)."""
+    n = len(point_counts)
+    return [int(point_counts[circuit_pair(i, n)[0]]) + int(point_counts[circuit_pair(i, n)[1]]) for i in range(n)]
 
 
 def circuit_pair(i: int, n_clouds: int):

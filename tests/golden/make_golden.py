@@ -32,6 +32,14 @@ def main(ref):
         np.savez_compressed(os.path.join(HERE, f"nclt_pair_{i:03d}.npz"), source=src, target=tgt, T_fgr=T_fgr,
                             T_gicp=T_gicp, pair=np.int64(i))
         print(f"pair {i}: source {src.shape[0]} pts, target {tgt.shape[0]} pts")
+    # point counts of the 901 NCLT scans (PCD header field POINTS): the size distribution the cost-balanced sharding is tested on
+    counts = []
+    for i in range(901):
+        with open(os.path.join(nclt, f"s{i}.pcd"), "rb") as f:
+            head = f.read(512).decode("ascii", errors="replace")
+        counts.append(int([l for l in head.splitlines() if l.startswith("POINTS")][0].split()[1]))
+    np.save(os.path.join(HERE, "nclt_point_counts.npy"), np.asarray(counts, dtype=np.int32))
+    print(f"NCLT point counts: min {min(counts)} max {max(counts)} total {sum(counts)}")
     # the whole Facade loop (terrestrial scanner, 7 clouds of 45k-84k points: BASELINE config 4's shipped data) with the FGR poses
     # stage 2 starts from and the GICP poses the author shipped.  Pair i registers cloud i+1 onto cloud i, the last one closes the
     # loop (cloud 0 onto cloud 6; file pose_0_6.txt).  The shipped Facade GICP poses were NOT made with script-2 parameters (the

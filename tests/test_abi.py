@@ -75,9 +75,10 @@ def test_io_roundtrip(tmp_path):
 
 def test_default_group_rule():
     """``register_pairs_plan(group=None)``: about 1.2M points per lockstep group, at most 8 pairs (the by-value argument batch of the fused
-    iteration kernel holds 8), 16 for clouds so small that the launch count decides, pair by pair from 2M-point clouds (config 5) up."""
+    iteration kernel holds 8), 16 for clouds so small that the launch count decides, pair by pair from 400k-point clouds up (the size from
+    which `pcr_pairs_plan.pair_forms` runs a pair alone with the single-pair kernel forms: configs 4 and 5)."""
     g = pkg().registration.default_group
-    assert [g(n) for n in (20_000, 50_000, 100_000, 200_000, 400_000, 2_000_000)] == [16, 8, 8, 6, 3, 1]
+    assert [g(n) for n in (20_000, 50_000, 100_000, 200_000, 399_999, 400_000, 2_000_000)] == [16, 8, 8, 6, 3, 1, 1]
     assert g(0) == 16 and g(1e9) == 1
     # ... rounded so that the groups of a batch fill whole rounds of the workers in flight
     b = pkg().registration.balanced_group

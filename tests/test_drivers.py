@@ -67,8 +67,9 @@ def test_stage1_stage2_on_a_two_cloud_circuit(tmp_path):
 def test_stage2_two_ranks_equal_one_rank_on_the_facade_circuit(tmp_path):
     """the shipped Facade circuit (7 clouds, 7 pairs incl. the loop closure) through `drivers stage2` as ONE
     process and as TWO ranks (contiguous blocks of 3 and 4 pairs, one all-gather of the pose records; both ranks on this box's one
-    device, gloo): the pose files rank 0 writes must be the same bits.  PCR_ICP_TILE pins the iteration kernel's tile so that
-    lockstep groups of different sizes sum in the same order (tests/test_gpu_groups.py)."""
+    device, gloo): the pose files rank 0 writes must be the same bits.  Nothing is pinned: the drivers size their groups by the clouds
+    (group=None), which makes the kernel forms a function of the pair alone (`pcr_pairs_plan.pair_forms`), whatever the cut -- with
+    --inflight 2 one rank runs groups of 4 + 3, two ranks 2 + 1 and 2 + 2."""
     import subprocess
     import sys
     from conftest import ROOT
@@ -79,7 +80,7 @@ def test_stage2_two_ranks_equal_one_rank_on_the_facade_circuit(tmp_path):
         pcr_amd.io.write_pcd_xyz(str(clouds / f"s{i}.pcd"), g[f"s{i}"])
         pcr_amd.io.write_pose(str(init / pcr_amd.io.relative_pose_name(i, n)), g["T_fgr"][i])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(PCR_ICP_TILE="512", PCR_REHEARSE="1", PYTHONPATH=ROOT)
+    env.update(PCR_REHEARSE="1", PYTHONPATH=ROOT)
     script = tmp_path / "run_stage.py"          # (the package name has hyphens: importlib, not `-m`)
     # (and torchrun's own argument parser trips over `--n`: the stage arguments travel in the environment)
     script.write_text("import importlib, json, os, sys\nsys.exit(importlib.import_module('point-cloud-registration-with-global-refinement_amd.drivers').main(json.loads(os.environ['PCR_STAGE_ARGS'])))\n")

@@ -53,6 +53,19 @@ def test_config2_default_group_path_matches_oracle(P, oracle, pair200k):
     for q, r in zip(pairs, res):
         ang, dt = pose_error(r.transformation, q.T_true)
         assert ang < 2e-3 and dt < 2e-2, (ang, dt)
+    # ... and with the loss the bench runs (L1, 2_MGICP...py:159-162 criteria), the SAME group: every pair's end pose must be as
+    # stationary for the reference iteration (oracle arithmetic, float64) as the oracle's own end pose of that pair -- the chaos-proof
+    # form of the L1 comparison (conftest.assert_reference_fixed_point) -- and recover its planted motion
+    from conftest import assert_reference_fixed_point
+    est1 = reg.TransformationEstimationForGeneralizedICP(reg.L1Loss())
+    res1 = reg.register_pairs_plan(work, "gicp", pair200k.voxel_sizes, pair200k.max_distances_script, est1, crit, inflight=1, group=None)
+    for k, (q, r) in enumerate(zip(pairs, res1)):
+        ref1 = oracle.multiscale_gicp(q.source, q.target, q.voxel_sizes, q.max_distances_script, q.T_init, loss=oracle.LOSS_L1)
+        for a, b in zip(r.scales, ref1.extra["scales"]):
+            assert a["n_voxel"] == tuple(b["n_voxel"]) and a["n_clean"] == tuple(b["n_clean"])
+        assert_reference_fixed_point(oracle, q.source, q.target, q.voxel_sizes[-1], q.max_distances_script[-1], r.transformation, ref1.transformation, f"config 2, group of six, pair {k}")
+        ang, dt = pose_error(r.transformation, q.T_true)
+        assert ang < 2e-3 and dt < 2e-2, (k, ang, dt)
 
 
 def test_config2_reference_parameters_l1(P, oracle, pair200k):

@@ -33,6 +33,18 @@ def test_groups_are_bit_identical_at_equal_summation_grouping(rule):
         assert all(g == groups[0] for g in groups), (ppl, groups)
 
 
+def test_groups_are_bit_identical_by_default_however_the_batch_is_cut():
+    """No switch pinned (round-3 advisor finding): a plan with lockstep groups runs EVERY unit with the group forms of the kernels -- a
+    ragged last group of one pair too (5 pairs in groups of 2 are 2 + 2 + 1, in groups of 4 they are 4 + 1) -- and with
+    `pair_forms` (what group=None sets) also a pair registered pair by pair: same bits for every cut."""
+    groups, _ = _helper({"GROUP_POSE_SIZES": "2,3,4,8"})
+    assert len(groups) == 4
+    assert all(g == groups[0] for g in groups), groups
+    forms, _ = _helper({"GROUP_POSE_SIZES": "1,2,0", "GROUP_POSE_PAIR_FORMS": "1"})
+    assert len(forms) == 3
+    assert all(g == groups[0] for g in forms), (groups[0], forms)
+
+
 def test_fgr_plus_gicp_groups_are_bit_identical():
     """Stage FGR + GICP (Coarse_to_fine / full_registration, ALL_FUNCTIONS.py:317-332, 349-392) with lockstep groups: registro_FGR runs
     pair by pair, the GICP of the group in lockstep from the FGR poses with the FGR normals as orientation prior and the AF radius rule,

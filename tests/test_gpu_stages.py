@@ -54,10 +54,23 @@ def test_bounds(P, small_pair):
     assert np.array_equal(pc.get_max_bound(), src.max(0).astype(np.float64))
 
 
+@pytest.fixture
+def knn_form(P):
+    """Selects the exact k-NN kernel for the calls of one test (pcr_set_option "knn_wave": 0 octet, 1 one query per lane) and puts
+    the default rule (-1: by size and call form) and budget back afterwards."""
+    yield lambda form: P._lib.set_option("knn_wave", form)
+    P._lib.set_option("knn_wave", -1)
+    P._lib.set_option("knnw_budget", 80)
+
+
+@pytest.mark.parametrize("wave", [0, 1])
 @pytest.mark.parametrize("k", [1, 20, 30, 33, 64])
-def test_knn_index_is_exact(P, oracle, small_pair, k):
+def test_knn_index_is_exact(P, oracle, small_pair, knn_form, k, wave):
+    """Both exact k-NN kernels -- the octet kernel and the one-query-per-lane kernel the lockstep groups run (52 % of the measured
+    path) -- directly against the oracle's kd-tree."""
     import ctypes as C
     import torch
+    knn_form(wave)
     pts = P.PointCloud(small_pair["source"]).voxel_down_sample(0.2).points.astype(np.float32)
     n = len(pts)
     ctx = P._lib.Context.current()
@@ -94,16 +107,16 @@ def _debug_knn(P, pts, k, radius=0.0):
 
 
 @pytest.mark.parametrize("k,radius,n", [(30, 0.0, None), (20, 0.25, 9000), (64, 0.0, 5000), (7, 0.0, 100), (30, 0.0, 11), (20, 0.0, 65), (30, 0.0, 1)])
-def test_knn_wave_equals_octet(P, small_pair, monkeypatch, k, radius, n):
-    """The one-query-per-lane search (pcr_knn_wave.h, PCR_KNN_WAVE=1) against the octet kernel (the default): two independent exact
+def test_knn_wave_equals_octet(P, small_pair, knn_form, k, radius, n):
+    """The one-query-per-lane search (pcr_knn_wave.h, option knn_wave = 1) against the octet kernel (the default): two independent exact
     searches must return the same distances row for row, and the same indices wherever distances do not tie -- also on clouds
     smaller than k, smaller than a wavefront, and under a radius cap (Open3D SearchHybrid)."""
     pts = P.PointCloud(small_pair["source"]).voxel_down_sample(0.2).points.astype(np.float32) if radius == 0.0 else small_pair["source"].astype(np.float32)
     if n is not None:
         pts = pts[:n].copy()
-    monkeypatch.setenv("PCR_KNN_WAVE", "1")
+    knn_form(1)
     wi, wd, wc = _debug_knn(P, pts, k, radius)
-    monkeypatch.setenv("PCR_KNN_WAVE", "0")
+    knn_form(0)
     oi, od, oc = _debug_knn(P, pts, k, radius)
     assert np.array_equal(wc, oc)
     assert (wc == np.minimum(k, len(pts))).all() or radius > 0
@@ -122,17 +135,17 @@ def test_knn_wave_equals_octet(P, small_pair, monkeypatch, k, radius, n):
         assert len(set(v.tolist())) == len(v)
 
 
-def test_knn_wave_hands_hard_wavefronts_to_the_octet_kernel(P, oracle, small_pair, monkeypatch):
-    """A wavefront of the one-query-per-lane search gives up after PCR_KNNW_BUDGET candidate batches and leaves its 64 queries to the octet
+def test_knn_wave_hands_hard_wavefronts_to_the_octet_kernel(P, oracle, small_pair, knn_form):
+    """A wavefront of the one-query-per-lane search gives up after `knnw_budget` candidate batches and leaves its 64 queries to the octet
     kernel (default 40 batches: ~1 % of the wavefronts).  With a budget of 3 most wavefronts give up, with 8 about half: the outlier
     mask must stay the oracle's bit for bit and the normals the same either way."""
     pc = P.PointCloud(small_pair["source"]).voxel_down_sample(0.2)
     pts = pc.points
     keep, avg, mu, sd = oracle.remove_statistical_outlier(pts, 30, 1.0)
     ref_n = oracle.estimate_normals(pts, oracle.SEARCH_KNN, 20)
-    monkeypatch.setenv("PCR_KNN_WAVE", "1")
-    for budget in ("3", "8", "40"):
-        monkeypatch.setenv("PCR_KNNW_BUDGET", budget)
+    knn_form(1)
+    for budget in (3, 8, 40):
+        P._lib.set_option("knnw_budget", budget)
         clean, index = pc.remove_statistical_outlier(30, 1.0)
         assert np.array_equal(np.asarray(index), np.nonzero(keep)[0])
         pc2 = P.PointCloud(pts); pc2.estimate_normals(P.KDTreeSearchParamKNN(knn=20))

@@ -14,10 +14,12 @@ work = work + [(t, s, np.linalg.inv(T)) for s, t, T in work[:2]]        # 5 pair
 vox = P.script2.create_scales(5)
 loss = reg.L2Loss() if os.environ.get("GROUP_POSE_LOSS") == "l2" else reg.L1Loss()
 rule = "af" if os.environ.get("GROUP_POSE_RULE") == "af" else "given"
+sizes = [int(v) for v in os.environ.get("GROUP_POSE_SIZES", "1,2,3,8").split(",")]       # 0 = group=None (sized by the clouds, forms by the pair)
+pair_forms = {"": None, "0": False, "1": True}[os.environ.get("GROUP_POSE_PAIR_FORMS", "")]
 stage = os.environ.get("GROUP_POSE_STAGE", "gicp")          # "fgr+gicp": registro_FGR per pair (fixed seeds), then the group's GICP from its poses, information matrices
-for g in (1, 2, 3, 8):
+for g in sizes:
     rs = reg.register_pairs_plan(work, stage, vox, P.script2.max_correspondence_distances(vox), reg.TransformationEstimationForGeneralizedICP(loss),
-                                 reg.ICPConvergenceCriteria(1e-6, 1e-6, 100), inflight=2, with_correspondences=True, group=g, radius_rule=rule,
+                                 reg.ICPConvergenceCriteria(1e-6, 1e-6, 100), inflight=2, with_correspondences=True, group=(g if g > 0 else None), pair_forms=pair_forms, radius_rule=rule,
                                  fgr_seed=77, prior_from_fgr=(stage != "gicp"), info_max_dist=(0.1 if stage != "gicp" else 0.0))
     h = hashlib.sha256()
     for r in rs:

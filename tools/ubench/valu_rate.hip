@@ -1,11 +1,13 @@
 // VALU issue-rate micro-benchmark (gfx950): 30-long chains of independent-register v_med3_f32 / v_min+v_max / v_fma_f32 / v_max3_f32 /
-// v_pk_fma_f32 per loop iteration, 4 wavefronts per SIMD on every CU.  Prints cycles per wave-instruction per SIMD.
+// v_max_i32 per loop iteration, at 1, 2, 4 and 8 wavefronts per SIMD on every CU.  Prints ns and cycles per wave-instruction per SIMD
+// (cycles from the kernel's own s_memtime / s_memrealtime clock ratio).
 // build + run on the GPU box: hipcc -O3 --offload-arch=gfx950 valu_rate.hip -o /tmp/valu_rate && /tmp/valu_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define N 30
 template <int OP>
-__global__ void __launch_bounds__(256) k(float *out, int iters, float seed) {
+__global__ void __launch_bounds__(256) k(float *out, int iters, float seed, unsigned long long *clk) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     float s[N];
     for (int j = 0; j < N; j++) s[j] = seed + j + threadIdx.x;
     float x = seed * 0.5f + threadIdx.x;
@@ -22,19 +24,27 @@ __global__ void __launch_bounds__(256) k(float *out, int iters, float seed) {
     }
     float r = 0; for (int j = 0; j < N; j++) r += s[j];
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = __builtin_amdgcn_s_memtime() - t0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
 }
-template <int OP> void run(const char *name, int per_iter) {
-    float *out; hipMalloc(&out, 256 * 4 * 256 * 4 * sizeof(float));
-    const int blocks = 256 * 4, iters = 20000;      // 4 workgroups of 4 wavefronts per CU = 4 wavefronts per SIMD
+template <int OP> void run(const char *name, int per_iter, int wps) {
+    float *out; hipMalloc(&out, 256 * 8 * 256 * sizeof(float));
+    unsigned long long *clk; hipMalloc(&clk, 16); unsigned long long h[2];
+    const int blocks = 256 * wps, iters = 20000;      // wps workgroups of 4 wavefronts per CU = wps wavefronts per SIMD
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    k<OP><<<blocks, 256>>>(out, 100, 1.0f); hipDeviceSynchronize();
-    hipEventRecord(a); k<OP><<<blocks, 256>>>(out, iters, 1.0f); hipEventRecord(b); hipEventSynchronize(b);
+    k<OP><<<blocks, 256>>>(out, 100, 1.0f, clk); hipDeviceSynchronize();
+    hipEventRecord(a); k<OP><<<blocks, 256>>>(out, iters, 1.0f, clk); hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
+    hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+    const double ghz = (double)h[0] / ((double)h[1] * 10.0);                   // s_memrealtime ticks at 100 MHz
     const double winst = (double)blocks * 4 * iters * per_iter;               // wave-instructions
-    printf("%-28s %8.3f ms  %.1f G wave-instr/s chip  -> %.2f ns per wave-instr per SIMD (x clock = cycles)\n", name, ms, winst / ms / 1e6, ms * 1e6 / (winst / 1024));
-    hipFree(out);
+    const double ns = ms * 1e6 / (winst / 1024);
+    printf("%-24s %d waves/SIMD %8.3f ms  %7.1f G wave-instr/s chip  %.3f ns per wave-instr per SIMD  clock %.2f GHz -> %.2f cycles\n", name, wps, ms, winst / ms / 1e6, ns, ghz, ns * ghz);
+    hipFree(out); hipFree(clk);
 }
 int main() {
-    run<0>("v_med3_f32", N - 1); run<1>("v_min_f32 + v_max_f32", 2 * (N - 1)); run<2>("v_fma_f32", N - 1); run<3>("v_max3_f32", N - 1); run<4>("v_max_i32", N - 1);
+    for (int wps : {1, 2, 4, 8}) {
+        run<0>("v_med3_f32", N - 1, wps); run<1>("v_min_f32 + v_max_f32", 2 * (N - 1), wps); run<2>("v_fma_f32", N - 1, wps);
+        run<3>("v_max3_f32", N - 1, wps); run<4>("v_max_i32", N - 1, wps);
+    }
     return 0;
 }
