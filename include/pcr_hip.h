@@ -209,6 +209,12 @@ typedef struct {
                                                            400 000 points; larger pairs run one by one with the single-pair forms) whatever `group` is:
                                                            a pair's pose bits are then the same in every batch, group size and shard (gathered
                                                            multi-GPU poses = the single-GPU run).  What registration.register_pairs_plan(group=None) sets. */
+    int32_t fgr_group;                                  /* > 1 (stages with FGR): that many consecutive pairs go through registro_FGR in LOCKSTEP -- imports, sorts,
+                                                           trees, hybrid normals, FPFH lists and histograms, the mutual feature search, cross check, tuple
+                                                           test, GNC optimiser and evaluation of all of them in the same launches, six host waits per
+                                                           GROUP instead of eight per pair (1_FGR...py:134-147 is ~125 small dependent launches per NCLT-size
+                                                           pair).  Same bits per pair as pair by pair.  Pairs the group form does not take (from ~70k points:
+                                                           the tile-pruned feature search) run one by one.  Stage FGR: `inflight` counts these groups. */
 } pcr_pairs_plan;
 typedef struct {
     pcr_pair base;                                      /* inputs, records (stages with GICP), correspondences of the LAST stage run, status */

@@ -56,7 +56,7 @@ class PcrPairsPlan(C.Structure):
     _fields_ = [("stage", C.c_int32), ("fgr", C.POINTER(PcrFgrParams)), ("voxel_sizes", C.POINTER(C.c_double)),
                 ("max_distances", C.POINTER(C.c_double)), ("n_scales", C.c_int32), ("radius_rule", C.c_int32),
                 ("sor_k", C.c_int32), ("sor_std", C.c_double), ("normal_k", C.c_int32), ("gicp", C.POINTER(PcrGicpParams)),
-                ("gicp_prior_from_fgr", C.c_int32), ("info_max_dist", C.c_double), ("inflight", C.c_int32), ("group", C.c_int32), ("pair_forms", C.c_int32)]
+                ("gicp_prior_from_fgr", C.c_int32), ("info_max_dist", C.c_double), ("inflight", C.c_int32), ("group", C.c_int32), ("pair_forms", C.c_int32), ("fgr_group", C.c_int32)]
 
 
 class PcrPairEx(C.Structure):

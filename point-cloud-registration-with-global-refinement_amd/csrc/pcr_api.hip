@@ -905,7 +905,9 @@ extern "C" int pcr_register_pairs_plan(int device, pcr_pair_ex *pairs, int n_pai
     const int inflight = plan->inflight;
     // lockstep groups: `group` consecutive pairs go through the same GICP launches, `inflight` groups in flight (stage FGR + GICP: the
     // worker runs registro_FGR pair by pair and then the group's GICP in lockstep from the FGR poses)
-    const int group = ((plan->stage == PCR_STAGE_GICP || plan->stage == PCR_STAGE_FGR_GICP) && plan->group > 1) ? (plan->group > 32 ? 32 : plan->group) : 1;
+    const int fgr_group = plan->fgr_group > 1 ? (plan->fgr_group > 64 ? 64 : plan->fgr_group) : 1;
+    const int group = plan->stage == PCR_STAGE_FGR ? fgr_group
+                    : (((plan->stage == PCR_STAGE_GICP || plan->stage == PCR_STAGE_FGR_GICP) && plan->group > 1) ? (plan->group > 32 ? 32 : plan->group) : 1);
     const int units = (n_pairs + group - 1) / group;
     const int workers = inflight < 1 ? 1 : (inflight > units ? units : (inflight > 16 ? 16 : inflight));
     // the workers wait for everything already enqueued on `after_stream` (NULL = the legacy default stream, which is what torch's
@@ -949,15 +951,35 @@ extern "C" int pcr_register_pairs_plan(int device, pcr_pair_ex *pairs, int n_pai
                             return PCR_OK;
                         });
                     staged.resize((size_t)cnt);
+                    std::vector<char> fgr_done((size_t)cnt, 0);
+                    std::vector<float *> snos((size_t)cnt), tnos((size_t)cnt);
+                    for (int k = 0; k < cnt; k++) {
+                        pcr_pair_ex &px = pairs[i + k];
+                        snos[k] = px.src_normals_out; tnos[k] = px.tgt_normals_out;
+                        if (rc_group == PCR_OK && plan->gicp_prior_from_fgr && !(snos[k] && tnos[k])) {
+                            float *base = (float *)ctx->aux + off[k];
+                            if (!snos[k]) snos[k] = base;
+                            if (!tnos[k]) tnos[k] = base + (size_t)(px.base.n_src + 1) * 3;
+                        }
+                    }
+                    if (rc_group == PCR_OK && fgr_group > 1 && cnt > 1)            // registro_FGR of the unit's pairs in lockstep chunks; what it declines runs below
+                        for (int k0 = 0; k0 < cnt; k0 += fgr_group) {
+                            const int m = k0 + fgr_group <= cnt ? fgr_group : cnt - k0;
+                            std::vector<pcr_fgr_group_pair> q((size_t)m);
+                            for (int k = 0; k < m; k++) {
+                                pcr_pair_ex &px = pairs[i + k0 + k];
+                                q[k] = pcr_fgr_group_pair{px.base.src_xyz, px.base.src_normals, px.base.n_src, px.base.tgt_xyz, px.base.tgt_normals, px.base.n_tgt, *plan->fgr,
+                                                          snos[k0 + k], tnos[k0 + k], &px.fgr, nullptr, PCR_OK};
+                                q[k].p.option.seed = plan->fgr->option.seed + (uint64_t)(i + k0 + k);
+                            }
+                            const int rc = pcr_api_call(ctx, [&]() -> int { return pcr_registro_fgr_group(ctx, q.data(), m); });
+                            if (rc == PCR_EHIP) { rc_group = rc; break; }
+                            if (rc == PCR_OK) for (int k = 0; k < m; k++) fgr_done[k0 + k] = q[k].status == PCR_OK;
+                        }
                     for (int k = 0; k < cnt && rc_group == PCR_OK; k++) {
                         pcr_pair_ex &px = pairs[i + k];
-                        float *sno = px.src_normals_out, *tno = px.tgt_normals_out;
-                        if (plan->gicp_prior_from_fgr && !(sno && tno)) {
-                            float *base = (float *)ctx->aux + off[k];
-                            if (!sno) sno = base;
-                            if (!tno) tno = base + (size_t)(px.base.n_src + 1) * 3;
-                        }
-                        const int rc = pcr_api_call(ctx, [&]() -> int {
+                        float *sno = snos[k], *tno = tnos[k];
+                        const int rc = fgr_done[k] ? PCR_OK : pcr_api_call(ctx, [&]() -> int {
                             pcr_fgr_params fp = *plan->fgr;
                             fp.option.seed = plan->fgr->option.seed + (uint64_t)(i + k);
                             return pcr_registro_fgr_impl(ctx, px.base.src_xyz, px.base.src_normals, px.base.n_src, px.base.tgt_xyz, px.base.tgt_normals, px.base.n_tgt, &fp, sno, tno, &px.fgr, nullptr);
@@ -991,6 +1013,29 @@ extern "C" int pcr_register_pairs_plan(int device, pcr_pair_ex *pairs, int n_pai
             }
             return rc_group;
         };
+        // stage FGR: `cnt` pairs through registro_FGR in lockstep (pcr_registro_fgr_group); pairs it leaves (status 1) and groups it declines run one by one
+        auto fgr_unit = [&](int i, int cnt) -> int {
+            std::vector<pcr_fgr_group_pair> q((size_t)cnt);
+            for (int k = 0; k < cnt; k++) {
+                pcr_pair_ex &px = pairs[i + k];
+                px.base.error[0] = 0;
+                q[k] = pcr_fgr_group_pair{px.base.src_xyz, px.base.src_normals, px.base.n_src, px.base.tgt_xyz, px.base.tgt_normals, px.base.n_tgt, *plan->fgr,
+                                          px.src_normals_out, px.tgt_normals_out, &px.fgr, px.base.correspondences, PCR_OK};
+                q[k].p.option.seed = plan->fgr->option.seed + (uint64_t)(i + k);
+            }
+            const int rc = pcr_api_call(ctx, [&]() -> int { return pcr_registro_fgr_group(ctx, q.data(), cnt); });
+            if (rc == PCR_EHIP) {
+                for (int k = 0; k < cnt; k++) { pairs[i + k].base.status = rc; failed++; snprintf(pairs[i + k].base.error, sizeof pairs[i + k].base.error, "%s", ctx->err.c_str()); }
+                return rc;
+            }
+            for (int k = 0; k < cnt; k++) {
+                pcr_pair &p = pairs[i + k].base;
+                if (rc == PCR_OK && q[k].status == PCR_OK) { p.status = PCR_OK; continue; }
+                p.status = run_pair(ctx, pairs[i + k], i + k, *plan);
+                if (p.status != PCR_OK) { failed++; snprintf(p.error, sizeof p.error, "%s", ctx->err.c_str()); }
+            }
+            return PCR_OK;
+        };
         auto solo_unit = [&](int i, int cnt) -> int {
             for (int k = 0; k < cnt; k++) {
                 pcr_pair &p = pairs[i + k].base;
@@ -1004,6 +1049,10 @@ extern "C" int pcr_register_pairs_plan(int device, pcr_pair_ex *pairs, int n_pai
             const int i = next.fetch_add(group);
             if (i >= n_pairs) break;
             const int cnt = i + group <= n_pairs ? group : n_pairs - i;
+            if (plan->stage == PCR_STAGE_FGR) {
+                if (group > 1 && cnt > 1 && plan->fgr) fgr_unit(i, cnt); else solo_unit(i, cnt);
+                continue;
+            }
             // kernel forms (ctx->group_forms: wavefront k-NN, 1024-point iteration tiles).  plan->pair_forms == 0: by the plan -- every unit
             // of a plan with group > 1 takes the group forms, a ragged last group of ONE pair included, so that a pair's arithmetic does not
             // depend on how the batch was cut.  pair_forms != 0: by the PAIR alone -- group forms iff both clouds are under

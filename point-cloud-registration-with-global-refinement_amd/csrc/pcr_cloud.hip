@@ -517,6 +517,65 @@ int pcr_dev_sort_cloud(pcr_context *ctx, const float *xyz, int64_t n, const doub
     return PCR_OK;
 }
 
+// ---- the same for `count` clouds in ONE pass (lockstep FGR groups): bounds (one read-back), keys, the batched radix sort, gathers and
+// all octrees in one batch of the six build kernels.  Per cloud the arithmetic of pcr_dev_sort_cloud: same lattice, same keys, same
+// stable order.  cs[c] must be allocated (pcr_alloc_cloud with a tree); perms[c]: sorted -> caller index.
+struct RawKeyArgs { const float *xyz; const float *nrm; int n; float ox, oy, oz, s; uint64_t *keys; uint32_t *vals; const uint32_t *perm; float4 *pts; float4 *nrm_out; int *n_dev; };
+__global__ void __launch_bounds__(BS) k_raw_keys_g(const RawKeyArgs *a_) {
+    const RawKeyArgs &a = a_[blockIdx.y];
+    const int i = blockIdx.x * BS + threadIdx.x;
+    if (i == 0) *a.n_dev = a.n;
+    if (i >= a.n) return;
+    const uint32_t ix = (uint32_t)fminf((a.xyz[i * 3] - a.ox) * a.s, 65535.0f);
+    const uint32_t iy = (uint32_t)fminf((a.xyz[i * 3 + 1] - a.oy) * a.s, 65535.0f);
+    const uint32_t iz = (uint32_t)fminf((a.xyz[i * 3 + 2] - a.oz) * a.s, 65535.0f);
+    a.keys[i] = pcr_morton3(ix, iy, iz);
+    a.vals[i] = (uint32_t)i;
+}
+__global__ void __launch_bounds__(BS) k_gather_sorted_g(const RawKeyArgs *a_) {
+    const RawKeyArgs &a = a_[blockIdx.y];
+    const int i = blockIdx.x * BS + threadIdx.x;
+    if (i >= a.n) return;
+    const uint32_t v = a.perm[i];
+    a.pts[i] = make_float4(a.xyz[v * 3], a.xyz[v * 3 + 1], a.xyz[v * 3 + 2], 0.0f);
+    if (a.nrm) a.nrm_out[i] = make_float4(a.nrm[v * 3], a.nrm[v * 3 + 1], a.nrm[v * 3 + 2], 0.0f);
+}
+int pcr_import_clouds_batch(pcr_context *ctx, int count, const float *const *xyz, const float *const *nrm, const int64_t *n, DevCloud *cs, uint32_t **perms) {
+    if (count < 1) return PCR_OK;
+    std::vector<double> b6((size_t)count * 6);
+    PCR_TRY(pcr_dev_bounds_batch(ctx, count, xyz, n, b6.data()));
+    std::vector<RawKeyArgs> a((size_t)count);
+    std::vector<void *> temps((size_t)count); std::vector<const uint64_t *> kin((size_t)count); std::vector<uint64_t *> kout((size_t)count);
+    std::vector<const uint32_t *> vin((size_t)count); std::vector<uint32_t *> vout((size_t)count); std::vector<size_t> nn((size_t)count);
+    int max_nb = 1;
+    for (int c = 0; c < count; c++) {
+        if (n[c] > 0x7fffffff / 4) { ctx->err = "cloud too large"; return PCR_EINVAL; }
+        DevCloud *out = &cs[c];
+        perms[c] = arena<uint32_t>(ctx, n[c]);
+        uint64_t *k0 = arena<uint64_t>(ctx, n[c]); uint32_t *v0 = arena<uint32_t>(ctx, n[c]);
+        temps[c] = pcr_arena_alloc(ctx, pcr_sort_temp_bytes(n[c]));
+        if (!perms[c] || !k0 || !v0 || !temps[c]) return PCR_ENOMEM;
+        double emax = 0.0;
+        for (int d = 0; d < 3; d++) emax = b6[6 * c + 3 + d] - b6[6 * c + d] > emax ? b6[6 * c + 3 + d] - b6[6 * c + d] : emax;
+        for (int d = 0; d < 3; d++) { out->key_org[d] = (float)b6[6 * c + d]; out->key_unit[d] = emax > 0 ? (float)(emax / 65535.0) : 1.0f; }
+        RawKeyArgs &r = a[c];
+        r.xyz = xyz[c]; r.nrm = nrm ? nrm[c] : nullptr; r.n = (int)n[c]; r.ox = (float)b6[6 * c]; r.oy = (float)b6[6 * c + 1]; r.oz = (float)b6[6 * c + 2];
+        r.s = emax > 0 ? (float)(65535.0 / emax) : 0.0f; r.keys = k0; r.vals = v0; r.perm = perms[c]; r.pts = out->pts; r.nrm_out = out->nrm; r.n_dev = out->n;
+        if (r.nrm && !r.nrm_out) { ctx->err = "import batch: cloud allocated without normals"; return PCR_EINVAL; }
+        kin[c] = k0; kout[c] = out->keys; vin[c] = v0; vout[c] = perms[c]; nn[c] = (size_t)n[c];
+        const int nb = (int)((n[c] + BS - 1) / BS);
+        max_nb = nb > max_nb ? nb : max_nb;
+    }
+    const RawKeyArgs *d = pcr_desc_upload(ctx, a.data(), count);
+    if (!d) return PCR_ENOMEM;
+    PCR_LAUNCH(ctx, k_raw_keys_g, dim3(max_nb, count), dim3(BS), 0, ctx->stream, d);
+    PCR_TRY(pcr_sort_pairs_batch(ctx, count, temps.data(), kin.data(), kout.data(), vin.data(), vout.data(), nn.data(), 48));
+    PCR_LAUNCH(ctx, k_gather_sorted_g, dim3(max_nb, count), dim3(BS), 0, ctx->stream, d);
+    std::vector<DevCloud *> cp((size_t)count);
+    for (int c = 0; c < count; c++) cp[c] = &cs[c];
+    return pcr_dev_build_bvh_batch(ctx, cp.data(), count);
+}
+
 // ====================================================================== linear octree build (K2, part 2)
 // A: level of the highest Morton bit in which consecutive keys differ (-1: identical keys) + histogram
 #define OCT_ROW 24      // ints per tile row: cumulative node-start counts of the 22 key levels (+ padding)
@@ -1017,6 +1076,8 @@ struct KnnArgs {
     int seed_span;                                       // Morton-index half-width of the seed range (-1: k)
     int *zero_a, *zero_b;                                // optional counters of LATER kernels, zeroed here (saves two memset launches)
     uint8_t *hard; int wave_budget;                      // wavefront kernel: optional, queries it gave up after wave_budget batches (1) or served (0)
+    int *hard_list, *hard_count;                         // ... and (hard_list != nullptr, instead of `hard`) the first query of every wavefront it gave up, appended with one atomic
+                                                         //   per wavefront; the octet kernel's list form (k_knn_list) serves exactly those
     const uint8_t *keep; const int *pos;                 // optional: search only among points with keep[i] != 0; results and `todo`
                                                          //   are indexed by pos[i] (the compacted order) -- the cleaned cloud needs no tree of its own
 };
@@ -1024,19 +1085,14 @@ struct KnnArgs {
 __device__ static inline double octet_sum(double v) { return pcr_octet_sum(v); }
 
 struct KnnBatch { KnnArgs a[PCR_MAX_BATCH]; };
+// One wavefront = 8 Morton-consecutive queries g0 .. g0 + 7 (one per octet).  `stamp_slot`: index of the wavefront in the diagnostics buffer.
 template <int MODE, int SLOTS>
-__device__ static inline void d_knn(const KnnArgs &a) {
-    constexpr int OPB = KNN_BS / OCT;
-    __shared__ OctMeta m;
-    __shared__ OctGroupStack gstk[KNN_BS / 64];
-    if (threadIdx.x == 0) m = *a.t.meta;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { if (a.zero_a) *a.zero_a = 0; if (a.zero_b) *a.zero_b = 0; }
-    __syncthreads();
+__device__ static inline void d_knn_item(const KnnArgs &a, const OctMeta &m, OctGroupStack &gstk_w, const int g0, const size_t stamp_slot) {
     const int n = m.n;
-    const int lane = threadIdx.x & 63, oct = lane >> 3, ol = lane & 7, ob = threadIdx.x >> 3;
+    const int lane = threadIdx.x & 63, oct = lane >> 3, ol = lane & 7;
     const unsigned long long t_begin = wall_clock64();
     const unsigned long long c_begin = a.stamps ? __builtin_readcyclecounter() : 0ull;
-    const int qi = blockIdx.x * OPB + ob;
+    const int qi = g0 + oct;
     const int oq = (a.keep && qi < n) ? a.pos[qi] : qi;                 // output / todo index of this query
     const bool live = qi < n && (!a.keep || a.keep[qi]) && (!a.todo || a.todo[oq]);
     if (__ballot(live) == 0ull) return;                      // nothing to do for this wavefront
@@ -1046,7 +1102,6 @@ __device__ static inline void d_knn(const KnnArgs &a) {
 
     // the wavefront's 8 queries are Morton-consecutive points g0..g0+7: seed every query with the index range
     // [g0-k, g0+7+k] (it already holds most true neighbours), then ONE shared bottom-up walk completes all 8 exactly
-    const int g0 = blockIdx.x * OPB + (threadIdx.x >> 6) * OCT;
     const int glast = g0 + OCT - 1 < n - 1 ? g0 + OCT - 1 : n - 1;
     const int span = a.seed_span >= 0 ? a.seed_span : a.k;
     const int half = (a.k < OCT * SLOTS ? a.k : OCT * SLOTS) / 2 + OCT;      // the seed range must hold the direct fill
@@ -1101,16 +1156,16 @@ __device__ static inline void d_knn(const KnnArgs &a) {
     const float seed_worst = tk.worst;
     int nvis = 0;
     const int first_live = g0 + (__builtin_ctzll(__ballot(live)) >> 3);
-    oct_search_group(a.t, m, gstk[threadIdx.x >> 6], live, a.t.leaf_of[first_live], q.x, q.y, q.z, [&]() { return tk.worst; }, visit,
+    oct_search_group(a.t, m, gstk_w, live, a.t.leaf_of[first_live], q.x, q.y, q.z, [&]() { return tk.worst; }, visit,
                      [&](int f, int c) { return f >= plo && f + c - 1 <= phi; }, ol,
                      ((MODE == KNN_MODE_DEBUG && a.dbg_visits) || a.stamps) ? &nvis : nullptr);
     if (a.stamps && ol == 0) {
-        unsigned long long *w = a.stamps + 24 * ((size_t)blockIdx.x * (KNN_BS / 64) + (threadIdx.x >> 6));
+        unsigned long long *w = a.stamps + 24 * stamp_slot;
         w[8 + oct] = ((unsigned long long)__float_as_uint(seed_worst) << 32) | __float_as_uint(tk.worst);
         w[16 + oct] = ((unsigned long long)__float_as_uint(q.x) << 32) | __float_as_uint(q.y);
     }
     if (a.stamps && lane == 0) {
-        unsigned long long *w = a.stamps + 24 * ((size_t)blockIdx.x * (KNN_BS / 64) + (threadIdx.x >> 6));
+        unsigned long long *w = a.stamps + 24 * stamp_slot;
         w[4] = ((unsigned long long)(unsigned)st_scan << 32) | (unsigned)st_rounds;
         w[5] = ((unsigned long long)__float_as_uint(q.x) << 32) | __float_as_uint(q.y);
         w[6] = ((unsigned long long)__float_as_uint(q.z) << 32) | __float_as_uint(tk.worst);
@@ -1193,7 +1248,36 @@ __device__ static inline void d_knn(const KnnArgs &a) {
     }
 }
 
+template <int MODE, int SLOTS>
+__device__ static inline void d_knn(const KnnArgs &a) {
+    constexpr int OPB = KNN_BS / OCT;
+    __shared__ OctMeta m;
+    __shared__ OctGroupStack gstk[KNN_BS / 64];
+    if (threadIdx.x == 0) m = *a.t.meta;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { if (a.zero_a) *a.zero_a = 0; if (a.zero_b) *a.zero_b = 0; }
+    __syncthreads();
+    d_knn_item<MODE, SLOTS>(a, m, gstk[threadIdx.x >> 6], blockIdx.x * OPB + (threadIdx.x >> 6) * OCT, (size_t)blockIdx.x * (KNN_BS / 64) + (threadIdx.x >> 6));
+}
+// LIST form: the queries of the wavefronts the one-query-per-lane kernel gave up (pcr_knn_wave.h: it appends the first query of every such
+// wavefront of 64 to a.hard_list, one atomic per wavefront) and nothing else -- a fixed, small grid whose wavefronts stride over the
+// 8-query pieces of the listed wavefronts.  The full-range launch it replaces (todo mask over every query) took 18 % of the path's kernel
+// time for 5 % of its instructions: ~99 % of its wavefronts found nothing to do, behind everything else on the chip.
+template <int MODE, int SLOTS>
+__device__ static inline void d_knn_list(const KnnArgs &a) {
+    __shared__ OctMeta m;
+    __shared__ OctGroupStack gstk[KNN_BS / 64];
+    const int n_items = *a.hard_count * 8;                   // written by the kernel before this one on the stream
+    if ((int)blockIdx.x * (KNN_BS / 64) >= n_items) return;  // (uniform over the workgroup)
+    if (threadIdx.x == 0) m = *a.t.meta;
+    __syncthreads();
+    const int wv = threadIdx.x >> 6, waves = gridDim.x * (KNN_BS / 64);
+    for (int item = blockIdx.x * (KNN_BS / 64) + wv; item < n_items; item += waves)
+        d_knn_item<MODE, SLOTS>(a, m, gstk[wv], a.hard_list[item >> 3] + (item & 7) * OCT, 0);
+}
 template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) { d_knn<MODE, SLOTS>(a); }
+template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn_list(KnnArgs a) { d_knn_list<MODE, SLOTS>(a); }
+template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn_list_batch(KnnBatch b) { d_knn_list<MODE, SLOTS>(b.a[blockIdx.y]); }
+template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn_list_batchp(const KnnArgs *a) { d_knn_list<MODE, SLOTS>(a[blockIdx.y]); }
 template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn_batch(KnnBatch b) { d_knn<MODE, SLOTS>(b.a[blockIdx.y]); }
 template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn_batchp(const KnnArgs *a) { d_knn<MODE, SLOTS>(a[blockIdx.y]); }
 
@@ -1212,7 +1296,7 @@ template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn_b
 #define KNN_WAVE_MIN_POINTS 1500000       // ... or of that much query CAPACITY in all (the scales of config 5, 2M each: 21.7 -> 22.6 pairs/s; a lone 200k-point pair, 3 x 200k in a batch, is faster with the octet kernel: 208 against 183 pairs/s)
 static bool knn_wave_enabled(const pcr_context *ctx, int batch, long long points) {
     const int forced = pcr_options().knn_wave.load(std::memory_order_relaxed);
-    return forced >= 0 ? forced != 0 : (ctx->group_forms || batch >= KNN_WAVE_MIN_BATCH || points >= KNN_WAVE_MIN_POINTS);
+    return forced >= 0 ? forced != 0 : (!ctx->octet_only && (ctx->group_forms || batch >= KNN_WAVE_MIN_BATCH || points >= KNN_WAVE_MIN_POINTS));
 }
 static bool knn_wave_fits(const KnnArgs &a) { return a.k >= 1 && a.k <= 64 && !a.todo && !a.stamps && !a.dbg_visits; }
 // the wavefront kernel appends every query's k-best to a row in global memory: the caller's list (SOR) or scratch from the arena
@@ -1226,21 +1310,31 @@ static int knn_wave_rows(pcr_context *ctx, KnnArgs &a, int cap) {
 template <int MODE> static int launch_knn_wave_only(pcr_context *ctx, KnnArgs *a, int count, int mc, int kmax);
 static int knn_wave_budget() { return pcr_options().knnw_budget.load(std::memory_order_relaxed); }      // batches of 64 candidates in pass 1 (mean 17, p99 43 at k = 30)
 template <int MODE> static int launch_knn_octet_batch(pcr_context *ctx, KnnArgs *a, const int *caps, int count);
+// grid of the list form: enough wavefronts for the usual ~1 % of hard wavefronts at once, striding when there are more
+static int knn_list_grid(int cap) { const int g = cap / (64 * 16); return g < 8 ? 8 : (g > 128 ? 128 : g); }
 template <int MODE>
 static int launch_knn_wave_batch(pcr_context *ctx, KnnArgs *a, const int *caps, int count, int mc, int kmax) {
     for (int k = 0; k < count; k++) PCR_TRY(knn_wave_rows<MODE>(ctx, a[k], caps[k]));
-    // the queries of the wavefronts that give up (budget, log) go to the octet kernel in a second launch (k <= 32: its batched form)
+    // the queries of the wavefronts that give up (budget, log) go to the octet kernel in a second launch, through a list (k_knn_list)
     const int budget = knn_wave_budget();
-    const bool handover = MODE != KNN_MODE_DEBUG && kmax <= 32 && budget > 0;
-    if (handover) for (int k = 0; k < count; k++) {
-        a[k].hard = arena<uint8_t>(ctx, (size_t)(caps[k] > 0 ? caps[k] : 1)); a[k].wave_budget = budget;
-        if (!a[k].hard) return PCR_ENOMEM;
+    const bool handover = MODE != KNN_MODE_DEBUG && kmax <= 64 && budget > 0;
+    if (handover) {
+        int *counts = arena<int>(ctx, count);
+        if (!counts) return PCR_ENOMEM;
+        PCR_HIP_CHECK(ctx, hipMemsetAsync(counts, 0, sizeof(int) * (size_t)count, ctx->stream));
+        for (int k = 0; k < count; k++) {
+            a[k].hard = nullptr; a[k].wave_budget = budget; a[k].hard_count = counts + k;
+            a[k].hard_list = arena<int>(ctx, (size_t)(caps[k] > 0 ? caps[k] : 1) / 64 + 1);
+            if (!a[k].hard_list) return PCR_ENOMEM;
+        }
     }
     PCR_TRY(launch_knn_wave_only<MODE>(ctx, a, count, mc, kmax));
     if (!handover) return PCR_OK;
     std::vector<KnnArgs> o(a, a + count);
-    for (int k = 0; k < count; k++) { o[k].todo = a[k].hard; o[k].hard = nullptr; o[k].zero_a = nullptr; o[k].zero_b = nullptr; o[k].seed_span = -1; }
-    return launch_knn_octet_batch<MODE>(ctx, o.data(), caps, count);
+    for (int k = 0; k < count; k++) { o[k].todo = nullptr; o[k].zero_a = nullptr; o[k].zero_b = nullptr; o[k].seed_span = -1; }
+    const dim3 grid(knn_list_grid(mc), count), block(KNN_BS);
+    if (kmax <= 32) return PCR_BATCH_LAUNCH(ctx, KnnBatch, (k_knn_list_batch<MODE, 4>), (k_knn_list_batchp<MODE, 4>), o.data(), count, grid, block);
+    return PCR_BATCH_LAUNCH(ctx, KnnBatch, (k_knn_list_batch<MODE, 8>), (k_knn_list_batchp<MODE, 8>), o.data(), count, grid, block);
 }
 template <int MODE>
 static int launch_knn_wave_only(pcr_context *ctx, KnnArgs *a, int count, int mc, int kmax) {
@@ -1272,18 +1366,20 @@ static int launch_knn_wave(pcr_context *ctx, int cap, KnnArgs a) {
     const int budget = knn_wave_budget();
     const bool handover = MODE != KNN_MODE_DEBUG && budget > 0;
     if (handover) {
-        a.hard = arena<uint8_t>(ctx, (size_t)(cap > 0 ? cap : 1)); a.wave_budget = budget;
-        if (!a.hard) return PCR_ENOMEM;
+        a.hard = nullptr; a.wave_budget = budget;
+        a.hard_count = arena<int>(ctx, 1); a.hard_list = arena<int>(ctx, (size_t)(cap > 0 ? cap : 1) / 64 + 1);
+        if (!a.hard_count || !a.hard_list) return PCR_ENOMEM;
+        PCR_HIP_CHECK(ctx, hipMemsetAsync(a.hard_count, 0, sizeof(int), ctx->stream));
     }
     if (a.k <= 20) PCR_LAUNCH(ctx, (k_knn_wave<MODE, 20>), grid, block, 0, ctx->stream, a);
     else if (a.k <= 30) PCR_LAUNCH(ctx, (k_knn_wave<MODE, 30>), grid, block, 0, ctx->stream, a);
     else PCR_LAUNCH(ctx, (k_knn_wave<MODE, 64>), grid, block, 0, ctx->stream, a);
-    if (handover) {                                  // the queries of the wavefronts that gave up: octet kernel, 8 per wavefront
+    if (handover) {                                  // the queries of the wavefronts that gave up: the octet kernel's list form, 8 per wavefront
         KnnArgs o = a;
-        o.todo = a.hard; o.hard = nullptr; o.zero_a = nullptr; o.zero_b = nullptr; o.seed_span = -1;
-        const dim3 og((unsigned)(((size_t)cap * OCT + KNN_BS - 1) / KNN_BS));
-        if (o.k <= 32) PCR_LAUNCH(ctx, (k_knn<MODE, 4>), og, dim3(KNN_BS), 0, ctx->stream, o);
-        else PCR_LAUNCH(ctx, (k_knn<MODE, 8>), og, dim3(KNN_BS), 0, ctx->stream, o);
+        o.todo = nullptr; o.zero_a = nullptr; o.zero_b = nullptr; o.seed_span = -1;
+        const dim3 og(knn_list_grid(cap));
+        if (o.k <= 32) PCR_LAUNCH(ctx, (k_knn_list<MODE, 4>), og, dim3(KNN_BS), 0, ctx->stream, o);
+        else PCR_LAUNCH(ctx, (k_knn_list<MODE, 8>), og, dim3(KNN_BS), 0, ctx->stream, o);
     }
     return PCR_OK;
 }
@@ -1311,13 +1407,18 @@ static int launch_knn_batch(pcr_context *ctx, KnnArgs *a, const int *caps, int c
 template <int MODE>
 static int launch_knn_octet_batch(pcr_context *ctx, KnnArgs *a, const int *caps, int count) {
     int mc = 0;
+    int kmax = 0;
     for (int k = 0; k < count; k++) {
-        if (a[k].k < 1 || a[k].k > 32) { ctx->err = "batched k-NN: k must be in 1..32"; return PCR_EINVAL; }
+        if (a[k].k < 1 || a[k].k > 200) { ctx->err = "batched k-NN: k must be in 1..200"; return PCR_EINVAL; }
         a[k].seed_span = -1;
-        mc = caps[k] > mc ? caps[k] : mc;
+        mc = caps[k] > mc ? caps[k] : mc; kmax = a[k].k > kmax ? a[k].k : kmax;
     }
     if (mc <= 0) return PCR_OK;
-    return PCR_BATCH_LAUNCH(ctx, KnnBatch, (k_knn_batch<MODE, 4>), (k_knn_batchp<MODE, 4>), a, count, dim3((unsigned)(((size_t)mc * OCT + KNN_BS - 1) / KNN_BS), count), dim3(KNN_BS));
+    // register slots per lane by the largest k of the batch, exactly as the one-cloud launch picks them (launch_knn_cap): same arithmetic
+    const dim3 grid((unsigned)(((size_t)mc * OCT + KNN_BS - 1) / KNN_BS), count), block(KNN_BS);
+    if (kmax <= 32) return PCR_BATCH_LAUNCH(ctx, KnnBatch, (k_knn_batch<MODE, 4>), (k_knn_batchp<MODE, 4>), a, count, grid, block);
+    if (kmax <= 64) return PCR_BATCH_LAUNCH(ctx, KnnBatch, (k_knn_batch<MODE, 8>), (k_knn_batchp<MODE, 8>), a, count, grid, block);
+    return PCR_BATCH_LAUNCH(ctx, KnnBatch, (k_knn_batch<MODE, 25>), (k_knn_batchp<MODE, 25>), a, count, grid, block);
 }
 
 template <int MODE>
@@ -1715,6 +1816,12 @@ int pcr_dev_sor_batch(pcr_context *ctx, const DevCloud *const *ins, DevCloud *co
 }
 // k-NN normals of `count` clouds over their own trees in one launch (todo masks optional): the incomplete lists of the cleaned targets
 int pcr_dev_normals_knn_batch(pcr_context *ctx, DevCloud *const *cs, int count, int knn, const float4 *const *priors, float4 *const *normals_out, const uint8_t *const *todos) {
+    return pcr_dev_normals_batch(ctx, cs, count, PCR_SEARCH_KNN, knn, 0.0, priors, normals_out, todos);
+}
+int pcr_dev_normals_batch(pcr_context *ctx, DevCloud *const *cs, int count, int search_kind, int knn, double radius, const float4 *const *priors, float4 *const *normals_out,
+                          const uint8_t *const *todos) {
+    if (search_kind != PCR_SEARCH_KNN && search_kind != PCR_SEARCH_HYBRID) { ctx->err = "normals batch: KNN or Hybrid search"; return PCR_EINVAL; }
+    if (search_kind == PCR_SEARCH_HYBRID && !(radius > 0)) { ctx->err = "radius <= 0"; return PCR_EINVAL; }
     if (knn < 1) { ctx->err = "knn < 1"; return PCR_EINVAL; }
     if (count > PCR_MAX_GROUP_BATCH) { ctx->err = "normals batch size"; return PCR_EINVAL; }
     std::vector<KnnArgs> bv((size_t)(count > 0 ? count : 1)); std::memset(bv.data(), 0, sizeof(KnnArgs) * bv.size());
@@ -1723,13 +1830,38 @@ int pcr_dev_normals_knn_batch(pcr_context *ctx, DevCloud *const *cs, int count, 
         if (cs[k]->cap <= 0) continue;
         KnnArgs &a = b.a[m];
         a.t = oct_view(cs[k]); a.n_ptr = cs[k]->n; a.k = knn; a.prior = priors ? priors[k] : nullptr; a.normals = normals_out[k]; a.todo = todos ? todos[k] : nullptr; a.seed_span = -1;
-        knn_radius(a, PCR_SEARCH_KNN, 0);
+        knn_radius(a, search_kind, radius);
         caps[m++] = cs[k]->cap;
     }
     if (m == 0) return PCR_OK;
     if (knn <= 32) return launch_knn_batch<KNN_MODE_NORMALS>(ctx, b.a, caps, m);
     for (int k = 0; k < m; k++) { DevCloud tmp; tmp.cap = caps[k]; PCR_TRY(launch_knn<KNN_MODE_NORMALS>(ctx, &tmp, b.a[k])); }
     return PCR_OK;
+}
+// the k-best lists of `count` clouds in one launch of the octet kernel (the FPFH neighbour lists of a lockstep FGR group): per cloud
+// exactly pcr_dev_knn_debug
+int pcr_dev_knn_lists_batch(pcr_context *ctx, const DevCloud *const *cs, int count, int k, double radius, int32_t *const *idx, float *const *d2) {
+    if (count < 1) return PCR_OK;
+    if (count > PCR_MAX_GROUP_BATCH) { ctx->err = "k-NN list batch size"; return PCR_EINVAL; }
+    std::vector<KnnArgs> av((size_t)count); std::memset(av.data(), 0, sizeof(KnnArgs) * av.size());
+    std::vector<int> caps((size_t)count); int m = 0;
+    for (int c = 0; c < count; c++) {
+        if (cs[c]->cap <= 0) continue;
+        KnnArgs &a = av[m];
+        a.t = oct_view(cs[c]); a.n_ptr = cs[c]->n; a.k = k;
+        knn_radius(a, radius > 0 ? PCR_SEARCH_HYBRID : PCR_SEARCH_KNN, radius);
+        if (radius > 0) a.r2cap_f = (float)(radius * radius);
+        a.dbg_idx = idx[c]; a.dbg_d2 = d2[c]; a.dbg_cnt = nullptr; a.dbg_visits = 0;
+        caps[m++] = cs[c]->cap;
+    }
+    if (m == 0) return PCR_OK;
+    return launch_knn_octet_batch<KNN_MODE_DEBUG>(ctx, av.data(), caps.data(), m);
+}
+int pcr_dev_flag_scan_batch(pcr_context *ctx, int count, uint8_t *const *flags, const int *const *n_ptr, const int *n_cap, int *const *pos, int *const *total_dev) {
+    if (count < 1) return PCR_OK;
+    std::vector<ScanArgs> a((size_t)count);
+    for (int c = 0; c < count; c++) PCR_TRY(scan_args(ctx, &a[c], flags[c], n_ptr ? n_ptr[c] : nullptr, n_cap[c], pos[c], total_dev[c], FlagSrc{nullptr, nullptr, nullptr}));
+    return flag_scan_batch(ctx, a.data(), count);
 }
 
 // ================================================================== covariances / normals (K5)

@@ -65,7 +65,7 @@ typedef float fn_f4 __attribute__((ext_vector_type(4)));
 // ---- column means of a feature matrix (the centring vector; any vector is valid, the mean keeps the norms small) -------------
 // part: gridDim.x rows of 34 = 33 column sums + the largest |value| (the f16 split needs |f - mu| * 128 < 65504)
 #define FN_PC (FN_D + 1)
-__global__ void __launch_bounds__(256) k_fn_colsum(const float *__restrict__ f, int n, double *__restrict__ part) {
+__device__ static inline void d_fn_colsum(const float *__restrict__ f, int n, double *__restrict__ part) {
     __shared__ double sh[256 / 64][FN_PC];
     double s[FN_D], mx = 0.0;
 #pragma unroll
@@ -86,9 +86,13 @@ __global__ void __launch_bounds__(256) k_fn_colsum(const float *__restrict__ f, 
         part[blockIdx.x * FN_PC + threadIdx.x] = v;
     }
 }
+__global__ void __launch_bounds__(256) k_fn_colsum(const float *__restrict__ f, int n, double *__restrict__ part) { d_fn_colsum(f, n, part); }
+// batch forms (lockstep FGR groups, pcr_feature_nn_mutual_batch): blockIdx.y picks the matrix / the pair / the (pair, direction) problem
+struct FnColsumDesc { const float *f; int n; double *part; };
+__global__ void __launch_bounds__(256) k_fn_colsum_g(const FnColsumDesc *d) { const FnColsumDesc a = d[blockIdx.y]; d_fn_colsum(a.f, a.n, a.part); }
 // mu[0..32] = column means of the first matrix, mu[33] = largest |value| over both
 // (also resets the first-zero-row words and the overflow flags of the call: it runs before the splits that use them)
-__global__ void k_fn_mean(const double *__restrict__ part, int nb, int n, double *__restrict__ mu, int *__restrict__ first_zero, int *__restrict__ flags) {
+__device__ static inline void d_fn_mean(const double *__restrict__ part, int nb, int n, double *__restrict__ mu, int *__restrict__ first_zero, int *__restrict__ flags) {
     if (threadIdx.x == 63) { first_zero[0] = 0x7fffffff; first_zero[1] = 0x7fffffff; flags[0] = 0; flags[1] = 0; }
     if (threadIdx.x < FN_PC) {
         double v = 0;
@@ -99,6 +103,9 @@ __global__ void k_fn_mean(const double *__restrict__ part, int nb, int n, double
         mu[threadIdx.x] = threadIdx.x == FN_D ? v : (n > 0 ? v / (double)n : 0.0);
     }
 }
+__global__ void k_fn_mean(const double *__restrict__ part, int nb, int n, double *__restrict__ mu, int *__restrict__ first_zero, int *__restrict__ flags) { d_fn_mean(part, nb, n, mu, first_zero, flags); }
+struct FnMeanDesc { const double *part; int nb, n; double *mu; int *first_zero, *flags; };
+__global__ void k_fn_mean_g(const FnMeanDesc *d) { const FnMeanDesc a = d[blockIdx.x]; d_fn_mean(a.part, a.nb, a.n, a.mu, a.first_zero, a.flags); }
 
 // ---- split: one thread per row.  A-form (database role) [hi | hi | lo | 0], B-form (query role) [hi | lo | hi | 0]; norm of the
 // exact centred, scaled row; nlo = (1 - c) |x|^2 rounded down (the lower-bound test needs no per-row multiply in the hot loop).
@@ -108,9 +115,9 @@ __global__ void k_fn_mean(const double *__restrict__ part, int nb, int n, double
 // the database, at distance exactly 0 -- so the split marks them (sign bit of nrm) and records the first zero row of each matrix.
 // perm (optional): row i of the forms is row perm[i] of f (the tile-pruned screen works on rows in Morton order of their leading
 // principal coordinates); first_zero is always an index into f.
-__global__ void __launch_bounds__(256) k_fn_split(const float *__restrict__ f_, int n, int n_pad, const double *__restrict__ mu,
-                                                  _Float16 *__restrict__ A, _Float16 *__restrict__ B, float *__restrict__ nlo, float *__restrict__ nrm,
-                                                  int *__restrict__ first_zero, const uint32_t *__restrict__ perm) {
+__device__ static inline void d_fn_split(const float *__restrict__ f_, int n, int n_pad, const double *__restrict__ mu,
+                                         _Float16 *__restrict__ A, _Float16 *__restrict__ B, float *__restrict__ nlo, float *__restrict__ nrm,
+                                         int *__restrict__ first_zero, const uint32_t *__restrict__ perm) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_pad) return;
     const int src = (i < n && perm) ? (int)perm[i] : i;
@@ -137,6 +144,11 @@ __global__ void __launch_bounds__(256) k_fn_split(const float *__restrict__ f_, 
         if (zero) atomicMin(first_zero, src);
     } else { nlo[i] = 1.0e30f; nrm[i] = 0.0f; }
 }
+__global__ void __launch_bounds__(256) k_fn_split(const float *__restrict__ f_, int n, int n_pad, const double *__restrict__ mu,
+                                                  _Float16 *__restrict__ A, _Float16 *__restrict__ B, float *__restrict__ nlo, float *__restrict__ nrm,
+                                                  int *__restrict__ first_zero, const uint32_t *__restrict__ perm) { d_fn_split(f_, n, n_pad, mu, A, B, nlo, nrm, first_zero, perm); }
+struct FnSplitDesc { const float *f; int n, n_pad; const double *mu; _Float16 *A, *B; float *nlo, *nrm; int *first_zero; };
+__global__ void __launch_bounds__(256) k_fn_split_g(const FnSplitDesc *d) { const FnSplitDesc a = d[blockIdx.y]; d_fn_split(a.f, a.n, a.n_pad, a.mu, a.A, a.B, a.nlo, a.nrm, a.first_zero, nullptr); }
 
 // ================================================================================================ tile pruning (round 2)
 // The all-pairs screen costs 4 MFMAs per 16 x 16 block whatever the data.  FPFH rows are far from uniform in their 33-D space (four
@@ -354,11 +366,12 @@ struct FnnArgs {
 // ---- the screen.  grid = (query groups of 512, splits of the database)
 // BOUND_ONLY: no candidates and no records, only the queries' upper bounds are lowered (over the first a.n_bound entries of the pre-pass list)
 template <bool BOUND_ONLY>
-__global__ void __launch_bounds__(FN_WG) k_feature_nn_screen(FnnArgs a) {
+__device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][FN_SUBS * FN_SUB_BYTES];
     __shared__ __attribute__((aligned(16))) float lnlo[2][FN_STEP];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int col = lane & 15, g = lane >> 4;
+    if ((int)blockIdx.x * FN_QPG >= a.n_q_pad) return;             // (batch launches: the grid is the largest problem's)
     const int q0 = (blockIdx.x * (FN_WG / 64) + wv) * FN_QPW;
     const int s0 = a.pre_mode ? 0 : a.step0 + blockIdx.y * a.steps_per_split;
     const int s1 = a.pre_mode ? 0 : min(a.step_end, s0 + a.steps_per_split);
@@ -574,6 +587,8 @@ __global__ void __launch_bounds__(FN_WG) k_feature_nn_screen(FnnArgs a) {
             if (q < a.n_q) atomicMin(&a.Ug[q], fn_ord(U[b]));
         }
 }
+template <bool BOUND_ONLY> __global__ void __launch_bounds__(FN_WG) k_feature_nn_screen(FnnArgs a) { d_feature_nn_screen<BOUND_ONLY>(a); }
+template <bool BOUND_ONLY> __global__ void __launch_bounds__(FN_WG) k_feature_nn_screen_g(const FnnArgs *a) { d_feature_nn_screen<BOUND_ONLY>(a[blockIdx.z]); }
 
 // ---- exact float64 distance exactly as the oracle's kd-tree leaf loop computes it: d2 += e * e with the product and the sum
 // rounded separately, k = 0 .. 32 in order
@@ -604,7 +619,7 @@ __device__ static inline bool fn_record(const FnxArgs &a, int r, int *q, int *ro
     return a.rec_w[r] <= thr;                             // else: could not be the minimum given the final bound
 }
 // pass 1: smallest exact distance per query
-__global__ void __launch_bounds__(256) k_fn_exact_min(FnxArgs a, int n_rec_cap) {
+__device__ static inline void d_fn_exact_min(const FnxArgs &a, int n_rec_cap) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     int q, row;
     if (r >= n_rec_cap || !fn_record(a, r, &q, &row)) return;
@@ -620,30 +635,41 @@ __global__ void __launch_bounds__(256) k_fn_exact_min(FnxArgs a, int n_rec_cap) 
     }
 }
 // pass 2: smallest row among the records that attain it (exact ties -> smaller index, as the oracle's heap orders them)
-__global__ void __launch_bounds__(256) k_fn_exact_arg(FnxArgs a, int n_rec_cap) {
+__global__ void __launch_bounds__(256) k_fn_exact_min(FnxArgs a, int n_rec_cap) { d_fn_exact_min(a, n_rec_cap); }
+__device__ static inline void d_fn_exact_arg(const FnxArgs &a, int n_rec_cap) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     int q, row;
     if (r >= n_rec_cap || !fn_record(a, r, &q, &row)) return;
     if ((unsigned long long)__double_as_longlong(a.rec_d[r]) == a.best_d[q]) atomicMin(&a.out[a.perm_q ? a.perm_q[q] : q], (int)(a.perm_db ? a.perm_db[row] : row));
 }
+__global__ void __launch_bounds__(256) k_fn_exact_arg(FnxArgs a, int n_rec_cap) { d_fn_exact_arg(a, n_rec_cap); }
 // pass 3: zero queries take the first zero row; a query without any record (empty database) gets -1
-__global__ void __launch_bounds__(256) k_fn_finish(FnxArgs a) {
+__device__ static inline void d_fn_finish(const FnxArgs &a) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= a.n_q) return;
     const int oq = a.perm_q ? (int)a.perm_q[q] : q;
     if (__builtin_signbit(a.q_nrm[q]) && *a.db_first_zero != 0x7fffffff) a.out[oq] = *a.db_first_zero;
     else if (a.out[oq] == 0x7fffffff) a.out[oq] = -1;
 }
+__global__ void __launch_bounds__(256) k_fn_finish(FnxArgs a) { d_fn_finish(a); }
+struct FnxDesc { FnxArgs x; int n_rec_cap; };
+__global__ void __launch_bounds__(256) k_fn_exact_min_g(const FnxDesc *d) { const FnxDesc &a = d[blockIdx.y]; if ((int)blockIdx.x * 256 < a.n_rec_cap) d_fn_exact_min(a.x, a.n_rec_cap); }
+__global__ void __launch_bounds__(256) k_fn_exact_arg_g(const FnxDesc *d) { const FnxDesc &a = d[blockIdx.y]; if ((int)blockIdx.x * 256 < a.n_rec_cap) d_fn_exact_arg(a.x, a.n_rec_cap); }
+__global__ void __launch_bounds__(256) k_fn_finish_g(const FnxDesc *d) { const FnxDesc &a = d[blockIdx.y]; if ((int)blockIdx.x * 256 < a.x.n_q) d_fn_finish(a.x); }
 
 // one launch instead of five memsets per direction (registro_FGR on NCLT-size clouds is bound by the rate of small dependent launches)
-__global__ void __launch_bounds__(256) k_fn_init(int *pool_used, int *chunk_fill, int n_chunks, int *Ug, int n_ug, unsigned long long *best_d, int32_t *out, int n_q,
-                                                 int *first_zero, int *flags) {
+__device__ static inline void d_fn_init(int *pool_used, int *chunk_fill, int n_chunks, int *Ug, int n_ug, unsigned long long *best_d, int32_t *out, int n_q,
+                                        int *first_zero, int *flags) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0) { *pool_used = 0; if (first_zero) { first_zero[0] = 0x7fffffff; first_zero[1] = 0x7fffffff; flags[0] = 0; flags[1] = 0; } }
     if (i < n_chunks) chunk_fill[i] = 0;
     if (i < n_ug) Ug[i] = 0x7f800000;                      // +inf
     if (i < n_q) { best_d[i] = ~0ull; out[i] = 0x7fffffff; }
 }
+__global__ void __launch_bounds__(256) k_fn_init(int *pool_used, int *chunk_fill, int n_chunks, int *Ug, int n_ug, unsigned long long *best_d, int32_t *out, int n_q,
+                                                 int *first_zero, int *flags) { d_fn_init(pool_used, chunk_fill, n_chunks, Ug, n_ug, best_d, out, n_q, first_zero, flags); }
+struct FnInitDesc { int *pool_used, *chunk_fill; int n_chunks; int *Ug; int n_ug; unsigned long long *best_d; int32_t *out; int n_q; };
+__global__ void __launch_bounds__(256) k_fn_init_g(const FnInitDesc *d) { const FnInitDesc a = d[blockIdx.y]; d_fn_init(a.pool_used, a.chunk_fill, a.n_chunks, a.Ug, a.n_ug, a.best_d, a.out, a.n_q, nullptr, nullptr); }
 
 // ------------------------------------------------------------------------------------------------------------------ driver
 size_t pcr_feature_nn_scratch_bytes(int64_t n0, int64_t n1) {
@@ -867,5 +893,132 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         if (h) return PCR_ECAPACITY;
     }
+    return PCR_OK;
+}
+
+// ---- the mutual search of G pairs through the same launches (lockstep FGR groups).  Only the form WITHOUT tile pruning (every pair under
+// 5e9 row pairs: NCLT-size clouds, where the chain of small launches per pair is the whole cost); per pair the arithmetic, the split of the
+// steps and the pool sizes are exactly those of pcr_feature_nn_mutual, so the matches are the same bits.  Returns PCR_ECAPACITY when a
+// pair wants the pruned form or its features leave the f16 range (the caller then runs the pairs one by one); `overflow_dev[g]` = a device
+// int (the words of all pairs lie in ONE array, two per pair, so overflow_dev[0] + 2 g is pair g's) the caller reads with its next read-back: != 0 means the record pool of pair g overflowed (that pair alone is redone on the float64 path).
+int pcr_feature_nn_mutual_batch(pcr_context *ctx, int G, const float *const *f0, const int *n0, const float *const *f1, const int *n1, int32_t *const *out_1to0,
+                                int32_t *const *out_0to1, const int **overflow_dev) {
+    if (G < 1) return PCR_OK;
+    for (int g = 0; g < G; g++) {
+        if (n0[g] < 64 || n1[g] < 64) return PCR_ECAPACITY;
+        if ((double)n0[g] * (double)n1[g] >= 5.0e9) return PCR_ECAPACITY;
+    }
+    const int nbm = 64;
+    struct Pair { const float *f[2]; int n[2], np[2]; double *part, *mu; int *first_zero, *flags; _Float16 *A[2], *B[2]; float *nlo[2], *nrm[2]; };
+    std::vector<Pair> P((size_t)G);
+    std::vector<FnColsumDesc> cs((size_t)2 * G); std::vector<FnMeanDesc> ms((size_t)G);
+    double *mu_all = arena<double>(ctx, (size_t)G * FN_PC);              // per-group arrays: one read-back each
+    int *flags_all = arena<int>(ctx, (size_t)2 * G), *zero_all = arena<int>(ctx, (size_t)2 * G);
+    if (!mu_all || !flags_all || !zero_all) return PCR_ENOMEM;
+    for (int g = 0; g < G; g++) {
+        Pair &p = P[g];
+        p.f[0] = f0[g]; p.f[1] = f1[g]; p.n[0] = n0[g]; p.n[1] = n1[g];
+        p.part = arena<double>(ctx, (size_t)2 * nbm * FN_PC);
+        p.first_zero = zero_all + 2 * g; p.flags = flags_all + 2 * g;
+        if (!p.part) return PCR_ENOMEM;
+        p.mu = mu_all + (size_t)g * FN_PC;
+        cs[2 * g] = FnColsumDesc{p.f[0], p.n[0], p.part}; cs[2 * g + 1] = FnColsumDesc{p.f[1], p.n[1], p.part + (size_t)nbm * FN_PC};
+        ms[g] = FnMeanDesc{p.part, nbm, p.n[0], p.mu, p.first_zero, p.flags};
+        for (int c = 0; c < 2; c++) p.np[c] = (p.n[c] + FN_QPG - 1) / FN_QPG * FN_QPG;
+    }
+    {
+        const FnColsumDesc *dc = pcr_desc_upload(ctx, cs.data(), 2 * G);
+        const FnMeanDesc *dm = pcr_desc_upload(ctx, ms.data(), G);
+        if (!dc || !dm) return PCR_ENOMEM;
+        PCR_LAUNCH(ctx, k_fn_colsum_g, dim3(nbm, 2 * G), dim3(256), 0, ctx->stream, dc);
+        PCR_LAUNCH(ctx, k_fn_mean_g, dim3(G), dim3(64), 0, ctx->stream, dm);
+    }
+    {   // the f16 split holds |f - mu| * 128 < 65504 (pcr_feature_nn_mutual): one read-back for the group
+        std::vector<double> hmu((size_t)G * FN_PC);
+        PCR_HIP_CHECK(ctx, hipMemcpyAsync(hmu.data(), mu_all, sizeof(double) * hmu.size(), hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int g = 0; g < G; g++) {
+            double mm = 0; for (int k = 0; k < FN_D; k++) mm = fmax(mm, fabs(hmu[(size_t)g * FN_PC + k]));
+            if (!((hmu[(size_t)g * FN_PC + FN_D] + mm) * FN_SCALE < 60000.0)) return PCR_ECAPACITY;
+        }
+    }
+    std::vector<FnSplitDesc> ss((size_t)2 * G);
+    int max_np = 0;
+    for (int g = 0; g < G; g++) {
+        Pair &p = P[g];
+        for (int c = 0; c < 2; c++) {
+            p.A[c] = arena<_Float16>(ctx, (size_t)p.np[c] * FN_K); p.B[c] = arena<_Float16>(ctx, (size_t)p.np[c] * FN_K);
+            p.nlo[c] = arena<float>(ctx, p.np[c]); p.nrm[c] = arena<float>(ctx, p.np[c]);
+            if (!p.A[c] || !p.B[c] || !p.nlo[c] || !p.nrm[c]) return PCR_ENOMEM;
+            ss[2 * g + c] = FnSplitDesc{p.f[c], p.n[c], p.np[c], p.mu, p.A[c], p.B[c], p.nlo[c], p.nrm[c], p.first_zero + c};
+            max_np = p.np[c] > max_np ? p.np[c] : max_np;
+        }
+    }
+    {
+        const FnSplitDesc *ds = pcr_desc_upload(ctx, ss.data(), 2 * G);
+        if (!ds) return PCR_ENOMEM;
+        PCR_LAUNCH(ctx, k_fn_split_g, dim3((max_np + 255) / 256, 2 * G), dim3(256), 0, ctx->stream, ds);
+    }
+    // problems = (pair, direction): direction 0 = queries of cloud 1 against the rows of cloud 0
+    const int NP = 2 * G;
+    std::vector<FnInitDesc> is((size_t)NP); std::vector<FnnArgs> bound((size_t)NP), rec((size_t)NP); std::vector<FnxDesc> xs((size_t)NP);
+    int max_init = 0, max_groups = 0, max_pb = 0, max_splits = 0, max_pool = 0, max_nq = 0;
+    for (int g = 0; g < G; g++)
+        for (int dir = 0; dir < 2; dir++) {
+            Pair &p = P[g];
+            const int qc = dir == 0 ? 1 : 0, dc = 1 - qc, k = 2 * g + dir;
+            int32_t *out = dir == 0 ? out_1to0[g] : out_0to1[g];
+            const int nq = p.n[qc], nqp = p.np[qc], steps = p.np[dc] / FN_STEP, groups = nqp / FN_QPG;
+            int splits_all = (2048 + groups - 1) / groups;
+            if (splits_all > 256) splits_all = 256;
+            if (splits_all < (steps + FN_LIST_CAP - 1) / FN_LIST_CAP) splits_all = (steps + FN_LIST_CAP - 1) / FN_LIST_CAP;
+            if (splits_all > steps) splits_all = steps;
+            const int sps_all = (steps + splits_all - 1) / splits_all;
+            if (sps_all > FN_LIST_CAP) return PCR_ECAPACITY;
+            // (the pool is sized as the one-pair call sizes it: its `splits` of the pruned form never exceeds splits_all when pruning is off)
+            const int pre = steps <= 128 ? steps : 64, rest = steps - pre;
+            int splits = rest > 0 ? (2048 + groups - 1) / groups : 1;
+            if (splits > 256) splits = 256;
+            if (splits < (rest + FN_LIST_CAP - 1) / FN_LIST_CAP) splits = (rest + FN_LIST_CAP - 1) / FN_LIST_CAP;
+            if (splits > rest) splits = rest > 0 ? rest : 1;
+            const size_t waves = (size_t)groups * (FN_WG / 64) * (size_t)(1 + (splits > splits_all ? splits : splits_all));
+            const int pool_cap = (int)(((size_t)nqp * FN_POOL_PER_QUERY + waves * FN_CHUNK + FN_CHUNK - 1) / FN_CHUNK * FN_CHUNK);
+            int *pool_used = arena<int>(ctx, 1), *chunk_fill = arena<int>(ctx, pool_cap / FN_CHUNK);
+            int *rec_q = arena<int>(ctx, pool_cap), *rec_row = arena<int>(ctx, pool_cap); float *rec_w = arena<float>(ctx, pool_cap);
+            int *Ug = arena<int>(ctx, nqp);
+            unsigned long long *best_d = arena<unsigned long long>(ctx, nq);
+            double *rec_d = arena<double>(ctx, pool_cap);
+            if (!pool_used || !chunk_fill || !rec_q || !rec_row || !rec_w || !Ug || !best_d || !rec_d) return PCR_ENOMEM;
+            const int n_chunks = pool_cap / FN_CHUNK, n_init = std::max(std::max(n_chunks, nqp), nq);
+            is[k] = FnInitDesc{pool_used, chunk_fill, n_chunks, Ug, nqp, best_d, out, nq};
+            FnnArgs a;
+            a.dbA = p.A[dc]; a.db_nlo = p.nlo[dc]; a.n_db_pad = p.np[dc]; a.qB = p.B[qc]; a.q_nrm = p.nrm[qc]; a.n_q = nq; a.n_q_pad = nqp;
+            a.db_first_zero = p.first_zero + dc; a.Ug = Ug;
+            a.pool_used = pool_used; a.pool_cap = pool_cap; a.chunk_fill = chunk_fill; a.rec_q = rec_q; a.rec_row = rec_row; a.rec_w = rec_w; a.flags = p.flags;
+            a.L = nullptr; a.L_stride = 0; a.n_qt = 0; a.prelist = nullptr; a.pre_mode = 0; a.n_bound = 0; a.stats = nullptr;
+            const int pre_b = steps < 64 ? steps : 64, pb_splits = pre_b < 8 ? pre_b : 8, pb_sps = (pre_b + pb_splits - 1) / pb_splits;
+            a.step0 = 0; a.steps_per_split = pb_sps; a.step_end = pre_b;
+            bound[k] = a;
+            a.step0 = 0; a.steps_per_split = sps_all; a.step_end = steps;
+            rec[k] = a;
+            FnxArgs x;
+            x.q = p.f[qc]; x.q_nrm = p.nrm[qc]; x.n_q = nq; x.db = p.f[dc]; x.n_db = p.n[dc]; x.db_nlo = p.nlo[dc]; x.db_first_zero = p.first_zero + dc; x.Ug = Ug;
+            x.pool_used = pool_used; x.chunk_fill = chunk_fill; x.rec_q = rec_q; x.rec_row = rec_row; x.rec_w = rec_w; x.best_d = best_d; x.out = out; x.dbg = nullptr;
+            x.perm_q = nullptr; x.perm_db = nullptr; x.rec_d = rec_d;
+            xs[k] = FnxDesc{x, pool_cap};
+            max_init = n_init > max_init ? n_init : max_init; max_groups = groups > max_groups ? groups : max_groups; max_pb = pb_splits > max_pb ? pb_splits : max_pb;
+            max_splits = splits_all > max_splits ? splits_all : max_splits; max_pool = pool_cap > max_pool ? pool_cap : max_pool; max_nq = nq > max_nq ? nq : max_nq;
+        }
+    const FnInitDesc *di = pcr_desc_upload(ctx, is.data(), NP);
+    const FnnArgs *db = pcr_desc_upload(ctx, bound.data(), NP), *dr = pcr_desc_upload(ctx, rec.data(), NP);
+    const FnxDesc *dx = pcr_desc_upload(ctx, xs.data(), NP);
+    if (!di || !db || !dr || !dx) return PCR_ENOMEM;
+    PCR_LAUNCH(ctx, k_fn_init_g, dim3((max_init + 255) / 256, NP), dim3(256), 0, ctx->stream, di);
+    PCR_LAUNCH(ctx, k_feature_nn_screen_g<true>, dim3(max_groups, max_pb, NP), dim3(FN_WG), 0, ctx->stream, db);
+    PCR_LAUNCH(ctx, k_feature_nn_screen_g<false>, dim3(max_groups, max_splits, NP), dim3(FN_WG), 0, ctx->stream, dr);
+    PCR_LAUNCH(ctx, k_fn_exact_min_g, dim3((max_pool + 255) / 256, NP), dim3(256), 0, ctx->stream, dx);
+    PCR_LAUNCH(ctx, k_fn_exact_arg_g, dim3((max_pool + 255) / 256, NP), dim3(256), 0, ctx->stream, dx);
+    PCR_LAUNCH(ctx, k_fn_finish_g, dim3((max_nq + 255) / 256, NP), dim3(256), 0, ctx->stream, dx);
+    for (int g = 0; g < G; g++) overflow_dev[g] = P[g].flags;         // pool overflow of a pair (either direction): its results are incomplete
     return PCR_OK;
 }

@@ -5,6 +5,8 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <array>
+#include <vector>
 #include "pcr_octree.h"
 
 #define FB 256
@@ -55,7 +57,7 @@ struct FpfhArgs {
     const uint32_t *perm; float *feat;          // output rows in caller order
 };
 
-__global__ void __launch_bounds__(FB) k_spfh(FpfhArgs a) {
+__device__ static inline void d_spfh(const FpfhArgs &a) {
     __shared__ int hist[FB / OCT][33];
     const int n = *a.n_ptr;
     const int ol = threadIdx.x & 7, ob = threadIdx.x >> 3;
@@ -88,7 +90,8 @@ __global__ void __launch_bounds__(FB) k_spfh(FpfhArgs a) {
     }
 }
 
-__global__ void __launch_bounds__(FB) k_fpfh(FpfhArgs a) {
+__global__ void __launch_bounds__(FB) k_spfh(FpfhArgs a) { d_spfh(a); }
+__device__ static inline void d_fpfh(const FpfhArgs &a) {
     const int n = *a.n_ptr;
     const int ol = threadIdx.x & 7, ob = threadIdx.x >> 3;
     const int qi = blockIdx.x * (FB / OCT) + ob;
@@ -137,6 +140,10 @@ __global__ void __launch_bounds__(FB) k_fpfh(FpfhArgs a) {
     }
 }
 
+__global__ void __launch_bounds__(FB) k_fpfh(FpfhArgs a) { d_fpfh(a); }
+// batch forms (lockstep FGR groups): blockIdx.y = cloud
+__global__ void __launch_bounds__(FB) k_spfh_g(const FpfhArgs *a) { d_spfh(a[blockIdx.y]); }
+__global__ void __launch_bounds__(FB) k_fpfh_g(const FpfhArgs *a) { d_fpfh(a[blockIdx.y]); }
 // FPFH of an imported cloud (Morton-sorted points + normals + octree); rows of feat33 in CALLER order (perm: sorted -> caller)
 static size_t fpfh_scratch_bytes(int64_t n, int knn) { return (size_t)(n > 0 ? n : 1) * ((size_t)knn * 8 + 33 * 8 + 64) + (1u << 16); }
 static int fpfh_of_cloud(pcr_context *ctx, const DevCloud &c, const uint32_t *perm, int64_t n, int search_kind, int knn, double radius, float *feat33) {
@@ -593,7 +600,7 @@ __device__ static inline void fgr_update(const double *S, double *trans /*16*/) 
 #define FSB 1024
 #define FGR_SINGLE_SMALL 2048
 template <int NT>
-__global__ void __launch_bounds__(NT) k_fgr_opt_single(FgrOptArgs a, int iterations) {
+__device__ static inline void d_fgr_opt_single(const FgrOptArgs &a, int iterations) {
     __shared__ double red[NT / 16][FNVP];
     __shared__ double S[FNVP];
     __shared__ double trans[16];
@@ -644,6 +651,8 @@ __global__ void __launch_bounds__(NT) k_fgr_opt_single(FgrOptArgs a, int iterati
     if (threadIdx.x < 16) st->trans[threadIdx.x] = trans[threadIdx.x];
     if (threadIdx.x == 0) { st->par = par_s; st->itr = itr; st->t_dbg[0] = tA; st->t_dbg[1] = tB; st->t_dbg[2] = tC; }
 }
+template <int NT> __global__ void __launch_bounds__(NT) k_fgr_opt_single(FgrOptArgs a, int iterations) { d_fgr_opt_single<NT>(a, iterations); }
+template <int NT> __global__ void __launch_bounds__(NT) k_fgr_opt_single_g(const FgrOptArgs *a, int iterations) { d_fgr_opt_single<NT>(a[blockIdx.y], iterations); }
 
 // ---- mid-size correspondence sets: ALL iterations in ONE launch of FMG co-resident workgroups.  Per iteration every
 // workgroup publishes its row of FC sums (write-through), arrives at a monotonic counter, waits until all FMG have arrived,
@@ -654,7 +663,7 @@ __global__ void __launch_bounds__(NT) k_fgr_opt_single(FgrOptArgs a, int iterati
 // back to one launch per iteration -- every wave reaches an exit.
 #define FMG 8
 #define FMB 512
-__global__ void __launch_bounds__(FMB) k_fgr_opt_multi(FgrOptArgs a, int iterations, double *rows /* 2 x FMG x FNVP */, unsigned long long timeout_ticks) {
+__device__ static inline void d_fgr_opt_multi(const FgrOptArgs &a, int iterations, double *rows /* 2 x FMG x FNVP */, unsigned long long timeout_ticks) {
     __shared__ double red[FMB / 16][FC];
     __shared__ double S[FC];
     __shared__ double trans[16];
@@ -725,6 +734,11 @@ __global__ void __launch_bounds__(FMB) k_fgr_opt_multi(FgrOptArgs a, int iterati
         if (threadIdx.x < 16) st->trans[threadIdx.x] = trans[threadIdx.x];
         if (threadIdx.x == 0) { st->par = par_s; st->itr = itr; }
     }
+}
+__global__ void __launch_bounds__(FMB) k_fgr_opt_multi(FgrOptArgs a, int iterations, double *rows, unsigned long long timeout_ticks) { d_fgr_opt_multi(a, iterations, rows, timeout_ticks); }
+// batch form: blockIdx.y = pair, every pair with its own state, barrier counter and row buffers (FMG x pairs co-resident workgroups)
+__global__ void __launch_bounds__(FMB) k_fgr_opt_multi_g(const FgrOptArgs *a, int iterations, double *rows, unsigned long long timeout_ticks) {
+    d_fgr_opt_multi(a[blockIdx.y], iterations, rows + (size_t)blockIdx.y * 2 * FMG * FNVP, timeout_ticks);
 }
 
 __global__ void __launch_bounds__(FB) k_fgr_iter(FgrOptArgs a) {
@@ -1064,4 +1078,399 @@ static int fgr_tail(pcr_context *ctx, DevCloud *c, uint32_t **perm, float **feat
 extern "C" int pcr_registro_fgr(pcr_context *ctx, const float *src_xyz, const float *src_prior, int64_t ns, const float *tgt_xyz, const float *tgt_prior, int64_t nt,
                                 const pcr_fgr_params *p, float *src_normals_out, float *tgt_normals_out, pcr_result *result, int32_t *correspondences) {
     return pcr_api_call(ctx, [&]() -> int { return pcr_registro_fgr_impl(ctx, src_xyz, src_prior, ns, tgt_xyz, tgt_prior, nt, p, src_normals_out, tgt_normals_out, result, correspondences); });
+}
+
+// ============================================================================================ registro_FGR of a GROUP of pairs in lockstep
+// The per-pair loop of 1_FGR_pairwise_registration_in_NCLT_dataset.py:134-147 (ALL_FUNCTIONS.py:349-357 in full_registration) for G pairs
+// through the SAME launches: registro_FGR on an NCLT-size pair is a chain of ~125 small dependent kernels and 8 host waits, and the device
+// retires ~90 k such kernels per second however many pairs are in flight -- so G pairs share every launch (blockIdx.y / .z = cloud, pair
+// or (pair, direction)) and every host wait (6 per GROUP).  Per pair the arithmetic is that of pcr_registro_fgr_impl -- same kernels
+// bodies, same grids per problem where a grid decides a summation order, same optimiser variant by correspondence count -- so poses,
+// normals and correspondence sets are the same bits (tests/test_gpu_fgr.py).  Taken for pairs whose mutual feature search runs
+// without tile pruning (under 5e9 row pairs: NCLT-size clouds); returns 1 = declined (the caller runs the pairs one by one).
+struct Sum3Desc { const float *xyz; int n, nb; double *part, *mean3, *out, *pmax; };
+__global__ void __launch_bounds__(FB) k_sum3_g(const Sum3Desc *d) {
+    const Sum3Desc a = d[blockIdx.y];
+    if ((int)blockIdx.x >= a.nb) return;
+    double s[3] = {0, 0, 0};
+    for (int i = blockIdx.x * FB + threadIdx.x; i < a.n; i += a.nb * FB) { s[0] += a.xyz[i * 3]; s[1] += a.xyz[i * 3 + 1]; s[2] += a.xyz[i * 3 + 2]; }
+    __shared__ double sh[FB / PCR_WAVE][3];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const double v = pcr_wave_sum(s[k]); if (lane == 0) sh[w][k] = v; }
+    __syncthreads();
+    if (threadIdx.x < 3) { double v = 0; for (int k = 0; k < FB / PCR_WAVE; k++) v += sh[k][threadIdx.x]; a.part[blockIdx.x * 3 + threadIdx.x] = v; }
+}
+__global__ void k_sum3_final_g(const Sum3Desc *d) {
+    const Sum3Desc a = d[blockIdx.x];
+    if (threadIdx.x < 3) { double v = 0; for (int k = 0; k < a.nb; k++) v += a.part[k * 3 + threadIdx.x]; a.mean3[threadIdx.x] = a.n > 0 ? v / (double)a.n : 0.0; }
+}
+__global__ void __launch_bounds__(FB) k_center_g(const Sum3Desc *d) {
+    const Sum3Desc a = d[blockIdx.y];
+    if ((int)blockIdx.x >= a.nb) return;
+    double mx = 0;
+    for (int i = blockIdx.x * FB + threadIdx.x; i < a.n; i += a.nb * FB) {
+        const double x = (double)a.xyz[i * 3] - a.mean3[0], y = (double)a.xyz[i * 3 + 1] - a.mean3[1], z = (double)a.xyz[i * 3 + 2] - a.mean3[2];
+        a.out[(size_t)i * 3] = x; a.out[(size_t)i * 3 + 1] = y; a.out[(size_t)i * 3 + 2] = z;
+        mx = fmax(mx, sqrt(x * x + y * y + z * z));
+    }
+    __shared__ double sh[FB];
+    sh[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = FB / 2; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]); __syncthreads(); }
+    if (threadIdx.x == 0) a.pmax[blockIdx.x] = sh[0];
+}
+struct ScaleDesc { double *p; long long n3; double inv; };
+__global__ void __launch_bounds__(FB) k_scale_g(const ScaleDesc *d) {
+    const ScaleDesc a = d[blockIdx.y];
+    const long long i = (long long)blockIdx.x * FB + threadIdx.x;
+    if (i < a.n3) a.p[i] = a.p[i] / a.inv;
+}
+struct CrossDesc { const int32_t *i_to_j, *j_to_i; int n_i; uint8_t *flags; const int *pos; int32_t *cross; };
+__global__ void __launch_bounds__(FB) k_cross_flags_g(const CrossDesc *d) {
+    const CrossDesc a = d[blockIdx.y];
+    const int i = blockIdx.x * FB + threadIdx.x;
+    if (i >= a.n_i) return;
+    const int j = a.i_to_j[i];
+    a.flags[i] = (j >= 0 && a.j_to_i[j] == i) ? 1 : 0;
+}
+__global__ void __launch_bounds__(FB) k_cross_emit_g(const CrossDesc *d) {
+    const CrossDesc a = d[blockIdx.y];
+    const int i = blockIdx.x * FB + threadIdx.x;
+    if (i >= a.n_i || !a.flags[i]) return;
+    a.cross[2 * (size_t)a.pos[i]] = i; a.cross[2 * (size_t)a.pos[i] + 1] = a.i_to_j[i];
+}
+struct TupleDesc { TupleArgs t; uint8_t *flags; const int *pos; int max_tuples, swapped; int32_t *corr; };
+__global__ void __launch_bounds__(FB) k_tuple_flags_g(const TupleDesc *d) {
+    const TupleDesc &a = d[blockIdx.y];
+    const long long t = (long long)blockIdx.x * FB + threadIdx.x;
+    if (t >= a.t.trials) return;
+    int r[3];
+    a.flags[t] = tuple_ok(a.t, t, r) ? 1 : 0;
+}
+__global__ void __launch_bounds__(FB) k_tuple_emit_g(const TupleDesc *d) {
+    const TupleDesc &a = d[blockIdx.y];
+    const long long t = (long long)blockIdx.x * FB + threadIdx.x;
+    if (t >= a.t.trials || !a.flags[t]) return;
+    const int rank = a.pos[t];
+    if (rank >= a.max_tuples) return;
+    int r[3];
+    (void)tuple_ok(a.t, t, r);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int ii = a.t.cross[2 * r[k]], jj = a.t.cross[2 * r[k] + 1];
+        a.corr[((size_t)rank * 3 + k) * 2] = a.swapped ? jj : ii;
+        a.corr[((size_t)rank * 3 + k) * 2 + 1] = a.swapped ? ii : jj;
+    }
+}
+struct OptPrepDesc { const double *p0, *q0; const int32_t *corr; int ncorr, stride; double *pq; FgrState *st; double par; };
+__global__ void __launch_bounds__(FB) k_fgr_prepare_g(const OptPrepDesc *d) {       // k_fgr_gather_pairs + k_fgr_init of every pair
+    const OptPrepDesc a = d[blockIdx.y];
+    const int c = blockIdx.x * FB + threadIdx.x;
+    if (c == 0) {
+        for (int k = 0; k < 16; k++) a.st->trans[k] = (k % 5 == 0) ? 1.0 : 0.0;
+        a.st->par = a.par; a.st->ticket = 0; a.st->itr = 0;
+        for (int k = 0; k < 4; k++) a.st->t_dbg[k] = 0;
+        a.st->arrive = 0; a.st->failed = 0;
+    }
+    if (c >= a.ncorr) return;
+    const double *p = a.p0 + (size_t)a.corr[2 * c] * 3, *q = a.q0 + (size_t)a.corr[2 * c + 1] * 3;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { a.pq[(size_t)k * a.stride + c] = p[k]; a.pq[(size_t)(3 + k) * a.stride + c] = q[k]; }
+}
+
+size_t pcr_registro_fgr_group_bytes(const pcr_fgr_group_pair *q, int G) {
+    size_t total = 64u << 20;
+    for (int g = 0; g < G; g++) {
+        const int fk = q[g].p.feature_max_nn > 0 && q[g].p.feature_max_nn <= 200 ? q[g].p.feature_max_nn : 1;
+        for (int64_t n : {q[g].ns, q[g].nt}) total += pcr_scratch_bytes_for(n) + (size_t)(n + 2) * (33 * 4 + 16 + 8 + 48) + fpfh_scratch_bytes(n, fk);
+        total += fgr_scratch_bytes(q[g].ns, q[g].nt, &q[g].p.option);
+    }
+    return total;
+}
+int pcr_registro_fgr_group(pcr_context *ctx, pcr_fgr_group_pair *q, int G) {
+    if (G < 1 || G > 64) return 1;
+    for (int g = 0; g < G; g++) {
+        pcr_fgr_group_pair &a = q[g];
+        if (!a.result) return PCR_EINVAL;
+        if (a.p.option.maximum_tuple_count < 0) a.p.option.maximum_tuple_count = (int32_t)((double)((a.ns + a.nt) / 2) * 0.2);       // the per-pair rule (pcr_hip.h)
+        if (fgr_check_args(ctx, &a.p.option, a.ns, a.nt) != PCR_OK) return 1;               // an argument error lands on its pair in the one-pair path
+        if (a.ns < 64 || a.nt < 64 || !a.src_xyz || !a.tgt_xyz) return 1;
+        if ((double)a.ns * (double)a.nt >= 5.0e9) return 1;                                  // the pruned feature search: one pair at a time
+        if (a.p.normal_max_nn < 1 || a.p.normal_max_nn > 32 || !(a.p.normal_radius > 0.0) || a.p.feature_max_nn < 1 || a.p.feature_max_nn > 200 || !(a.p.feature_radius > 0.0)) return 1;
+        if (!a.p.option.tuple_test || a.p.option.maximum_tuple_count < 1) return 1;
+        const pcr_fgr_params &p0 = q[0].p;
+        if (a.p.normal_max_nn != p0.normal_max_nn || a.p.normal_radius != p0.normal_radius || a.p.feature_max_nn != p0.feature_max_nn || a.p.feature_radius != p0.feature_radius ||
+            a.p.option.maximum_correspondence_distance != p0.option.maximum_correspondence_distance || a.p.option.iteration_number != p0.option.iteration_number) return 1;
+        a.status = PCR_OK;
+    }
+    const pcr_fgr_params &p0 = q[0].p;
+    struct Flags { pcr_context *c; bool forms, octet; ~Flags() { c->group_forms = forms; c->octet_only = octet; } } flags_guard{ctx, ctx->group_forms, ctx->octet_only};
+    ctx->group_forms = false; ctx->octet_only = true;                  // the one-cloud searches of registro_FGR run the octet kernel
+    PCR_TRY(pcr_arena_reserve(ctx, pcr_registro_fgr_group_bytes(q, G)));
+    const int C = 2 * G;                                                  // cloud c = 2 g + which (0 source, 1 target)
+    std::vector<DevCloud> c((size_t)C); std::vector<uint32_t *> perm((size_t)C, nullptr); std::vector<float *> feat((size_t)C, nullptr);
+    std::vector<const float *> xyz((size_t)C), prior((size_t)C); std::vector<int64_t> n((size_t)C); std::vector<float *> nout((size_t)C);
+    bool any_prior = false;
+    for (int g = 0; g < G; g++) {
+        xyz[2 * g] = q[g].src_xyz; xyz[2 * g + 1] = q[g].tgt_xyz; prior[2 * g] = q[g].src_prior; prior[2 * g + 1] = q[g].tgt_prior;
+        n[2 * g] = q[g].ns; n[2 * g + 1] = q[g].nt; nout[2 * g] = q[g].src_normals_out; nout[2 * g + 1] = q[g].tgt_normals_out;
+        any_prior = any_prior || q[g].src_prior || q[g].tgt_prior;
+    }
+    // ---- import (bounds read-back: wait 1), hybrid normals, FPFH neighbour lists, SPFH, FPFH: 2 G clouds per launch
+    for (int k = 0; k < C; k++) PCR_TRY(pcr_alloc_cloud(ctx, &c[k], (int)n[k], true, true));
+    PCR_TRY(pcr_import_clouds_batch(ctx, C, xyz.data(), any_prior ? prior.data() : nullptr, n.data(), c.data(), perm.data()));
+    {
+        std::vector<DevCloud *> cp((size_t)C); std::vector<const float4 *> pr((size_t)C); std::vector<float4 *> nn((size_t)C);
+        for (int k = 0; k < C; k++) {
+            cp[k] = &c[k]; pr[k] = prior[k] ? c[k].nrm : nullptr;
+            nn[k] = arena<float4>(ctx, n[k]); feat[k] = arena<float>(ctx, (size_t)n[k] * 33);
+            if (!nn[k] || !feat[k]) return PCR_ENOMEM;
+        }
+        PCR_TRY(pcr_dev_normals_batch(ctx, cp.data(), C, PCR_SEARCH_HYBRID, p0.normal_max_nn, p0.normal_radius, pr.data(), nn.data(), nullptr));
+        for (int k = 0; k < C; k++) {
+            c[k].nrm = nn[k];
+            if (nout[k]) PCR_TRY(pcr_dev_scatter_rows_f4_to_f3(ctx, nn[k], perm[k], c[k].n, c[k].cap, nout[k]));
+        }
+    }
+    std::vector<FpfhArgs> fa((size_t)C);
+    {
+        std::vector<const DevCloud *> cp((size_t)C); std::vector<int32_t *> nbr((size_t)C); std::vector<float *> nd2((size_t)C);
+        int64_t nmax = 0;
+        for (int k = 0; k < C; k++) {
+            cp[k] = &c[k];
+            nbr[k] = arena<int32_t>(ctx, (size_t)n[k] * p0.feature_max_nn); nd2[k] = arena<float>(ctx, (size_t)n[k] * p0.feature_max_nn);
+            double *spfh = arena<double>(ctx, (size_t)n[k] * 33);
+            if (!nbr[k] || !nd2[k] || !spfh) return PCR_ENOMEM;
+            FpfhArgs &a = fa[k];
+            a.pts = c[k].pts; a.nrm = c[k].nrm; a.n_ptr = c[k].n; a.nbr = nbr[k]; a.k = p0.feature_max_nn; a.r2 = p0.feature_radius * p0.feature_radius;
+            a.spfh = spfh; a.perm = perm[k]; a.feat = feat[k];
+            nmax = n[k] > nmax ? n[k] : nmax;
+        }
+        PCR_TRY(pcr_dev_knn_lists_batch(ctx, cp.data(), C, p0.feature_max_nn, p0.feature_radius, nbr.data(), nd2.data()));
+        const FpfhArgs *dfa = pcr_desc_upload(ctx, fa.data(), C);
+        if (!dfa) return PCR_ENOMEM;
+        const dim3 grid((unsigned)(((size_t)nmax * OCT + FB - 1) / FB), C);
+        PCR_LAUNCH(ctx, k_spfh_g, grid, dim3(FB), 0, ctx->stream, dfa);
+        PCR_LAUNCH(ctx, k_fpfh_g, grid, dim3(FB), 0, ctx->stream, dfa);
+    }
+    // ---- NormalizePointCloud of the 2 G clouds: means and largest norms come back with the feature search's own wait (wait 2)
+    std::vector<double *> P((size_t)C);
+    std::vector<Sum3Desc> sd((size_t)C);
+    int max_nb = 1;
+    constexpr int NROW = 3 + 256;                                         // per cloud: mean (3) + per-block largest norms (<= 256), one contiguous read-back
+    double *norm_all = arena<double>(ctx, (size_t)C * NROW);
+    if (!norm_all) return PCR_ENOMEM;
+    for (int k = 0; k < C; k++) {
+        const int nb = (int)((n[k] + FB - 1) / FB < 256 ? (n[k] + FB - 1) / FB : 256);
+        P[k] = arena<double>(ctx, (size_t)n[k] * 3);
+        double *part = arena<double>(ctx, (size_t)nb * 3);
+        if (!P[k] || !part) return PCR_ENOMEM;
+        sd[k] = Sum3Desc{xyz[k], (int)n[k], nb, part, norm_all + (size_t)k * NROW, P[k], norm_all + (size_t)k * NROW + 3};
+        max_nb = nb > max_nb ? nb : max_nb;
+    }
+    std::vector<double> hnorm((size_t)C * NROW);
+    {
+        const Sum3Desc *dsd = pcr_desc_upload(ctx, sd.data(), C);
+        if (!dsd) return PCR_ENOMEM;
+        PCR_LAUNCH(ctx, k_sum3_g, dim3(max_nb, C), dim3(FB), 0, ctx->stream, dsd);
+        PCR_LAUNCH(ctx, k_sum3_final_g, dim3(C), dim3(64), 0, ctx->stream, dsd);
+        PCR_LAUNCH(ctx, k_center_g, dim3(max_nb, C), dim3(FB), 0, ctx->stream, dsd);
+        PCR_HIP_CHECK(ctx, hipMemcpyAsync(hnorm.data(), norm_all, sizeof(double) * hnorm.size(), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    // ---- AdvancedMatching: mutual nearest feature rows of all pairs, both directions (i = the larger cloud of a pair)
+    std::vector<int> swapped((size_t)G), nPti((size_t)G), nPtj((size_t)G);
+    std::vector<int32_t *> j_to_i((size_t)G), i_to_j((size_t)G);
+    std::vector<const float *> fi((size_t)G), fj((size_t)G);
+    for (int g = 0; g < G; g++) {
+        swapped[g] = q[g].nt > q[g].ns ? 1 : 0;
+        fi[g] = swapped[g] ? feat[2 * g + 1] : feat[2 * g]; fj[g] = swapped[g] ? feat[2 * g] : feat[2 * g + 1];
+        nPti[g] = (int)(swapped[g] ? q[g].nt : q[g].ns); nPtj[g] = (int)(swapped[g] ? q[g].ns : q[g].nt);
+        j_to_i[g] = arena<int32_t>(ctx, nPtj[g]); i_to_j[g] = arena<int32_t>(ctx, nPti[g]);
+        if (!j_to_i[g] || !i_to_j[g]) return PCR_ENOMEM;
+    }
+    std::vector<const int *> overflow_dev((size_t)G, nullptr);
+    {
+        const int rc = pcr_feature_nn_mutual_batch(ctx, G, fi.data(), nPti.data(), fj.data(), nPtj.data(), j_to_i.data(), i_to_j.data(), overflow_dev.data());
+        if (rc == PCR_ECAPACITY) { PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); return 1; }
+        if (rc != PCR_OK) return rc;
+    }
+    std::vector<double> scale_global((size_t)G), scale_start((size_t)G);
+    std::vector<std::array<double, 3>> mean((size_t)C);
+    for (int g = 0; g < G; g++) {                                       // (the feature search has waited for the stream: the norms are here)
+        double mx[2];
+        for (int w = 0; w < 2; w++) {
+            const double *h = &hnorm[(size_t)(2 * g + w) * NROW];
+            for (int d = 0; d < 3; d++) mean[2 * g + w][d] = h[d];
+            double m = 0; for (int k = 0; k < sd[2 * g + w].nb; k++) m = h[3 + k] > m ? h[3 + k] : m;
+            mx[w] = m;
+        }
+        const double scale = mx[0] > mx[1] ? mx[0] : mx[1];
+        scale_global[g] = q[g].p.option.use_absolute_scale ? 1.0 : scale; scale_start[g] = q[g].p.option.use_absolute_scale ? scale : 1.0;
+    }
+    {
+        std::vector<ScaleDesc> sc; long long mx3 = 0;
+        for (int g = 0; g < G; g++) if (scale_global[g] != 1.0)
+            for (int w = 0; w < 2; w++) { sc.push_back(ScaleDesc{P[2 * g + w], (long long)n[2 * g + w] * 3, scale_global[g]}); mx3 = (long long)n[2 * g + w] * 3 > mx3 ? (long long)n[2 * g + w] * 3 : mx3; }
+        if (!sc.empty()) {
+            const ScaleDesc *dsc = pcr_desc_upload(ctx, sc.data(), (int)sc.size());
+            if (!dsc) return PCR_ENOMEM;
+            PCR_LAUNCH(ctx, k_scale_g, dim3((unsigned)((mx3 + FB - 1) / FB), (unsigned)sc.size()), dim3(FB), 0, ctx->stream, dsc);
+        }
+    }
+    // ---- cross check (wait 3: the counts, with the overflow flags of the feature search)
+    std::vector<uint8_t *> cflags((size_t)G); std::vector<int *> cpos((size_t)G), ncross_dev((size_t)G); std::vector<int32_t *> cross((size_t)G);
+    std::vector<CrossDesc> cd((size_t)G); std::vector<int> cap_i((size_t)G);
+    int max_i = 1;
+    int *counts_all = arena<int>(ctx, (size_t)2 * G);                    // [g]: cross-checked pairs, [G + g]: accepted tuples
+    if (!counts_all) return PCR_ENOMEM;
+    for (int g = 0; g < G; g++) {
+        cflags[g] = arena<uint8_t>(ctx, nPti[g]); cpos[g] = arena<int>(ctx, nPti[g]); ncross_dev[g] = counts_all + g; cross[g] = arena<int32_t>(ctx, (size_t)nPti[g] * 2);
+        if (!cflags[g] || !cpos[g] || !cross[g]) return PCR_ENOMEM;
+        cd[g] = CrossDesc{i_to_j[g], j_to_i[g], nPti[g], cflags[g], cpos[g], cross[g]};
+        cap_i[g] = nPti[g]; max_i = nPti[g] > max_i ? nPti[g] : max_i;
+    }
+    std::vector<int> ncross((size_t)G, 0), overflow((size_t)G, 0);
+    {
+        const CrossDesc *dcd = pcr_desc_upload(ctx, cd.data(), G);
+        if (!dcd) return PCR_ENOMEM;
+        PCR_LAUNCH(ctx, k_cross_flags_g, dim3((max_i + FB - 1) / FB, G), dim3(FB), 0, ctx->stream, dcd);
+        PCR_TRY(pcr_dev_flag_scan_batch(ctx, G, cflags.data(), nullptr, cap_i.data(), cpos.data(), ncross_dev.data()));
+        PCR_LAUNCH(ctx, k_cross_emit_g, dim3((max_i + FB - 1) / FB, G), dim3(FB), 0, ctx->stream, dcd);
+        std::vector<int> hflags((size_t)2 * G, 0);                        // (the feature search keeps its per-pair flag words in one array, two per pair)
+        PCR_HIP_CHECK(ctx, hipMemcpyAsync(ncross.data(), counts_all, sizeof(int) * (size_t)G, hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP_CHECK(ctx, hipMemcpyAsync(hflags.data(), overflow_dev[0], sizeof(int) * (size_t)2 * G, hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        for (int g = 0; g < G; g++) { overflow[g] = hflags[2 * g]; if (overflow[g]) q[g].status = 1; }        // record pool exhausted: that pair alone takes the float64 path
+    }
+    // ---- tuple test (wait 4: the accepted counts)
+    std::vector<int32_t *> corr((size_t)G, nullptr); std::vector<int64_t> ncorr((size_t)G, 0);
+    {
+        std::vector<TupleDesc> td; std::vector<int> owner; std::vector<uint8_t *> tfl; std::vector<int *> tps, ntd; std::vector<int> tcap;
+        long long max_trials = 0;
+        for (int g = 0; g < G; g++) {
+            if (q[g].status != PCR_OK || ncross[g] <= 0) continue;
+            const pcr_fgr_option &opt = q[g].p.option;
+            const long long trials = 100ll * ncross[g];
+            uint8_t *tflags = arena<uint8_t>(ctx, trials);
+            int *tpos = arena<int>(ctx, trials), *ntup_dev = counts_all + G + g;
+            corr[g] = arena<int32_t>(ctx, (size_t)opt.maximum_tuple_count * 6);
+            if (!tflags || !tpos || !corr[g]) return PCR_ENOMEM;
+            TupleDesc t;
+            t.t.pi = swapped[g] ? P[2 * g + 1] : P[2 * g]; t.t.pj = swapped[g] ? P[2 * g] : P[2 * g + 1]; t.t.cross = cross[g]; t.t.ncross = ncross[g];
+            t.t.seed = opt.seed; t.t.tuple_scale = opt.tuple_scale; t.t.trials = trials;
+            t.flags = tflags; t.pos = tpos; t.max_tuples = opt.maximum_tuple_count; t.swapped = swapped[g]; t.corr = corr[g];
+            td.push_back(t); owner.push_back(g); tfl.push_back(tflags); tps.push_back(tpos); ntd.push_back(ntup_dev); tcap.push_back((int)trials);
+            max_trials = trials > max_trials ? trials : max_trials;
+        }
+        if (!td.empty()) {
+            const int m = (int)td.size();
+            const TupleDesc *dtd = pcr_desc_upload(ctx, td.data(), m);
+            if (!dtd) return PCR_ENOMEM;
+            const dim3 grid((unsigned)((max_trials + FB - 1) / FB), m);
+            PCR_LAUNCH(ctx, k_tuple_flags_g, grid, dim3(FB), 0, ctx->stream, dtd);
+            PCR_TRY(pcr_dev_flag_scan_batch(ctx, m, tfl.data(), nullptr, tcap.data(), tps.data(), ntd.data()));
+            PCR_LAUNCH(ctx, k_tuple_emit_g, grid, dim3(FB), 0, ctx->stream, dtd);
+            std::vector<int> nacc((size_t)G, 0);
+            PCR_HIP_CHECK(ctx, hipMemcpyAsync(nacc.data(), counts_all + G, sizeof(int) * (size_t)G, hipMemcpyDeviceToHost, ctx->stream));
+            PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            for (int k = 0; k < m; k++) {
+                const int g = owner[k];
+                const int64_t a = nacc[g] > q[g].p.option.maximum_tuple_count ? q[g].p.option.maximum_tuple_count : nacc[g];
+                ncorr[g] = a * 3;
+            }
+        }
+    }
+    // ---- OptimizePairwiseRegistration: the variant by correspondence count, as the one-pair path picks it (wait 5: the states)
+    static const int single_max = getenv("PCR_FGR_SINGLE_MAX") ? atoi(getenv("PCR_FGR_SINGLE_MAX")) : 11000;
+    static const int multi_min = getenv("PCR_FGR_MULTI_MIN") ? atoi(getenv("PCR_FGR_MULTI_MIN")) : 6000;
+    static const int multi_max = getenv("PCR_FGR_MULTI_MAX") ? atoi(getenv("PCR_FGR_MULTI_MAX")) : 400000;
+    static const unsigned long long fm_timeout = getenv("PCR_FGR_MULTI_TIMEOUT") ? strtoull(getenv("PCR_FGR_MULTI_TIMEOUT"), nullptr, 10) : 5000000ull;
+    std::vector<FgrState> hst((size_t)G); std::vector<FgrState *> st((size_t)G, nullptr);
+    FgrState *st_all = arena<FgrState>(ctx, G);
+    if (!st_all) return PCR_ENOMEM;
+    {
+        std::vector<OptPrepDesc> pd; std::vector<FgrOptArgs> cls[3]; std::vector<int> who;
+        int max_corr = 1;
+        for (int g = 0; g < G; g++) {
+            if (q[g].status != PCR_OK || ncorr[g] < 10) continue;
+            const pcr_fgr_option &opt = q[g].p.option;
+            int nb = (int)((ncorr[g] + FB - 1) / FB); if (nb > 256) nb = 256;
+            st[g] = st_all + g;
+            double *partials = arena<double>(ctx, (size_t)nb * FNVP);
+            const int stride = (int)((ncorr[g] + 63) / 64 * 64);
+            double *pq = arena<double>(ctx, (size_t)stride * 6);
+            if (!st[g] || !partials || !pq) return PCR_ENOMEM;
+            pd.push_back(OptPrepDesc{P[2 * g], P[2 * g + 1], corr[g], (int)ncorr[g], stride, pq, st[g], scale_start[g]});
+            FgrOptArgs oa;
+            oa.pq = pq; oa.stride = stride; oa.ncorr = (int)ncorr[g]; oa.st = st[g]; oa.partials = partials;
+            oa.decrease_mu = opt.decrease_mu; oa.max_corr_dist = opt.maximum_correspondence_distance; oa.division_factor = opt.division_factor;
+            const bool multi = ncorr[g] >= multi_min && ncorr[g] <= multi_max;
+            if (multi) cls[2].push_back(oa);
+            else if (ncorr[g] <= single_max && ncorr[g] <= FGR_SINGLE_SMALL) cls[0].push_back(oa);
+            else if (ncorr[g] <= single_max) cls[1].push_back(oa);
+            else { q[g].status = 1; pd.pop_back(); st[g] = nullptr; continue; }              // one launch per iteration: the one-pair path
+            who.push_back(g);
+            max_corr = (int)ncorr[g] > max_corr ? (int)ncorr[g] : max_corr;
+        }
+        if (!pd.empty()) {
+            const OptPrepDesc *dpd = pcr_desc_upload(ctx, pd.data(), (int)pd.size());
+            if (!dpd) return PCR_ENOMEM;
+            PCR_LAUNCH(ctx, k_fgr_prepare_g, dim3((max_corr + FB - 1) / FB, (unsigned)pd.size()), dim3(FB), 0, ctx->stream, dpd);
+            const int iters = (int)p0.option.iteration_number;
+            for (int v = 0; v < 3; v++) {
+                if (cls[v].empty()) continue;
+                const int m = (int)cls[v].size();
+                const FgrOptArgs *doa = pcr_desc_upload(ctx, cls[v].data(), m);
+                if (!doa) return PCR_ENOMEM;
+                if (v == 0) PCR_LAUNCH(ctx, k_fgr_opt_single_g<256>, dim3(1, m), dim3(256), 0, ctx->stream, doa, iters);
+                else if (v == 1) PCR_LAUNCH(ctx, k_fgr_opt_single_g<FSB>, dim3(1, m), dim3(FSB), 0, ctx->stream, doa, iters);
+                else {
+                    double *rows = arena<double>(ctx, (size_t)m * 2 * FMG * FNVP);
+                    if (!rows) return PCR_ENOMEM;
+                    // FMG x m co-resident 512-thread workgroups (at most 8 x 64 of the chip's 1024 slots of that size)
+                    PCR_LAUNCH(ctx, k_fgr_opt_multi_g, dim3(FMG, m), dim3(FMB), 0, ctx->stream, doa, iters, rows, fm_timeout);
+                }
+            }
+            PCR_HIP_CHECK(ctx, hipMemcpyAsync(hst.data(), st_all, sizeof(FgrState) * (size_t)G, hipMemcpyDeviceToHost, ctx->stream));
+            PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            for (int g : who) if (hst[g].failed) q[g].status = 1;                             // barrier timeout: the one-pair path reruns it launch by launch
+        }
+    }
+    // ---- GetTransformationOriginalScale + inverse per pair (host), then evaluate_registration of all pairs (wait 6)
+    std::vector<double> T((size_t)G * 16);
+    for (int g = 0; g < G; g++) {
+        double trans[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        if (st[g] && q[g].status == PCR_OK) memcpy(trans, hst[g].trans, sizeof trans);
+        const std::array<double, 3> &m0 = mean[2 * g], &m1 = mean[2 * g + 1];
+        double To[16] = {0};
+        for (int r = 0; r < 3; r++) {
+            for (int cc = 0; cc < 3; cc++) To[r * 4 + cc] = trans[r * 4 + cc];
+            To[r * 4 + 3] = -(trans[r * 4 + 0] * m1[0] + trans[r * 4 + 1] * m1[1] + trans[r * 4 + 2] * m1[2]) + trans[r * 4 + 3] * scale_global[g] + m0[r];
+        }
+        To[15] = 1;
+        double *Ts = &T[16 * g];
+        for (int k = 0; k < 16; k++) Ts[k] = (k % 5 == 0) ? 1.0 : 0.0;
+        for (int r = 0; r < 3; r++) {
+            for (int cc = 0; cc < 3; cc++) Ts[r * 4 + cc] = To[cc * 4 + r];
+            Ts[r * 4 + 3] = -(To[0 * 4 + r] * To[3] + To[1 * 4 + r] * To[7] + To[2 * 4 + r] * To[11]);
+        }
+        for (int k = 0; k < 16; k++) if (!std::isfinite(Ts[k])) { q[g].status = 1; for (int j = 0; j < 16; j++) Ts[j] = (j % 5 == 0) ? 1.0 : 0.0; break; }
+    }
+    {
+        std::vector<const DevCloud *> ss((size_t)G), tt((size_t)G); std::vector<int32_t *> match((size_t)G); std::vector<pcr_result> res((size_t)G);
+        for (int g = 0; g < G; g++) {
+            ss[g] = &c[2 * g]; tt[g] = &c[2 * g + 1];
+            match[g] = arena<int32_t>(ctx, q[g].ns);
+            if (!match[g]) return PCR_ENOMEM;
+        }
+        PCR_TRY(pcr_dev_evaluate_group(ctx, G, ss.data(), tt.data(), p0.option.maximum_correspondence_distance, T.data(), res.data(), match.data()));
+        for (int g = 0; g < G; g++) {
+            if (q[g].status != PCR_OK) continue;
+            *q[g].result = res[g];
+            for (int k = 0; k < 16; k++) q[g].result->transformation[k] = T[16 * g + k];
+            if (q[g].correspondences) PCR_TRY(pcr_dev_compact_matches(ctx, match[g], c[2 * g].n, c[2 * g].cap, perm[2 * g], perm[2 * g + 1], q[g].correspondences, nullptr));
+        }
+    }
+    return PCR_OK;
 }

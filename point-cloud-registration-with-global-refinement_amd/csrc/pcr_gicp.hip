@@ -799,6 +799,9 @@ __device__ static inline void d_icp_iter(const IcpArgs &a) {
     icp_finish<MODE, LIN_BS>(a, st, T, acc, nb, ns, launches, t_entry, (int)blockIdx.x);
 }
 template <int MODE> __global__ void __launch_bounds__(LIN_BS) k_icp_iter(IcpArgs a) { d_icp_iter<MODE>(a); }
+// group form: blockIdx.y = pair.  A pair uses min(its own tile count, the grid's width) partial rows, which is what the one-pair launch
+// uses (its grid is min(tiles, LIN_MAX_BLOCKS) wide and the group's grid is the widest of those): same sums, same order.
+template <int MODE> __global__ void __launch_bounds__(LIN_BS) k_icp_iter_g(const IcpArgs *__restrict__ a) { d_icp_iter<MODE>(a[blockIdx.y]); }
 // tile form (every GICP linearisation that is not fused into k_icp_fused): workgroup b owns the 512-point tile b, so the partial rows and
 // their order are those of k_icp_fused<512>; held at 128 VGPRs = two workgroups per CU (the strided loop of k_icp_iter takes 218 and is
 // capped at 128 workgroups: a cold launch over 1.6M points took 0.8-3 ms)
@@ -1468,6 +1471,39 @@ int pcr_dev_evaluate(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt,
         int t = 0;
         for (int r = 0; r < 6; r++) for (int c = r; c < 6; c++) { info36[r * 6 + c] = h.sums[t]; info36[c * 6 + r] = h.sums[t]; t++; }
     }
+    return PCR_OK;
+}
+
+int pcr_dev_evaluate_group(pcr_context *ctx, int G, const DevCloud *const *src, const DevCloud *const *tgt, double max_dist, const double *T,
+                           pcr_result *out, int32_t *const *match_dev) {
+    if (!(max_dist > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
+    if (G < 1) return PCR_OK;
+    ArenaMark mark(ctx);
+    std::vector<IcpArgs> args((size_t)G); std::vector<IcpInit> inits((size_t)G);
+    IcpState *st = arena<IcpState>(ctx, G);
+    if (!st) return PCR_ENOMEM;
+    int gmax = 1, gnn = 1;
+    for (int g = 0; g < G; g++) {
+        const int cap = src[g]->cap > 0 ? src[g]->cap : 1;
+        const int nbmax = (cap + LIN_BS - 1) / LIN_BS < LIN_MAX_BLOCKS ? (cap + LIN_BS - 1) / LIN_BS : LIN_MAX_BLOCKS;
+        const int nbnn = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT);
+        double *partials = arena<double>(ctx, (size_t)nbmax * NVP);
+        if (!partials || !match_dev[g]) return PCR_ENOMEM;
+        memset(&args[g], 0, sizeof(IcpArgs));
+        fill_args(args[g], src[g], tgt[g], max_dist, nullptr, match_dev[g], st + g, partials, 1);
+        memcpy(inits[g].T, T + 16 * g, sizeof inits[g].T);
+        gmax = nbmax > gmax ? nbmax : gmax; gnn = nbnn > gnn ? nbnn : gnn;
+    }
+    const IcpArgs *da = pcr_desc_upload(ctx, args.data(), G);
+    const IcpInit *di = pcr_desc_upload(ctx, inits.data(), G);
+    if (!da || !di) return PCR_ENOMEM;
+    PCR_LAUNCH(ctx, k_icp_init_g, dim3(G), dim3(64), 0, ctx->stream, st, di);
+    PCR_LAUNCH(ctx, k_icp_nn_g<false>, dim3(gnn, G), dim3(ICP_BS), 0, ctx->stream, da);
+    PCR_LAUNCH(ctx, k_icp_iter_g<ICP_MODE_EVAL>, dim3(gmax, G), dim3(LIN_BS), 0, ctx->stream, da);
+    std::vector<IcpState> h((size_t)G);
+    PCR_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), st, sizeof(IcpState) * (size_t)G, hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int g = 0; g < G; g++) { state_to_result(h[g], &out[g]); out[g].iterations = 0; out[g].converged = 0; }
     return PCR_OK;
 }
 

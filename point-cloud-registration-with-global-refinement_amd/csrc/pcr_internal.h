@@ -59,6 +59,7 @@ struct pcr_context {
     // its size: a ragged last group of one pair, or a one-pair shard of another world size, is then the same arithmetic as the pair
     // inside a full group (gathered poses are the single-GPU bits)
     bool group_forms = false;
+    bool octet_only = false;     // lockstep FGR groups: every batched search runs the octet kernel, as registro_FGR's one-cloud searches do
 };
 
 // every extern "C" entry point runs its body between these two (pcr_api.hip): device, stream, fences, launch errors
@@ -203,6 +204,12 @@ int pcr_dev_sor(pcr_context *ctx, const DevCloud *in, int nb_neighbors, double s
 int pcr_dev_sor_batch(pcr_context *ctx, const DevCloud *const *ins, DevCloud *const *outs, int count, int nb_neighbors, double std_ratio, int normal_k,
                       const float4 *const *priors, uint8_t *const *todos, int *const *todo_counts, int *const *cnt_in, int *const *cnt_kept, bool fallback_here);
 int pcr_dev_normals_knn_batch(pcr_context *ctx, DevCloud *const *cs, int count, int knn, const float4 *const *priors, float4 *const *normals_out, const uint8_t *const *todos);
+int pcr_dev_normals_batch(pcr_context *ctx, DevCloud *const *cs, int count, int search_kind, int knn, double radius, const float4 *const *priors, float4 *const *normals_out,
+                          const uint8_t *const *todos);
+int pcr_dev_knn_lists_batch(pcr_context *ctx, const DevCloud *const *cs, int count, int k, double radius, int32_t *const *idx, float *const *d2);
+int pcr_dev_flag_scan_batch(pcr_context *ctx, int count, uint8_t *const *flags, const int *const *n_ptr, const int *n_cap, int *const *pos, int *const *total_dev);
+// `count` caller clouds Morton-sorted with their octrees in one pass (cs[c] allocated with a tree by the caller; perms[c]: sorted -> caller)
+int pcr_import_clouds_batch(pcr_context *ctx, int count, const float *const *xyz, const float *const *nrm, const int64_t *n, DevCloud *cs, uint32_t **perms);
 // normals (and optionally covariances) by k-NN / hybrid / radius neighbourhoods over the BVH
 int pcr_dev_normals(pcr_context *ctx, DevCloud *c, int search_kind, int knn, double radius, const float4 *prior,
                     float4 *normals_out, float *cov6_out /*optional, sorted order, 6 per point*/, const uint8_t *todo = nullptr);
@@ -223,6 +230,13 @@ int pcr_import_cloud(pcr_context *ctx, const float *xyz, const float *nrm, int64
 
 int pcr_registro_fgr_impl(pcr_context *ctx, const float *src_xyz, const float *src_prior, int64_t ns, const float *tgt_xyz, const float *tgt_prior, int64_t nt,
                           const pcr_fgr_params *p, float *src_normals_out, float *tgt_normals_out, pcr_result *result, int32_t *correspondences);
+// registro_FGR of G pairs through the same launches (pcr_fgr.hip); 1 = declined (sizes / parameters): run the pairs one by one
+struct pcr_fgr_group_pair {                 // one pair of a lockstep FGR group (what pcr_registro_fgr_impl takes, per pair)
+    const float *src_xyz, *src_prior; int64_t ns; const float *tgt_xyz, *tgt_prior; int64_t nt;
+    pcr_fgr_params p; float *src_normals_out, *tgt_normals_out; pcr_result *result; int32_t *correspondences;
+    int status;                              // out: PCR_OK, or 1 = this pair must be redone alone (record pool overflow, optimiser fallback)
+};
+int pcr_registro_fgr_group(pcr_context *ctx, pcr_fgr_group_pair *pairs, int G);
 int pcr_evaluate_registration_impl(pcr_context *ctx, const float *src_xyz, int64_t n_src, const float *tgt_xyz, int64_t n_tgt,
                                    double max_dist, const double *T, pcr_result *result, int32_t *correspondences);
 
@@ -230,6 +244,9 @@ int pcr_evaluate_registration_impl(pcr_context *ctx, const float *src_xyz, int64
 size_t pcr_feature_nn_scratch_bytes(int64_t n0, int64_t n1);
 int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float *f1, int n1, int32_t *out_1to0, int32_t *out_0to1,
                           int prune_mode /* -1: by size (PCR_FEATNN_PRUNE overrides), 0: off, 1: on */);
+
+int pcr_feature_nn_mutual_batch(pcr_context *ctx, int G, const float *const *f0, const int *n0, const float *const *f1, const int *n1, int32_t *const *out_1to0,
+                                int32_t *const *out_0to1, const int **overflow_dev);
 
 // ---- gicp (pcr_gicp.hip) --------------------------------------------------------------------------
 struct IcpOutputs { pcr_result res; };
@@ -241,5 +258,8 @@ int pcr_dev_linearize_once(pcr_context *ctx, const DevCloud *src, const DevCloud
                            const pcr_gicp_params *p, double *JTJ36, double *JTr6, double *stats3, int32_t *match_dev);
 int pcr_dev_evaluate(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, double max_dist, const double *T,
                      pcr_result *out, int32_t *match_dev, double *info36 /*optional*/);
+// evaluate_registration of G pairs in one launch pair (per pair the arithmetic of pcr_dev_evaluate); results on the host after ONE read-back
+int pcr_dev_evaluate_group(pcr_context *ctx, int G, const DevCloud *const *src, const DevCloud *const *tgt, double max_dist, const double *T /* G x 16 */,
+                           pcr_result *out /* G */, int32_t *const *match_dev /* G, required */);
 int pcr_dev_compact_matches(pcr_context *ctx, const int32_t *match, const int *n, int cap, const uint32_t *src_perm,
                             const uint32_t *tgt_perm, int32_t *corr_out, int64_t *n_corr);

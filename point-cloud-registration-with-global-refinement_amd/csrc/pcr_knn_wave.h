@@ -373,10 +373,12 @@ __device__ static inline void d_knn_wave(const KnnArgs &a) {
     // A wavefront whose 64 queries lie far apart (sparse regions, a jump of the Morton curve inside the group) would drag all its lanes
     // through the neighbourhoods of each: ~1 % of the wavefronts took 3-6x the mean and set the length of the launch.  They stop after
     // a.wave_budget batches (or when the log is full) and flag their queries in a.hard for the octet kernel, which serves 8 per wavefront.
-    const bool finished = kw_pass<false, STATS>(a.t, m, sh.stk, live, start_node, g0, q.x, q.y, q.z, plo, phi, a.keep, sh.stage, a.hard ? a.wave_budget : 0x7fffffff, [&]() { return sd[0]; }, scan1, st1);
-    if (a.hard) {
-        const bool give_up = !finished || nlog > KwShared<K>::LOG;
-        if (qi < n) a.hard[oq] = (give_up && live) ? 1 : 0;
+    const bool handing = a.hard || a.hard_list;
+    const bool finished = kw_pass<false, STATS>(a.t, m, sh.stk, live, start_node, g0, q.x, q.y, q.z, plo, phi, a.keep, sh.stage, handing ? a.wave_budget : 0x7fffffff, [&]() { return sd[0]; }, scan1, st1);
+    if (handing) {
+        const bool give_up = !finished || nlog > KwShared<K>::LOG;      // (wave-uniform)
+        if (a.hard) { if (qi < n) a.hard[oq] = (give_up && live) ? 1 : 0; }
+        else if (give_up && lane == 0) a.hard_list[atomicAdd(a.hard_count, 1)] = g0;      // one atomic per wavefront that gives up (~1 %)
         if (give_up) return;
     }
     const unsigned long long c_mid = STATS ? __builtin_readcyclecounter() : 0ull;

@@ -250,6 +250,15 @@ def default_group(points_per_cloud: float) -> int:
     return 16 if g > 32 else max(1, min(8, g))
 
 
+def default_fgr_group(points_per_cloud: float) -> int:
+    """Pairs per lockstep ``registro_FGR`` group (``pcr_pairs_plan.fgr_group``): NCLT-size pairs are ~125 small dependent launches and 8
+    host waits each, which a group shares (16 pairs of 20k points per group); from ~70k points the tile-pruned feature search takes over
+    and pairs run one by one."""
+    if points_per_cloud >= 70_000:
+        return 1
+    return max(1, min(16, int(round(320_000 / max(float(points_per_cloud), 1.0)))))
+
+
 def balanced_group(group: int, n_pairs: int, inflight: int) -> int:
     """Group size near ``group`` for which the groups of a batch of ``n_pairs`` fill whole rounds of ``inflight`` workers: 96 pairs in
     groups of 16 are 6 groups -- a round of 4 and a round of 2 -- in groups of 12 they are two full rounds (NCLT-size pairs, 5-scale
@@ -264,7 +273,7 @@ def balanced_group(group: int, n_pairs: int, inflight: int) -> int:
 def register_pairs_plan(pairs, stage: str = "gicp", voxel_sizes=None, max_correspondence_distances=None, estimation_method=None, criteria=None,
                         nb_neighbors: int = 30, std_ratio: float = 1.0, normal_knn: int = 20, inflight: int = 3, with_correspondences: bool = True,
                         fgr_voxel_size: float = 0.1, fgr_use_absolute_scale: bool = True, fgr_seed=None, radius_rule: str = "given",
-                        prior_from_fgr: bool = False, info_max_dist: float = 0.0, keep_fgr_normals: bool = False, group=1, pair_forms=None) -> list:
+                        prior_from_fgr: bool = False, info_max_dist: float = 0.0, keep_fgr_normals: bool = False, group=1, pair_forms=None, fgr_group=None) -> list:
     """The per-pair loops of the reference as ONE library call (``pcr_register_pairs_plan``): `pairs` = [(source PointCloud,
     target PointCloud, initial 4x4 or None), ...].
 
@@ -276,6 +285,8 @@ def register_pairs_plan(pairs, stage: str = "gicp", voxel_sizes=None, max_corres
     batched over clouds and scales, one GICP loop per scale for the whole group; same per-pair arithmetic; with "fgr+gicp" the worker runs
     registro_FGR pair by pair first); ``inflight`` counts groups.
     ``group=None`` picks by cloud size (``default_group``).
+    ``fgr_group`` (stages with FGR; None = ``default_fgr_group`` of the mean cloud size, 1 = pair by pair): that many consecutive pairs go
+    through ``registro_FGR`` in lockstep (``pcr_pairs_plan.fgr_group``); the same bits per pair either way.
     ``pair_forms`` (default: on exactly when ``group`` is None): the kernel forms of the GICP stage go by the PAIR alone
     (``pcr_pairs_plan.pair_forms``), so a pair's pose bits are the same in every batch, group size and shard of a multi-GPU run.
     The library keeps ``inflight`` pairs in flight on the current device.  Returns RegistrationResults in input order (for
@@ -298,6 +309,10 @@ def register_pairs_plan(pairs, stage: str = "gicp", voxel_sizes=None, max_corres
         return []
     if pair_forms is None:
         pair_forms = group is None
+    if fgr_group is None:
+        fgr_group = default_fgr_group(float(np.mean([len(s_) + len(t_) for s_, t_, _ in pairs])) / 2) if do_fgr else 1
+        if stage == "fgr":
+            fgr_group = balanced_group(fgr_group, n, int(inflight))
     if group is None:
         mean_pts = float(np.mean([len(s_) + len(t_) for s_, t_, _ in pairs])) / 2
         group = balanced_group(default_group(mean_pts), n, int(inflight))
@@ -309,8 +324,8 @@ def register_pairs_plan(pairs, stage: str = "gicp", voxel_sizes=None, max_corres
             v = PointCloud(); v._xyz = pc.device_xyz(); v._nrm = pc.device_normals() if pc.has_normals() else None
             return v
         views = [(view(s_), view(t_), None) for s_, t_, _ in pairs]
-        fg = register_pairs_plan(views, "fgr", None, None, estimation, criteria, nb_neighbors, std_ratio, normal_knn, max(int(inflight), 8), False,
-                                 fgr_voxel_size, fgr_use_absolute_scale, fgr_seed, "given", False, 0.0, True, 1)
+        fg = register_pairs_plan(views, "fgr", None, None, estimation, criteria, nb_neighbors, std_ratio, normal_knn, max(int(inflight), 8) if fgr_group <= 1 else max(int(inflight), 4), False,
+                                 fgr_voxel_size, fgr_use_absolute_scale, fgr_seed, "given", False, 0.0, True, 1, fgr_group=fgr_group)
         second = [((vs if prior_from_fgr else s_), (vt if prior_from_fgr else t_), f.transformation) for (vs, vt, _), (s_, t_, _), f in zip(views, pairs, fg)]
         out = register_pairs_plan(second, "gicp", voxel_sizes, max_correspondence_distances, estimation, criteria, nb_neighbors, std_ratio, normal_knn, inflight,
                                   with_correspondences, radius_rule=radius_rule, info_max_dist=info_max_dist, group=group, pair_forms=pair_forms)
@@ -352,7 +367,7 @@ def register_pairs_plan(pairs, stage: str = "gicp", voxel_sizes=None, max_corres
     plan.voxel_sizes = vox.ctypes.data_as(C.POINTER(C.c_double)); plan.max_distances = dst.ctypes.data_as(C.POINTER(C.c_double))
     plan.n_scales = int(vox.size); plan.radius_rule = rule
     plan.sor_k = int(nb_neighbors); plan.sor_std = float(std_ratio); plan.normal_k = int(normal_knn)
-    plan.gicp = C.pointer(p); plan.gicp_prior_from_fgr = int(bool(prior_from_fgr)); plan.info_max_dist = float(info_max_dist); plan.inflight = int(inflight); plan.group = int(group); plan.pair_forms = int(pair_forms)
+    plan.gicp = C.pointer(p); plan.gicp_prior_from_fgr = int(bool(prior_from_fgr)); plan.info_max_dist = float(info_max_dist); plan.inflight = int(inflight); plan.group = int(group); plan.pair_forms = int(pair_forms); plan.fgr_group = int(fgr_group)
     dev = torch.cuda.current_device()
     rc = lib.pcr_register_pairs_plan(C.c_int(dev), arr, C.c_int(n), C.byref(plan), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     out = []

@@ -99,3 +99,37 @@ def test_stage2_two_ranks_equal_one_rank_on_the_facade_circuit(tmp_path):
     for i in range(n):                                                                      # and they are registrations, not garbage: near the shipped GICP poses
         ang, dt = pose_error(a[i], g["T_gicp"][i])
         assert ang < 2e-2 and dt < 0.2, (i, ang, dt)
+
+
+@pytest.mark.gpu
+def test_stage12_two_ranks_equal_one_rank_on_the_facade_circuit(tmp_path):
+    """BASELINE config 3's per-rank building block -- FGR (script-1 parameters) + 5-scale MGICP (script-2 table) of every pair as ONE
+    `fgr+gicp` plan per rank (`drivers stage12`) -- on the shipped Facade circuit as one process and as two ranks (cost-balanced blocks,
+    both on this box's one device, gloo): the FGR and the GICP pose files must be the same bits, and they must be registrations
+    (the refined poses close to the shipped ones)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    g = np.load(os.path.join(GOLDEN, "facade_loop.npz"))
+    n = 7
+    clouds = tmp_path / "clouds"; clouds.mkdir()
+    for i in range(n):
+        pcr_amd.io.write_pcd_xyz(str(clouds / f"s{i}.pcd"), g[f"s{i}"])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PCR_REHEARSE="1", PYTHONPATH=ROOT)
+    script = tmp_path / "run_stage.py"
+    script.write_text("import importlib, json, os, sys\nsys.exit(importlib.import_module('point-cloud-registration-with-global-refinement_amd.drivers').main(json.loads(os.environ['PCR_STAGE_ARGS'])))\n")
+    common = ["stage12", "--clouds", str(clouds), "--n", str(n), "--scales", "5", "--iterations", "30", "--inflight", "2", "--seed", "11"]
+    runs = {}
+    for name, launcher in (("one", [sys.executable]), ("two", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                                               "--master-port", "29541"])):
+        args = common + ["--out", str(tmp_path / name / "gicp"), "--fgr-out", str(tmp_path / name / "fgr")]
+        r = subprocess.run(launcher + [str(script)], cwd=ROOT, env=dict(env, PCR_STAGE_ARGS=json.dumps(args)), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs[name] = (pcr_amd.io.load_relative_poses(str(tmp_path / name / "gicp"), n), pcr_amd.io.load_relative_poses(str(tmp_path / name / "fgr"), n))
+    assert np.array_equal(np.stack(runs["one"][1]), np.stack(runs["two"][1]))          # FGR poses: same seeds per pair index whatever the shard
+    assert np.array_equal(np.stack(runs["one"][0]), np.stack(runs["two"][0]))          # refined poses: every pair, every bit
+    for i in range(n):
+        ang, dt = pose_error(runs["one"][0][i], g["T_gicp"][i])
+        assert ang < 2e-2 and dt < 0.2, (i, ang, dt)

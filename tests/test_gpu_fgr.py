@@ -361,3 +361,33 @@ def test_feature_nn_tile_pruning_full_cloud(P, fgr_inputs):
     assert np.array_equal(res[3][0], res[4][0]) and np.array_equal(res[3][1], res[4][1])
     sel = np.random.default_rng(11).permutation(len(f1))[:3000]
     assert np.array_equal(res[3][0][sel], _exact_nn(f0, f1[sel]))
+
+
+def test_fgr_lockstep_groups_are_bit_identical_to_pair_by_pair(P, golden_pair_list):
+    """Stage FGR of the pair loop (1_FGR_pairwise_registration_in_NCLT_dataset.py:134-147) with `fgr_group` pairs in lockstep
+    (pcr_registro_fgr_group: every launch and host wait shared by the group) against pair by pair: the 8 golden NCLT pairs -- eight
+    different cloud sizes, so per-pair tuple counts, grids and optimiser variants differ inside a group -- with groups of 3 (ragged) and 8:
+    poses, fitness, RMSE, correspondence sets and the normals registro_FGR leaves on the clouds are the same bits; and the poses are
+    registrations (near the shipped FGR poses)."""
+    reg = P.registration
+
+    def run(fgr_group, absolute):
+        work = [(P.PointCloud(g["source"]), P.PointCloud(g["target"]), None) for g in golden_pair_list]
+        rs = reg.register_pairs_plan(work, "fgr", inflight=2, with_correspondences=True, fgr_voxel_size=0.1, fgr_use_absolute_scale=absolute, fgr_seed=2024,
+                                     keep_fgr_normals=True, fgr_group=fgr_group)
+        return work, rs
+
+    for absolute in (False, True):                       # script 1 (:54) and ALL_FUNCTIONS (:191) flavours: the scale kernel runs or not
+        base_w, base = run(1, absolute)
+        for fg in (3, 8):
+            w, rs = run(fg, absolute)
+            for k, (a, b) in enumerate(zip(base, rs)):
+                assert np.array_equal(a.transformation, b.transformation), (absolute, fg, k)
+                assert a.fitness == b.fitness and a.inlier_rmse == b.inlier_rmse, (absolute, fg, k)
+                assert np.array_equal(a.correspondence_set, b.correspondence_set), (absolute, fg, k)
+                assert np.array_equal(base_w[k][0].normals, w[k][0].normals) and np.array_equal(base_w[k][1].normals, w[k][1].normals), (absolute, fg, k)
+    ok = 0
+    for g, r in zip(golden_pair_list, base):
+        a, d = pose_error(r.transformation, g["T_fgr"])
+        ok += a < 3e-2 and d < 0.5
+    assert ok >= len(golden_pair_list) - 1, ok           # (FGR is a randomised estimator: the statistical band of SURVEY 8c)

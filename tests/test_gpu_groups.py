@@ -104,10 +104,13 @@ def test_a_bad_pair_in_a_group_fails_alone():
     for group in (1, 2):
         try:
             rs = reg.register_pairs_plan(pairs, "gicp", [1.0, 0.5], [2.0, 1.0], inflight=1, group=group)
-            outs.append(("ok", rs[0].transformation.tobytes(), rs[1].fitness))
+            outs.append(("ok", rs[0].transformation, rs[1].fitness))
         except RuntimeError as e:
             outs.append(("error", str(e)))
-    assert outs[0] == outs[1]
+    assert outs[0][0] == outs[1][0] and outs[0][2:] == outs[1][2:]
+    if outs[0][0] == "ok":      # the group plan runs every unit with the group forms of the kernels (other summation grouping): smooth loss, rounding only
+        ang, d = pose_error(outs[0][1], outs[1][1])
+        assert ang < 1e-7 and d < 1e-6, (ang, d)
 
 
 def test_group_none_sizes_groups_by_the_clouds(golden_pair_list):

@@ -23,6 +23,47 @@ def test_partition_covers_every_pair_once():
     assert list(sh.partition(901, 8, 7))[-1] == 900               # the closure pair falls to the last rank
 
 
+def test_cost_balanced_partition_on_the_nclt_size_distribution():
+    """NCLT scans hold 6.9k-31k points, and the time of a sharded stage is its slowest rank's.  Blocks balanced by the
+    points of the pairs' clouds (the 901 shipped point counts, tests/golden/nclt_point_counts.npy): contiguous, every pair once, the
+    closure pair on the last rank, the most loaded of 8 ranks within 1.1x the mean (the index split: 1.25x), every rank loads
+    block + 1 clouds."""
+    sh = pkg("sharding")
+    from conftest import GOLDEN
+    counts = np.load(os.path.join(GOLDEN, "nclt_point_counts.npy"))
+    assert len(counts) == 901 and counts.min() == 6865 and counts.max() == 31008
+    cost = sh.circuit_costs(counts)
+    assert cost[0] == counts[1] + counts[0] and cost[900] == counts[0] + counts[900]
+    for world in (2, 4, 8, 16):
+        blocks = [sh.partition(901, world, r, cost) for r in range(world)]
+        assert [i for b in blocks for i in b] == list(range(901))
+        assert blocks[-1][-1] == 900
+        load = np.array([sum(cost[i] for i in b) for b in blocks], dtype=np.float64)
+        assert load.max() <= 1.1 * load.mean(), (world, load.max() / load.mean())
+        assert [sh.partition(901, world, r, cost) for r in range(world)] == blocks          # deterministic: every rank computes the same cuts
+    plain = np.array([sum(cost[i] for i in sh.partition(901, 8, r)) for r in range(8)], dtype=np.float64)
+    assert plain.max() > 1.2 * plain.mean()                                                # what the index split leaves on the table
+    # degenerate shapes: more ranks than pairs (nobody holds two while another holds none), one heavy pair, one pair, no pair
+    assert sh.block_bounds([1, 1], 4) == [0, 1, 2, 2, 2] and sh.block_bounds([5, 1, 1], 3) == [0, 1, 2, 3]
+    assert sh.block_bounds([10, 1, 1, 1], 3) == [0, 1, 3, 4] and sh.block_bounds([3], 2) == [0, 1, 1] and sh.block_bounds([], 3) == [0, 0, 0, 0]
+    assert sh.block_bounds([1] * 7, 7) == list(range(8)) and sh.block_bounds([4, 4, 4], 1) == [0, 3]
+    with pytest.raises(ValueError):
+        sh.partition(5, 2, 0, [1, 2, 3])
+
+
+def test_pcd_point_count_reads_the_header_only(tmp_path):
+    pio = pkg("io")
+    xyz = np.random.default_rng(1).standard_normal((137, 3)).astype(np.float32)
+    p = str(tmp_path / "c.pcd")
+    pio.write_pcd_xyz(p, xyz)
+    assert pio.pcd_point_count(p) == 137
+    with open(p, "rb") as f:
+        head = f.read().split(b"DATA")[0]
+    q = str(tmp_path / "w.pcd")
+    open(q, "wb").write(b"\n".join(l for l in head.split(b"\n") if not l.startswith(b"POINTS")) + b"DATA binary\n")      # no POINTS line: WIDTH x HEIGHT
+    assert pio.pcd_point_count(q) == 137
+
+
 def _worker(rank, world, port, n_pairs, q):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)

@@ -1,0 +1,25 @@
+"""FGR stage (script-1 parameters) on the shipped-size golden NCLT clouds: the 8 golden pairs tiled to 96 pairs, through register_pairs_plan with
+`fgr_group` pairs in lockstep and `inflight` groups in flight; prints pairs/s and the error band against the shipped GICP poses.
+usage: fgr_group_sweep.py "g1xf1,g2xf2,..."   (default: 1x8,8x4,12x4,16x3,16x2,24x2)"""
+import glob, importlib, os, sys, time
+import numpy as np
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+P = importlib.import_module("point-cloud-registration-with-global-refinement_amd")
+reg = P.registration
+gold = [np.load(f) for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "nclt_pair_*.npz")))]
+work = [(P.PointCloud(g["source"]), P.PointCloud(g["target"]), None) for g in gold] * 12
+truth = [g["T_gicp"] for g in gold] * 12
+def err(T, R):
+    dR = T[:3, :3].T @ R[:3, :3]
+    return float(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))), float(np.linalg.norm(T[:3, 3] - R[:3, 3]))
+combos = [tuple(int(v) for v in c.split("x")) for c in (sys.argv[1] if len(sys.argv) > 1 else "1x8,8x4,12x4,16x3,16x2,24x2").split(",")]
+for g, f in combos:
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        rs = reg.register_pairs_plan(work, "fgr", inflight=f, with_correspondences=False, fgr_voxel_size=0.1, fgr_use_absolute_scale=False, fgr_seed=5, fgr_group=g)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    e = [err(r.transformation, T) for r, T in zip(rs, truth)]
+    good = sum(1 for a, d in e if a < 3e-2 and d < 0.5)
+    print(f"fgr_group {g} x {f} in flight: {len(work) / dt:.1f} pairs/s; {good}/{len(e)} within 3e-2 rad / 0.5 m of the shipped GICP pose (median {np.median([a for a, _ in e]):.2e} rad {np.median([d for _, d in e]):.2e} m)", flush=True)

@@ -1,7 +1,8 @@
 // VALU issue-rate micro-benchmark (gfx950): 30-long chains of independent-register v_med3_f32 / v_min+v_max / v_fma_f32 / v_max3_f32 /
-// v_max_i32 per loop iteration, at 1, 2, 4 and 8 wavefronts per SIMD on every CU.  Prints ns and cycles per wave-instruction per SIMD
+// v_max_i32 / v_add_f32 / v_mul_f32 per loop iteration, at 1, 2, 4 and 8 wavefronts per SIMD on every CU.  Prints ns and cycles per wave-instruction per SIMD
 // (cycles from the kernel's own s_memtime / s_memrealtime clock ratio).
-// build + run on the GPU box: hipcc -O3 --offload-arch=gfx950 valu_rate.hip -o /tmp/valu_rate && /tmp/valu_rate
+// build + run on the GPU box: hipcc -O3 -fno-slp-vectorize --offload-arch=gfx950 valu_rate.hip -o /tmp/valu_rate && /tmp/valu_rate
+// (-fno-slp-vectorize: otherwise the compiler packs neighbouring chains into v_pk_* instructions)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define N 30
@@ -19,6 +20,10 @@ __global__ void __launch_bounds__(256) k(float *out, int iters, float seed, unsi
             if (OP == 2) s[j] = __builtin_fmaf(x, s[j], s[j + 1]);
             if (OP == 3) s[j] = __builtin_fmaxf(__builtin_fmaxf(x, s[j]), s[j + 1]);   // v_max3_f32
             if (OP == 4) s[j] = __int_as_float(max(__float_as_int(x), __float_as_int(s[j + 1])));
+            if (OP == 5) s[j] = s[j] + x;                                                       // v_add_f32, two VGPR sources
+            if (OP == 6) s[j] = s[j] * 1.0001f;                                                 // v_mul_f32, one VGPR source + a literal
+            if (OP == 7) s[j] = __builtin_fmaf(x, x, s[j]);                                     // v_fma_f32 with two distinct VGPR sources
+            if (OP == 8) s[j] = __builtin_fmaf(s[j], 1.0001f, 0.5f);                            // v_fmaak / v_fma with one VGPR source
         }
         x += 1.0f;
     }
@@ -45,6 +50,7 @@ int main() {
     for (int wps : {1, 2, 4, 8}) {
         run<0>("v_med3_f32", N - 1, wps); run<1>("v_min_f32 + v_max_f32", 2 * (N - 1), wps); run<2>("v_fma_f32", N - 1, wps);
         run<3>("v_max3_f32", N - 1, wps); run<4>("v_max_i32", N - 1, wps);
+        run<5>("v_add_f32 (2 VGPR)", N - 1, wps); run<6>("v_mul_f32 (1 VGPR + lit)", N - 1, wps); run<7>("v_fma_f32 (x, x, s)", N - 1, wps); run<8>("v_fma (1 VGPR + 2 lit)", N - 1, wps);
     }
     return 0;
 }
