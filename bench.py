@@ -330,8 +330,12 @@ def main(argv=None) -> int:
         if tj:
             try:
                 t = json.load(open(tj))
+                grp = t.get("groups/k_icp_fused")               # the timed configuration: k_icp_fused_b<1024> of a lockstep group of six (per launch = six pairs)
                 traffic_file = {"file": tname, "taken_at_commit": tcommit, "hbm_bytes_per_launch": t.get("k_icp_fused", {}).get("hbm_bytes_per_launch"),
-                                "note": "tracked rocprofv3 --pmc result (FETCH_SIZE x2 + WRITE_SIZE), a previous run of the same kernel, not this run"}
+                                "hbm_bytes_per_launch_group_of_6": grp.get("hbm_bytes_per_launch") if grp else None,
+                                "k_knn_wave_batchp_hbm_bytes_per_launch": t.get("groups/k_knn_wave_batchp<SOR,30>", {}).get("hbm_bytes_per_launch"),
+                                "note": "tracked rocprofv3 --pmc result (FETCH_SIZE x2 + WRITE_SIZE), a previous run of the same kernels, not this run: one pair at a time (the solo "
+                                        "roofline pass above) and the default lockstep-group path"}
             except Exception:       # noqa: BLE001
                 traffic_file = None
         rule_txt = "radius_from_cloud_pair * 2^-i per pair (ALL_FUNCTIONS.py:277-278)" if args.radius_rule == "af" else "radii " + "/".join(f"{d:g}" for d in pairs[0].max_distances_script) + " m"
@@ -492,11 +496,14 @@ def extras(args, P, syn, reg, est, crit, pairs, clouds, run_batch, pool_prof, po
         torch.cuda.synchronize(); t0 = time.perf_counter()
         r5 = run5(n5, fl5)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        # the iteration kernel's own period: one pair at a time, HIP events on its launch stream
+        # the iteration kernel's own period: one pair at a time, HIP events on its launch stream, every scale's loop started after the preprocessing
+        # of the later scales has finished (option "fence_prep": their 7-ms k-NN searches otherwise share the chip with the loop being timed)
+        P._lib.set_option("fence_prep", 1)
         pool_prof(enable=1, reset=True)
         run5(2, 1)
         torch.cuda.synchronize()
         f5 = pool_prof(enable=0, reset=True)
+        P._lib.set_option("fence_prep", 0)
         us = 1e3 * f5[0] / f5[1] if f5[1] else None
         bpl = f5[4] / f5[3] if f5[3] else 0.0
         out["config5_2M_points_5_scales_64nn"] = {
@@ -504,7 +511,7 @@ def extras(args, P, syn, reg, est, crit, pairs, clouds, run_batch, pool_prof, po
             "scales": [dict(voxel=s["voxel"], n_clean=s["n_clean"], iterations=s["iterations"]) for s in r5[0].scales],
             "err_vs_planted": pose_err(r5[0], p5[0]),
             "roofline": {"bound": "hbm", "kernel": "k_icp_cert + k_icp_search + k_icp_lin (one GICP iteration as streaming kernels: clouds from 400k points)", "bytes_per_launch": bpl, "us_per_launch_hip_events": us,
-                         "measured_on": "2 pairs, one at a time, after the timed batch",
+                         "measured_on": "2 pairs, one at a time, after the timed batch, each scale's loop fenced against the later scales' preprocessing (pcr_set_option fence_prep)",
                          "achieved": (bpl / (us * 1e-6) / 1e9) if us else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (bpl / (us * 1e-6) / 1e9 / HBM_PEAK_GBS) if us else 0.0},
             "what": "BASELINE config 5: 2M-point clouds (10 tiles of the 200k scene, synthetic.tile_pair), script-2 5-scale table, 64-NN normals"}

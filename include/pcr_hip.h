@@ -279,7 +279,9 @@ int pcr_debug_feature_nn(pcr_context *ctx, const float *f0, int64_t n0, const fl
  * name in upper case with the PCR_ prefix when the library first needs it; this call overrides it afterwards without touching the
  * environment (worker threads read an atomic, never getenv).  "knn_wave": -1 by size and call form (default), 0 the octet k-NN kernel,
  * 1 the one-query-per-lane kernel for every search that fits it; "knnw_budget": candidate batches a wavefront of that kernel takes before
- * it hands its queries over.  Returns PCR_EINVAL for an unknown name. */
+ * it hands its queries over; "fence_prep": measurement only -- with profiling on, every scale's GICP loop of the pipelined multiscale path
+ * (clouds the batched preprocessing declines: config 5) starts after ALL preprocessing enqueued so far has finished, so that HIP-event times
+ * per launch are the iteration kernels' own.  Returns PCR_EINVAL for an unknown name. */
 int pcr_set_option(const char *name, long long value);
 
 #ifdef __cplusplus

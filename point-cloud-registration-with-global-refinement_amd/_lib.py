@@ -12,7 +12,7 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libpcr_hip.so")
+SO_PATH = os.environ.get("PCR_HIP_SO") or os.path.join(_HERE, "libpcr_hip.so")      # (PCR_HIP_SO: diagnostic builds of tools/build_variant.sh)
 
 PCR_OK, PCR_EINVAL, PCR_ENOMEM, PCR_EHIP, PCR_ENUMERIC, PCR_ECAPACITY = 0, -1, -2, -3, -4, -5
 SEARCH_KNN, SEARCH_RADIUS, SEARCH_HYBRID = 0, 1, 2
@@ -110,7 +110,8 @@ def load():
             lib.pcr_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
             lib.pcr_destroy.argtypes = [C.c_void_p]
             lib.pcr_set_stream.argtypes = [C.c_void_p, C.c_void_p]
-            lib.pcr_set_option.argtypes = [C.c_char_p, C.c_longlong]
+            if hasattr(lib, "pcr_set_option"):       # (absent only from older diagnostic builds loaded through PCR_HIP_SO)
+                lib.pcr_set_option.argtypes = [C.c_char_p, C.c_longlong]
             _lib = lib
     return _lib
 

@@ -3,8 +3,8 @@
 set -e
 cd "$(dirname "$0")"
 ARCH=${PCR_ARCH:-gfx950}
-FLAGS="-O3 --offload-arch=$ARCH -fPIC -std=c++17 -Wall -Wno-unused-function -Wno-unused-variable"
-OUT=../libpcr_hip.so
+FLAGS="-O3 --offload-arch=$ARCH -fPIC -std=c++17 -Wall -Wno-unused-function -Wno-unused-variable $PCR_EXTRA_FLAGS"
+OUT=${PCR_OUT:-../libpcr_hip.so}
 objs=""
 for f in pcr_sort pcr_cloud pcr_gicp pcr_featnn pcr_fgr pcr_api; do
   [ -f $f.hip ] || continue

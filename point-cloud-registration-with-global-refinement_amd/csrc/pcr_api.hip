@@ -20,6 +20,7 @@ PcrOptions &pcr_options() {
     std::call_once(once, []() {
         if (const char *e = getenv("PCR_KNN_WAVE")) o.knn_wave = atoi(e);
         if (const char *e = getenv("PCR_KNNW_BUDGET")) o.knnw_budget = atoi(e);
+        if (const char *e = getenv("PCR_FENCE_PREP")) o.fence_prep = atoi(e);
     });
     return o;
 }
@@ -28,6 +29,7 @@ extern "C" int pcr_set_option(const char *name, long long value) {
     PcrOptions &o = pcr_options();
     if (!strcmp(name, "knn_wave")) { o.knn_wave = (int)value; return PCR_OK; }
     if (!strcmp(name, "knnw_budget")) { o.knnw_budget = (int)value; return PCR_OK; }
+    if (!strcmp(name, "fence_prep")) { o.fence_prep = (int)value; return PCR_OK; }
     return PCR_EINVAL;
 }
 
@@ -778,6 +780,11 @@ static int multiscale_gicp_impl(pcr_context *ctx, const float *src_xyz, const fl
         PCR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->lane_ev[2 * r + 1], 0));
         int32_t *match = arena<int32_t>(ctx, n_src > 0 ? n_src : 1);
         if (!match) return PCR_ENOMEM;
+        // measurement only (option "fence_prep" with profiling on: bench.py's solo roofline pass of config 5): no later scale's preprocessing shares
+        // the chip with this scale's loop, so the HIP-event time per launch is the iteration kernels' own
+        if (ctx->profiling && pcr_options().fence_prep.load(std::memory_order_relaxed)) {
+            PCR_HIP_CHECK(ctx, hipStreamSynchronize(lane_t)); PCR_HIP_CHECK(ctx, hipStreamSynchronize(lane_s));
+        }
         PCR_TRY(pcr_dev_gicp(ctx, &cs[r], &ct[r], dists[s], T, params, &records[s].icp, match));
         int h[4];
         PCR_HIP_CHECK(ctx, hipMemcpyAsync(h, cnt4 + 4 * r, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

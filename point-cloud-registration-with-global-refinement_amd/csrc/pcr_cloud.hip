@@ -1085,9 +1085,26 @@ struct KnnArgs {
 __device__ static inline double octet_sum(double v) { return pcr_octet_sum(v); }
 
 struct KnnBatch { KnnArgs a[PCR_MAX_BATCH]; };
-// One wavefront = 8 Morton-consecutive queries g0 .. g0 + 7 (one per octet).  `stamp_slot`: index of the wavefront in the diagnostics buffer.
-template <int MODE, int SLOTS>
-__device__ static inline void d_knn_item(const KnnArgs &a, const OctMeta &m, OctGroupStack &gstk_w, const int g0, const size_t stamp_slot) {
+// One wavefront = 8 Morton-consecutive queries g0 .. g0 + 7 (one per octet): the lambda `item` below.  LIST = false: wavefront w of workgroup b
+// serves queries (4 b + w) 8 ...; LIST = true: the queries of the wavefronts the one-query-per-lane kernel gave up (pcr_knn_wave.h: it appends
+// the first query of every such wavefront of 64 to a.hard_list, one atomic per wavefront) and nothing else -- a fixed, small grid whose
+// wavefronts stride over the 8-query pieces of the listed wavefronts (the full-range launch with a todo mask it replaces started ~100x the
+// workgroups to find the same few).  (The body is a lambda INSIDE the kernel function so that `m` and `gstk` stay LDS objects to the
+// compiler: passed by reference to a helper they became generic pointers -- 131 VGPRs and 3 wavefronts per SIMD instead of 7.)
+template <int MODE, int SLOTS, bool LIST>
+__device__ static inline void d_knn_(const KnnArgs &a) {
+    constexpr int OPB = KNN_BS / OCT;
+    __shared__ OctMeta m;
+    __shared__ OctGroupStack gstk[KNN_BS / 64];
+    int n_items = 0;
+    if (LIST) {
+        n_items = *a.hard_count * 8;                         // written by the kernel before this one on the stream
+        if ((int)blockIdx.x * (KNN_BS / 64) >= n_items) return;      // (uniform over the workgroup)
+    }
+    if (threadIdx.x == 0) m = *a.t.meta;
+    if (!LIST && blockIdx.x == 0 && threadIdx.x == 0) { if (a.zero_a) *a.zero_a = 0; if (a.zero_b) *a.zero_b = 0; }
+    __syncthreads();
+    auto item = [&](const int g0, const size_t stamp_slot) {
     const int n = m.n;
     const int lane = threadIdx.x & 63, oct = lane >> 3, ol = lane & 7;
     const unsigned long long t_begin = wall_clock64();
@@ -1156,7 +1173,7 @@ __device__ static inline void d_knn_item(const KnnArgs &a, const OctMeta &m, Oct
     const float seed_worst = tk.worst;
     int nvis = 0;
     const int first_live = g0 + (__builtin_ctzll(__ballot(live)) >> 3);
-    oct_search_group(a.t, m, gstk_w, live, a.t.leaf_of[first_live], q.x, q.y, q.z, [&]() { return tk.worst; }, visit,
+    oct_search_group(a.t, m, gstk[threadIdx.x >> 6], live, a.t.leaf_of[first_live], q.x, q.y, q.z, [&]() { return tk.worst; }, visit,
                      [&](int f, int c) { return f >= plo && f + c - 1 <= phi; }, ol,
                      ((MODE == KNN_MODE_DEBUG && a.dbg_visits) || a.stamps) ? &nvis : nullptr);
     if (a.stamps && ol == 0) {
@@ -1246,34 +1263,13 @@ __device__ static inline void d_knn_item(const KnnArgs &a, const OctMeta &m, Oct
         for (int o = 1; o < OCT; o <<= 1) c += __shfl_xor(c, o, OCT);
         if (ol == 0 && a.dbg_cnt) a.dbg_cnt[qi] = a.dbg_visits == 2 ? (int)(wall_clock64() - t_begin) : (a.dbg_visits ? nvis : c);
     }
+    };
+    const int wv = threadIdx.x >> 6;
+    if (!LIST) item((int)blockIdx.x * OPB + wv * OCT, (size_t)blockIdx.x * (KNN_BS / 64) + wv);
+    else for (int it = blockIdx.x * (KNN_BS / 64) + wv; it < n_items; it += gridDim.x * (KNN_BS / 64)) item(a.hard_list[it >> 3] + (it & 7) * OCT, 0);
 }
-
-template <int MODE, int SLOTS>
-__device__ static inline void d_knn(const KnnArgs &a) {
-    constexpr int OPB = KNN_BS / OCT;
-    __shared__ OctMeta m;
-    __shared__ OctGroupStack gstk[KNN_BS / 64];
-    if (threadIdx.x == 0) m = *a.t.meta;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { if (a.zero_a) *a.zero_a = 0; if (a.zero_b) *a.zero_b = 0; }
-    __syncthreads();
-    d_knn_item<MODE, SLOTS>(a, m, gstk[threadIdx.x >> 6], blockIdx.x * OPB + (threadIdx.x >> 6) * OCT, (size_t)blockIdx.x * (KNN_BS / 64) + (threadIdx.x >> 6));
-}
-// LIST form: the queries of the wavefronts the one-query-per-lane kernel gave up (pcr_knn_wave.h: it appends the first query of every such
-// wavefront of 64 to a.hard_list, one atomic per wavefront) and nothing else -- a fixed, small grid whose wavefronts stride over the
-// 8-query pieces of the listed wavefronts.  The full-range launch it replaces (todo mask over every query) took 18 % of the path's kernel
-// time for 5 % of its instructions: ~99 % of its wavefronts found nothing to do, behind everything else on the chip.
-template <int MODE, int SLOTS>
-__device__ static inline void d_knn_list(const KnnArgs &a) {
-    __shared__ OctMeta m;
-    __shared__ OctGroupStack gstk[KNN_BS / 64];
-    const int n_items = *a.hard_count * 8;                   // written by the kernel before this one on the stream
-    if ((int)blockIdx.x * (KNN_BS / 64) >= n_items) return;  // (uniform over the workgroup)
-    if (threadIdx.x == 0) m = *a.t.meta;
-    __syncthreads();
-    const int wv = threadIdx.x >> 6, waves = gridDim.x * (KNN_BS / 64);
-    for (int item = blockIdx.x * (KNN_BS / 64) + wv; item < n_items; item += waves)
-        d_knn_item<MODE, SLOTS>(a, m, gstk[wv], a.hard_list[item >> 3] + (item & 7) * OCT, 0);
-}
+template <int MODE, int SLOTS> __device__ static inline void d_knn(const KnnArgs &a) { d_knn_<MODE, SLOTS, false>(a); }
+template <int MODE, int SLOTS> __device__ static inline void d_knn_list(const KnnArgs &a) { d_knn_<MODE, SLOTS, true>(a); }
 template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn(KnnArgs a) { d_knn<MODE, SLOTS>(a); }
 template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn_list(KnnArgs a) { d_knn_list<MODE, SLOTS>(a); }
 template <int MODE, int SLOTS> __global__ void __launch_bounds__(KNN_BS) k_knn_list_batch(KnnBatch b) { d_knn_list<MODE, SLOTS>(b.a[blockIdx.y]); }

@@ -44,6 +44,7 @@ __device__ static inline float pcr_dpp_f(float v) { return __int_as_float(pcr_dp
 #define PCR_DPP_XOR1 0xB1      // quad_perm [1,0,3,2]
 #define PCR_DPP_XOR2 0x4E      // quad_perm [2,3,0,1]
 #define PCR_DPP_HMIRROR 0x141  // row_half_mirror
+#define PCR_DPP_MIRROR 0x140   // row_mirror (lane i <-> 15-i of each 16-lane row)
 // max / min over the octet for values that are >= 0 or exactly -1 (the k-best sentinel): their float order equals the
 // signed-integer order of their bit patterns, and integer max needs no NaN canonicalisation
 __device__ static inline float pcr_octet_max(float v) {
@@ -72,7 +73,6 @@ __device__ static inline double pcr_octet_sum(double v) {       // fixed tree =>
     return v;
 }
 
-#define PCR_DPP_MIRROR 0x140   // row_mirror (lane i <-> 15-i of each 16-lane row)
 __device__ static inline double pcr_row16_sum(double v) {       // sum over each 16-lane DPP row, result in all 16 lanes
     union { double d; int i[2]; } a, b;
     a.d = v; b.i[0] = pcr_dpp_i<PCR_DPP_XOR1>(a.i[0]); b.i[1] = pcr_dpp_i<PCR_DPP_XOR1>(a.i[1]); v += b.d;
@@ -80,6 +80,43 @@ __device__ static inline double pcr_row16_sum(double v) {       // sum over each
     a.d = v; b.i[0] = pcr_dpp_i<PCR_DPP_HMIRROR>(a.i[0]); b.i[1] = pcr_dpp_i<PCR_DPP_HMIRROR>(a.i[1]); v += b.d;
     a.d = v; b.i[0] = pcr_dpp_i<PCR_DPP_MIRROR>(a.i[0]); b.i[1] = pcr_dpp_i<PCR_DPP_MIRROR>(a.i[1]); v += b.d;
     return v;
+}
+
+// ------------------------------------------------------------------------ whole-wavefront reductions inside the VALU
+// gfx950 adds v_permlane16_swap / v_permlane32_swap: with both operands the same value, one instruction hands every lane the value of
+// lane ^ 16 (resp. ^ 32) -- an exchange between the 16-lane rows without the LDS crossbar (a __shfl_xor is ds_bpermute + s_waitcnt, ~60-100
+// cycles per step: the six steps of a 64-lane butterfly cost more than the 16 MFMAs they sat between in the feature screen).
+__device__ static inline unsigned pcr_swap16(unsigned v, unsigned *other) { auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); *other = r[1]; return r[0]; }
+__device__ static inline unsigned pcr_swap32(unsigned v, unsigned *other) { auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); *other = r[1]; return r[0]; }
+// over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} (same position in the four rows); all four get the result
+__device__ static inline float pcr_xrow_min(float v) {
+    unsigned o; unsigned a = pcr_swap16(__float_as_uint(v), &o);
+    v = fminf(__uint_as_float(a), __uint_as_float(o));
+    a = pcr_swap32(__float_as_uint(v), &o);
+    return fminf(__uint_as_float(a), __uint_as_float(o));
+}
+__device__ static inline float pcr_xrow_max(float v) {
+    unsigned o; unsigned a = pcr_swap16(__float_as_uint(v), &o);
+    v = fmaxf(__uint_as_float(a), __uint_as_float(o));
+    a = pcr_swap32(__float_as_uint(v), &o);
+    return fmaxf(__uint_as_float(a), __uint_as_float(o));
+}
+__device__ static inline unsigned pcr_xrow_or(unsigned v) {
+    unsigned o; unsigned a = pcr_swap16(v, &o);
+    v = a | o;
+    a = pcr_swap32(v, &o);
+    return a | o;
+}
+// over all 64 lanes, result in every lane: DPP inside each row (xor 1, xor 2, half mirror, mirror), then across the rows
+__device__ static inline float pcr_wave_max_all(float v) {
+    v = fmaxf(v, pcr_dpp_f<PCR_DPP_XOR1>(v)); v = fmaxf(v, pcr_dpp_f<PCR_DPP_XOR2>(v));
+    v = fmaxf(v, pcr_dpp_f<PCR_DPP_HMIRROR>(v)); v = fmaxf(v, pcr_dpp_f<PCR_DPP_MIRROR>(v));
+    return pcr_xrow_max(v);
+}
+__device__ static inline unsigned pcr_wave_or_all(unsigned v) {
+    v |= (unsigned)pcr_dpp_i<PCR_DPP_XOR1>((int)v); v |= (unsigned)pcr_dpp_i<PCR_DPP_XOR2>((int)v);
+    v |= (unsigned)pcr_dpp_i<PCR_DPP_HMIRROR>((int)v); v |= (unsigned)pcr_dpp_i<PCR_DPP_MIRROR>((int)v);
+    return pcr_xrow_or(v);
 }
 
 // ------------------------------------------------------------------------------------- reductions

@@ -38,12 +38,15 @@
 
 #define FN_D 33
 #define FN_K 128                 // [hi | hi | lo] / [hi | lo | hi] padded: 3 * 33 = 99 -> 128
+#ifndef FN_WG
 #define FN_WG 512
+#endif
 #define FN_QB 4                  // query blocks of 16 per wavefront
 #define FN_QPW (16 * FN_QB)      // queries per wavefront
 #define FN_QPG (FN_QPW * (FN_WG / 64))
 #define FN_STEP 64               // database rows per staged step (four 16-row MFMA tiles)
 #define FN_SUBS (FN_STEP / 16)
+#define FN_MIN_SPS 32              // steps a workgroup of the unpruned screen walks at least (see pcr_feature_nn_mutual)
 #define FN_CHUNK 64              // records a wavefront takes from the pool at a time
 #define FN_POOL_PER_QUERY 96     // pool capacity = this many records per query (expected: 20-40)
 #define FN_SCALE 128.0           // features are centred and scaled by a power of two before the split (keeps lo out of the f16 subnormals)
@@ -134,10 +137,18 @@ __device__ static inline void d_fn_split(const float *__restrict__ f_, int n, in
         lo[k] = (_Float16)(float)(x - (double)(float)h);
         s += x * x;
     }
-    _Float16 *a = A + (size_t)i * FN_K, *b = B + (size_t)i * FN_K;
+    // the two 256-byte rows are put together in registers and leave as sixteen 16-byte stores each (element-wise 2-byte stores made
+    // this kernel 1.2 ms per lockstep group of 16 NCLT-size pairs: 0.3 TB/s)
+    fn_h8 ra[FN_K / 8], rb[FN_K / 8];
 #pragma unroll
-    for (int k = 0; k < FN_D; k++) { a[k] = hi[k]; a[FN_D + k] = hi[k]; a[2 * FN_D + k] = lo[k]; b[k] = hi[k]; b[FN_D + k] = lo[k]; b[2 * FN_D + k] = hi[k]; }
-    for (int k = 3 * FN_D; k < FN_K; k++) { a[k] = (_Float16)0.0f; b[k] = (_Float16)0.0f; }
+    for (int k = 0; k < FN_K; k++) {
+        const _Float16 va = k < FN_D ? hi[k] : (k < 2 * FN_D ? hi[k - FN_D] : (k < 3 * FN_D ? lo[k - 2 * FN_D] : (_Float16)0.0f));
+        const _Float16 vb = k < FN_D ? hi[k] : (k < 2 * FN_D ? lo[k - FN_D] : (k < 3 * FN_D ? hi[k - 2 * FN_D] : (_Float16)0.0f));
+        ra[k / 8][k % 8] = va; rb[k / 8][k % 8] = vb;
+    }
+    fn_h8 *a = (fn_h8 *)(A + (size_t)i * FN_K), *b = (fn_h8 *)(B + (size_t)i * FN_K);
+#pragma unroll
+    for (int c = 0; c < FN_K / 8; c++) { a[c] = ra[c]; b[c] = rb[c]; }
     if (i < n) {
         nlo[i] = __double2float_rd(s * (1.0 - FN_C));
         nrm[i] = zero ? -__double2float_ru(s) : __double2float_ru(s);
@@ -164,7 +175,12 @@ __global__ void __launch_bounds__(256) k_fn_split_g(const FnSplitDesc *d) { cons
 #define FN_MD 4                            // principal coordinates in the Morton key
 #define FN_MB 8                            //   bits of each
 #define FN_NPRE 48                         // pre-pass: tiles per workgroup
-#define FN_LIST_CAP 1024                   // steps of one (workgroup, split): capacity of its list
+#ifdef FN_LIST_CAP_OVERRIDE
+#define FN_LIST_CAP FN_LIST_CAP_OVERRIDE
+#else
+#define FN_LIST_CAP 1024
+#endif
+//                  // steps of one (workgroup, split): capacity of its list
 #define FN_GRAM_SKIP 4                     // the second moments are taken on a quarter of the rows (the axes only have to be good; the means are exact)
 
 // raw second moments sum_i f_i[a] f_i[b], a <= b (thread t owns one pair; rows staged through LDS 32 at a time)
@@ -404,9 +420,7 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
         float d = -__builtin_inff();
 #pragma unroll
         for (int b = 0; b < FN_QB; b++) d = fmaxf(d, cq[b] == -__builtin_inff() ? -__builtin_inff() : __fmaf_rn(2.4e-7f, fabsf(U[b]) + nqv[b], U[b] + nqv[b]));
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) d = fmaxf(d, __shfl_xor(d, o, 64));
-        return d;
+        return pcr_wave_max_all(d);                     // (DPP + permlane swaps: no LDS round trips -- this runs after every step with a candidate)
     };
     float Dw = wave_D();
     const int qt = blockIdx.x * (FN_WG / 64) + wv;         // the wavefront's query tile (row of L)
@@ -440,21 +454,24 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
     const int n_list = n_list_s;
     if (a.stats && tid == 0) atomicAdd(&a.stats[0], (unsigned long long)n_list);
     if (n_list == 0) return;                               // nothing in this range can improve any of the 512 queries (their bounds are in Ug already)
-    // staging: thread t moves two 16-byte k-chunks (rows r and r + 32 of the step, chunk j); norms by the first 64 threads
-    const int st_r = tid >> 4, st_j = tid & 15;             // r = 0..31
+    // staging: thread t moves FN_NCH 16-byte k-chunks of the step (rows r, r + FN_WG / 16, ..., chunk j); norms by the first 64 threads
+    constexpr int FN_NCH = FN_STEP * 16 / FN_WG, FN_RSTEP = FN_WG / 16;       // 2 chunks per thread at 512 threads, 4 at 256
+    const int st_r = tid >> 4, st_j = tid & 15;             // r = 0 .. FN_RSTEP - 1
     auto st_dst = [&](int r) { return (r >> 4) * FN_SUB_BYTES + (st_j >> 2) * FN_GROUP + (r & 15) * FN_PITCH + (st_j & 3) * 16; };
-    struct Slot { uint4 v0, v1; float nv, lw; };
+    struct Slot { uint4 v[FN_NCH]; float nv, lw; };
     auto fetch = [&](int step, Slot &x) {
         x.lw = (prune && !a.pre_mode && qt < a.n_qt) ? a.L[(size_t)qt * a.L_stride + step] : 0.0f;
         const _Float16 *src = a.dbA + ((size_t)step * FN_STEP + st_r) * FN_K + st_j * 8;
-        x.v0 = *(const uint4 *)src;
-        x.v1 = *(const uint4 *)(src + (size_t)32 * FN_K);
+#pragma unroll
+        for (int c = 0; c < FN_NCH; c++) x.v[c] = *(const uint4 *)(src + (size_t)c * FN_RSTEP * FN_K);
         x.nv = tid < FN_STEP ? a.db_nlo[(size_t)step * FN_STEP + tid] : 0.0f;
     };
     auto stash = [&](int buf, const Slot &x) {
-        unsigned char *d0 = &lds[buf][st_dst(st_r)], *d1 = &lds[buf][st_dst(st_r + 32)];
-        *(uint2 *)d0 = make_uint2(x.v0.x, x.v0.y); *(uint2 *)(d0 + 8) = make_uint2(x.v0.z, x.v0.w);
-        *(uint2 *)d1 = make_uint2(x.v1.x, x.v1.y); *(uint2 *)(d1 + 8) = make_uint2(x.v1.z, x.v1.w);
+#pragma unroll
+        for (int c = 0; c < FN_NCH; c++) {
+            unsigned char *d = &lds[buf][st_dst(st_r + c * FN_RSTEP)];
+            *(uint2 *)d = make_uint2(x.v[c].x, x.v[c].y); *(uint2 *)(d + 8) = make_uint2(x.v[c].z, x.v[c].w);
+        }
         if (tid < FN_STEP) lnlo[buf][tid] = x.nv;
     };
     // The database does not fit the L2s (51 MB at 200k rows): a row block comes from the Infinity Cache or HBM, 1-2 us away, while a
@@ -466,6 +483,12 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
     float lw_cur[2] = {slot[0].lw, 0.0f};
     if (1 < n_list) { fetch(slist[1], slot[1]); lw_cur[1] = slot[1].lw; }
     unsigned long long n_comp = 0;
+#ifdef FN_STAMPS          // diagnostics build (tools/build_variant.sh ... -DFN_STAMPS): shader cycles of a wavefront per phase of the step loop
+    unsigned long long tc_bar = 0, tc_fast = 0, tc_cand = 0, tc_stash = 0, tc_fetch = 0, n_hitblk = 0;
+#define FN_T(...) __VA_ARGS__
+#else
+#define FN_T(...)
+#endif
     const float kc = (float)(2.0 * FN_C * 1.002);          // whi = wlo + kc * nlo  >=  d~ + E - nq
     const unsigned a_off = (unsigned)(g * FN_GROUP + col * FN_PITCH);
     int chunk_base = -1, chunk_fill = FN_CHUNK;            // wave-uniform: current chunk of the record pool (none yet)
@@ -478,8 +501,11 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
         const int step = slist[kk];
         const int buf = ph;
         const float lw = lw_cur[ph];                      // box distance of this step's tile from the wavefront's queries
+        FN_T(const unsigned long long t0 = __builtin_amdgcn_s_memtime();)
         if (kk + 2 < n_list) { fetch(slist[kk + 2], slot[ph]); lw_cur[ph] = slot[ph].lw; }     // slot ph held this step's rows, which are in LDS already
+        FN_T(const unsigned long long t1 = __builtin_amdgcn_s_memtime();)
         __syncthreads();                                  // buffer `buf` is complete; buffer buf^1 is no longer read by anyone
+        FN_T(const unsigned long long t2 = __builtin_amdgcn_s_memtime(); unsigned long long t3 = t2, t4 = t2;)
         const bool wave_on = !(lw > Dw);                  // wave-uniform
         if (wave_on) {
         n_comp++;
@@ -510,13 +536,13 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
                 }
             }
         }
+        FN_T(t3 = __builtin_amdgcn_s_memtime(); t4 = t3;)
         // ---- candidate path: blocks in which some lane saw a value under its threshold are recomputed from the LDS image
         unsigned long long any = BOUND_ONLY ? 0ull : __ballot(hits != 0u);
         if (any != 0ull && !dead) {
-            unsigned wave_hits = hits;                    // union over the wavefront, by a 6-step or-butterfly
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) wave_hits |= (unsigned)__shfl_xor((int)wave_hits, o, 64);
+            unsigned wave_hits = (unsigned)__builtin_amdgcn_readfirstlane((int)pcr_wave_or_all(hits));   // union over the wavefront (in a scalar register: the block loop below branches uniformly)
             while (wave_hits != 0u) {
+                FN_T(n_hitblk++;)
                 const int blk = __builtin_ctz(wave_hits);
                 wave_hits &= wave_hits - 1u;
                 const int sub = blk / FN_QB, b = blk % FN_QB;
@@ -550,7 +576,7 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
                                 if (chunk_base >= 0) a.chunk_fill[chunk_base / FN_CHUNK] = chunk_fill;
                                 nb_ = atomicAdd(a.pool_used, FN_CHUNK);
                             }
-                            chunk_base = __shfl(nb_, 0, 64); chunk_fill = 0;
+                            chunk_base = __builtin_amdgcn_readfirstlane(nb_); chunk_fill = 0;
                             if (chunk_base + FN_CHUNK > a.pool_cap) { if (lane == 0) a.flags[0] = 1; dead = true; chunk_base = -1; chunk_fill = FN_CHUNK; }
                         }
                         if (!dead) {
@@ -564,22 +590,24 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
                     if (h) { Ub = fminf(Ub, __fmaf_rn(kc, nl[i], w)); tb = Ub + cqb; }
                 }
                 // share the improved bound between the 4 row groups of a query, then store it back into the block's state
-                Ub = fminf(Ub, __shfl_xor(Ub, 16, 64));
-                Ub = fminf(Ub, __shfl_xor(Ub, 32, 64));
+                Ub = pcr_xrow_min(Ub);
 #pragma unroll
                 for (int bb = 0; bb < FN_QB; bb++) if (b == bb) { U[bb] = Ub; thr[bb] = Ub + cq[bb]; }
             }
             if (prune) Dw = wave_D();
         }
+        FN_T(t4 = __builtin_amdgcn_s_memtime();)
         }
         if (kk + 1 < n_list) stash(buf ^ 1, slot[ph ^ 1]);  // everyone passed this step's barrier, so buf^1 (read in step - 1) is free
+        FN_T(const unsigned long long t5 = __builtin_amdgcn_s_memtime(); tc_fetch += t1 - t0; tc_bar += t2 - t1; tc_fast += t3 - t2; tc_cand += t4 - t3; tc_stash += t5 - t4;)
       }
     }
     if (lane == 0 && chunk_base >= 0) a.chunk_fill[chunk_base / FN_CHUNK] = chunk_fill;
     if (a.stats && lane == 0) { atomicAdd(&a.stats[1], n_comp); atomicAdd(&a.stats[2], (unsigned long long)n_list); }
+    FN_T(if (a.stats && lane == 0) { atomicAdd(&a.stats[4], tc_fetch); atomicAdd(&a.stats[5], tc_bar); atomicAdd(&a.stats[6], tc_fast); atomicAdd(&a.stats[7], tc_cand); atomicAdd(&a.stats[8], tc_stash); atomicAdd(&a.stats[9], n_hitblk); })
     if (BOUND_ONLY)
 #pragma unroll
-        for (int b = 0; b < FN_QB; b++) { U[b] = fminf(U[b], __shfl_xor(U[b], 16, 64)); U[b] = fminf(U[b], __shfl_xor(U[b], 32, 64)); }
+        for (int b = 0; b < FN_QB; b++) U[b] = pcr_xrow_min(U[b]);
     if (g == 0)
 #pragma unroll
         for (int b = 0; b < FN_QB; b++) {
@@ -619,8 +647,7 @@ __device__ static inline bool fn_record(const FnxArgs &a, int r, int *q, int *ro
     return a.rec_w[r] <= thr;                             // else: could not be the minimum given the final bound
 }
 // pass 1: smallest exact distance per query
-__device__ static inline void d_fn_exact_min(const FnxArgs &a, int n_rec_cap) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
+__device__ static inline void d_fn_exact_min(const FnxArgs &a, int n_rec_cap, const int r) {
     int q, row;
     if (r >= n_rec_cap || !fn_record(a, r, &q, &row)) return;
     const size_t oq = a.perm_q ? a.perm_q[q] : (size_t)q, orow = a.perm_db ? a.perm_db[row] : (size_t)row;
@@ -635,14 +662,13 @@ __device__ static inline void d_fn_exact_min(const FnxArgs &a, int n_rec_cap) {
     }
 }
 // pass 2: smallest row among the records that attain it (exact ties -> smaller index, as the oracle's heap orders them)
-__global__ void __launch_bounds__(256) k_fn_exact_min(FnxArgs a, int n_rec_cap) { d_fn_exact_min(a, n_rec_cap); }
-__device__ static inline void d_fn_exact_arg(const FnxArgs &a, int n_rec_cap) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(256) k_fn_exact_min(FnxArgs a, int n_rec_cap) { d_fn_exact_min(a, n_rec_cap, blockIdx.x * 256 + threadIdx.x); }
+__device__ static inline void d_fn_exact_arg(const FnxArgs &a, int n_rec_cap, const int r) {
     int q, row;
     if (r >= n_rec_cap || !fn_record(a, r, &q, &row)) return;
     if ((unsigned long long)__double_as_longlong(a.rec_d[r]) == a.best_d[q]) atomicMin(&a.out[a.perm_q ? a.perm_q[q] : q], (int)(a.perm_db ? a.perm_db[row] : row));
 }
-__global__ void __launch_bounds__(256) k_fn_exact_arg(FnxArgs a, int n_rec_cap) { d_fn_exact_arg(a, n_rec_cap); }
+__global__ void __launch_bounds__(256) k_fn_exact_arg(FnxArgs a, int n_rec_cap) { d_fn_exact_arg(a, n_rec_cap, blockIdx.x * 256 + threadIdx.x); }
 // pass 3: zero queries take the first zero row; a query without any record (empty database) gets -1
 __device__ static inline void d_fn_finish(const FnxArgs &a) {
     const int q = blockIdx.x * 256 + threadIdx.x;
@@ -653,8 +679,17 @@ __device__ static inline void d_fn_finish(const FnxArgs &a) {
 }
 __global__ void __launch_bounds__(256) k_fn_finish(FnxArgs a) { d_fn_finish(a); }
 struct FnxDesc { FnxArgs x; int n_rec_cap; };
-__global__ void __launch_bounds__(256) k_fn_exact_min_g(const FnxDesc *d) { const FnxDesc &a = d[blockIdx.y]; if ((int)blockIdx.x * 256 < a.n_rec_cap) d_fn_exact_min(a.x, a.n_rec_cap); }
-__global__ void __launch_bounds__(256) k_fn_exact_arg_g(const FnxDesc *d) { const FnxDesc &a = d[blockIdx.y]; if ((int)blockIdx.x * 256 < a.n_rec_cap) d_fn_exact_arg(a.x, a.n_rec_cap); }
+// (batch forms: a fixed grid strides over the USED part of a problem's pool -- a fifth of its capacity -- instead of one thread per slot of the capacity)
+__global__ void __launch_bounds__(256) k_fn_exact_min_g(const FnxDesc *d) {
+    const FnxDesc &a = d[blockIdx.y];
+    const int used = *a.x.pool_used < a.n_rec_cap ? *a.x.pool_used : a.n_rec_cap;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < used; r += gridDim.x * 256) d_fn_exact_min(a.x, a.n_rec_cap, r);
+}
+__global__ void __launch_bounds__(256) k_fn_exact_arg_g(const FnxDesc *d) {
+    const FnxDesc &a = d[blockIdx.y];
+    const int used = *a.x.pool_used < a.n_rec_cap ? *a.x.pool_used : a.n_rec_cap;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < used; r += gridDim.x * 256) d_fn_exact_arg(a.x, a.n_rec_cap, r);
+}
 __global__ void __launch_bounds__(256) k_fn_finish_g(const FnxDesc *d) { const FnxDesc &a = d[blockIdx.y]; if ((int)blockIdx.x * 256 < a.x.n_q) d_fn_finish(a.x); }
 
 // one launch instead of five memsets per direction (registro_FGR on NCLT-size clouds is bound by the rate of small dependent launches)
@@ -808,6 +843,9 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         if (sps > FN_LIST_CAP || pre > FN_LIST_CAP) return PCR_ECAPACITY;
         int splits_all = (2048 + groups - 1) / groups;                                // the pass with records over ALL steps (unpruned form)
         if (splits_all > 256) splits_all = 256;
+        // a workgroup first loads the B operands of its 512 queries (128 KB): under FN_MIN_SPS steps of 16 KB each that load is most of its
+        // traffic (NCLT-size clouds: 40 groups x 52 splits of 6 steps read 8x what 9 splits of 35 read; the matches are exact either way)
+        if (splits_all > (steps + FN_MIN_SPS - 1) / FN_MIN_SPS) splits_all = (steps + FN_MIN_SPS - 1) / FN_MIN_SPS;
         if (splits_all < (steps + FN_LIST_CAP - 1) / FN_LIST_CAP) splits_all = (steps + FN_LIST_CAP - 1) / FN_LIST_CAP;
         if (splits_all > steps) splits_all = steps;
         const int sps_all = (steps + splits_all - 1) / splits_all;
@@ -833,7 +871,7 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         a.pool_used = pool_used; a.pool_cap = pool_cap; a.chunk_fill = chunk_fill; a.rec_q = rec_q; a.rec_row = rec_row; a.rec_w = rec_w; a.flags = flags;
         a.L = nullptr; a.L_stride = 0; a.n_qt = 0; a.prelist = nullptr; a.pre_mode = 0; a.n_bound = 0; a.stats = nullptr;
         unsigned long long *stats = nullptr;
-        if (check) { stats = arena<unsigned long long>(ctx, 4); if (!stats) return PCR_ENOMEM; PCR_HIP_CHECK(ctx, hipMemsetAsync(stats, 0, 32, ctx->stream)); a.stats = stats; }
+        if (check) { stats = arena<unsigned long long>(ctx, 16); if (!stats) return PCR_ENOMEM; PCR_HIP_CHECK(ctx, hipMemsetAsync(stats, 0, 128, ctx->stream)); a.stats = stats; }
         if (prune) {
             const int nqt = (nq + 63) / 64, nbt = steps;
             float *L = arena<float>(ctx, (size_t)nqt * nbt);
@@ -877,9 +915,11 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
             PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h[0], pool_used, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h[1], flags, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             PCR_HIP_CHECK(ctx, hipMemcpyAsync(hd, dbg, 8, hipMemcpyDeviceToHost, ctx->stream));
-            unsigned long long hs[4] = {0, 0, 0, 0};
-            PCR_HIP_CHECK(ctx, hipMemcpyAsync(hs, stats, 32, hipMemcpyDeviceToHost, ctx->stream));
+            unsigned long long hs[16] = {0};
+            PCR_HIP_CHECK(ctx, hipMemcpyAsync(hs, stats, 128, hipMemcpyDeviceToHost, ctx->stream));
             PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            if (hs[4] + hs[5] + hs[6]) fprintf(stderr, "featnn dir %d: wavefront cycles per phase of the step loop (FN_STAMPS, summed over wavefronts, M cycles): fetch issue %.1f, barrier wait %.1f, fast path %.1f, "
+                                                       "candidate path %.1f (%llu hit blocks), stash %.1f\n", dir, hs[4] * 1e-6, hs[5] * 1e-6, hs[6] * 1e-6, hs[7] * 1e-6, hs[9], hs[8] * 1e-6);
             fprintf(stderr, "featnn dir %d: tile pruning %s: %llu steps staged of %lld (workgroup x step), %llu (wavefront, step) pairs computed of %lld\n", dir, prune ? "on" : "off",
                     hs[0], (long long)groups * steps, hs[1], (long long)groups * (FN_WG / 64) * steps);
             fprintf(stderr, "featnn dir %d: %d queries x %d rows, pre %d + %d splits x %d steps of %d rows; pool %d of %d records allocated (%.1f per query)%s, %.0f survived the final bound (%.2f per query); "
@@ -969,8 +1009,12 @@ int pcr_feature_nn_mutual_batch(pcr_context *ctx, int G, const float *const *f0,
             const int qc = dir == 0 ? 1 : 0, dc = 1 - qc, k = 2 * g + dir;
             int32_t *out = dir == 0 ? out_1to0[g] : out_0to1[g];
             const int nq = p.n[qc], nqp = p.np[qc], steps = p.np[dc] / FN_STEP, groups = nqp / FN_QPG;
-            int splits_all = (2048 + groups - 1) / groups;
+            // the grid is shared by 2 G problems: ~3072 workgroups in all, and no workgroup under FN_MIN_SPS steps (it loads 128 KB of query
+            // operands first; a group of 16 NCLT-size pairs cut as the one-pair call cuts them spent 26 ms per launch on 66 000 workgroups of 6 steps)
+            int splits_all = (3072 + groups * NP - 1) / (groups * NP);
             if (splits_all > 256) splits_all = 256;
+            if (splits_all > (steps + FN_MIN_SPS - 1) / FN_MIN_SPS) splits_all = (steps + FN_MIN_SPS - 1) / FN_MIN_SPS;
+            if (splits_all < 1) splits_all = 1;
             if (splits_all < (steps + FN_LIST_CAP - 1) / FN_LIST_CAP) splits_all = (steps + FN_LIST_CAP - 1) / FN_LIST_CAP;
             if (splits_all > steps) splits_all = steps;
             const int sps_all = (steps + splits_all - 1) / splits_all;
@@ -996,7 +1040,9 @@ int pcr_feature_nn_mutual_batch(pcr_context *ctx, int G, const float *const *f0,
             a.db_first_zero = p.first_zero + dc; a.Ug = Ug;
             a.pool_used = pool_used; a.pool_cap = pool_cap; a.chunk_fill = chunk_fill; a.rec_q = rec_q; a.rec_row = rec_row; a.rec_w = rec_w; a.flags = p.flags;
             a.L = nullptr; a.L_stride = 0; a.n_qt = 0; a.prelist = nullptr; a.pre_mode = 0; a.n_bound = 0; a.stats = nullptr;
-            const int pre_b = steps < 64 ? steps : 64, pb_splits = pre_b < 8 ? pre_b : 8, pb_sps = (pre_b + pb_splits - 1) / pb_splits;
+            int pb_want = (2048 + groups * NP - 1) / (groups * NP);                // the bound-only sweep over the first 64 steps: as many cuts as fill the chip once
+            if (pb_want > 8) pb_want = 8;
+            const int pre_b = steps < 64 ? steps : 64, pb_splits = pre_b < pb_want ? pre_b : pb_want, pb_sps = (pre_b + pb_splits - 1) / pb_splits;
             a.step0 = 0; a.steps_per_split = pb_sps; a.step_end = pre_b;
             bound[k] = a;
             a.step0 = 0; a.steps_per_split = sps_all; a.step_end = steps;
@@ -1016,8 +1062,9 @@ int pcr_feature_nn_mutual_batch(pcr_context *ctx, int G, const float *const *f0,
     PCR_LAUNCH(ctx, k_fn_init_g, dim3((max_init + 255) / 256, NP), dim3(256), 0, ctx->stream, di);
     PCR_LAUNCH(ctx, k_feature_nn_screen_g<true>, dim3(max_groups, max_pb, NP), dim3(FN_WG), 0, ctx->stream, db);
     PCR_LAUNCH(ctx, k_feature_nn_screen_g<false>, dim3(max_groups, max_splits, NP), dim3(FN_WG), 0, ctx->stream, dr);
-    PCR_LAUNCH(ctx, k_fn_exact_min_g, dim3((max_pool + 255) / 256, NP), dim3(256), 0, ctx->stream, dx);
-    PCR_LAUNCH(ctx, k_fn_exact_arg_g, dim3((max_pool + 255) / 256, NP), dim3(256), 0, ctx->stream, dx);
+    const int xgrid = std::min((max_pool + 255) / 256, std::max(64, 4096 / NP));
+    PCR_LAUNCH(ctx, k_fn_exact_min_g, dim3(xgrid, NP), dim3(256), 0, ctx->stream, dx);
+    PCR_LAUNCH(ctx, k_fn_exact_arg_g, dim3(xgrid, NP), dim3(256), 0, ctx->stream, dx);
     PCR_LAUNCH(ctx, k_fn_finish_g, dim3((max_nq + 255) / 256, NP), dim3(256), 0, ctx->stream, dx);
     for (int g = 0; g < G; g++) overflow_dev[g] = P[g].flags;         // pool overflow of a pair (either direction): its results are incomplete
     return PCR_OK;

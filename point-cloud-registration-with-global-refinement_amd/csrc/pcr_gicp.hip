@@ -1313,6 +1313,8 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
             for (auto &gr : ctx->icp_graphs) if (gr.key == key) { hit = &gr; break; }
             if (!hit) {
                 IcpGraph e; e.key = key;
+                // (the graph objects belong to `e` until it is stored: an early error return below must not leak them)
+                struct Owner { IcpGraph *g; ~Owner() { if (g) { if (g->exec) (void)hipGraphExecDestroy(g->exec); if (g->graph) (void)hipGraphDestroy(g->graph); } } } owner{&e};
                 PCR_HIP_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
                 for (int k = 0; k < CHUNK; k++) enqueue(which == 0 ? k : CHUNK + k);
                 PCR_HIP_CHECK(ctx, hipStreamEndCapture(ctx->stream, &e.graph));
@@ -1320,7 +1322,11 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
                 // the captured chunk is a chain: walk it from its root so that nodes[] is in launch order
                 size_t nr = 1; hipGraphNode_t node = nullptr;
                 PCR_HIP_CHECK(ctx, hipGraphGetRootNodes(e.graph, &node, &nr));
+                if (nr != 1) { ctx->err = "GICP group: captured chunk has more than one root"; return PCR_EHIP; }
                 while (node) {
+                    hipGraphNodeType nt;
+                    PCR_HIP_CHECK(ctx, hipGraphNodeGetType(node, &nt));
+                    if (nt != hipGraphNodeTypeKernel) { ctx->err = "GICP group: captured chunk holds a node that is not a kernel"; return PCR_EHIP; }
                     e.nodes.push_back(node);
                     size_t nd = 0;
                     PCR_HIP_CHECK(ctx, hipGraphNodeGetDependentNodes(node, nullptr, &nd));
@@ -1329,6 +1335,11 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
                     hipGraphNode_t next = nullptr;
                     PCR_HIP_CHECK(ctx, hipGraphNodeGetDependentNodes(node, &next, &nd));
                     node = next;
+                }
+                {   // launch order of a chunk: launch 0 is search + linearisation (two kernels), every later launch one fused kernel (or the same two)
+                    size_t expect = 0;
+                    for (int k = 0; k < CHUNK; k++) expect += ((which == 0 ? k : CHUNK + k) > 0 && use_fused_g) ? 1 : 2;
+                    if (e.nodes.size() != expect) { ctx->err = "GICP group: captured chunk does not match its launch list"; return PCR_EHIP; }
                 }
                 e.baked = now;
                 if (ctx->icp_graphs.size() >= 32) {
@@ -1340,6 +1351,7 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
                         ctx->icp_graphs.erase(ctx->icp_graphs.begin() + victim);
                     }
                 }
+                owner.g = nullptr;                            // stored: the context owns the graph from here on
                 ctx->icp_graphs.push_back(std::move(e));
                 hit = &ctx->icp_graphs.back();
             } else if (hit->baked != now) {

@@ -9,7 +9,7 @@
 #include "../../include/pcr_hip.h"
 
 // process-wide switches (pcr_set_option, include/pcr_hip.h): latched from the environment once, atomics afterwards
-struct PcrOptions { std::atomic<int> knn_wave{-1}, knnw_budget{80}; };
+struct PcrOptions { std::atomic<int> knn_wave{-1}, knnw_budget{80}, fence_prep{0}; };
 PcrOptions &pcr_options();
 #define PCR_GROUP_FORMS_MAX_POINTS 400000      // pcr_pairs_plan.pair_forms: pairs with both clouds under this take the group forms of the kernels
 

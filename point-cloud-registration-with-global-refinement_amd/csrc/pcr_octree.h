@@ -208,7 +208,7 @@ __device__ static inline int2 pcr_grid_lookup(const GridView &g, unsigned mask, 
     if (x < 0 || y < 0 || z < 0 || x >= lim || y >= lim || z >= lim) return make_int2(0, 0);
     const unsigned long long code = pcr_morton3((uint32_t)x, (uint32_t)y, (uint32_t)z);
     unsigned h = pcr_grid_hash(code, mask);
-    for (int probe = 0; probe < 64; probe++) {
+    for (unsigned probe = 0; probe <= mask; probe++) {                             // until the cell or an empty slot, as k_grid_build inserts (load factor <= 0.5: 1-2 probes)
         const int4 e = *(const int4 *)&g.tab[h];                                   // one 16-B load
         const unsigned long long c = ((unsigned long long)(unsigned)e.y << 32) | (unsigned)e.x;
         if (c == code) return make_int2(e.z, e.w);

@@ -4,8 +4,8 @@
 #   profiles/rNN_pmc_hbm_traffic.csv      per-kernel HBM traffic from separate --pmc passes (FETCH_SIZE, WRITE_SIZE, TCC hit/miss)
 #   profiles/rNN_traffic.json             the same numbers keyed by kernel (bench.py reads it for roofline.traffic)
 #   profiles/rNN_config5_kernel_stats.csv / rNN_nclt_kernel_stats.csv: the same summary for config 5 (2M points, 5 scales) and NCLT-size pairs
-# usage: tools/make_profiles.sh r03
-TAG=${1:-r03}
+# usage: tools/make_profiles.sh r04
+TAG=${1:-r04}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/profiles_$TAG
@@ -19,6 +19,10 @@ python3 "$ROOT/tools/trace_overview.py" "$OUT/stats" 0.4 > "$ROOT/profiles/${TAG
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/fgr" -o run -- python3 "$ROOT/bench.py" --variant fgr --no-cpu-baseline --steps 1 --warmup 1 --pairs-per-step 16 > "$OUT/bench_fgr.log" 2> "$OUT/bench_fgr.err" || exit 1
 cp "$(find "$OUT/fgr" -name '*kernel_stats.csv' | head -1)" "$ROOT/profiles/${TAG}_fgr_kernel_stats.csv"
 grep '^{"metric' "$OUT/bench_fgr.log" | tail -1 > "$ROOT/profiles/${TAG}_bench_line_fgr_under_rocprof.json"
+# the script-1 FGR stage on the shipped-size golden NCLT clouds in lockstep FGR groups (16 pairs per group, 4 groups in flight)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/fgrn" -o run -- python3 "$ROOT/tools/fgr_group_sweep.py" 16x4 > "$OUT/fgr_nclt.log" 2> "$OUT/fgr_nclt.err" || exit 1
+cp "$(find "$OUT/fgrn" -name '*kernel_stats.csv' | head -1)" "$ROOT/profiles/${TAG}_fgr_nclt_groups_kernel_stats.csv"
+grep '^fgr_group' "$OUT/fgr_nclt.log" | tail -1 > "$ROOT/profiles/${TAG}_fgr_nclt_groups_line.txt"
 # one pair at a time: gaps of the iteration chain without other pairs
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/solo" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 1 --warmup 1 --pairs-per-step 8 --inflight 1 --group 1 > "$OUT/bench_solo.log" 2> "$OUT/bench_solo.err" || exit 1
 python3 "$ROOT/tools/icp_gap_hist.py" "$OUT/solo" "$ROOT/profiles/${TAG}_icp_gaps_solo.txt" > /dev/null
@@ -36,12 +40,24 @@ for pass in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$d" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 1 --warmup 1 --pairs-per-step 4 --inflight 1 --group 1 > "$d.log" 2> "$d.err" || exit 1
   echo "pmc pass [$pass] done"
 done
+# the same three passes on the DEFAULT path (lockstep groups of six: k_knn_wave_batchp, k_icp_fused_b<1024>), 12 pairs per step
+for pass in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+  d=$OUT/pmcg_$(echo $pass | tr ' ' '_')
+  rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$d" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 1 --warmup 1 --pairs-per-step 12 --inflight 2 > "$d.log" 2> "$d.err" || exit 1
+  echo "pmc pass (groups) [$pass] done"
+done
 python3 - "$OUT" "$ROOT/profiles/${TAG}" <<'PY'
 import csv, glob, json, sys, collections
 out, dst = sys.argv[1], sys.argv[2]
 def norm(name):                      # whatever the tile, the search form and the argument form
     if "k_icp_fused" in name: return "k_icp_fused"
     if name.startswith("void k_icp_nn<") or name.startswith("k_icp_nn("): return "k_icp_nn"
+    if "k_icp_nn_g" in name: return "k_icp_nn_g"
+    if "k_icp_lin_g" in name: return "k_icp_lin_g"
+    if "k_normals_from_lists_batchp" in name: return "k_normals_from_lists_batchp"
+    if name.startswith("void k_knn_wave_batchp<0, 30>"): return "k_knn_wave_batchp<SOR,30>"
+    if name.startswith("void k_knn_list_batchp<0, 4>"): return "k_knn_list_batchp<SOR,4>"
+    if name.startswith("void k_knn_batchp<1, 4>"): return "k_knn_batchp<NORMALS,4>"
     return {"void k_icp_iter<0>(IcpArgs)": "k_icp_iter<GICP>", "void k_knn_batch<0, 4>(KnnBatch)": "k_knn_batch<SOR,4>", "void k_knn_batch<1, 4>(KnnBatch)": "k_knn_batch<NORMALS,4>",
             "k_normals_from_lists_batch(NflBatch)": "k_normals_from_lists_batch", "k_grid_build(GridBuildDesc const*)": "k_grid_build"}.get(name, name.split("(")[0])
 def load(pat):
@@ -52,20 +68,24 @@ def load(pat):
         name = norm(r["Kernel_Name"])
         d[name][r["Counter_Name"]].append((float(r["Counter_Value"]), dur))
     return d
-fetch, write, tcc = load("pmc_FETCH_SIZE"), load("pmc_WRITE_SIZE"), load("pmc_TCC_HIT_sum_TCC_MISS_sum")
 rows, js = [], {}
-for name in ["k_icp_fused", "k_icp_nn", "k_icp_iter<GICP>", "k_knn_batch<SOR,4>", "k_knn_batch<NORMALS,4>", "k_normals_from_lists_batch", "k_grid_build", "k_rs_scatter"]:
-    full = name
-    live = lambda lst: [v for v, dur in lst if dur > 6.0]            # launches after 'done' return at once: not live
-    f = live(fetch[full]["FETCH_SIZE"]); w = live(write[full]["WRITE_SIZE"])
-    h = live(tcc[full]["TCC_HIT_sum"]); m = live(tcc[full]["TCC_MISS_sum"])
-    us = [dur for v, dur in fetch[full]["FETCH_SIZE"] if dur > 6.0]
-    if not f or not w or not h: continue
-    fk, wk = sum(f) / len(f), sum(w) / len(w)
-    hbm = int((2.0 * fk + wk) * 1024)                                # gfx950: FETCH_SIZE counts 64 B per 128-B request (guide, HBM section)
-    hit = sum(h) / max(1.0, sum(h) + sum(m))
-    rows.append([name, len(f), round(fk, 1), round(wk, 1), hbm, round(hit, 3), round(sum(us) / len(us), 1)])
-    js[name] = {"hbm_bytes_per_launch": hbm, "fetch_kb": fk, "write_kb": wk, "l2_hit": hit}
+for group_form, names in ((False, ["k_icp_fused", "k_icp_nn", "k_icp_iter<GICP>", "k_knn_batch<SOR,4>", "k_knn_batch<NORMALS,4>", "k_normals_from_lists_batch", "k_grid_build", "k_rs_scatter"]),
+                          (True, ["k_icp_fused", "k_knn_wave_batchp<SOR,30>", "k_knn_list_batchp<SOR,4>", "k_knn_batchp<NORMALS,4>", "k_normals_from_lists_batchp", "k_icp_nn_g", "k_icp_lin_g"])):
+  pre = "pmcg_" if group_form else "pmc_"
+  fetch, write, tcc = load(pre + "FETCH_SIZE"), load(pre + "WRITE_SIZE"), load(pre + "TCC_HIT_sum_TCC_MISS_sum")
+  for name in names:
+      full = name
+      live = lambda lst: [v for v, dur in lst if dur > 6.0]            # launches after 'done' return at once: not live
+      f = live(fetch[full]["FETCH_SIZE"]); w = live(write[full]["WRITE_SIZE"])
+      h = live(tcc[full]["TCC_HIT_sum"]); m = live(tcc[full]["TCC_MISS_sum"])
+      us = [dur for v, dur in fetch[full]["FETCH_SIZE"] if dur > 6.0]
+      if not f or not w or not h: continue
+      fk, wk = sum(f) / len(f), sum(w) / len(w)
+      hbm = int((2.0 * fk + wk) * 1024)                                # gfx950: FETCH_SIZE counts 64 B per 128-B request (guide, HBM section)
+      hit = sum(h) / max(1.0, sum(h) + sum(m))
+      label = name + (" [default path: lockstep group of 6]" if group_form else " [one pair at a time]")
+      rows.append([label, len(f), round(fk, 1), round(wk, 1), hbm, round(hit, 3), round(sum(us) / len(us), 1)])
+      js[("groups/" if group_form else "") + name] = {"hbm_bytes_per_launch": hbm, "fetch_kb": fk, "write_kb": wk, "l2_hit": hit}
 with open(dst + "_pmc_hbm_traffic.csv", "w", newline="") as fcsv:
     wr = csv.writer(fcsv); wr.writerow(["kernel", "live_launches", "FETCH_SIZE_KB_avg", "WRITE_SIZE_KB_avg", "hbm_bytes_per_launch_corrected", "L2_hit_rate", "avg_us_live_under_pmc"]); wr.writerows(rows)
 json.dump(js, open(dst + "_traffic.json", "w"), indent=1)
@@ -84,7 +104,8 @@ for r in csv.DictReader(open(f)):
 npairs = max(1.0, len(d["void k_knn_batch<0, 4>(KnnBatch)"]["SQ_INSTS_VALU"]) / 2)          # two batched SOR searches per pair
 rows = sorted(((sum(x[0] for x in v["SQ_INSTS_VALU"]), k, len(v["SQ_INSTS_VALU"]), sum(x[1] for x in v["SQ_INSTS_VALU"])) for k, v in d.items()), reverse=True)
 tot = sum(r[0] for r in rows)
-PEAK = 256 * 4 * 2400 / 4.0                                                                  # wave64 VALU instructions per us: 1024 SIMDs, 4 cycles each at 2.4 GHz
+PEAK = 256 * 4 * 2400 / 4.0                                                                  # wave64 VALU instructions per us: 1024 SIMDs, 4 cycles each at 2.4 GHz -- the MEASURED rate of
+                                                                                             # three-source VOP3 (v_med3 / v_fma, profiles/r04_valu_rate.txt); two-source VOP2 issue at ~2.4 cycles (1024 k/us)
 with open(dst + "_pmc_valu_per_pair.csv", "w", newline="") as fo:
     w = csv.writer(fo)
     w.writerow(["kernel", "launches_per_pair", "kernel_ms_per_pair_serialised", "valu_wave_instructions_per_pair_M", "share_of_valu_instructions", "valu_instructions_per_us", "share_of_peak_issue_614k_per_us"])
