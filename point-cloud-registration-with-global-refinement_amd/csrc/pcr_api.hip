@@ -463,7 +463,8 @@ static int prep_scale(pcr_context *ctx, const float *xyz, const float *nrm, int6
     }
     if (need_tree) {     // a GICP target: its tree serves the correspondence search and the few incomplete normal lists
         PCR_TRY(pcr_dev_build_bvh(ctx, clean));
-        PCR_TRY(pcr_dev_normals(ctx, clean, PCR_SEARCH_KNN, normal_k, 0.0, prior, clean->nrm, nullptr, todo));
+        // (the SOR lists serve the normals only while normal_k <= sor_k <= 32: otherwise every point is searched and no mask is passed)
+        PCR_TRY(pcr_dev_normals(ctx, clean, PCR_SEARCH_KNN, normal_k, 0.0, prior, clean->nrm, nullptr, (sor_k <= 32 && normal_k <= sor_k) ? todo : nullptr));
     }
     return PCR_OK;
 }

@@ -1764,7 +1764,10 @@ static int sor_batch(pcr_context *ctx, SorProblem *pr, int count, int nb_neighbo
                 // the incomplete lists are searched right here, over the INPUT cloud's tree restricted to the kept points: the
                 // cleaned cloud then needs no tree of its own (7 launches less; only a GICP target needs one)
                 KnnArgs &b = fb.a[m];
-                b.t = oct_view(in); b.n_ptr = in->n; b.k = normal_k; b.prior = q.prior_out; b.normals = out->nrm_final; b.todo = q.todo_out;
+                // (lists that cannot serve -- normal_k > nb_neighbors: config 5's 64-NN normals -- leave EVERY kept point to this search: no todo
+                // mask then, so that it may run as the one-query-per-lane kernel; with the mask of all ones it ran as the octet kernel over the
+                // whole cloud, 25 % of config 5's kernel time)
+                b.t = oct_view(in); b.n_ptr = in->n; b.k = normal_k; b.prior = q.prior_out; b.normals = out->nrm_final; b.todo = fuse ? q.todo_out : nullptr;
                 b.keep = flags; b.pos = pos; b.seed_span = -1;
                 knn_radius(b, PCR_SEARCH_KNN, 0);
             }

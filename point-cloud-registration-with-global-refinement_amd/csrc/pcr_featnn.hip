@@ -41,6 +41,9 @@
 #ifndef FN_WG
 #define FN_WG 512
 #endif
+#ifndef FN_GRP
+#define FN_GRP 1                 // database tiles staged and computed between two workgroup barriers (LDS: 2 x FN_GRP x 18 KB); 2 / 4 measured: no gain, see below
+#endif
 #define FN_QB 4                  // query blocks of 16 per wavefront
 #define FN_QPW (16 * FN_QB)      // queries per wavefront
 #define FN_QPG (FN_QPW * (FN_WG / 64))
@@ -383,8 +386,8 @@ struct FnnArgs {
 // BOUND_ONLY: no candidates and no records, only the queries' upper bounds are lowered (over the first a.n_bound entries of the pre-pass list)
 template <bool BOUND_ONLY>
 __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][FN_SUBS * FN_SUB_BYTES];
-    __shared__ __attribute__((aligned(16))) float lnlo[2][FN_STEP];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * FN_GRP][FN_SUBS * FN_SUB_BYTES];
+    __shared__ __attribute__((aligned(16))) float lnlo[2 * FN_GRP][FN_STEP];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int col = lane & 15, g = lane >> 4;
     if ((int)blockIdx.x * FN_QPG >= a.n_q_pad) return;             // (batch launches: the grid is the largest problem's)
@@ -474,14 +477,25 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
         }
         if (tid < FN_STEP) lnlo[buf][tid] = x.nv;
     };
-    // The database does not fit the L2s (51 MB at 200k rows): a row block comes from the Infinity Cache or HBM, 1-2 us away, while a
-    // step computes for ~1 us.  The global loads run TWO steps ahead through two register slots, the LDS image is double buffered,
-    // and the step loop is unrolled by two so that slots and buffers are named.
-    Slot slot[2];
-    fetch(slist[0], slot[0]);
-    stash(0, slot[0]);
-    float lw_cur[2] = {slot[0].lw, 0.0f};
-    if (1 < n_list) { fetch(slist[1], slot[1]); lw_cur[1] = slot[1].lw; }
+    // The database does not fit the L2s (51 MB at 200k rows): a row block comes from the Infinity Cache or HBM, 1-2 us away.  Steps are
+    // staged FN_GRP at a time with ONE workgroup barrier per group: the LDS image is double buffered by group, the global loads of group
+    // g + 2 are issued once group g + 1 has been written to LDS and land while group g + 1 is computed on.  Round 4 measured where a
+    // wavefront's cycles go in this loop (tools/build_variant.sh stamps pcr_featnn -DFN_STAMPS, 200k x 200k rows, per direction): barrier
+    // waits 37 %, MFMA path 36 %, candidate path 10 %, LDS stash 10 %, load issue 7 % -- and then that the barriers are NOT the lever: groups
+    // of 2 / 4 tiles per barrier (13.0 / 12.9 ms against 12.6 for both directions) and workgroups of 4 / 2 wavefronts (12.1 / 12.0 against
+    // 13.0 before the other changes of the round) leave the time where it is.  A wavefront computes in 62 % of the staged steps of its
+    // workgroup, its SIMD partner likewise, and whichever way the waiting is cut the workgroup lasts as long as its busiest wavefront:
+    // the matrix pipes idle because the work of a step cannot move between wavefronts (the B operands of a wavefront's 64 queries live
+    // in its registers).  FN_GRP = 1 is the form kept (41 KB of LDS, 184 VGPRs).
+    Slot slot[FN_GRP];
+    float lw_now[FN_GRP], lw_next[FN_GRP];
+    const int n_groups = (n_list + FN_GRP - 1) / FN_GRP;
+#pragma unroll
+    for (int t = 0; t < FN_GRP; t++) { lw_now[t] = 0.0f; lw_next[t] = 0.0f; if (t < n_list) { fetch(slist[t], slot[t]); } }
+#pragma unroll
+    for (int t = 0; t < FN_GRP; t++) if (t < n_list) { stash(t, slot[t]); lw_now[t] = slot[t].lw; }
+#pragma unroll
+    for (int t = 0; t < FN_GRP; t++) if (FN_GRP + t < n_list) fetch(slist[FN_GRP + t], slot[t]);
     unsigned long long n_comp = 0;
 #ifdef FN_STAMPS          // diagnostics build (tools/build_variant.sh ... -DFN_STAMPS): shader cycles of a wavefront per phase of the step loop
     unsigned long long tc_bar = 0, tc_fast = 0, tc_cand = 0, tc_stash = 0, tc_fetch = 0, n_hitblk = 0;
@@ -493,19 +507,9 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
     const unsigned a_off = (unsigned)(g * FN_GROUP + col * FN_PITCH);
     int chunk_base = -1, chunk_fill = FN_CHUNK;            // wave-uniform: current chunk of the record pool (none yet)
     bool dead = false;                                      // the pool overflowed: flags[0] is set and the caller falls back
-    for (int k2 = 0; k2 < n_list; k2 += 2) {
-#pragma unroll
-      for (int ph = 0; ph < 2; ph++) {
-        const int kk = k2 + ph;
-        if (kk >= n_list) break;
-        const int step = slist[kk];
-        const int buf = ph;
-        const float lw = lw_cur[ph];                      // box distance of this step's tile from the wavefront's queries
-        FN_T(const unsigned long long t0 = __builtin_amdgcn_s_memtime();)
-        if (kk + 2 < n_list) { fetch(slist[kk + 2], slot[ph]); lw_cur[ph] = slot[ph].lw; }     // slot ph held this step's rows, which are in LDS already
-        FN_T(const unsigned long long t1 = __builtin_amdgcn_s_memtime();)
-        __syncthreads();                                  // buffer `buf` is complete; buffer buf^1 is no longer read by anyone
-        FN_T(const unsigned long long t2 = __builtin_amdgcn_s_memtime(); unsigned long long t3 = t2, t4 = t2;)
+    // one staged tile: LDS buffer `buf`, database step `step`, box distance `lw` of the tile from this wavefront's queries
+    auto tile = [&](const int buf, const int step, const float lw) {
+        FN_T(const unsigned long long t2 = __builtin_amdgcn_s_memtime();)
         const bool wave_on = !(lw > Dw);                  // wave-uniform
         if (wave_on) {
         n_comp++;
@@ -536,7 +540,7 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
                 }
             }
         }
-        FN_T(t3 = __builtin_amdgcn_s_memtime(); t4 = t3;)
+        FN_T(const unsigned long long t3 = __builtin_amdgcn_s_memtime(); tc_fast += t3 - t2;)
         // ---- candidate path: blocks in which some lane saw a value under its threshold are recomputed from the LDS image
         unsigned long long any = BOUND_ONLY ? 0ull : __ballot(hits != 0u);
         if (any != 0ull && !dead) {
@@ -596,11 +600,29 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
             }
             if (prune) Dw = wave_D();
         }
-        FN_T(t4 = __builtin_amdgcn_s_memtime();)
+        FN_T(tc_cand += __builtin_amdgcn_s_memtime() - t3;)
         }
-        if (kk + 1 < n_list) stash(buf ^ 1, slot[ph ^ 1]);  // everyone passed this step's barrier, so buf^1 (read in step - 1) is free
-        FN_T(const unsigned long long t5 = __builtin_amdgcn_s_memtime(); tc_fetch += t1 - t0; tc_bar += t2 - t1; tc_fast += t3 - t2; tc_cand += t4 - t3; tc_stash += t5 - t4;)
-      }
+    };
+    for (int gi = 0; gi < n_groups; gi++) {
+        const int half = (gi & 1) * FN_GRP;
+        FN_T(const unsigned long long t1 = __builtin_amdgcn_s_memtime();)
+        __syncthreads();                                  // the buffers of this group are complete; the other group's are no longer read by anyone
+        FN_T(tc_bar += __builtin_amdgcn_s_memtime() - t1;)
+#pragma unroll
+        for (int t = 0; t < FN_GRP; t++) if (gi * FN_GRP + t < n_list) tile(half + t, slist[gi * FN_GRP + t], lw_now[t]);
+        FN_T(const unsigned long long t4 = __builtin_amdgcn_s_memtime();)
+        if (gi + 1 < n_groups) {
+#pragma unroll
+            for (int t = 0; t < FN_GRP; t++) if ((gi + 1) * FN_GRP + t < n_list) { stash((FN_GRP - half) + t, slot[t]); lw_next[t] = slot[t].lw; }
+        }
+        FN_T(const unsigned long long t5 = __builtin_amdgcn_s_memtime(); tc_stash += t5 - t4;)
+        if (gi + 2 < n_groups) {
+#pragma unroll
+            for (int t = 0; t < FN_GRP; t++) if ((gi + 2) * FN_GRP + t < n_list) fetch(slist[(gi + 2) * FN_GRP + t], slot[t]);
+        }
+        FN_T(tc_fetch += __builtin_amdgcn_s_memtime() - t5;)
+#pragma unroll
+        for (int t = 0; t < FN_GRP; t++) lw_now[t] = lw_next[t];
     }
     if (lane == 0 && chunk_base >= 0) a.chunk_fill[chunk_base / FN_CHUNK] = chunk_fill;
     if (a.stats && lane == 0) { atomicAdd(&a.stats[1], n_comp); atomicAdd(&a.stats[2], (unsigned long long)n_list); }

@@ -32,7 +32,7 @@
 // candidate batch in LDS, structure of arrays: a step of 4 candidates is three wave-uniform 16-B reads (and their register pairs could
 // feed packed float32 math, see PK below)
 #ifndef KW_STEP
-#define KW_STEP 4          // candidates per scan step (read back from LDS with a wave-uniform address)
+#define KW_STEP 4          // candidates per scan step (read back from LDS with a wave-uniform address); 2: diagnostic variant
 #endif
 struct KwStage { float x[68], y[68], z[68]; int i[68]; };          // 64 + one step of read-ahead
 typedef float kw_f2 __attribute__((ext_vector_type(2)));
@@ -333,18 +333,7 @@ __device__ static inline void d_knn_wave(const KnnArgs &a) {
     int nlog = 0;
     const kw_f2 qx2 = {q.x, q.x}, qy2 = {q.y, q.y}, qz2 = {q.z, q.z};
     auto scan1 = [&](int nb) {
-#if KW_STEP == 2         // diagnostic variant: two candidates per step -- 16 VGPRs of read-ahead instead of 32 (the K = 30 instance spills 15)
-        float2 nX = *(const float2 *)&sh.stage.x[0], nY = *(const float2 *)&sh.stage.y[0], nZ = *(const float2 *)&sh.stage.z[0];
-        int2 nI = *(const int2 *)&sh.stage.i[0];
-        for (int j4 = 0; j4 < nb; j4 += 2) {
-            const float2 X = nX, Y = nY, Z = nZ;
-            const int i4[2] = {nI.x, nI.y};
-            nX = *(const float2 *)&sh.stage.x[j4 + 2]; nY = *(const float2 *)&sh.stage.y[j4 + 2]; nZ = *(const float2 *)&sh.stage.z[j4 + 2];
-            nI = *(const int2 *)&sh.stage.i[j4 + 2];
-            float d4[2];
-            d4[0] = pcr_d2(X.x - q.x, Y.x - q.y, Z.x - q.z); d4[1] = pcr_d2(X.y - q.x, Y.y - q.y, Z.y - q.z);
-#else
-#if KW_STEP == 2         // diagnostic variant: two candidates per step -- 16 VGPRs of read-ahead instead of 32 (the K = 30 instance spills 15)
+#if KW_STEP == 2         // two candidates per step: 16 VGPRs of read-ahead instead of 32
         float2 nX = *(const float2 *)&sh.stage.x[0], nY = *(const float2 *)&sh.stage.y[0], nZ = *(const float2 *)&sh.stage.z[0];
         int2 nI = *(const int2 *)&sh.stage.i[0];
         for (int j4 = 0; j4 < nb; j4 += 2) {
@@ -371,7 +360,6 @@ __device__ static inline void d_knn_wave(const KnnArgs &a) {
                 d4[0] = pcr_d2(X.x - q.x, Y.x - q.y, Z.x - q.z); d4[1] = pcr_d2(X.y - q.x, Y.y - q.y, Z.y - q.z);
                 d4[2] = pcr_d2(X.z - q.x, Y.z - q.y, Z.z - q.z); d4[3] = pcr_d2(X.w - q.x, Y.w - q.y, Z.w - q.z);
             }
-#endif
 #endif
 #pragma unroll
             for (int u = 0; u < KW_STEP; u++) {
@@ -419,6 +407,17 @@ __device__ static inline void d_knn_wave(const KnnArgs &a) {
     if (!live || bound == a.r2cap_f) ties = 0;
     int cnt = 0, tcnt = 0;
     auto scan2 = [&](int nb) {
+#if KW_STEP == 2         // two candidates per step: 16 VGPRs of read-ahead instead of 32
+        float2 nX = *(const float2 *)&sh.stage.x[0], nY = *(const float2 *)&sh.stage.y[0], nZ = *(const float2 *)&sh.stage.z[0];
+        int2 nI = *(const int2 *)&sh.stage.i[0];
+        for (int j4 = 0; j4 < nb; j4 += 2) {
+            const float2 X = nX, Y = nY, Z = nZ;
+            const int i4[2] = {nI.x, nI.y};
+            nX = *(const float2 *)&sh.stage.x[j4 + 2]; nY = *(const float2 *)&sh.stage.y[j4 + 2]; nZ = *(const float2 *)&sh.stage.z[j4 + 2];
+            nI = *(const int2 *)&sh.stage.i[j4 + 2];
+            float d4[2];
+            d4[0] = pcr_d2(X.x - q.x, Y.x - q.y, Z.x - q.z); d4[1] = pcr_d2(X.y - q.x, Y.y - q.y, Z.y - q.z);
+#else
         float4 nX = *(const float4 *)&sh.stage.x[0], nY = *(const float4 *)&sh.stage.y[0], nZ = *(const float4 *)&sh.stage.z[0];
         int4 nI = *(const int4 *)&sh.stage.i[0];
         for (int j4 = 0; j4 < nb; j4 += 4) {
@@ -435,6 +434,7 @@ __device__ static inline void d_knn_wave(const KnnArgs &a) {
                 d4[0] = pcr_d2(X.x - q.x, Y.x - q.y, Z.x - q.z); d4[1] = pcr_d2(X.y - q.x, Y.y - q.y, Z.y - q.z);
                 d4[2] = pcr_d2(X.z - q.x, Y.z - q.y, Z.z - q.z); d4[3] = pcr_d2(X.w - q.x, Y.w - q.y, Z.w - q.z);
             }
+#endif
 #pragma unroll
             for (int u = 0; u < KW_STEP; u++) {
             const float d2 = d4[u];
