@@ -812,6 +812,26 @@ __global__ void __launch_bounds__(FB) k_fgr_iter(FgrOptArgs a) {
     }
 }
 
+// Which form of the GNC optimiser a correspondence count takes (one rule for the one-pair call and for lockstep groups: a pair must meet the
+// same variant -- the same summation order -- in both).  0: one 256-thread workgroup, 1: one 1024-thread workgroup, 2: FMG co-resident
+// workgroups in one launch, 3: one launch per iteration.
+struct FgrOptRule { int single_max, multi_min, multi_max; unsigned long long multi_timeout; };
+static const FgrOptRule &fgr_opt_rule() {
+    static const FgrOptRule r = {
+        getenv("PCR_FGR_SINGLE_MAX") ? atoi(getenv("PCR_FGR_SINGLE_MAX")) : 11000,   // one CU needs 0.8 us of float64 work per 1000 correspondences and iteration (+1.4 us solve); a launch per iteration costs 11 us
+        getenv("PCR_FGR_MULTI_MIN") ? atoi(getenv("PCR_FGR_MULTI_MIN")) : 6000,      // from here on FMG co-resident workgroups in one launch
+        getenv("PCR_FGR_MULTI_MAX") ? atoi(getenv("PCR_FGR_MULTI_MAX")) : 400000,
+        // ticks of the 100 MHz wall clock a workgroup waits at the barrier (tests set 0 to force the fallback)
+        getenv("PCR_FGR_MULTI_TIMEOUT") ? strtoull(getenv("PCR_FGR_MULTI_TIMEOUT"), nullptr, 10) : 5000000ull};
+    return r;
+}
+static int fgr_opt_variant(int64_t ncorr) {
+    const FgrOptRule &r = fgr_opt_rule();
+    if (ncorr >= r.multi_min && ncorr <= r.multi_max) return 2;
+    if (ncorr <= r.single_max) return ncorr <= FGR_SINGLE_SMALL ? 0 : 1;
+    return 3;
+}
+
 // ======================================================================== driver
 static int normalise(pcr_context *ctx, const float *xyz, int64_t n, double *out64, double *mean_host, double *max_host) {
     const int nb = (int)((n + FB - 1) / FB < 256 ? (n + FB - 1) / FB : 256);
@@ -933,20 +953,16 @@ static int fgr_pose(pcr_context *ctx, const float *src_xyz, const float *src_fea
             oa.pq = pq; oa.stride = stride; oa.ncorr = (int)ncorr; oa.st = st; oa.partials = partials;
             oa.decrease_mu = opt->decrease_mu; oa.max_corr_dist = opt->maximum_correspondence_distance; oa.division_factor = opt->division_factor;
             PCR_LAUNCH(ctx, k_fgr_init, dim3(1), dim3(64), 0, ctx->stream, st, scale_start);
-            static const int single_max = getenv("PCR_FGR_SINGLE_MAX") ? atoi(getenv("PCR_FGR_SINGLE_MAX")) : 11000;   // one CU needs 0.8 us of float64 work per 1000 correspondences and iteration (+1.4 us solve); a launch per iteration costs 11 us
             if (getenv("PCR_DEBUG_FGR")) fprintf(stderr, "fgr: ncross %lld ncorr %lld iterations %d\n", (long long)ncross, (long long)ncorr, (int)opt->iteration_number);
-            static const int multi_min = getenv("PCR_FGR_MULTI_MIN") ? atoi(getenv("PCR_FGR_MULTI_MIN")) : 6000;       // from here on FMG co-resident workgroups in one launch
-            static const int multi_max = getenv("PCR_FGR_MULTI_MAX") ? atoi(getenv("PCR_FGR_MULTI_MAX")) : 400000;
             double *rows = arena<double>(ctx, (size_t)2 * FMG * FNVP);
             if (!rows) return PCR_ENOMEM;
-            const bool multi = ncorr >= multi_min && ncorr <= multi_max;
+            const int variant = fgr_opt_variant(ncorr);
+            const bool multi = variant == 2;
             FgrState h;
             auto per_iteration = [&]() { for (int it = 0; it < opt->iteration_number; it++) PCR_LAUNCH(ctx, k_fgr_iter, dim3(nb), dim3(FB), 0, ctx->stream, oa); };
-            // PCR_FGR_MULTI_TIMEOUT: ticks of the 100 MHz wall clock a workgroup waits at the barrier (tests set 0 to force the fallback)
-            static const unsigned long long fm_timeout = getenv("PCR_FGR_MULTI_TIMEOUT") ? strtoull(getenv("PCR_FGR_MULTI_TIMEOUT"), nullptr, 10) : 5000000ull;
-            if (multi) PCR_LAUNCH(ctx, k_fgr_opt_multi, dim3(FMG), dim3(FMB), 0, ctx->stream, oa, (int)opt->iteration_number, rows, fm_timeout);
-            else if (ncorr <= single_max && ncorr <= FGR_SINGLE_SMALL) PCR_LAUNCH(ctx, k_fgr_opt_single<256>, dim3(1), dim3(256), 0, ctx->stream, oa, (int)opt->iteration_number);
-            else if (ncorr <= single_max) PCR_LAUNCH(ctx, k_fgr_opt_single<FSB>, dim3(1), dim3(FSB), 0, ctx->stream, oa, (int)opt->iteration_number);
+            if (multi) PCR_LAUNCH(ctx, k_fgr_opt_multi, dim3(FMG), dim3(FMB), 0, ctx->stream, oa, (int)opt->iteration_number, rows, fgr_opt_rule().multi_timeout);
+            else if (variant == 0) PCR_LAUNCH(ctx, k_fgr_opt_single<256>, dim3(1), dim3(256), 0, ctx->stream, oa, (int)opt->iteration_number);
+            else if (variant == 1) PCR_LAUNCH(ctx, k_fgr_opt_single<FSB>, dim3(1), dim3(FSB), 0, ctx->stream, oa, (int)opt->iteration_number);
             else per_iteration();
             PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h, st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
             PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1382,10 +1398,6 @@ int pcr_registro_fgr_group(pcr_context *ctx, pcr_fgr_group_pair *q, int G) {
         }
     }
     // ---- OptimizePairwiseRegistration: the variant by correspondence count, as the one-pair path picks it (wait 5: the states)
-    static const int single_max = getenv("PCR_FGR_SINGLE_MAX") ? atoi(getenv("PCR_FGR_SINGLE_MAX")) : 11000;
-    static const int multi_min = getenv("PCR_FGR_MULTI_MIN") ? atoi(getenv("PCR_FGR_MULTI_MIN")) : 6000;
-    static const int multi_max = getenv("PCR_FGR_MULTI_MAX") ? atoi(getenv("PCR_FGR_MULTI_MAX")) : 400000;
-    static const unsigned long long fm_timeout = getenv("PCR_FGR_MULTI_TIMEOUT") ? strtoull(getenv("PCR_FGR_MULTI_TIMEOUT"), nullptr, 10) : 5000000ull;
     std::vector<FgrState> hst((size_t)G); std::vector<FgrState *> st((size_t)G, nullptr);
     FgrState *st_all = arena<FgrState>(ctx, G);
     if (!st_all) return PCR_ENOMEM;
@@ -1405,10 +1417,8 @@ int pcr_registro_fgr_group(pcr_context *ctx, pcr_fgr_group_pair *q, int G) {
             FgrOptArgs oa;
             oa.pq = pq; oa.stride = stride; oa.ncorr = (int)ncorr[g]; oa.st = st[g]; oa.partials = partials;
             oa.decrease_mu = opt.decrease_mu; oa.max_corr_dist = opt.maximum_correspondence_distance; oa.division_factor = opt.division_factor;
-            const bool multi = ncorr[g] >= multi_min && ncorr[g] <= multi_max;
-            if (multi) cls[2].push_back(oa);
-            else if (ncorr[g] <= single_max && ncorr[g] <= FGR_SINGLE_SMALL) cls[0].push_back(oa);
-            else if (ncorr[g] <= single_max) cls[1].push_back(oa);
+            const int variant = fgr_opt_variant(ncorr[g]);
+            if (variant < 3) cls[variant].push_back(oa);
             else { q[g].status = 1; pd.pop_back(); st[g] = nullptr; continue; }              // one launch per iteration: the one-pair path
             who.push_back(g);
             max_corr = (int)ncorr[g] > max_corr ? (int)ncorr[g] : max_corr;
@@ -1429,7 +1439,7 @@ int pcr_registro_fgr_group(pcr_context *ctx, pcr_fgr_group_pair *q, int G) {
                     double *rows = arena<double>(ctx, (size_t)m * 2 * FMG * FNVP);
                     if (!rows) return PCR_ENOMEM;
                     // FMG x m co-resident 512-thread workgroups (at most 8 x 64 of the chip's 1024 slots of that size)
-                    PCR_LAUNCH(ctx, k_fgr_opt_multi_g, dim3(FMG, m), dim3(FMB), 0, ctx->stream, doa, iters, rows, fm_timeout);
+                    PCR_LAUNCH(ctx, k_fgr_opt_multi_g, dim3(FMG, m), dim3(FMB), 0, ctx->stream, doa, iters, rows, fgr_opt_rule().multi_timeout);
                 }
             }
             PCR_HIP_CHECK(ctx, hipMemcpyAsync(hst.data(), st_all, sizeof(FgrState) * (size_t)G, hipMemcpyDeviceToHost, ctx->stream));
