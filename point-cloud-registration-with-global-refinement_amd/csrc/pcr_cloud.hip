@@ -1076,6 +1076,7 @@ struct KnnArgs {
     int seed_span;                                       // Morton-index half-width of the seed range (-1: k)
     int *zero_a, *zero_b;                                // optional counters of LATER kernels, zeroed here (saves two memset launches)
     uint8_t *hard; int wave_budget;                      // wavefront kernel: optional, queries it gave up after wave_budget batches (1) or served (0)
+    int hard_piece;                                      // k_knn_list: 1 = the entries of hard_list are the first queries of 8-query pieces (k_radius_list), 0 = of 64-query wavefronts
     int *hard_list, *hard_count;                         // ... and (hard_list != nullptr, instead of `hard`) the first query of every wavefront it gave up, appended with one atomic
                                                          //   per wavefront; the octet kernel's list form (k_knn_list) serves exactly those
     const uint8_t *keep; const int *pos;                 // optional: search only among points with keep[i] != 0; results and `todo`
@@ -1098,7 +1099,7 @@ __device__ static inline void d_knn_(const KnnArgs &a) {
     __shared__ OctGroupStack gstk[KNN_BS / 64];
     int n_items = 0;
     if (LIST) {
-        n_items = *a.hard_count * 8;                         // written by the kernel before this one on the stream
+        n_items = *a.hard_count * (a.hard_piece ? 1 : 8);    // written by the kernel before this one on the stream; entries = wavefronts of 64 queries, or (hard_piece) pieces of 8
         if ((int)blockIdx.x * (KNN_BS / 64) >= n_items) return;      // (uniform over the workgroup)
     }
     if (threadIdx.x == 0) m = *a.t.meta;
@@ -1255,7 +1256,7 @@ __device__ static inline void d_knn_(const KnnArgs &a) {
             const int slot = ol + OCT * j;
             if (slot < a.k) {
                 a.dbg_idx[(size_t)qi * a.k + slot] = tk.si[j];
-                a.dbg_d2[(size_t)qi * a.k + slot] = tk.si[j] >= 0 ? tk.sd[j] : __builtin_inff();
+                if (a.dbg_d2) a.dbg_d2[(size_t)qi * a.k + slot] = tk.si[j] >= 0 ? tk.sd[j] : __builtin_inff();
                 c += tk.si[j] >= 0 ? 1 : 0;
             }
         }
@@ -1266,7 +1267,7 @@ __device__ static inline void d_knn_(const KnnArgs &a) {
     };
     const int wv = threadIdx.x >> 6;
     if (!LIST) item((int)blockIdx.x * OPB + wv * OCT, (size_t)blockIdx.x * (KNN_BS / 64) + wv);
-    else for (int it = blockIdx.x * (KNN_BS / 64) + wv; it < n_items; it += gridDim.x * (KNN_BS / 64)) item(a.hard_list[it >> 3] + (it & 7) * OCT, 0);
+    else for (int it = blockIdx.x * (KNN_BS / 64) + wv; it < n_items; it += gridDim.x * (KNN_BS / 64)) item(a.hard_piece ? a.hard_list[it] : a.hard_list[it >> 3] + (it & 7) * OCT, 0);
 }
 template <int MODE, int SLOTS> __device__ static inline void d_knn(const KnnArgs &a) { d_knn_<MODE, SLOTS, false>(a); }
 template <int MODE, int SLOTS> __device__ static inline void d_knn_list(const KnnArgs &a) { d_knn_<MODE, SLOTS, true>(a); }
@@ -1530,6 +1531,100 @@ __global__ void __launch_bounds__(KNN_BS) k_radius_moments(RadArgs a) {
             a.normals[qi] = make_float4((float)nv[0], (float)nv[1], (float)nv[2], 0.0f);
         }
     }
+}
+
+// ============================================== neighbour lists under a radius cap (the Hybrid(r, max_nn) lists of FPFH, round 4)
+// On an outdoor scan most points have FEWER than max_nn = 200 neighbours inside r (NCLT: 50-68 on average, 1-8 % capped), and then the list is
+// simply every point inside the ball -- no k-best selection.  The k-best kernel nevertheless ran every in-ball candidate through a 25-slot
+// sorted insertion (99 VALU instructions per round): 13.6 % of the FGR stage.  Here an octet APPENDS what it finds (same float32 test against
+// r^2 as the k-best kernel, same shared walk with the fixed bound): row = the query's in-ball points in walk order, cnt = their number.  A
+// piece of 8 queries in which one ball holds more than k points is listed (one atomic per piece) and redone by the k-best kernel's list form
+// (k_knn_list with hard_piece), which writes the k nearest in its slot layout; cnt = -1 tells the readers to scan all k slots of such a row.
+struct RadListArgs {
+    OctView t; const int *n_ptr; float r2f; int k;
+    int32_t *idx; int32_t *cnt;                  // rows of k int32 per query; entries per row (-1: row in the k-best kernel's slot layout, scan all k)
+    int *over_list, *over_count;                 // first queries of the 8-query pieces with an overfull ball
+};
+__device__ static inline void d_radius_list(const RadListArgs &a) {
+    constexpr int OPB = KNN_BS / OCT;
+    __shared__ OctMeta m;
+    __shared__ OctGroupStack gstk[KNN_BS / 64];
+    if (threadIdx.x == 0) m = *a.t.meta;
+    __syncthreads();
+    const int n = m.n;
+    const int lane = threadIdx.x & 63, oct = lane >> 3, ol = lane & 7, ob = threadIdx.x >> 3;
+    const int qi = blockIdx.x * OPB + ob;
+    const bool live = qi < n;
+    if (__ballot(live) == 0ull) return;
+    const float4 q = a.t.pts[live ? qi : 0];
+    int32_t *const row = a.idx + (size_t)(live ? qi : 0) * a.k;
+    int cnt = 0;                                 // octet-uniform
+    auto visit = [&](int first, int count) {
+        for (int base = first; base < first + count; base += OCT) {
+            const int idx = base + ol;
+            bool hit = false;
+            if (live && cnt <= a.k && idx < first + count) {
+                const float4 p = a.t.pts[idx];
+                hit = pcr_d2(p.x - q.x, p.y - q.y, p.z - q.z) < a.r2f;
+            }
+            const unsigned mask = (unsigned)(__ballot(hit) >> (oct * 8)) & 0xffu;
+            const int pos = cnt + __builtin_popcount(mask & ((1u << ol) - 1u));
+            if (hit && pos < a.k) row[pos] = idx;
+            cnt += __builtin_popcount(mask);
+        }
+    };
+    const int g0 = blockIdx.x * OPB + (threadIdx.x >> 6) * OCT;
+    // a ball that is overfull already needs nothing more from the walk: its bound drops to nothing
+    oct_search_group(a.t, m, gstk[threadIdx.x >> 6], live, a.t.leaf_of[g0 < n ? g0 : 0], q.x, q.y, q.z, [&]() { return cnt > a.k ? -1.0f : a.r2f; }, visit,
+                     [](int, int) { return false; }, ol, nullptr);
+    const bool over = __ballot(live && cnt > a.k) != 0ull;                 // (a wavefront = one piece of 8 queries)
+    if (live && ol == 0) a.cnt[qi] = over ? -1 : cnt;
+    if (over && lane == 0) a.over_list[atomicAdd(a.over_count, 1)] = g0;
+}
+__global__ void __launch_bounds__(KNN_BS) k_radius_list(RadListArgs a) { d_radius_list(a); }
+__global__ void __launch_bounds__(KNN_BS) k_radius_list_g(const RadListArgs *a) { d_radius_list(a[blockIdx.y]); }
+// `count` clouds in one launch pair: the append kernel, then the k-best list form over the listed pieces.  Rows idx[c]: cap x k int32,
+// cnt[c]: cap int32.  (Hybrid search only: radius > 0.)
+int pcr_dev_radius_lists_batch(pcr_context *ctx, const DevCloud *const *cs, int count, int k, double radius, int32_t *const *idx, int32_t *const *cnt) {
+    if (count < 1) return PCR_OK;
+    if (count > PCR_MAX_GROUP_BATCH) { ctx->err = "radius list batch size"; return PCR_EINVAL; }
+    if (!(radius > 0) || k < 1 || k > 200) { ctx->err = "radius lists: radius <= 0 or k outside 1..200"; return PCR_EINVAL; }
+    std::vector<RadListArgs> ra; std::vector<KnnArgs> ka; std::vector<int> caps;
+    int *counts = arena<int>(ctx, count);
+    if (!counts) return PCR_ENOMEM;
+    PCR_HIP_CHECK(ctx, hipMemsetAsync(counts, 0, sizeof(int) * (size_t)count, ctx->stream));
+    int mc = 0;
+    for (int c = 0; c < count; c++) {
+        if (cs[c]->cap <= 0) continue;
+        RadListArgs r;
+        r.t = oct_view(cs[c]); r.n_ptr = cs[c]->n; r.r2f = (float)(radius * radius); r.k = k; r.idx = idx[c]; r.cnt = cnt[c];
+        r.over_list = arena<int>(ctx, (size_t)cs[c]->cap / OCT + 1); r.over_count = counts + c;
+        if (!r.over_list) return PCR_ENOMEM;
+        ra.push_back(r);
+        KnnArgs a; std::memset(&a, 0, sizeof a);                        // the k-best search of pcr_dev_knn_debug, over the listed pieces only
+        a.t = r.t; a.n_ptr = cs[c]->n; a.k = k;
+        knn_radius(a, PCR_SEARCH_HYBRID, radius);
+        a.r2cap_f = r.r2f;
+        a.dbg_idx = idx[c]; a.dbg_d2 = nullptr; a.dbg_cnt = nullptr; a.seed_span = -1;
+        a.hard_piece = 1; a.hard_list = r.over_list; a.hard_count = r.over_count;
+        ka.push_back(a); caps.push_back(cs[c]->cap);
+        mc = cs[c]->cap > mc ? cs[c]->cap : mc;
+    }
+    const int m = (int)ra.size();
+    if (m == 0) return PCR_OK;
+    if (m == 1) {
+        PCR_LAUNCH(ctx, k_radius_list, dim3((unsigned)(((size_t)mc * OCT + KNN_BS - 1) / KNN_BS)), dim3(KNN_BS), 0, ctx->stream, ra[0]);
+    } else {
+        const RadListArgs *d = pcr_desc_upload(ctx, ra.data(), m);
+        if (!d) return PCR_ENOMEM;
+        PCR_LAUNCH(ctx, k_radius_list_g, dim3((unsigned)(((size_t)mc * OCT + KNN_BS - 1) / KNN_BS), m), dim3(KNN_BS), 0, ctx->stream, d);
+    }
+    // the overfull pieces: as many wavefronts as a dense cloud may list (every piece), striding
+    int lg = mc / (OCT * (KNN_BS / 64) * 4); lg = lg < 8 ? 8 : (lg > 2048 ? 2048 : lg);
+    const dim3 grid(lg, m), block(KNN_BS);
+    if (k <= 32) return PCR_BATCH_LAUNCH(ctx, KnnBatch, (k_knn_list_batch<KNN_MODE_DEBUG, 4>), (k_knn_list_batchp<KNN_MODE_DEBUG, 4>), ka.data(), m, grid, block);
+    if (k <= 64) return PCR_BATCH_LAUNCH(ctx, KnnBatch, (k_knn_list_batch<KNN_MODE_DEBUG, 8>), (k_knn_list_batchp<KNN_MODE_DEBUG, 8>), ka.data(), m, grid, block);
+    return PCR_BATCH_LAUNCH(ctx, KnnBatch, (k_knn_list_batch<KNN_MODE_DEBUG, 25>), (k_knn_list_batchp<KNN_MODE_DEBUG, 25>), ka.data(), m, grid, block);
 }
 
 // ============================================= normals of the CLEANED cloud from the SOR pass's k-best lists (K5')

@@ -107,6 +107,10 @@ __device__ static inline unsigned pcr_xrow_or(unsigned v) {
     a = pcr_swap32(v, &o);
     return a | o;
 }
+// over the eight lanes {l ^ 8 a ^ 16 b ^ 32 c} (the same position in the eight octets of the wavefront): row_ror:8 inside each row, then the rows
+#define PCR_DPP_ROR8 0x128     // row_ror:8 (lane i <-> i ^ 8 of each 16-lane row)
+__device__ static inline float pcr_xoct_min(float v) { v = fminf(v, pcr_dpp_f<PCR_DPP_ROR8>(v)); return pcr_xrow_min(v); }
+__device__ static inline float pcr_xoct_max(float v) { v = fmaxf(v, pcr_dpp_f<PCR_DPP_ROR8>(v)); return pcr_xrow_max(v); }
 // over all 64 lanes, result in every lane: DPP inside each row (xor 1, xor 2, half mirror, mirror), then across the rows
 __device__ static inline float pcr_wave_max_all(float v) {
     v = fmaxf(v, pcr_dpp_f<PCR_DPP_XOR1>(v)); v = fmaxf(v, pcr_dpp_f<PCR_DPP_XOR2>(v));

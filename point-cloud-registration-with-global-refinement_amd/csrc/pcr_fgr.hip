@@ -53,6 +53,7 @@ __device__ static inline void pair_bins(const double *p1, const double *n1, cons
 struct FpfhArgs {
     const float4 *pts, *nrm; const int *n_ptr;
     const int32_t *nbr; int k; double r2;       // neighbour lists (sorted-cloud indices, -1 padded)
+    const int32_t *cnt;                         // optional: entries of each row (pcr_dev_radius_lists_batch; -1 or null: all k slots)
     double *spfh;                               // n x 33
     const uint32_t *perm; float *feat;          // output rows in caller order
 };
@@ -68,7 +69,8 @@ __device__ static inline void d_spfh(const FpfhArgs &a) {
     if (qi < n) {
         const float4 pf = a.pts[qi], nf = a.nrm[qi];
         const double p1[3] = {pf.x, pf.y, pf.z}, n1[3] = {nf.x, nf.y, nf.z};
-        for (int slot = ol; slot < a.k; slot += OCT) {
+        const int kk = a.cnt ? (a.cnt[qi] < 0 ? a.k : a.cnt[qi]) : a.k;
+        for (int slot = ol; slot < kk; slot += OCT) {
             const int id = a.nbr[(size_t)qi * a.k + slot];
             if (id < 0 || id == qi) continue;
             const float4 qf = a.pts[id], mf = a.nrm[id];
@@ -81,8 +83,7 @@ __device__ static inline void d_spfh(const FpfhArgs &a) {
             cnt++;
         }
     }
-#pragma unroll
-    for (int o = 1; o < OCT; o <<= 1) cnt += __shfl_xor(cnt, o, OCT);
+    cnt = pcr_octet_sum_i(cnt);
     __syncthreads();
     if (qi < n) {
         const double inc = cnt > 0 ? 100.0 / (double)cnt : 0.0;       // 100 / (m - 1), m counts the point itself
@@ -101,7 +102,8 @@ __device__ static inline void d_fpfh(const FpfhArgs &a) {
     int cnt = 0;
     if (qi < n) {
         const float4 pf = a.pts[qi];
-        for (int slot = ol; slot < a.k; slot += OCT) {
+        const int kk = a.cnt ? (a.cnt[qi] < 0 ? a.k : a.cnt[qi]) : a.k;
+        for (int slot = ol; slot < kk; slot += OCT) {
             const int id = a.nbr[(size_t)qi * a.k + slot];
             if (id < 0 || id == qi) continue;
             const float4 qf = a.pts[id];
@@ -116,13 +118,11 @@ __device__ static inline void d_fpfh(const FpfhArgs &a) {
             for (int j = 0; j < 33; j++) acc[j] += s[j] * inv;
         }
     }
+    // octet sums by DPP (pcr_octet_sum: the same pairwise tree as a xor-1 / 2 / 4 butterfly, so the same bits): the butterfly by
+    // __shfl_xor was 2 x 99 ds_bpermute round trips per wavefront, more than the gathers above
+    cnt = pcr_octet_sum_i(cnt);
 #pragma unroll
-    for (int o = 1; o < OCT; o <<= 1) cnt += __shfl_xor(cnt, o, OCT);
-#pragma unroll
-    for (int j = 0; j < 33; j++) {
-#pragma unroll
-        for (int o = 1; o < OCT; o <<= 1) acc[j] += __shfl_xor(acc[j], o, OCT);
-    }
+    for (int j = 0; j < 33; j++) acc[j] = pcr_octet_sum(acc[j]);
     if (qi < n && ol == 0) {
         float *out = a.feat + (size_t)a.perm[qi] * 33;
         if (cnt > 0) {
@@ -153,12 +153,21 @@ static int fpfh_of_cloud(pcr_context *ctx, const DevCloud &c, const uint32_t *pe
     if (n == 0) return PCR_OK;
     ArenaMark mark(ctx);
     int32_t *nbr = arena<int32_t>(ctx, (size_t)n * knn);
-    float *nd2 = arena<float>(ctx, (size_t)n * knn);
     double *spfh = arena<double>(ctx, (size_t)n * 33);
-    if (!nbr || !nd2 || !spfh) return PCR_ENOMEM;
-    PCR_TRY(pcr_dev_knn_debug(ctx, &c, knn, search_kind == PCR_SEARCH_HYBRID ? radius : 0.0, nbr, nd2, nullptr));
+    if (!nbr || !spfh) return PCR_ENOMEM;
+    int32_t *ncnt = nullptr;
+    if (search_kind == PCR_SEARCH_HYBRID) {      // every point inside the ball, appended; the k nearest only where a ball is overfull
+        ncnt = arena<int32_t>(ctx, n);
+        if (!ncnt) return PCR_ENOMEM;
+        const DevCloud *cp = &c;
+        PCR_TRY(pcr_dev_radius_lists_batch(ctx, &cp, 1, knn, radius, &nbr, &ncnt));
+    } else {
+        float *nd2 = arena<float>(ctx, (size_t)n * knn);
+        if (!nd2) return PCR_ENOMEM;
+        PCR_TRY(pcr_dev_knn_debug(ctx, &c, knn, 0.0, nbr, nd2, nullptr));
+    }
     FpfhArgs a;
-    a.pts = c.pts; a.nrm = c.nrm; a.n_ptr = c.n; a.nbr = nbr; a.k = knn;
+    a.pts = c.pts; a.nrm = c.nrm; a.n_ptr = c.n; a.nbr = nbr; a.k = knn; a.cnt = ncnt;
     a.r2 = search_kind == PCR_SEARCH_HYBRID ? radius * radius : 1e300;
     a.spfh = spfh; a.perm = perm; a.feat = feat33;
     const dim3 grid((unsigned)(((size_t)n * OCT + FB - 1) / FB));
@@ -1251,19 +1260,19 @@ int pcr_registro_fgr_group(pcr_context *ctx, pcr_fgr_group_pair *q, int G) {
     }
     std::vector<FpfhArgs> fa((size_t)C);
     {
-        std::vector<const DevCloud *> cp((size_t)C); std::vector<int32_t *> nbr((size_t)C); std::vector<float *> nd2((size_t)C);
+        std::vector<const DevCloud *> cp((size_t)C); std::vector<int32_t *> nbr((size_t)C), ncnt((size_t)C);
         int64_t nmax = 0;
         for (int k = 0; k < C; k++) {
             cp[k] = &c[k];
-            nbr[k] = arena<int32_t>(ctx, (size_t)n[k] * p0.feature_max_nn); nd2[k] = arena<float>(ctx, (size_t)n[k] * p0.feature_max_nn);
+            nbr[k] = arena<int32_t>(ctx, (size_t)n[k] * p0.feature_max_nn); ncnt[k] = arena<int32_t>(ctx, n[k]);
             double *spfh = arena<double>(ctx, (size_t)n[k] * 33);
-            if (!nbr[k] || !nd2[k] || !spfh) return PCR_ENOMEM;
+            if (!nbr[k] || !ncnt[k] || !spfh) return PCR_ENOMEM;
             FpfhArgs &a = fa[k];
-            a.pts = c[k].pts; a.nrm = c[k].nrm; a.n_ptr = c[k].n; a.nbr = nbr[k]; a.k = p0.feature_max_nn; a.r2 = p0.feature_radius * p0.feature_radius;
+            a.pts = c[k].pts; a.nrm = c[k].nrm; a.n_ptr = c[k].n; a.nbr = nbr[k]; a.k = p0.feature_max_nn; a.r2 = p0.feature_radius * p0.feature_radius; a.cnt = ncnt[k];
             a.spfh = spfh; a.perm = perm[k]; a.feat = feat[k];
             nmax = n[k] > nmax ? n[k] : nmax;
         }
-        PCR_TRY(pcr_dev_knn_lists_batch(ctx, cp.data(), C, p0.feature_max_nn, p0.feature_radius, nbr.data(), nd2.data()));
+        PCR_TRY(pcr_dev_radius_lists_batch(ctx, cp.data(), C, p0.feature_max_nn, p0.feature_radius, nbr.data(), ncnt.data()));
         const FpfhArgs *dfa = pcr_desc_upload(ctx, fa.data(), C);
         if (!dfa) return PCR_ENOMEM;
         const dim3 grid((unsigned)(((size_t)nmax * OCT + FB - 1) / FB), C);

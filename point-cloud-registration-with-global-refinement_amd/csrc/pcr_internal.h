@@ -207,6 +207,8 @@ int pcr_dev_normals_knn_batch(pcr_context *ctx, DevCloud *const *cs, int count, 
 int pcr_dev_normals_batch(pcr_context *ctx, DevCloud *const *cs, int count, int search_kind, int knn, double radius, const float4 *const *priors, float4 *const *normals_out,
                           const uint8_t *const *todos);
 int pcr_dev_knn_lists_batch(pcr_context *ctx, const DevCloud *const *cs, int count, int k, double radius, int32_t *const *idx, float *const *d2);
+// Hybrid(r, k) neighbour lists of `count` clouds: rows of k sorted-cloud indices, cnt = entries per row (-1: scan all k slots, -1 = empty slot)
+int pcr_dev_radius_lists_batch(pcr_context *ctx, const DevCloud *const *cs, int count, int k, double radius, int32_t *const *idx, int32_t *const *cnt);
 int pcr_dev_flag_scan_batch(pcr_context *ctx, int count, uint8_t *const *flags, const int *const *n_ptr, const int *n_cap, int *const *pos, int *const *total_dev);
 // `count` caller clouds Morton-sorted with their octrees in one pass (cs[c] allocated with a tree by the caller; perms[c]: sorted -> caller)
 int pcr_import_clouds_batch(pcr_context *ctx, int count, const float *const *xyz, const float *const *nrm, const int64_t *n, DevCloud *cs, uint32_t **perms);

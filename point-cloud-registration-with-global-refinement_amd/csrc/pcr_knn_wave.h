@@ -67,16 +67,10 @@ __device__ static inline float kw_octet_fmax(float v) {
     return v;
 }
 __device__ static inline float kw_wave_fmin(float v) {
-    v = kw_octet_fmin(v);
-#pragma unroll
-    for (int o = OCT; o < 64; o <<= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
+    return pcr_xoct_min(kw_octet_fmin(v));             // (across the octets inside the VALU: row_ror:8 + the permlane swaps of gfx950, no ds_bpermute)
 }
 __device__ static inline float kw_wave_fmax(float v) {
-    v = kw_octet_fmax(v);
-#pragma unroll
-    for (int o = OCT; o < 64; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    return pcr_xoct_max(kw_octet_fmax(v));
 }
 // squared distance between two boxes, same operation order as pcr_box_d2 (monotone: never above the box distance of a point inside g)
 __device__ static inline float kw_boxbox_d2(const float4 lo, const float4 hi, const float *glo, const float *ghi) {
@@ -109,9 +103,7 @@ __device__ static inline bool kw_pass(const OctView &t, const OctMeta &m, KwStac
     for (int d = 0; d < 3; d++) { sglo[d] = kw_octet_fmin(sglo[d]); sghi[d] = kw_octet_fmax(sghi[d]); }
 #pragma unroll
     for (int d = 0; d < 3; d++) {
-        glo[d] = sglo[d]; ghi[d] = sghi[d];
-#pragma unroll
-        for (int o = OCT; o < 64; o <<= 1) { glo[d] = fminf(glo[d], __shfl_xor(glo[d], o, 64)); ghi[d] = fmaxf(ghi[d], __shfl_xor(ghi[d], o, 64)); }
+        glo[d] = pcr_xoct_min(sglo[d]); ghi[d] = pcr_xoct_max(sghi[d]);
     }
     auto beats = [&](float d2, float bound) -> bool { return INCL ? d2 <= bound : d2 < bound; };
     // children [cs, cs + cnt) of level li: bit c set when the box of child c comes within the bound of some subgroup (conservative: the

@@ -314,11 +314,10 @@ __device__ static inline int oct_greedy_leaf(const OctView &t, const OctMeta &m,
                 d = pcr_box_d2(t.nodes[2 * j], t.nodes[2 * j + 1], qx, qy, qz); c = ol;
             }
         }
-#pragma unroll
-        for (int o = 1; o < OCT; o <<= 1) {
-            const float od = __shfl_xor(d, o, OCT); const int oc = __shfl_xor(c, o, OCT);
-            if (od < d || (od == d && oc < c)) { d = od; c = oc; }
-        }
+        // arg-min over the octet by DPP (xor 1, xor 2, then the half mirror: after two steps a quad is uniform, so the mirror acts as xor 4)
+        { const float od = pcr_dpp_f<PCR_DPP_XOR1>(d); const int oc = pcr_dpp_i<PCR_DPP_XOR1>(c); if (od < d || (od == d && oc < c)) { d = od; c = oc; } }
+        { const float od = pcr_dpp_f<PCR_DPP_XOR2>(d); const int oc = pcr_dpp_i<PCR_DPP_XOR2>(c); if (od < d || (od == d && oc < c)) { d = od; c = oc; } }
+        { const float od = pcr_dpp_f<PCR_DPP_HMIRROR>(d); const int oc = pcr_dpp_i<PCR_DPP_HMIRROR>(c); if (od < d || (od == d && oc < c)) { d = od; c = oc; } }
         if (want && li > 0) { node = cs + c; li--; }
     }
     return node;
@@ -338,11 +337,7 @@ struct OctGroupStack {            // per wavefront (LDS)
     unsigned gd2[OCT_MAXL][OCT];   // per child: min over the group's live queries of the squared box distance (float bits)
 };
 
-__device__ static inline float wave_or_octets_max(float v) {     // max over the 8 octets (v is octet-uniform)
-#pragma unroll
-    for (int o = OCT; o < 64; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
+__device__ static inline float wave_or_octets_max(float v) { return pcr_xoct_max(v); }     // max over the 8 octets (v is octet-uniform), inside the VALU
 
 // worst() -> this lane's (octet-uniform) squared bound; visit(first, count) scans points for all 8 queries;
 // skip(first, count) -> leaf already covered.  q*: this lane's query; live: octet-uniform.
@@ -353,10 +348,9 @@ __device__ static inline void oct_search_group(const OctView &t, const OctMeta &
     // group box (live queries only)
     float glo[3] = {live ? qx : 3.4e38f, live ? qy : 3.4e38f, live ? qz : 3.4e38f};
     float ghi[3] = {live ? qx : -3.4e38f, live ? qy : -3.4e38f, live ? qz : -3.4e38f};
+    // (the queries of a wavefront's 8 octets: one query per octet, so the group box is the min / max across the octets)
 #pragma unroll
-    for (int d = 0; d < 3; d++)
-#pragma unroll
-        for (int o = OCT; o < 64; o <<= 1) { glo[d] = fminf(glo[d], __shfl_xor(glo[d], o, 64)); ghi[d] = fmaxf(ghi[d], __shfl_xor(ghi[d], o, 64)); }
+    for (int d = 0; d < 3; d++) { glo[d] = pcr_xoct_min(glo[d]); ghi[d] = pcr_xoct_max(ghi[d]); }
     start_leaf = __builtin_amdgcn_readfirstlane(start_leaf);
 
     // children [cs, cs+cnt) of level li: bit c set when any live query can still improve inside child c; gd2[li][c] <- the
