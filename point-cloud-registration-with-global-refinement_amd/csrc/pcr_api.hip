@@ -970,20 +970,24 @@ extern "C" int pcr_register_pairs_plan(int device, pcr_pair_ex *pairs, int n_pai
                             if (!tnos[k]) tnos[k] = base + (size_t)(px.base.n_src + 1) * 3;
                         }
                     }
-                    if (rc_group == PCR_OK && fgr_group > 1 && cnt > 1)            // registro_FGR of the unit's pairs in lockstep chunks; what it declines runs below
-                        for (int k0 = 0; k0 < cnt; k0 += fgr_group) {
-                            const int m = k0 + fgr_group <= cnt ? fgr_group : cnt - k0;
-                            std::vector<pcr_fgr_group_pair> q((size_t)m);
-                            for (int k = 0; k < m; k++) {
-                                pcr_pair_ex &px = pairs[i + k0 + k];
-                                q[k] = pcr_fgr_group_pair{px.base.src_xyz, px.base.src_normals, px.base.n_src, px.base.tgt_xyz, px.base.tgt_normals, px.base.n_tgt, *plan->fgr,
-                                                          snos[k0 + k], tnos[k0 + k], &px.fgr, nullptr, PCR_OK};
-                                q[k].p.option.seed = plan->fgr->option.seed + (uint64_t)(i + k0 + k);
+                    if (rc_group == PCR_OK && fgr_group > 1 && cnt > 1) {          // registro_FGR of the unit's pairs in lockstep chunks; what the group form does not take runs below
+                        std::vector<int> take;
+                        for (int k = 0; k < cnt; k++) if (pcr_fgr_group_takes(pairs[i + k].base.n_src, pairs[i + k].base.n_tgt)) take.push_back(k);
+                        for (size_t t0 = 0; t0 < take.size() && take.size() >= 2; t0 += (size_t)fgr_group) {
+                            const size_t m = t0 + (size_t)fgr_group <= take.size() ? (size_t)fgr_group : take.size() - t0;
+                            std::vector<pcr_fgr_group_pair> q(m);
+                            for (size_t t = 0; t < m; t++) {
+                                const int k = take[t0 + t];
+                                pcr_pair_ex &px = pairs[i + k];
+                                q[t] = pcr_fgr_group_pair{px.base.src_xyz, px.base.src_normals, px.base.n_src, px.base.tgt_xyz, px.base.tgt_normals, px.base.n_tgt, *plan->fgr,
+                                                          snos[k], tnos[k], &px.fgr, nullptr, PCR_OK};
+                                q[t].p.option.seed = plan->fgr->option.seed + (uint64_t)(i + k);
                             }
-                            const int rc = pcr_api_call(ctx, [&]() -> int { return pcr_registro_fgr_group(ctx, q.data(), m); });
+                            const int rc = pcr_api_call(ctx, [&]() -> int { return pcr_registro_fgr_group(ctx, q.data(), (int)m); });
                             if (rc == PCR_EHIP) { rc_group = rc; break; }
-                            if (rc == PCR_OK) for (int k = 0; k < m; k++) fgr_done[k0 + k] = q[k].status == PCR_OK;
+                            if (rc == PCR_OK) for (size_t t = 0; t < m; t++) fgr_done[take[t0 + t]] = q[t].status == PCR_OK;
                         }
+                    }
                     for (int k = 0; k < cnt && rc_group == PCR_OK; k++) {
                         pcr_pair_ex &px = pairs[i + k];
                         float *sno = snos[k], *tno = tnos[k];
@@ -1023,22 +1027,27 @@ extern "C" int pcr_register_pairs_plan(int device, pcr_pair_ex *pairs, int n_pai
         };
         // stage FGR: `cnt` pairs through registro_FGR in lockstep (pcr_registro_fgr_group); pairs it leaves (status 1) and groups it declines run one by one
         auto fgr_unit = [&](int i, int cnt) -> int {
-            std::vector<pcr_fgr_group_pair> q((size_t)cnt);
-            for (int k = 0; k < cnt; k++) {
-                pcr_pair_ex &px = pairs[i + k];
-                px.base.error[0] = 0;
-                q[k] = pcr_fgr_group_pair{px.base.src_xyz, px.base.src_normals, px.base.n_src, px.base.tgt_xyz, px.base.tgt_normals, px.base.n_tgt, *plan->fgr,
-                                          px.src_normals_out, px.tgt_normals_out, &px.fgr, px.base.correspondences, PCR_OK};
-                q[k].p.option.seed = plan->fgr->option.seed + (uint64_t)(i + k);
+            std::vector<int> take;                                   // the pairs of the unit the group form takes (sizes); the others run alone below
+            for (int k = 0; k < cnt; k++) { pairs[i + k].base.error[0] = 0; if (pcr_fgr_group_takes(pairs[i + k].base.n_src, pairs[i + k].base.n_tgt)) take.push_back(k); }
+            std::vector<char> done((size_t)cnt, 0);
+            if (take.size() >= 2) {
+                std::vector<pcr_fgr_group_pair> q(take.size());
+                for (size_t t = 0; t < take.size(); t++) {
+                    pcr_pair_ex &px = pairs[i + take[t]];
+                    q[t] = pcr_fgr_group_pair{px.base.src_xyz, px.base.src_normals, px.base.n_src, px.base.tgt_xyz, px.base.tgt_normals, px.base.n_tgt, *plan->fgr,
+                                              px.src_normals_out, px.tgt_normals_out, &px.fgr, px.base.correspondences, PCR_OK};
+                    q[t].p.option.seed = plan->fgr->option.seed + (uint64_t)(i + take[t]);
+                }
+                const int rc = pcr_api_call(ctx, [&]() -> int { return pcr_registro_fgr_group(ctx, q.data(), (int)q.size()); });
+                if (rc == PCR_EHIP) {
+                    for (int k = 0; k < cnt; k++) { pairs[i + k].base.status = rc; failed++; snprintf(pairs[i + k].base.error, sizeof pairs[i + k].base.error, "%s", ctx->err.c_str()); }
+                    return rc;
+                }
+                if (rc == PCR_OK) for (size_t t = 0; t < take.size(); t++) if (q[t].status == PCR_OK) { done[take[t]] = 1; pairs[i + take[t]].base.status = PCR_OK; }
             }
-            const int rc = pcr_api_call(ctx, [&]() -> int { return pcr_registro_fgr_group(ctx, q.data(), cnt); });
-            if (rc == PCR_EHIP) {
-                for (int k = 0; k < cnt; k++) { pairs[i + k].base.status = rc; failed++; snprintf(pairs[i + k].base.error, sizeof pairs[i + k].base.error, "%s", ctx->err.c_str()); }
-                return rc;
-            }
             for (int k = 0; k < cnt; k++) {
+                if (done[k]) continue;
                 pcr_pair &p = pairs[i + k].base;
-                if (rc == PCR_OK && q[k].status == PCR_OK) { p.status = PCR_OK; continue; }
                 p.status = run_pair(ctx, pairs[i + k], i + k, *plan);
                 if (p.status != PCR_OK) { failed++; snprintf(p.error, sizeof p.error, "%s", ctx->err.c_str()); }
             }

@@ -1220,8 +1220,7 @@ int pcr_registro_fgr_group(pcr_context *ctx, pcr_fgr_group_pair *q, int G) {
         if (!a.result) return PCR_EINVAL;
         if (a.p.option.maximum_tuple_count < 0) a.p.option.maximum_tuple_count = (int32_t)((double)((a.ns + a.nt) / 2) * 0.2);       // the per-pair rule (pcr_hip.h)
         if (fgr_check_args(ctx, &a.p.option, a.ns, a.nt) != PCR_OK) return 1;               // an argument error lands on its pair in the one-pair path
-        if (a.ns < 64 || a.nt < 64 || !a.src_xyz || !a.tgt_xyz) return 1;
-        if ((double)a.ns * (double)a.nt >= 5.0e9) return 1;                                  // the pruned feature search: one pair at a time
+        if (!pcr_fgr_group_takes(a.ns, a.nt) || !a.src_xyz || !a.tgt_xyz) return 1;       // tiny clouds, or the pruned feature search: one pair at a time
         if (a.p.normal_max_nn < 1 || a.p.normal_max_nn > 32 || !(a.p.normal_radius > 0.0) || a.p.feature_max_nn < 1 || a.p.feature_max_nn > 200 || !(a.p.feature_radius > 0.0)) return 1;
         if (!a.p.option.tuple_test || a.p.option.maximum_tuple_count < 1) return 1;
         const pcr_fgr_params &p0 = q[0].p;

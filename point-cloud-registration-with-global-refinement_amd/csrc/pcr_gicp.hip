@@ -323,7 +323,7 @@ __device__ static inline void d_icp_nn(const IcpArgs &a) {
         const unsigned long long nb = __ballot(need && ol == 0);
         int base = 0;
         if (lane == 0 && nb != 0ull) base = atomicAdd(&n_rec, __builtin_popcountll(nb));
-        base = __shfl(base, 0, 64);
+        base = __builtin_amdgcn_readfirstlane(base);            // (lane 0 holds it; no ds_bpermute round trip)
         if (need && ol == 0) {
             const int slot = base + __builtin_popcountll(nb & ((1ull << lane) - 1ull));
             rec_q[slot] = make_float4(qx, qy, qz, __int_as_float(hint)); rec_i[slot] = i; rec_c[slot] = cert_flag ? (rb >= 0 ? rb : -1) : -2;
@@ -417,7 +417,7 @@ __device__ static inline void d_icp_ab(const IcpArgs &a) {
         const unsigned long long nbm = __ballot(need);
         int base = 0;
         if (lane == 0 && nbm != 0ull) base = atomicAdd(&n_rec, __builtin_popcountll(nbm));
-        base = __shfl(base, 0, 64);
+        base = __builtin_amdgcn_readfirstlane(base);            // (lane 0 holds it; no ds_bpermute round trip)
         if (need) {
             const int slot = base + __builtin_popcountll(nbm & ((1ull << lane) - 1ull));
             rec_q[slot] = make_float4(qx, qy, qz, __int_as_float(hint)); rec_i[slot] = i;
@@ -904,7 +904,7 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
         const unsigned long long nbm = __ballot(need);
         int base = 0;
         if (lane == 0 && nbm != 0ull) base = atomicAdd(&n_rec, __builtin_popcountll(nbm));
-        base = __shfl(base, 0, 64);
+        base = __builtin_amdgcn_readfirstlane(base);            // (lane 0 holds it; no ds_bpermute round trip)
         if (need) {
             const int slot = base + __builtin_popcountll(nbm & ((1ull << lane) - 1ull));
             rec_q[slot] = make_float4(qx, qy, qz, __int_as_float(hint)); rec_l[slot] = (short)(p * FUSED_BS + tid);

@@ -239,6 +239,8 @@ struct pcr_fgr_group_pair {                 // one pair of a lockstep FGR group 
     int status;                              // out: PCR_OK, or 1 = this pair must be redone alone (record pool overflow, optimiser fallback)
 };
 int pcr_registro_fgr_group(pcr_context *ctx, pcr_fgr_group_pair *pairs, int G);
+// whether the group form takes a pair of these sizes (both clouds of at least 64 points, under 5e9 feature-row pairs: no tile pruning)
+static inline bool pcr_fgr_group_takes(int64_t ns, int64_t nt) { return ns >= 64 && nt >= 64 && (double)ns * (double)nt < 5.0e9; }
 int pcr_evaluate_registration_impl(pcr_context *ctx, const float *src_xyz, int64_t n_src, const float *tgt_xyz, int64_t n_tgt,
                                    double max_dist, const double *T, pcr_result *result, int32_t *correspondences);
 

@@ -85,6 +85,19 @@ def test_default_group_rule():
     assert [b(16, 96, 4), b(6, 48, 4), b(16, 192, 4), b(16, 20, 4), b(1, 100, 4), b(6, 48, 1)] == [12, 6, 16, 16, 1, 6]
 
 
+def test_set_option_and_fgr_group_rule():
+    """`pcr_set_option` (process-wide test / diagnostic switches, no GPU needed): known names are accepted, unknown ones refused; the Python
+    policy for lockstep `registro_FGR` groups: 16 pairs of NCLT-size clouds per group, pair by pair from 70k points (the tile-pruned screen)."""
+    P = pkg()
+    lib = P._lib.load()
+    assert lib.pcr_set_option(b"knn_wave", -1) == 0 and lib.pcr_set_option(b"knnw_budget", 80) == 0 and lib.pcr_set_option(b"fence_prep", 0) == 0
+    assert lib.pcr_set_option(b"no_such_option", 1) != 0
+    with pytest.raises(ValueError):
+        P._lib.set_option("no_such_option", 1)
+    g = P.registration.default_fgr_group
+    assert [g(n) for n in (5_000, 20_000, 40_000, 69_999, 70_000, 200_000)] == [16, 16, 8, 5, 1, 1]
+
+
 def test_profiles_manifest_lists_the_tracked_evidence():
     """bench.py quotes tracked rocprof results with the commit they were taken at (profiles/MANIFEST.json): every file of the newest round
     is listed there with a commit, and every listed file exists."""

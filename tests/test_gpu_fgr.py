@@ -391,3 +391,27 @@ def test_fgr_lockstep_groups_are_bit_identical_to_pair_by_pair(P, golden_pair_li
         a, d = pose_error(r.transformation, g["T_fgr"])
         ok += a < 3e-2 and d < 0.5
     assert ok >= len(golden_pair_list) - 1, ok           # (FGR is a randomised estimator: the statistical band of SURVEY 8c)
+
+
+@pytest.mark.gpu
+def test_fgr_group_with_a_pair_the_group_form_does_not_take(P, golden_pair_list):
+    """A unit of four pairs of which one has a 50-point source (below the 64 points the group form takes, pcr_fgr_group_takes): the other
+    three still go through the lockstep group, the small one runs alone, and every result equals the pair-by-pair run bit for bit --
+    including whether the small pair fails (its status and message are its own)."""
+    reg = P.registration
+
+    def run(fgr_group):
+        work = [(P.PointCloud(g["source"]), P.PointCloud(g["target"]), None) for g in golden_pair_list[:4]]
+        work[2] = (P.PointCloud(golden_pair_list[2]["source"][:50]), work[2][1], None)
+        try:
+            return reg.register_pairs_plan(work, "fgr", inflight=1, fgr_voxel_size=0.1, fgr_seed=7, fgr_group=fgr_group)
+        except RuntimeError as e:
+            return str(e)
+
+    base, rs = run(1), run(4)
+    assert isinstance(base, str) == isinstance(rs, str), (base, rs)
+    if isinstance(base, str):
+        assert base == rs
+        return
+    for k, (a, b) in enumerate(zip(base, rs)):
+        assert np.array_equal(a.transformation, b.transformation) and a.fitness == b.fitness and a.inlier_rmse == b.inlier_rmse, k
