@@ -403,12 +403,13 @@ def fgr_roofline(prof):
             "kernel": "k_feature_nn_screen (33-D nearest feature: f16 hi/lo split MFMA screen over the (query wavefront, 64-row tile) pairs whose "
                       "boxes in principal coordinates are close enough, ~20 % of them; survivors re-checked in float64)",
             "flops_per_launch": flops / launches if launches else 0.0, "ms_per_launch_hip_events": ms / launches if launches else None,
-            "executed_over_algorithmic": 0.2 * 128.0 / 33.0,
-            "executed_mfma_utilisation": tf * (0.2 * 128.0 / 33.0) / F16_MFMA_PEAK_TFLOPS,
-            "peak_note": "achieved = ALGORITHMIC flops of the all-pairs search (2 x 33 x Ns x Nt per direction) over the dense f16 MFMA peak.  The screen spends K = 128 "
-                         "per 33 dimensions (hi/lo split: 3 f16 products per float32-accurate product, padded) but, with tile pruning, only on ~0.2 of the (wavefront, "
-                         "tile) pairs (profiles/README.md): executed MFMA flops = 0.2 x 128/33 = 0.78 x algorithmic, so executed_mfma_utilisation is what the f16 pipe "
-                         "actually sustains; the float64 MFMA path it replaces peaks at 78.6 TFLOP/s"}
+            "executed_over_algorithmic": 0.2 * 64.0 / 33.0,
+            "executed_mfma_utilisation": tf * (0.2 * 64.0 / 33.0) / F16_MFMA_PEAK_TFLOPS,
+            "peak_note": "achieved = ALGORITHMIC flops of the all-pairs search (2 x 33 x Ns x Nt per direction) over the dense f16 MFMA peak.  The screen spends K = 64 "
+                         "per 33 dimensions (round 4: 33 hi halves + both hi.lo cross terms of the 15 widest columns; K = 128 with all cross terms before) and, with tile "
+                         "pruning, only on ~0.2 of the (wavefront, tile) pairs (profiles/README.md): executed MFMA flops = 0.2 x 64/33 = 0.39 x algorithmic.  The kernel is "
+                         "no longer paced by its matrix pipe at all (DESIGN section 4, round 4: staging traffic and latency); executed_mfma_utilisation is reported for "
+                         "continuity; the float64 MFMA path the screen replaces peaks at 78.6 TFLOP/s"}
 
 
 def extras(args, P, syn, reg, est, crit, pairs, clouds, run_batch, pool_prof, pose_err, workload):

@@ -6,26 +6,35 @@
 //
 // Why a screen.  All Ns x Nt distances in float64 (v_mfma_f64_16x16x4, 78.6 TFLOP/s peak on MI355X) took 2 x 55 ms at 200k x 200k
 // points -- 80 % of registro_FGR.  The f16 matrix pipe is 32x faster but 11 bits wide.  So every centred feature x = (f - mu) * 128
-// is split into two halves, hi = f16(x), lo = f16(x - hi) (22 bits together), and
-//     x_q . x_b  ~=  hi_q.hi_b + lo_q.hi_b + hi_q.lo_b
-// is ONE dot product of length 99 (padded to K = 128) between the rows [hi | hi | lo] of the database and [hi | lo | hi] of the
-// queries: 4 v_mfma_f32_16x16x32_f16 per 16 x 16 block of the distance matrix instead of 9 float64 MFMAs of 4x the cycles each.
-// With the exact float64 norms, d~(q, b) = |x_q|^2 + |x_b|^2 - 2 dot  satisfies  |d~ - d| <= c (|x_q|^2 + |x_b|^2)  (c = FN_C below:
-// split truncation 3 * 2^-22 |x_q||x_b|, f32 accumulation and combination), so with L = d~ - E a lower and U = min_b (d~ + E) an upper
+// is split into two halves, hi = f16(x), lo = f16(x - hi) (22 bits together), and the screen's dot product is
+//     x_q . x_b  ~=  hi_q.hi_b  +  sum over the COVERED dimensions of (lo_q hi_b + hi_q lo_b)
+// -- ONE product of length K between the rows [hi | hi_c | lo_c] of the database and [hi | lo_c | hi_c] of the queries.  Rounds 2-3 covered
+// all 33 dimensions (K = 99 -> 128: 4 v_mfma_f32_16x16x32_f16 per 16 x 16 block).  Round 4: K = 64 -- the 15 dimensions of the largest variance
+// are covered (33 + 2 * 15 = 63; on NCLT scans they hold 93 % of the variance of the FPFH bins), the other 18 enter with their hi halves
+// only: 2 MFMAs per block, half the operand registers (124 VGPRs instead of 188: two workgroups per CU instead of one), half the bytes staged
+// and read from LDS.  The price is a wider bound on the uncovered part, which costs candidates, not correctness:
+// with the exact float64 norms, d~(q, b) = |x_q|^2 + |x_b|^2 - 2 dot  satisfies  |d~ - d| <= E_q + E_b,
+//     E_row = FN_C |x|^2 + FN_CU |x|_U^2 + FN_EABS
+// (|x|_U = the norm over the uncovered dimensions; FN_C: split truncation 3 * 2^-22 |x_q||x_b| of a covered dimension, f32 accumulation and
+// combination; FN_CU: a hi-only dimension misses hi_q e_b + e_q hi_b + e_q e_b with |e| <= 2^-11 |x|, i.e. (2^-10 + 2^-20) |x_q,d||x_b,d|
+// in the dot product, twice that in d~, and |a||b| <= (a^2 + b^2) / 2).  So with L = d~ - E a lower and U = min_b (d~ + E) an upper
 // bound of the true minimum, every row with L(b) <= U is a CANDIDATE and the true nearest row (and every exact tie of it) is among
-// them.  The screen keeps U per query in registers and writes every candidate as a RECORD (query, row, lower bound) into a pool
+// them (measured on the oracle's features of an NCLT pair: 15.4 records per query against 14.7 with all cross terms; hi halves alone would
+// have given 19 with a tail of several hundred on 1 % of the queries).  The per-row terms are prepared by the split (FnRows: nlo = |x|^2 - E,
+// nup = 2 E, cq = 2 E with their margins), so the hot loop has no per-row multiply.  The screen keeps U per query in registers and writes
+// every candidate as a RECORD (query, row, lower bound) into a pool
 // (a few dozen per query: the running minimum of a sequence improves ~ln N times; wavefronts take 64-record chunks of the pool with
 // one atomic per chunk and fill them with plain stores, so the hot loop never waits for a returning atomic).  k_fn_exact_min /
 // k_fn_exact_arg then evaluate sum_k (a_k - b_k)^2 in float64, in index order with separately rounded products and sums exactly like
 // the oracle's kd-tree leaf loop, on the records that survive the FINAL bound of their query: minimum distance first, then the
 // smallest row among the records that attain it.  The result is therefore the exact float64 nearest row whatever the screen's
 // rounding does inside its bound; if the pool overflows (pathological duplicate structure) the caller falls back to the all-pairs
-// float64 path.  PCR_FEATNN_CHECK=1 measures the bound's slack.
+// float64 path.  PCR_FEATNN_CHECK=1 measures the bound's slack (largest |d~ - d| / (E_q + E_b) over the records: must stay under 1).
 //
 // Kernel shape (gfx950): workgroup = 8 wavefronts = 512 queries; a wavefront keeps the B operands of its 64 queries (4 blocks of
-// 16) in 64 VGPRs for the whole kernel; the database streams through LDS in steps of 64 rows (16 KB), staged once per workgroup,
-// double buffered, in a [k-group][row] image with a 72-byte row pitch on which the 8-byte operand reads are conflict free;
-// per 16-row tile a wavefront issues 16 MFMAs (256 cycles on its SIMD) and 29 VALU instructions of bound tests and keeps only one
+// 16) in 32 VGPRs for the whole kernel; the database streams through LDS in steps of 64 rows (8 KB), staged once per workgroup,
+// double buffered, in a [k-group][row] image with a 40-byte row pitch on which the 8-byte operand reads are conflict free;
+// per 16-row tile a wavefront issues 8 MFMAs (128 cycles on its SIMD) and 29 VALU instructions of bound tests and keeps only one
 // hit bit per 16 x 16 block; blocks with a hit (a few per cent) are recomputed after the step's four tiles by the candidate path,
 // so that nothing but the barrier separates the MFMA streams of consecutive tiles.
 #include <cmath>
@@ -37,9 +46,13 @@
 #include "pcr_device.h"
 
 #define FN_D 33
-#define FN_K 128                 // [hi | hi | lo] / [hi | lo | hi] padded: 3 * 33 = 99 -> 128
+#ifndef FN_K
+#define FN_K 64                  // length of the screen's dot product: 64 (33 hi + both cross terms of the FN_NCOV widest dimensions) or 128 (all cross terms, round 2-3)
+#endif
+#define FN_NM (FN_K / 32)        // MFMAs per 16 x 16 block
+#define FN_NCOV ((FN_K - FN_D - 1) / 2 < FN_D ? (FN_K - FN_D - 1) / 2 : FN_D)     // dimensions whose hi.lo cross terms are in the product: 15 at K = 64, all 33 at K = 128
 #ifndef FN_WG
-#define FN_WG 512
+#define FN_WG 256                // 4 wavefronts = 256 queries per workgroup, four workgroups per CU at K = 64 (512 threads: 10.1 ms against 9.6 at 200k x 200k rows, both directions)
 #endif
 #ifndef FN_GRP
 #define FN_GRP 1                 // database tiles staged and computed between two workgroup barriers (LDS: 2 x FN_GRP x 18 KB); 2 / 4 measured: no gain, see below
@@ -53,10 +66,12 @@
 #define FN_CHUNK 64              // records a wavefront takes from the pool at a time
 #define FN_POOL_PER_QUERY 96     // pool capacity = this many records per query (expected: 20-40)
 #define FN_SCALE 128.0           // features are centred and scaled by a power of two before the split (keeps lo out of the f16 subnormals)
-#define FN_C 2.0e-6              // |d~ - d| <= FN_C (|x_q|^2 + |x_b|^2); worst case of the analysis above is 0.8e-6
-#define FN_SUB_BYTES 4608        // LDS image of one 16-row tile: 4 k-groups x 1152 B, row pitch 72 B
-#define FN_PITCH 72
-#define FN_GROUP 1152
+#define FN_C 2.0e-6              // |d~ - d| <= FN_C (|x_q|^2 + |x_b|^2) over the covered dimensions; worst case of the analysis above is 0.8e-6
+#define FN_CU 9.9e-4             // ... + FN_CU (|x_q|_U^2 + |x_b|_U^2) over the dimensions WITHOUT cross terms (hi . hi only: 2 * (2^-10 + 2^-22) / 2, rounded up)
+#define FN_EABS 1.0e-6           // ... + an absolute term per row (f16 subnormals of a hi half: 33 * 2^-40 in scaled units, with room)
+#define FN_PITCH (FN_NM * 16 + 8)        // LDS image of one 16-row tile: 4 k-groups x 16 rows; row pitch 72 B (K = 128) / 40 B (K = 64): the 8-byte
+#define FN_GROUP (16 * FN_PITCH)         //   operand reads of a half-wavefront (16 rows x 2 k-groups) fall on 64 different banks either way
+#define FN_SUB_BYTES (4 * FN_GROUP)
 
 // 32-bit LDS byte address of a __shared__ object (what ds_read takes)
 __device__ static inline unsigned fn_lds_addr(const void *p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) void *)p; }
@@ -65,30 +80,36 @@ __device__ static inline unsigned fn_lds_addr(const void *p) { return (unsigned)
 __device__ static inline int fn_ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }
 __device__ static inline float fn_unord(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
 
+// a + b rounded up: the nearest-rounded sum plus 2^-23 of its magnitude (no directed-rounding add on the device side of this toolchain)
+__device__ static inline float fn_add_up(float a, float b) { const float s = a + b; return __fmaf_rn(fabsf(s), 1.2e-7f, s); }
+
 typedef _Float16 fn_h8 __attribute__((ext_vector_type(8)));
 typedef float fn_f4 __attribute__((ext_vector_type(4)));
 
 // ---- column means of a feature matrix (the centring vector; any vector is valid, the mean keeps the norms small) -------------
 // part: gridDim.x rows of 34 = 33 column sums + the largest |value| (the f16 split needs |f - mu| * 128 < 65504)
-#define FN_PC (FN_D + 1)
+#define FN_PC (2 * FN_D + 1)      // [0, 33) column sums, [33] largest |value|, [34, 67) column sums of squares; the mu vector has the same length: [0, 33) means, [33] largest
+                                  // |value|, [34, 34 + FN_NCOV) the covered dimensions (ascending, as doubles)
 __device__ static inline void d_fn_colsum(const float *__restrict__ f, int n, double *__restrict__ part) {
     __shared__ double sh[256 / 64][FN_PC];
-    double s[FN_D], mx = 0.0;
+    double s[FN_D], sq[FN_D], mx = 0.0;
 #pragma unroll
-    for (int k = 0; k < FN_D; k++) s[k] = 0.0;
+    for (int k = 0; k < FN_D; k++) { s[k] = 0.0; sq[k] = 0.0; }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
 #pragma unroll
-        for (int k = 0; k < FN_D; k++) { const double v = (double)f[(size_t)i * FN_D + k]; s[k] += v; mx = fmax(mx, fabs(v)); }
+        for (int k = 0; k < FN_D; k++) { const double v = (double)f[(size_t)i * FN_D + k]; s[k] += v; sq[k] += v * v; mx = fmax(mx, fabs(v)); }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < FN_D; k++) { const double v = pcr_wave_sum(s[k]); if (lane == 0) sh[w][k] = v; }
+#pragma unroll
+    for (int k = 0; k < FN_D; k++) { const double v = pcr_wave_sum(sq[k]); if (lane == 0) sh[w][FN_D + 1 + k] = v; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
     if (lane == 0) sh[w][FN_D] = mx;
     __syncthreads();
     if (threadIdx.x < FN_PC) {
         double v = 0;
-        for (int k = 0; k < 256 / 64; k++) v = threadIdx.x < FN_D ? v + sh[k][threadIdx.x] : fmax(v, sh[k][threadIdx.x]);
+        for (int k = 0; k < 256 / 64; k++) v = threadIdx.x != FN_D ? v + sh[k][threadIdx.x] : fmax(v, sh[k][threadIdx.x]);
         part[blockIdx.x * FN_PC + threadIdx.x] = v;
     }
 }
@@ -99,14 +120,34 @@ __global__ void __launch_bounds__(256) k_fn_colsum_g(const FnColsumDesc *d) { co
 // mu[0..32] = column means of the first matrix, mu[33] = largest |value| over both
 // (also resets the first-zero-row words and the overflow flags of the call: it runs before the splits that use them)
 __device__ static inline void d_fn_mean(const double *__restrict__ part, int nb, int n, double *__restrict__ mu, int *__restrict__ first_zero, int *__restrict__ flags) {
+    __shared__ double var[FN_D];
+    __shared__ int taken[FN_D];
     if (threadIdx.x == 63) { first_zero[0] = 0x7fffffff; first_zero[1] = 0x7fffffff; flags[0] = 0; flags[1] = 0; }
     if (threadIdx.x < FN_PC) {
         double v = 0;
-        for (int k = 0; k < 2 * nb; k++) {
-            const double x = part[k * FN_PC + threadIdx.x];
-            if (threadIdx.x == FN_D) v = fmax(v, x); else if (k < nb) v += x;
+        for (int k0 = 0; k0 < 2 * nb; k0 += 16) {          // (16 loads in flight: one after the other this loop alone was 80 us)
+            double x[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) x[u] = k0 + u < 2 * nb ? part[(k0 + u) * FN_PC + threadIdx.x] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; u++) { const int k = k0 + u; if (threadIdx.x == FN_D) v = fmax(v, x[u]); else if (k < nb) v += x[u]; }
         }
-        mu[threadIdx.x] = threadIdx.x == FN_D ? v : (n > 0 ? v / (double)n : 0.0);
+        if (threadIdx.x <= FN_D) mu[threadIdx.x] = threadIdx.x == FN_D ? v : (n > 0 ? v / (double)n : 0.0);
+        else var[threadIdx.x - FN_D - 1] = v;                              // sum of squares of the column (first matrix)
+    }
+    __syncthreads();
+    // the FN_NCOV columns of the largest variance get their cross terms into the screen's product (any choice is valid: it only sets how tight the
+    // screen's bound is; on NCLT scans 15 of the 33 FPFH bins hold 93 % of the variance)
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < FN_D; k++) { taken[k] = 0; var[k] = n > 0 ? var[k] / (double)n - mu[k] * mu[k] : 0.0; }
+        for (int j = 0; j < FN_NCOV; j++) {
+            int best = -1;
+            for (int k = 0; k < FN_D; k++) if (!taken[k] && (best < 0 || var[k] > var[best])) best = k;
+            taken[best] = 1;
+        }
+        int j = 0;
+        for (int k = 0; k < FN_D; k++) if (taken[k]) mu[FN_D + 1 + j++] = (double)k;
+        for (; j < FN_D; j++) mu[FN_D + 1 + j] = -1.0;
     }
 }
 __global__ void k_fn_mean(const double *__restrict__ part, int nb, int n, double *__restrict__ mu, int *__restrict__ first_zero, int *__restrict__ flags) { d_fn_mean(part, nb, n, mu, first_zero, flags); }
@@ -122,8 +163,8 @@ __global__ void k_fn_mean_g(const FnMeanDesc *d) { const FnMeanDesc a = d[blockI
 // perm (optional): row i of the forms is row perm[i] of f (the tile-pruned screen works on rows in Morton order of their leading
 // principal coordinates); first_zero is always an index into f.
 __device__ static inline void d_fn_split(const float *__restrict__ f_, int n, int n_pad, const double *__restrict__ mu,
-                                         _Float16 *__restrict__ A, _Float16 *__restrict__ B, float *__restrict__ nlo, float *__restrict__ nrm,
-                                         int *__restrict__ first_zero, const uint32_t *__restrict__ perm) {
+                                         _Float16 *__restrict__ A, _Float16 *__restrict__ B, float *__restrict__ nlo, float *__restrict__ nup, float *__restrict__ nrm,
+                                         float *__restrict__ cq, int *__restrict__ first_zero, const uint32_t *__restrict__ perm) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n_pad) return;
     const int src = (i < n && perm) ? (int)perm[i] : i;
@@ -140,29 +181,55 @@ __device__ static inline void d_fn_split(const float *__restrict__ f_, int n, in
         lo[k] = (_Float16)(float)(x - (double)(float)h);
         s += x * x;
     }
-    // the two 256-byte rows are put together in registers and leave as sixteen 16-byte stores each (element-wise 2-byte stores made
-    // this kernel 1.2 ms per lockstep group of 16 NCLT-size pairs: 0.3 TB/s)
+    // covered dimensions (the same for every row of the call): hc / lc = their halves, taken from the row again (it is in the L1 by now; picking
+    // them out of hi[] / lo[] by a run-time index costs a thousand selects per row), su = the squared norm over the others
+    _Float16 hc[FN_NCOV], lc[FN_NCOV];
+    double sc = 0.0;
+    if (FN_NCOV == FN_D) {
+#pragma unroll
+        for (int j = 0; j < FN_NCOV; j++) { hc[j] = hi[j]; lc[j] = lo[j]; }
+        sc = s;
+    } else {
+#pragma unroll
+        for (int j = 0; j < FN_NCOV; j++) {
+            const int cd = (int)mu[FN_D + 1 + j];
+            const double x = i < n ? ((double)f[(size_t)src * FN_D + cd] - mu[cd]) * FN_SCALE : 0.0;      // the same arithmetic as above: the same halves
+            const _Float16 h = (_Float16)(float)x;
+            hc[j] = h; lc[j] = (_Float16)(float)(x - (double)(float)h); sc += x * x;
+        }
+    }
+    const double su = fmax(s - sc, 0.0) * (1.0 + 1e-12) + (FN_NCOV == FN_D ? 0.0 : 1e-9 * s);    // (s - sc carries the rounding of 33 float64 sums)
+    // the two rows are put together in registers and leave as 16-byte stores (element-wise 2-byte stores made this kernel 1.2 ms per
+    // lockstep group of 16 NCLT-size pairs: 0.3 TB/s)
     fn_h8 ra[FN_K / 8], rb[FN_K / 8];
 #pragma unroll
     for (int k = 0; k < FN_K; k++) {
-        const _Float16 va = k < FN_D ? hi[k] : (k < 2 * FN_D ? hi[k - FN_D] : (k < 3 * FN_D ? lo[k - 2 * FN_D] : (_Float16)0.0f));
-        const _Float16 vb = k < FN_D ? hi[k] : (k < 2 * FN_D ? lo[k - FN_D] : (k < 3 * FN_D ? hi[k - 2 * FN_D] : (_Float16)0.0f));
+        const _Float16 z = (_Float16)0.0f;
+        const _Float16 va = k < FN_D ? hi[k] : (k < FN_D + FN_NCOV ? hc[k - FN_D] : (k < FN_D + 2 * FN_NCOV ? lc[k - FN_D - FN_NCOV] : z));
+        const _Float16 vb = k < FN_D ? hi[k] : (k < FN_D + FN_NCOV ? lc[k - FN_D] : (k < FN_D + 2 * FN_NCOV ? hc[k - FN_D - FN_NCOV] : z));
         ra[k / 8][k % 8] = va; rb[k / 8][k % 8] = vb;
     }
     fn_h8 *a = (fn_h8 *)(A + (size_t)i * FN_K), *b = (fn_h8 *)(B + (size_t)i * FN_K);
 #pragma unroll
     for (int c = 0; c < FN_K / 8; c++) { a[c] = ra[c]; b[c] = rb[c]; }
     if (i < n) {
-        nlo[i] = __double2float_rd(s * (1.0 - FN_C));
+        const double E = FN_C * s + FN_CU * su + FN_EABS;                  // this row's share of the bound |d~ - d| <= E_q + E_b
+        const float lo_f = __double2float_rd(s - E);
+        nlo[i] = lo_f;
+        nup[i] = __double2float_ru(2.0 * E * 1.002 + ((s - E) - (double)lo_f));      // wlo + nup >= d~ + E_b - |x_q|^2 (with what rounding nlo down lost)
         nrm[i] = zero ? -__double2float_ru(s) : __double2float_ru(s);
+        cq[i] = __double2float_ru(2.0 * E * 1.001);
         if (zero) atomicMin(first_zero, src);
-    } else { nlo[i] = 1.0e30f; nrm[i] = 0.0f; }
+    } else { nlo[i] = 1.0e30f; nup[i] = 0.0f; nrm[i] = 0.0f; cq[i] = 0.0f; }
 }
+// the four per-row floats of a cloud: nlo = |x|^2 - E rounded down (database role, lower bounds), nup = 2 E with margins (database role, upper
+// bounds), nrm = |x|^2 rounded up with the sign bit marking an all-zero feature row, cq = 2 E with margins (query role, candidate threshold)
+struct FnRows { float *nlo, *nup, *nrm, *cq; };
 __global__ void __launch_bounds__(256) k_fn_split(const float *__restrict__ f_, int n, int n_pad, const double *__restrict__ mu,
-                                                  _Float16 *__restrict__ A, _Float16 *__restrict__ B, float *__restrict__ nlo, float *__restrict__ nrm,
-                                                  int *__restrict__ first_zero, const uint32_t *__restrict__ perm) { d_fn_split(f_, n, n_pad, mu, A, B, nlo, nrm, first_zero, perm); }
-struct FnSplitDesc { const float *f; int n, n_pad; const double *mu; _Float16 *A, *B; float *nlo, *nrm; int *first_zero; };
-__global__ void __launch_bounds__(256) k_fn_split_g(const FnSplitDesc *d) { const FnSplitDesc a = d[blockIdx.y]; d_fn_split(a.f, a.n, a.n_pad, a.mu, a.A, a.B, a.nlo, a.nrm, a.first_zero, nullptr); }
+                                                  _Float16 *__restrict__ A, _Float16 *__restrict__ B, FnRows r,
+                                                  int *__restrict__ first_zero, const uint32_t *__restrict__ perm) { d_fn_split(f_, n, n_pad, mu, A, B, r.nlo, r.nup, r.nrm, r.cq, first_zero, perm); }
+struct FnSplitDesc { const float *f; int n, n_pad; const double *mu; _Float16 *A, *B; FnRows r; int *first_zero; };
+__global__ void __launch_bounds__(256) k_fn_split_g(const FnSplitDesc *d) { const FnSplitDesc a = d[blockIdx.y]; d_fn_split(a.f, a.n, a.n_pad, a.mu, a.A, a.B, a.r.nlo, a.r.nup, a.r.nrm, a.r.cq, a.first_zero, nullptr); }
 
 // ================================================================================================ tile pruning (round 2)
 // The all-pairs screen costs 4 MFMAs per 16 x 16 block whatever the data.  FPFH rows are far from uniform in their 33-D space (four
@@ -178,6 +245,21 @@ __global__ void __launch_bounds__(256) k_fn_split_g(const FnSplitDesc *d) { cons
 #define FN_MD 4                            // principal coordinates in the Morton key
 #define FN_MB 8                            //   bits of each
 #define FN_NPRE 48                         // pre-pass: tiles per workgroup
+#ifndef FN_WGS_PRUNED
+#define FN_WGS_PRUNED 18432                // workgroups of the pruned main pass (query groups x splits of the database)
+#endif
+#ifndef FN_XCD_ORDER
+#define FN_XCD_ORDER 0                     // XCD-aware order of the query groups in the pruned main pass: measured 9.8 ms against 9.1 (200k x 200k rows) -- the hard
+#endif                                     //   queries are neighbours and pile up on one XCD, as in the k-NN kernels (DESIGN section 8, round-2 list, item 2); off
+#ifndef FN_PRE_SPLIT
+#define FN_PRE_SPLIT 3                     // workgroups that share the pre-pass list of a query group (records pass / bound-only sweep)
+#endif
+#ifndef FN_PRE_SPLIT_B
+#define FN_PRE_SPLIT_B 3
+#endif
+#ifndef FN_NBOUND
+#define FN_NBOUND 48                       // of which the bound-only sweep covers the nearest ...
+#endif
 #ifdef FN_LIST_CAP_OVERRIDE
 #define FN_LIST_CAP FN_LIST_CAP_OVERRIDE
 #else
@@ -366,8 +448,8 @@ __global__ void __launch_bounds__(256) k_fn_prelist(const float *__restrict__ L,
 }
 
 struct FnnArgs {
-    const _Float16 *dbA; const float *db_nlo; int n_db_pad;        // database rows (A-form) and (1 - c)|x|^2
-    const _Float16 *qB; const float *q_nrm; int n_q, n_q_pad;      // query rows (B-form) and |x|^2 (sign bit set: all-zero feature row)
+    const _Float16 *dbA; const float *db_nlo, *db_nup; int n_db_pad;      // database rows (A-form), |x|^2 - E and 2 E (FnRows)
+    const _Float16 *qB; const float *q_nrm, *q_cq; int n_q, n_q_pad;      // query rows (B-form), |x|^2 (sign bit set: all-zero feature row) and 2 E
     const int *db_first_zero;                                      // first all-zero row of the database (INT_MAX: none)
     int step0, steps_per_split, step_end;                          // 64-row steps [step0 + split * sps, +sps) clipped to step_end
     // tile pruning (null L: every step of the range is processed)
@@ -375,6 +457,7 @@ struct FnnArgs {
     const int *prelist;                                            // FN_NPRE steps per query workgroup (-1: unused)
     int pre_mode;                                                  // 1: process the workgroup's prelist; 0: the split's range minus the prelist
     int n_bound;                                                   // BOUND_ONLY launch: entries of the prelist it covers
+    int xcd_chunk;                                                 // > 0: query groups in XCD-aware order, grid.x = 8 * xcd_chunk (see the kernel)
     unsigned long long *stats;                                     // diagnostics (PCR_FEATNN_CHECK): [0] steps staged, [1] (wavefront, step) pairs computed, [2] of all
     int *Ug;                                                       // per query: upper bound of (minimum - |x_q|^2): read when a workgroup starts, lowered
                                                                    //   (atomicMin on the order-preserving int image) when it ends
@@ -388,10 +471,15 @@ template <bool BOUND_ONLY>
 __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * FN_GRP][FN_SUBS * FN_SUB_BYTES];
     __shared__ __attribute__((aligned(16))) float lnlo[2 * FN_GRP][FN_STEP];
+    __shared__ __attribute__((aligned(16))) float lnup[2 * FN_GRP][FN_STEP];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int col = lane & 15, g = lane >> 4;
-    if ((int)blockIdx.x * FN_QPG >= a.n_q_pad) return;             // (batch launches: the grid is the largest problem's)
-    const int q0 = (blockIdx.x * (FN_WG / 64) + wv) * FN_QPW;
+    // XCD-aware order of the query groups (xcd_chunk > 0: the grid is 8 * xcd_chunk wide): workgroup ids go round-robin over the 8 XCDs, so XCD x
+    // takes the contiguous groups [x * chunk, (x + 1) * chunk) -- neighbours in the Morton order of the queries, whose step lists overlap: the
+    // part of the database one L2 has to hold is what THEY need, not what all the queries of the cloud need
+    const int bx = a.xcd_chunk > 0 ? (int)(blockIdx.x & 7u) * a.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (bx * FN_QPG >= a.n_q_pad) return;             // (batch launches: the grid is the largest problem's)
+    const int q0 = (bx * (FN_WG / 64) + wv) * FN_QPW;
     const int s0 = a.pre_mode ? 0 : a.step0 + blockIdx.y * a.steps_per_split;
     const int s1 = a.pre_mode ? 0 : min(a.step_end, s0 + a.steps_per_split);
     if (!a.pre_mode && s0 >= s1) return;
@@ -400,33 +488,36 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
     __shared__ float sD[FN_WG / 64];
     __shared__ unsigned pre_bits[FN_LIST_CAP / 32];
     // B operands of the wavefront's 64 queries: block b, MFMA m <- k-chunk (g, m) of query q0 + 16 b + col
-    fn_h8 qb[FN_QB][4];
-    float cq[FN_QB], U[FN_QB], thr[FN_QB], nqv[FN_QB];
+    fn_h8 qb[FN_QB][FN_NM];
+    float cq[FN_QB], U[FN_QB], thrh[FN_QB], nqv[FN_QB];        // thrh = -(U + cq) / 2: the hit threshold on the accumulator scale
 #pragma unroll
     for (int b = 0; b < FN_QB; b++) {
         const int q = q0 + 16 * b + col;
         const int qc = q < a.n_q_pad ? q : 0;
-        const uint4 *src = (const uint4 *)(a.qB + (size_t)qc * FN_K + g * 32);
+        const uint4 *src = (const uint4 *)(a.qB + (size_t)qc * FN_K + g * (FN_K / 4));
 #pragma unroll
-        for (int m = 0; m < 4; m++) { union { uint4 u; fn_h8 h; } x; x.u = src[m]; qb[b][m] = x.h; }
-        // candidate iff (lower bound of d~ - nq) < U + 2 c nq ; queries beyond n_q and zero queries with a known answer never produce candidates
+        for (int m = 0; m < FN_NM; m++) { union { uint4 u; fn_h8 h; } x; x.u = src[m]; qb[b][m] = x.h; }
+        // candidate iff (lower bound of d~ - nq) < U + 2 E_q ; queries beyond n_q and zero queries with a known answer never produce candidates
         const float nr = a.q_nrm[qc];
         const bool known = __builtin_signbit(nr) && *a.db_first_zero != 0x7fffffff;
-        cq[b] = (q < a.n_q && !known) ? (float)(2.0 * FN_C * 1.001) * fabsf(nr) : -__builtin_inff();
+        cq[b] = (q < a.n_q && !known) ? a.q_cq[qc] : -__builtin_inff();
         nqv[b] = fabsf(nr);
         U[b] = fn_unord(a.Ug[qc]);                        // what the pre-pass has established
-        thr[b] = U[b] + cq[b];
+        thrh[b] = -0.5f * (U[b] + cq[b]);
     }
     // D = the largest (upper bound of the best squared distance) over the wavefront's live queries: a tile whose box is farther than
     // that from the wavefront's box holds neither a nearest row nor a tie of it
     auto wave_D = [&]() {
         float d = -__builtin_inff();
 #pragma unroll
-        for (int b = 0; b < FN_QB; b++) d = fmaxf(d, cq[b] == -__builtin_inff() ? -__builtin_inff() : __fmaf_rn(2.4e-7f, fabsf(U[b]) + nqv[b], U[b] + nqv[b]));
+        for (int b = 0; b < FN_QB; b++) {       // true best distance <= U + |x_q|^2 + E_q (cq = 2 E_q with a margin), rounded up
+            const float t = U[b] + nqv[b] + 0.5f * cq[b];
+            d = fmaxf(d, cq[b] == -__builtin_inff() ? -__builtin_inff() : __fmaf_rn(4.0e-7f, fabsf(U[b]) + nqv[b] + cq[b], t));
+        }
         return pcr_wave_max_all(d);                     // (DPP + permlane swaps: no LDS round trips -- this runs after every step with a candidate)
     };
     float Dw = wave_D();
-    const int qt = blockIdx.x * (FN_WG / 64) + wv;         // the wavefront's query tile (row of L)
+    const int qt = bx * (FN_WG / 64) + wv;         // the wavefront's query tile (row of L)
     const bool prune = a.L != nullptr;
     // ---- the workgroup's list of steps
     if (tid == 0) n_list_s = 0;
@@ -435,20 +526,21 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
     __syncthreads();
     if (a.pre_mode) {               // the list comes nearest-first with its unused entries at the end
         if (tid < 64) {
-            const int t = tid < (BOUND_ONLY ? a.n_bound : FN_NPRE) ? a.prelist[(size_t)blockIdx.x * FN_NPRE + tid] : -1;
+            // (gridDim.y workgroups share the list, entry e to workgroup e % gridDim.y: each gets some of the very nearest tiles)
+            const int t = (tid < (BOUND_ONLY ? a.n_bound : FN_NPRE) && tid % (int)gridDim.y == (int)blockIdx.y) ? a.prelist[(size_t)bx * FN_NPRE + tid] : -1;
             const bool ok = t >= 0 && t < a.step_end;
             const unsigned long long okm = __ballot(ok);
             if (ok) slist[__builtin_popcountll(okm & ((1ull << tid) - 1ull))] = t;
             if (tid == 0) n_list_s = __builtin_popcountll(okm);
         }
     } else {
-        if (a.prelist && tid < FN_NPRE) { const int t = a.prelist[(size_t)blockIdx.x * FN_NPRE + tid]; if (t >= s0 && t < s1) atomicOr(&pre_bits[(t - s0) >> 5], 1u << ((t - s0) & 31)); }
+        if (a.prelist && tid < FN_NPRE) { const int t = a.prelist[(size_t)bx * FN_NPRE + tid]; if (t >= s0 && t < s1) atomicOr(&pre_bits[(t - s0) >> 5], 1u << ((t - s0) & 31)); }
         __syncthreads();
         for (int t = s0 + tid; t < s1; t += FN_WG) {
             bool need = !((pre_bits[(t - s0) >> 5] >> ((t - s0) & 31)) & 1u);
             if (need && prune) {
                 need = false;
-                for (int w = 0; w < FN_WG / 64; w++) { const int r = blockIdx.x * (FN_WG / 64) + w; if (r < a.n_qt && a.L[(size_t)r * a.L_stride + t] <= sD[w]) need = true; }
+                for (int w = 0; w < FN_WG / 64; w++) { const int r = bx * (FN_WG / 64) + w; if (r < a.n_qt && a.L[(size_t)r * a.L_stride + t] <= sD[w]) need = true; }
             }
             if (need) slist[atomicAdd(&n_list_s, 1)] = t;
         }
@@ -458,16 +550,19 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
     if (a.stats && tid == 0) atomicAdd(&a.stats[0], (unsigned long long)n_list);
     if (n_list == 0) return;                               // nothing in this range can improve any of the 512 queries (their bounds are in Ug already)
     // staging: thread t moves FN_NCH 16-byte k-chunks of the step (rows r, r + FN_WG / 16, ..., chunk j); norms by the first 64 threads
-    constexpr int FN_NCH = FN_STEP * 16 / FN_WG, FN_RSTEP = FN_WG / 16;       // 2 chunks per thread at 512 threads, 4 at 256
-    const int st_r = tid >> 4, st_j = tid & 15;             // r = 0 .. FN_RSTEP - 1
-    auto st_dst = [&](int r) { return (r >> 4) * FN_SUB_BYTES + (st_j >> 2) * FN_GROUP + (r & 15) * FN_PITCH + (st_j & 3) * 16; };
-    struct Slot { uint4 v[FN_NCH]; float nv, lw; };
+    constexpr int FN_CPR = FN_K / 8;                                          // 16-byte chunks per row: k-group j / FN_NM, MFMA j % FN_NM
+    constexpr int FN_NCH = FN_STEP * FN_CPR / FN_WG, FN_RSTEP = FN_WG / FN_CPR;   // chunks per thread (K = 64: 1 at 512 threads, 2 at 256), rows per round
+    static_assert(FN_NCH >= 1 && FN_NCH * FN_RSTEP == FN_STEP, "staging: the workgroup must cover a step in whole rounds");
+    const int st_r = tid / FN_CPR, st_j = tid % FN_CPR;     // r = 0 .. FN_RSTEP - 1
+    auto st_dst = [&](int r) { return (r >> 4) * FN_SUB_BYTES + (st_j / FN_NM) * FN_GROUP + (r & 15) * FN_PITCH + (st_j % FN_NM) * 16; };
+    struct Slot { uint4 v[FN_NCH]; float nv, nu, lw; };
     auto fetch = [&](int step, Slot &x) {
         x.lw = (prune && !a.pre_mode && qt < a.n_qt) ? a.L[(size_t)qt * a.L_stride + step] : 0.0f;
         const _Float16 *src = a.dbA + ((size_t)step * FN_STEP + st_r) * FN_K + st_j * 8;
 #pragma unroll
         for (int c = 0; c < FN_NCH; c++) x.v[c] = *(const uint4 *)(src + (size_t)c * FN_RSTEP * FN_K);
         x.nv = tid < FN_STEP ? a.db_nlo[(size_t)step * FN_STEP + tid] : 0.0f;
+        x.nu = tid < FN_STEP ? a.db_nup[(size_t)step * FN_STEP + tid] : 0.0f;
     };
     auto stash = [&](int buf, const Slot &x) {
 #pragma unroll
@@ -475,7 +570,10 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
             unsigned char *d = &lds[buf][st_dst(st_r + c * FN_RSTEP)];
             *(uint2 *)d = make_uint2(x.v[c].x, x.v[c].y); *(uint2 *)(d + 8) = make_uint2(x.v[c].z, x.v[c].w);
         }
-        if (tid < FN_STEP) lnlo[buf][tid] = x.nv;
+        // the accumulators start at -nlo / 2 (the BOUND_ONLY form: at -(nlo + nup) / 2, rounded towards the safe side with room for the
+        // roundings of the accumulation): the MFMAs then leave acc = dot - nlo / 2 = -w / 2 and the test w < thr is acc > -thr / 2 -- one max3, one
+        // max and one compare per block instead of four fused multiply-adds and three minimums
+        if (tid < FN_STEP) { lnlo[buf][tid] = BOUND_ONLY ? -0.5f * (fn_add_up(x.nv, x.nu) * 1.0000006f) : -0.5f * x.nv; lnup[buf][tid] = x.nu; }
     };
     // The database does not fit the L2s (51 MB at 200k rows): a row block comes from the Infinity Cache or HBM, 1-2 us away.  Steps are
     // staged FN_GRP at a time with ONE workgroup barrier per group: the LDS image is double buffered by group, the global loads of group
@@ -503,7 +601,6 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
 #else
 #define FN_T(...)
 #endif
-    const float kc = (float)(2.0 * FN_C * 1.002);          // whi = wlo + kc * nlo  >=  d~ + E - nq
     const unsigned a_off = (unsigned)(g * FN_GROUP + col * FN_PITCH);
     int chunk_base = -1, chunk_fill = FN_CHUNK;            // wave-uniform: current chunk of the record pool (none yet)
     bool dead = false;                                      // the pool overflowed: flags[0] is set and the caller falls back
@@ -514,54 +611,51 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
         if (wave_on) {
         n_comp++;
         // ---- fast path: 4 tiles x 4 query blocks, one hit bit per 16 x 16 block, nothing else kept
-        unsigned hits = 0;
+        unsigned wave_hits = 0;                           // bit (sub, b): some lane saw one of its four rows of the block under its threshold (scalar register)
 #pragma unroll
         for (int sub = 0; sub < FN_SUBS; sub++) {
             // A operands: 4 k-chunks x 16 bytes per lane, 8-byte LDS reads on the conflict-free image (plain loads: the compiler keeps
             // counted waits for them and runs the next tile's reads under this tile's MFMAs)
-            union { uint2 u[2]; fn_h8 h; } av[4];
+            union { uint2 u[2]; fn_h8 h; } av[FN_NM];
             const unsigned char *base = &lds[buf][sub * FN_SUB_BYTES + a_off];
 #pragma unroll
-            for (int m = 0; m < 4; m++) { av[m].u[0] = *(const uint2 *)(base + m * 16); av[m].u[1] = *(const uint2 *)(base + m * 16 + 8); }
+            for (int m = 0; m < FN_NM; m++) { av[m].u[0] = *(const uint2 *)(base + m * 16); av[m].u[1] = *(const uint2 *)(base + m * 16 + 8); }
             const fn_f4 nl = *(const fn_f4 *)(&lnlo[buf][sub * 16 + 4 * g]);       // rows 4 g .. 4 g + 3 of the tile: this lane's accumulator rows
 #pragma unroll
             for (int b = 0; b < FN_QB; b++) {
-                fn_f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                fn_f4 acc = nl;
 #pragma unroll
-                for (int m = 0; m < 4; m++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[m].h, qb[b][m], acc, 0, 0, 0);
-                if (BOUND_ONLY) {           // upper bounds d~ + E - nq of the four rows: whi = wlo + kc * nlo
-                    const float kn = 1.0f + (float)(2.0 * FN_C * 1.002);
-                    U[b] = fminf(U[b], fminf(fminf(__fmaf_rn(-2.0f, acc[0], kn * nl[0] * 1.0000002f), __fmaf_rn(-2.0f, acc[1], kn * nl[1] * 1.0000002f)),
-                                             fminf(__fmaf_rn(-2.0f, acc[2], kn * nl[2] * 1.0000002f), __fmaf_rn(-2.0f, acc[3], kn * nl[3] * 1.0000002f))));
-                } else {
-                const float mn = fminf(fminf(__fmaf_rn(-2.0f, acc[0], nl[0]), __fmaf_rn(-2.0f, acc[1], nl[1])),
-                                       fminf(__fmaf_rn(-2.0f, acc[2], nl[2]), __fmaf_rn(-2.0f, acc[3], nl[3])));
-                hits |= (mn < thr[b]) ? (1u << (sub * FN_QB + b)) : 0u;
+                for (int m = 0; m < FN_NM; m++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[m].h, qb[b][m], acc, 0, 0, 0);
+                if (BOUND_ONLY) {
+                    const float mx = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));    // = -(smallest w of the four rows) / 2
+                    U[b] = fminf(U[b], -2.0f * mx);       // upper bounds d~ + E_b - nq of the four rows
+                } else {    // four compares into scalar masks: no per-lane state, the union over the wavefront costs nothing
+                    const unsigned long long m = __ballot(acc[0] > thrh[b]) | __ballot(acc[1] > thrh[b]) | __ballot(acc[2] > thrh[b]) | __ballot(acc[3] > thrh[b]);
+                    wave_hits |= m != 0ull ? (1u << (sub * FN_QB + b)) : 0u;
                 }
             }
         }
         FN_T(const unsigned long long t3 = __builtin_amdgcn_s_memtime(); tc_fast += t3 - t2;)
         // ---- candidate path: blocks in which some lane saw a value under its threshold are recomputed from the LDS image
-        unsigned long long any = BOUND_ONLY ? 0ull : __ballot(hits != 0u);
-        if (any != 0ull && !dead) {
-            unsigned wave_hits = (unsigned)__builtin_amdgcn_readfirstlane((int)pcr_wave_or_all(hits));   // union over the wavefront (in a scalar register: the block loop below branches uniformly)
+        if (!BOUND_ONLY && wave_hits != 0u && !dead) {
             while (wave_hits != 0u) {
                 FN_T(n_hitblk++;)
                 const int blk = __builtin_ctz(wave_hits);
                 wave_hits &= wave_hits - 1u;
                 const int sub = blk / FN_QB, b = blk % FN_QB;
-                union { uint2 u[2]; fn_h8 h; } av[4];
+                union { uint2 u[2]; fn_h8 h; } av[FN_NM];
                 const unsigned char *base = &lds[buf][sub * FN_SUB_BYTES + a_off];
 #pragma unroll
-                for (int m = 0; m < 4; m++) { av[m].u[0] = *(const uint2 *)(base + m * 16); av[m].u[1] = *(const uint2 *)(base + m * 16 + 8); }
+                for (int m = 0; m < FN_NM; m++) { av[m].u[0] = *(const uint2 *)(base + m * 16); av[m].u[1] = *(const uint2 *)(base + m * 16 + 8); }
                 const fn_f4 nl = *(const fn_f4 *)(&lnlo[buf][sub * 16 + 4 * g]);
+                const fn_f4 nu = *(const fn_f4 *)(&lnup[buf][sub * 16 + 4 * g]);
                 // block b is a run-time index here: select its operands and state with uniform branches (registers stay registers)
-                fn_f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                fn_f4 acc = nl;
                 float Ub = 0.0f, cqb = 0.0f;
 #pragma unroll
                 for (int bb = 0; bb < FN_QB; bb++) if (b == bb) {
 #pragma unroll
-                    for (int m = 0; m < 4; m++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[m].h, qb[bb][m], acc, 0, 0, 0);
+                    for (int m = 0; m < FN_NM; m++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[m].h, qb[bb][m], acc, 0, 0, 0);
                     Ub = U[bb]; cqb = cq[bb];
                 }
                 float tb = Ub + cqb;
@@ -569,7 +663,7 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
                 const int row0 = step * FN_STEP + sub * 16 + 4 * g;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
-                    const float w = __fmaf_rn(-2.0f, acc[i], nl[i]);
+                    const float w = -2.0f * acc[i];
                     const bool h = w < tb;
                     const unsigned long long mask = __ballot(h);
                     const int n_new = __builtin_popcountll(mask);
@@ -591,12 +685,12 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
                             chunk_fill += n_new;
                         }
                     }
-                    if (h) { Ub = fminf(Ub, __fmaf_rn(kc, nl[i], w)); tb = Ub + cqb; }
+                    if (h) { Ub = fminf(Ub, fn_add_up(w, nu[i])); tb = Ub + cqb; }
                 }
                 // share the improved bound between the 4 row groups of a query, then store it back into the block's state
                 Ub = pcr_xrow_min(Ub);
 #pragma unroll
-                for (int bb = 0; bb < FN_QB; bb++) if (b == bb) { U[bb] = Ub; thr[bb] = Ub + cq[bb]; }
+                for (int bb = 0; bb < FN_QB; bb++) if (b == bb) { U[bb] = Ub; thrh[bb] = -0.5f * (Ub + cq[bb]); }
             }
             if (prune) Dw = wave_D();
         }
@@ -637,8 +731,12 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
             if (q < a.n_q) atomicMin(&a.Ug[q], fn_ord(U[b]));
         }
 }
-template <bool BOUND_ONLY> __global__ void __launch_bounds__(FN_WG) k_feature_nn_screen(FnnArgs a) { d_feature_nn_screen<BOUND_ONLY>(a); }
-template <bool BOUND_ONLY> __global__ void __launch_bounds__(FN_WG) k_feature_nn_screen_g(const FnnArgs *a) { d_feature_nn_screen<BOUND_ONLY>(a[blockIdx.z]); }
+// (waves_per_eu: with at most 128 / 168 registers per lane the compiler keeps the MFMA accumulators in ordinary VGPRs -- no v_accvgpr_read before every bound test)
+#ifndef FN_WAVES_ATTR
+#define FN_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
+template <bool BOUND_ONLY> __global__ void __launch_bounds__(FN_WG) FN_WAVES_ATTR k_feature_nn_screen(FnnArgs a) { d_feature_nn_screen<BOUND_ONLY>(a); }
+template <bool BOUND_ONLY> __global__ void __launch_bounds__(FN_WG) FN_WAVES_ATTR k_feature_nn_screen_g(const FnnArgs *a) { d_feature_nn_screen<BOUND_ONLY>(a[blockIdx.z]); }
 
 // ---- exact float64 distance exactly as the oracle's kd-tree leaf loop computes it: d2 += e * e with the product and the sum
 // rounded separately, k = 0 .. 32 in order
@@ -650,8 +748,8 @@ __device__ static inline double fn_exact_d2(const float *__restrict__ x, const f
 }
 
 struct FnxArgs {
-    const float *q; const float *q_nrm; int n_q;        // original float32 query rows; scaled centred norms (sign bit: zero row)
-    const float *db; int n_db; const float *db_nlo; const int *db_first_zero;
+    const float *q; const float *q_nrm, *q_cq; int n_q;  // original float32 query rows; scaled centred norms (sign bit: zero row), 2 E_q
+    const float *db; int n_db; const float *db_nlo, *db_nup, *db_nrm; const int *db_first_zero;
     const int *Ug;                                      // final bound of the screen per query
     const int *pool_used; const int *chunk_fill; const int *rec_q; const int *rec_row; const float *rec_w;
     const uint32_t *perm_q, *perm_db;                   // tile-pruned screen: query q / row r of the screen is row perm[.] of q / db (null: identity)
@@ -664,8 +762,7 @@ __device__ static inline bool fn_record(const FnxArgs &a, int r, int *q, int *ro
     if (r >= *a.pool_used || (r % FN_CHUNK) >= a.chunk_fill[r / FN_CHUNK]) return false;
     *q = a.rec_q[r]; *row = a.rec_row[r];
     if (*q >= a.n_q || *row >= a.n_db) return false;
-    const float nr = a.q_nrm[*q];
-    const float thr = fn_unord(a.Ug[*q]) + (float)(2.0 * FN_C * 1.001) * fabsf(nr);
+    const float thr = fn_unord(a.Ug[*q]) + a.q_cq[*q];
     return a.rec_w[r] <= thr;                             // else: could not be the minimum given the final bound
 }
 // pass 1: smallest exact distance per query
@@ -677,9 +774,10 @@ __device__ static inline void d_fn_exact_min(const FnxArgs &a, int n_rec_cap, co
     a.rec_d[r] = d;
     atomicMin(&a.best_d[q], (unsigned long long)__double_as_longlong(d));
     if (a.dbg) {          // the screen's value of this pair against the exact one, in units of the bound
-        const double nq = fabs((double)a.q_nrm[q]), nb = (double)a.db_nlo[row] / (1.0 - FN_C);
-        const double dt = (double)a.rec_w[r] + FN_C * nb + nq;                    // d~ in scaled units
-        atomicMax((unsigned int *)&a.dbg[0], __float_as_uint((float)(fabs(dt - d * FN_SCALE * FN_SCALE) / (nq + nb))));
+        const double nq = fabs((double)a.q_nrm[q]), nb = fabs((double)a.db_nrm[row]);
+        const double dt = (double)a.rec_w[r] - (double)a.db_nlo[row] + nb + nq;   // d~ in scaled units (to the rounding of nrm)
+        const double budget = 0.5 * ((double)a.q_cq[q] + (double)a.db_nup[row]);  // E_q + E_b
+        atomicMax((unsigned int *)&a.dbg[0], __float_as_uint((float)(fabs(dt - d * FN_SCALE * FN_SCALE) / budget)));
         atomicAdd(&a.dbg[1], 1.0f);
     }
 }
@@ -731,12 +829,12 @@ __global__ void __launch_bounds__(256) k_fn_init_g(const FnInitDesc *d) { const 
 // ------------------------------------------------------------------------------------------------------------------ driver
 size_t pcr_feature_nn_scratch_bytes(int64_t n0, int64_t n1) {
     const size_t p0 = ((size_t)n0 + FN_QPG) / FN_QPG * FN_QPG, p1 = ((size_t)n1 + FN_QPG) / FN_QPG * FN_QPG;
-    const size_t per_row = 2 * FN_K * sizeof(_Float16) + 2 * sizeof(float);                 // both forms + two norms
+    const size_t per_row = 2 * FN_K * sizeof(_Float16) + 4 * sizeof(float);                 // both forms + the four floats of FnRows
     const size_t per_query = (size_t)FN_POOL_PER_QUERY * 21 + 8 + 4 + 16;                   // records (+ exact distances), best distance, bound, chunk table share
     // tile pruning: principal coordinates, keys / values (in, out) and sort scratch per row; boxes; the (query tile x row tile) bound matrix
     const size_t prune_rows = (p0 + p1) * (FN_D * sizeof(float) + 2 * (8 + 4)) + pcr_sort_temp_bytes(p0 > p1 ? p0 : p1) + (p0 + p1) / 64 * (2 * FN_D * 4 + 64);
     const size_t lmat = (p0 / 64 + 64) * (p1 / 64 + 64) * sizeof(float);
-    return (p0 + p1) * per_row + (p0 > p1 ? p0 : p1) * per_query + (size_t)(4608 + 64 * 9) * 8 * FN_CHUNK * 21 + (1u << 22) + prune_rows
+    return (p0 + p1) * per_row + (p0 > p1 ? p0 : p1) * per_query + (size_t)(FN_WGS_PRUNED + 2048 + (2 + FN_PRE_SPLIT) * ((p0 > p1 ? p0 : p1) / FN_QPG) + 256) * (FN_WG / 64) * FN_CHUNK * 21 + (1u << 22) + prune_rows
            + (lmat <= ((size_t)512 << 20) ? lmat : 0) + (1u << 20);
 }
 
@@ -747,7 +845,7 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
     if (n0 <= 0 || n1 <= 0) return PCR_OK;
     ArenaMark mark(ctx);
     const float *f[2] = {f0, f1}; const int n[2] = {n0, n1}; int np[2];
-    _Float16 *A[2], *B[2]; float *nlo[2], *nrm[2];
+    _Float16 *A[2], *B[2]; FnRows rows[2];
     static const bool check = getenv("PCR_FEATNN_CHECK") != nullptr;
     const int nbm = 64;
     double *part = arena<double>(ctx, (size_t)2 * nbm * FN_PC + FN_PC);
@@ -757,7 +855,7 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
     PCR_LAUNCH(ctx, k_fn_colsum, dim3(nbm), dim3(256), 0, ctx->stream, f1, n1, part + (size_t)nbm * FN_PC);
     int *first_zero = arena<int>(ctx, 2), *flags = arena<int>(ctx, 2);
     if (!first_zero || !flags) return PCR_ENOMEM;
-    PCR_LAUNCH(ctx, k_fn_mean, dim3(1), dim3(64), 0, ctx->stream, part, nbm, n0, mu, first_zero, flags);
+    PCR_LAUNCH(ctx, k_fn_mean, dim3(1), dim3(128), 0, ctx->stream, part, nbm, n0, mu, first_zero, flags);
     for (int c = 0; c < 2; c++) np[c] = (n[c] + FN_QPG - 1) / FN_QPG * FN_QPG;   // multiple of 512 (queries per workgroup) and of 64 (rows per step)
     // ---- tile pruning: worth its set-up (two small sorts, a host eigen-decomposition) from ~70k x 70k rows (60k x 60k: 4.1 ms with, 3.5 ms
     // without; 80k: 4.6 / 5.4; 100k: 5.6 / 7.5; 200k x 200k: 12.1 / 25.9 ms); the bound matrix must fit
@@ -839,9 +937,10 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
     }
     for (int c = 0; c < 2; c++) {
         A[c] = arena<_Float16>(ctx, (size_t)np[c] * FN_K); B[c] = arena<_Float16>(ctx, (size_t)np[c] * FN_K);
-        nlo[c] = arena<float>(ctx, np[c]); nrm[c] = arena<float>(ctx, np[c]);
-        if (!A[c] || !B[c] || !nlo[c] || !nrm[c]) return PCR_ENOMEM;
-        PCR_LAUNCH(ctx, k_fn_split, dim3((np[c] + 255) / 256), dim3(256), 0, ctx->stream, f[c], n[c], np[c], mu, A[c], B[c], nlo[c], nrm[c], first_zero + c, (const uint32_t *)perm[c]);
+        float *r4 = arena<float>(ctx, (size_t)4 * np[c]);
+        if (!A[c] || !B[c] || !r4) return PCR_ENOMEM;
+        rows[c] = FnRows{r4, r4 + np[c], r4 + (size_t)2 * np[c], r4 + (size_t)3 * np[c]};
+        PCR_LAUNCH(ctx, k_fn_split, dim3((np[c] + 255) / 256), dim3(256), 0, ctx->stream, f[c], n[c], np[c], mu, A[c], B[c], rows[c], first_zero + c, (const uint32_t *)perm[c]);
     }
     float *dbg = nullptr;
     if (check) { dbg = arena<float>(ctx, 2); if (!dbg) return PCR_ENOMEM; }
@@ -856,7 +955,7 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         const int pre = prune ? 0 : (steps <= 128 ? steps : 64);
         const int rest = steps - pre;
         int splits = rest > 0 ? (2048 + groups - 1) / groups : 1;
-        if (prune && rest > 0) splits = (4608 + groups - 1) / groups;                // lists hold ~1/5 of their range and differ in length: more, shorter
+        if (prune && rest > 0) splits = (FN_WGS_PRUNED + groups - 1) / groups;                // lists hold ~1/5 of their range and differ in length: more, shorter
                                                                                      //   ranges balance better (200k x 200k: 13.4 / 12.6 / 12.1 / 12.3 ms for 4 / 8 / 12 / 16)
         if (splits > 256) splits = 256;
         if (splits < (rest + FN_LIST_CAP - 1) / FN_LIST_CAP) splits = (rest + FN_LIST_CAP - 1) / FN_LIST_CAP;
@@ -873,7 +972,7 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         const int sps_all = (steps + splits_all - 1) / splits_all;
         if (sps_all > FN_LIST_CAP) return PCR_ECAPACITY;
         // capacity: records per query plus the chunk every wavefront of either pass may leave partly filled
-        const size_t waves = (size_t)groups * (FN_WG / 64) * (size_t)(1 + (splits > splits_all ? splits : splits_all));
+        const size_t waves = (size_t)groups * (FN_WG / 64) * (size_t)(FN_PRE_SPLIT + (splits > splits_all ? splits : splits_all));
         const int pool_cap = (int)(((size_t)nqp * FN_POOL_PER_QUERY + waves * FN_CHUNK + FN_CHUNK - 1) / FN_CHUNK * FN_CHUNK);
         int *pool_used = arena<int>(ctx, 1), *chunk_fill = arena<int>(ctx, pool_cap / FN_CHUNK);
         int *rec_q = arena<int>(ctx, pool_cap), *rec_row = arena<int>(ctx, pool_cap); float *rec_w = arena<float>(ctx, pool_cap);
@@ -888,10 +987,10 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         }
         if (dbg) PCR_HIP_CHECK(ctx, hipMemsetAsync(dbg, 0, 8, ctx->stream));
         FnnArgs a;
-        a.dbA = A[dc]; a.db_nlo = nlo[dc]; a.n_db_pad = np[dc]; a.qB = B[qc]; a.q_nrm = nrm[qc]; a.n_q = nq; a.n_q_pad = nqp;
+        a.dbA = A[dc]; a.db_nlo = rows[dc].nlo; a.db_nup = rows[dc].nup; a.n_db_pad = np[dc]; a.qB = B[qc]; a.q_nrm = rows[qc].nrm; a.q_cq = rows[qc].cq; a.n_q = nq; a.n_q_pad = nqp;
         a.db_first_zero = first_zero + dc; a.Ug = Ug;
         a.pool_used = pool_used; a.pool_cap = pool_cap; a.chunk_fill = chunk_fill; a.rec_q = rec_q; a.rec_row = rec_row; a.rec_w = rec_w; a.flags = flags;
-        a.L = nullptr; a.L_stride = 0; a.n_qt = 0; a.prelist = nullptr; a.pre_mode = 0; a.n_bound = 0; a.stats = nullptr;
+        a.L = nullptr; a.L_stride = 0; a.n_qt = 0; a.prelist = nullptr; a.pre_mode = 0; a.n_bound = 0; a.xcd_chunk = 0; a.stats = nullptr;
         unsigned long long *stats = nullptr;
         if (check) { stats = arena<unsigned long long>(ctx, 16); if (!stats) return PCR_ENOMEM; PCR_HIP_CHECK(ctx, hipMemsetAsync(stats, 0, 128, ctx->stream)); a.stats = stats; }
         if (prune) {
@@ -905,12 +1004,22 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
             a.L = L; a.L_stride = nbt; a.n_qt = nqt; a.prelist = prelist;
             // (i) bounds only over the 16 nearest tiles (in a sorted database the running minimum improves row after row: with records
             // that is a record per improvement), (ii) the 48 nearest tiles with records under that bound, (iii) everything else that survives
-            const int n_bound = 16;
+            const int n_bound = FN_NBOUND;
             a.step0 = 0; a.steps_per_split = 0; a.step_end = steps; a.pre_mode = 1; a.n_bound = n_bound < FN_NPRE ? n_bound : FN_NPRE;
-            if (a.n_bound > 0) PCR_LAUNCH(ctx, k_feature_nn_screen<true>, dim3(groups, 1), dim3(FN_WG), 0, ctx->stream, a);
-            PCR_LAUNCH(ctx, k_feature_nn_screen<false>, dim3(groups, 1), dim3(FN_WG), 0, ctx->stream, a);
+            if (a.n_bound > 0) PCR_LAUNCH(ctx, k_feature_nn_screen<true>, dim3(groups, FN_PRE_SPLIT_B), dim3(FN_WG), 0, ctx->stream, a);
+            PCR_LAUNCH(ctx, k_feature_nn_screen<false>, dim3(groups, FN_PRE_SPLIT), dim3(FN_WG), 0, ctx->stream, a);
+            if (check) {    // the pre-pass by itself (diagnostics: a wait and a read-back in the middle of the direction)
+                unsigned long long hs[16] = {0}; int used = 0;
+                PCR_HIP_CHECK(ctx, hipMemcpyAsync(hs, stats, 128, hipMemcpyDeviceToHost, ctx->stream));
+                PCR_HIP_CHECK(ctx, hipMemcpyAsync(&used, pool_used, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                fprintf(stderr, "featnn dir %d pre-pass (%d nearest tiles per workgroup): %d records allocated (%.1f per query); stamps (M ticks): fetch %.1f, barrier %.1f, fast path %.1f, candidate path %.1f (%llu hit blocks), stash %.1f\n",
+                        dir, FN_NPRE, used, (double)used / nq, hs[4] * 1e-6, hs[5] * 1e-6, hs[6] * 1e-6, hs[7] * 1e-6, hs[9], hs[8] * 1e-6);
+            }
             a.pre_mode = 0; a.step0 = 0; a.steps_per_split = sps; a.step_end = steps;
-            PCR_LAUNCH(ctx, k_feature_nn_screen<false>, dim3(groups, splits), dim3(FN_WG), 0, ctx->stream, a);
+            a.xcd_chunk = FN_XCD_ORDER ? (groups + 7) / 8 : 0;
+            PCR_LAUNCH(ctx, k_feature_nn_screen<false>, dim3(a.xcd_chunk > 0 ? 8 * a.xcd_chunk : groups, splits), dim3(FN_WG), 0, ctx->stream, a);
+            a.xcd_chunk = 0;
         } else {
             // Seeding the bounds: a sweep over the first 4096 rows that only lowers the queries' upper bounds (no candidates, no records)
             // can be split over many workgroups -- the bounds meet in Ug by atomicMin -- where a pre-pass WITH records had to be one
@@ -925,7 +1034,8 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
             }
         }
         FnxArgs x;
-        x.q = f[qc]; x.q_nrm = nrm[qc]; x.n_q = nq; x.db = f[dc]; x.n_db = n[dc]; x.db_nlo = nlo[dc]; x.db_first_zero = first_zero + dc; x.Ug = Ug;
+        x.q = f[qc]; x.q_nrm = rows[qc].nrm; x.q_cq = rows[qc].cq; x.n_q = nq; x.db = f[dc]; x.n_db = n[dc]; x.db_nlo = rows[dc].nlo; x.db_nup = rows[dc].nup; x.db_nrm = rows[dc].nrm;
+        x.db_first_zero = first_zero + dc; x.Ug = Ug;
         x.pool_used = pool_used; x.chunk_fill = chunk_fill; x.rec_q = rec_q; x.rec_row = rec_row; x.rec_w = rec_w; x.best_d = best_d; x.out = out; x.dbg = dbg;
         x.perm_q = perm[qc]; x.perm_db = perm[dc]; x.rec_d = rec_d;
         // the record kernels cover the whole pool capacity (the used part is only known on the device); unused slots exit at once
@@ -945,8 +1055,8 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
             fprintf(stderr, "featnn dir %d: tile pruning %s: %llu steps staged of %lld (workgroup x step), %llu (wavefront, step) pairs computed of %lld\n", dir, prune ? "on" : "off",
                     hs[0], (long long)groups * steps, hs[1], (long long)groups * (FN_WG / 64) * steps);
             fprintf(stderr, "featnn dir %d: %d queries x %d rows, pre %d + %d splits x %d steps of %d rows; pool %d of %d records allocated (%.1f per query)%s, %.0f survived the final bound (%.2f per query); "
-                            "max |d~-d|/(nq+nb) = %.3e (bound %.1e)\n", dir, nq, n[dc], pre, rest > 0 ? splits : 0, sps, FN_STEP, h[0], pool_cap, (double)h[0] / nq,
-                    h[1] ? " OVERFLOW" : "", hd[1], hd[1] / nq, hd[0], FN_C);
+                            "max |d~-d| / (E_q + E_b) = %.3f (must stay under 1; K = %d, %d covered dimensions)\n", dir, nq, n[dc], pre, rest > 0 ? splits : 0, sps, FN_STEP, h[0], pool_cap, (double)h[0] / nq,
+                    h[1] ? " OVERFLOW" : "", hd[1], hd[1] / nq, hd[0], FN_K, FN_NCOV);
         }
     }
     {   // pool overflow (either direction): the results are incomplete, the caller recomputes on the float64 path
@@ -971,7 +1081,7 @@ int pcr_feature_nn_mutual_batch(pcr_context *ctx, int G, const float *const *f0,
         if ((double)n0[g] * (double)n1[g] >= 5.0e9) return PCR_ECAPACITY;
     }
     const int nbm = 64;
-    struct Pair { const float *f[2]; int n[2], np[2]; double *part, *mu; int *first_zero, *flags; _Float16 *A[2], *B[2]; float *nlo[2], *nrm[2]; };
+    struct Pair { const float *f[2]; int n[2], np[2]; double *part, *mu; int *first_zero, *flags; _Float16 *A[2], *B[2]; FnRows rows[2]; };
     std::vector<Pair> P((size_t)G);
     std::vector<FnColsumDesc> cs((size_t)2 * G); std::vector<FnMeanDesc> ms((size_t)G);
     double *mu_all = arena<double>(ctx, (size_t)G * FN_PC);              // per-group arrays: one read-back each
@@ -993,7 +1103,7 @@ int pcr_feature_nn_mutual_batch(pcr_context *ctx, int G, const float *const *f0,
         const FnMeanDesc *dm = pcr_desc_upload(ctx, ms.data(), G);
         if (!dc || !dm) return PCR_ENOMEM;
         PCR_LAUNCH(ctx, k_fn_colsum_g, dim3(nbm, 2 * G), dim3(256), 0, ctx->stream, dc);
-        PCR_LAUNCH(ctx, k_fn_mean_g, dim3(G), dim3(64), 0, ctx->stream, dm);
+        PCR_LAUNCH(ctx, k_fn_mean_g, dim3(G), dim3(128), 0, ctx->stream, dm);
     }
     {   // the f16 split holds |f - mu| * 128 < 65504 (pcr_feature_nn_mutual): one read-back for the group
         std::vector<double> hmu((size_t)G * FN_PC);
@@ -1010,9 +1120,10 @@ int pcr_feature_nn_mutual_batch(pcr_context *ctx, int G, const float *const *f0,
         Pair &p = P[g];
         for (int c = 0; c < 2; c++) {
             p.A[c] = arena<_Float16>(ctx, (size_t)p.np[c] * FN_K); p.B[c] = arena<_Float16>(ctx, (size_t)p.np[c] * FN_K);
-            p.nlo[c] = arena<float>(ctx, p.np[c]); p.nrm[c] = arena<float>(ctx, p.np[c]);
-            if (!p.A[c] || !p.B[c] || !p.nlo[c] || !p.nrm[c]) return PCR_ENOMEM;
-            ss[2 * g + c] = FnSplitDesc{p.f[c], p.n[c], p.np[c], p.mu, p.A[c], p.B[c], p.nlo[c], p.nrm[c], p.first_zero + c};
+            float *r4 = arena<float>(ctx, (size_t)4 * p.np[c]);
+            if (!p.A[c] || !p.B[c] || !r4) return PCR_ENOMEM;
+            p.rows[c] = FnRows{r4, r4 + p.np[c], r4 + (size_t)2 * p.np[c], r4 + (size_t)3 * p.np[c]};
+            ss[2 * g + c] = FnSplitDesc{p.f[c], p.n[c], p.np[c], p.mu, p.A[c], p.B[c], p.rows[c], p.first_zero + c};
             max_np = p.np[c] > max_np ? p.np[c] : max_np;
         }
     }
@@ -1058,10 +1169,10 @@ int pcr_feature_nn_mutual_batch(pcr_context *ctx, int G, const float *const *f0,
             const int n_chunks = pool_cap / FN_CHUNK, n_init = std::max(std::max(n_chunks, nqp), nq);
             is[k] = FnInitDesc{pool_used, chunk_fill, n_chunks, Ug, nqp, best_d, out, nq};
             FnnArgs a;
-            a.dbA = p.A[dc]; a.db_nlo = p.nlo[dc]; a.n_db_pad = p.np[dc]; a.qB = p.B[qc]; a.q_nrm = p.nrm[qc]; a.n_q = nq; a.n_q_pad = nqp;
+            a.dbA = p.A[dc]; a.db_nlo = p.rows[dc].nlo; a.db_nup = p.rows[dc].nup; a.n_db_pad = p.np[dc]; a.qB = p.B[qc]; a.q_nrm = p.rows[qc].nrm; a.q_cq = p.rows[qc].cq; a.n_q = nq; a.n_q_pad = nqp;
             a.db_first_zero = p.first_zero + dc; a.Ug = Ug;
             a.pool_used = pool_used; a.pool_cap = pool_cap; a.chunk_fill = chunk_fill; a.rec_q = rec_q; a.rec_row = rec_row; a.rec_w = rec_w; a.flags = p.flags;
-            a.L = nullptr; a.L_stride = 0; a.n_qt = 0; a.prelist = nullptr; a.pre_mode = 0; a.n_bound = 0; a.stats = nullptr;
+            a.L = nullptr; a.L_stride = 0; a.n_qt = 0; a.prelist = nullptr; a.pre_mode = 0; a.n_bound = 0; a.xcd_chunk = 0; a.stats = nullptr;
             int pb_want = (2048 + groups * NP - 1) / (groups * NP);                // the bound-only sweep over the first 64 steps: as many cuts as fill the chip once
             if (pb_want > 8) pb_want = 8;
             const int pre_b = steps < 64 ? steps : 64, pb_splits = pre_b < pb_want ? pre_b : pb_want, pb_sps = (pre_b + pb_splits - 1) / pb_splits;
@@ -1070,7 +1181,8 @@ int pcr_feature_nn_mutual_batch(pcr_context *ctx, int G, const float *const *f0,
             a.step0 = 0; a.steps_per_split = sps_all; a.step_end = steps;
             rec[k] = a;
             FnxArgs x;
-            x.q = p.f[qc]; x.q_nrm = p.nrm[qc]; x.n_q = nq; x.db = p.f[dc]; x.n_db = p.n[dc]; x.db_nlo = p.nlo[dc]; x.db_first_zero = p.first_zero + dc; x.Ug = Ug;
+            x.q = p.f[qc]; x.q_nrm = p.rows[qc].nrm; x.q_cq = p.rows[qc].cq; x.n_q = nq; x.db = p.f[dc]; x.n_db = p.n[dc]; x.db_nlo = p.rows[dc].nlo; x.db_nup = p.rows[dc].nup; x.db_nrm = p.rows[dc].nrm;
+            x.db_first_zero = p.first_zero + dc; x.Ug = Ug;
             x.pool_used = pool_used; x.chunk_fill = chunk_fill; x.rec_q = rec_q; x.rec_row = rec_row; x.rec_w = rec_w; x.best_d = best_d; x.out = out; x.dbg = nullptr;
             x.perm_q = nullptr; x.perm_db = nullptr; x.rec_d = rec_d;
             xs[k] = FnxDesc{x, pool_cap};

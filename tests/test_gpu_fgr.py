@@ -298,7 +298,7 @@ def _exact_nn(db, q):
     return out
 
 
-@pytest.mark.parametrize("case", ["fpfh", "ties", "wide_norms", "small", "degenerate", "lopsided"])
+@pytest.mark.parametrize("case", ["fpfh", "ties", "wide_norms", "small", "degenerate", "lopsided", "flat_spectrum"])
 def test_feature_nn_screen_is_exact(P, fgr_inputs, case):
     """pcr_featnn.hip: the f16-split MFMA screen + float64 re-check returns the exact float64 nearest feature row (ties -> smaller
     index) -- on real FPFH features, on adversarial inputs (blocks of exact duplicates and all-zero rows: candidate lists overflow
@@ -324,6 +324,12 @@ def test_feature_nn_screen_is_exact(P, fgr_inputs, case):
         f0 = np.tile(f0[:25], (40, 1)).copy(); f1 = np.tile(f1[:30], (20, 1)).copy()      # query, inside the record pool), one constant column
         f0[:, 7] = 3.0; f1[:, 7] = 3.0
         f1[::50] = f0[1]
+    elif case == "flat_spectrum":   # the K = 64 screen carries the f16 cross terms of the 15 widest columns only: here all 33 columns are equally wide
+        # (18 of them enter with 11-bit halves) and every query has near-duplicates in the database at 1e-3 of the rows' norms, so the answer
+        # hangs on differences far below the screen's resolution: the bound must keep every such row a candidate for the float64 re-check
+        f0 = rng.uniform(0.0, 200.0, (3000, 33)).astype(np.float32)
+        f1 = (f0[rng.integers(0, 3000, 2500)] + rng.normal(0.0, 0.05, (2500, 33))).astype(np.float32)
+        f0[1500:1800] = f0[:300] + rng.normal(0.0, 0.02, (300, 33)).astype(np.float32)     # near-duplicates inside the database as well
     elif case == "lopsided":        # 4000 rows against 130: many query tiles against three row tiles and the other way round
         f0, f1 = f0[:4000], f1[:130]
     else:
