@@ -670,7 +670,11 @@ template <int NT> __global__ void __launch_bounds__(NT) k_fgr_opt_single_g(const
 // workgroup can be at most one barrier ahead).  FMG = 8 workgroups of 512 threads always fit next to anything else; should
 // they nevertheless not become co-resident, every waiter gives up after `timeout_ticks` (50 ms), sets `failed`, and the host falls
 // back to one launch per iteration -- every wave reaches an exit.
-#define FMG 8
+#define FMG 8                 // workgroups of the multi-workgroup form up to FGR_MULTI_WIDE correspondences (and of every pair of a lockstep group)
+#define FMG_MAX 32            // ... above (200k-point pairs: ~120k correspondences, 29 per thread and iteration with 8 workgroups, 7 with 32); rows of absent workgroups are zeros
+#ifndef FGR_MULTI_WIDE
+#define FGR_MULTI_WIDE 50000
+#endif
 #define FMB 512
 __device__ static inline void d_fgr_opt_multi(const FgrOptArgs &a, int iterations, double *rows /* 2 x FMG x FNVP */, unsigned long long timeout_ticks) {
     __shared__ double red[FMB / 16][FC];
@@ -696,7 +700,7 @@ __device__ static inline void d_fgr_opt_multi(const FgrOptArgs &a, int iteration
 #pragma unroll
         for (int k = 0; k < FC; k++) { const double s = pcr_row16_sum(acc[k]); if ((threadIdx.x & 15) == 0) red[threadIdx.x >> 4][k] = s; }
         __syncthreads();
-        double *buf = rows + (size_t)(it & 1) * FMG * FNVP;
+        double *buf = rows + (size_t)(it & 1) * FMG_MAX * FNVP;
         if (threadIdx.x < FC) {
             double s = 0;
             for (int r = 0; r < FMB / 16; r++) s += red[r][threadIdx.x];
@@ -719,14 +723,14 @@ __device__ static inline void d_fgr_opt_multi(const FgrOptArgs &a, int iteration
             return;
         }
         // one coherent load per lane (the compiler issues relaxed-atomic loads one at a time: a loop of FMG of them is FMG round trips)
-        if (threadIdx.x < FMG * FC) {
+        if (threadIdx.x < FMG_MAX * FC) {
             const int b = threadIdx.x / FC, col = threadIdx.x % FC;
             red[b][col] = b < G ? __hip_atomic_load(&buf[(size_t)b * FNVP + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
         }
         __syncthreads();
         if (threadIdx.x < FC) {
             double s = 0;
-            for (int b = 0; b < FMG; b++) s += red[b][threadIdx.x];
+            for (int b = 0; b < FMG_MAX; b++) s += red[b][threadIdx.x];      // (fixed order; s + 0.0 is s: the 8-workgroup form sums as it always did)
             S[threadIdx.x] = s;
         }
         __syncthreads();
@@ -747,7 +751,7 @@ __device__ static inline void d_fgr_opt_multi(const FgrOptArgs &a, int iteration
 __global__ void __launch_bounds__(FMB) k_fgr_opt_multi(FgrOptArgs a, int iterations, double *rows, unsigned long long timeout_ticks) { d_fgr_opt_multi(a, iterations, rows, timeout_ticks); }
 // batch form: blockIdx.y = pair, every pair with its own state, barrier counter and row buffers (FMG x pairs co-resident workgroups)
 __global__ void __launch_bounds__(FMB) k_fgr_opt_multi_g(const FgrOptArgs *a, int iterations, double *rows, unsigned long long timeout_ticks) {
-    d_fgr_opt_multi(a[blockIdx.y], iterations, rows + (size_t)blockIdx.y * 2 * FMG * FNVP, timeout_ticks);
+    d_fgr_opt_multi(a[blockIdx.y], iterations, rows + (size_t)blockIdx.y * 2 * FMG_MAX * FNVP, timeout_ticks);
 }
 
 __global__ void __launch_bounds__(FB) k_fgr_iter(FgrOptArgs a) {
@@ -963,13 +967,15 @@ static int fgr_pose(pcr_context *ctx, const float *src_xyz, const float *src_fea
             oa.decrease_mu = opt->decrease_mu; oa.max_corr_dist = opt->maximum_correspondence_distance; oa.division_factor = opt->division_factor;
             PCR_LAUNCH(ctx, k_fgr_init, dim3(1), dim3(64), 0, ctx->stream, st, scale_start);
             if (getenv("PCR_DEBUG_FGR")) fprintf(stderr, "fgr: ncross %lld ncorr %lld iterations %d\n", (long long)ncross, (long long)ncorr, (int)opt->iteration_number);
-            double *rows = arena<double>(ctx, (size_t)2 * FMG * FNVP);
+            double *rows = arena<double>(ctx, (size_t)2 * FMG_MAX * FNVP);
             if (!rows) return PCR_ENOMEM;
             const int variant = fgr_opt_variant(ncorr);
             const bool multi = variant == 2;
             FgrState h;
             auto per_iteration = [&]() { for (int it = 0; it < opt->iteration_number; it++) PCR_LAUNCH(ctx, k_fgr_iter, dim3(nb), dim3(FB), 0, ctx->stream, oa); };
-            if (multi) PCR_LAUNCH(ctx, k_fgr_opt_multi, dim3(FMG), dim3(FMB), 0, ctx->stream, oa, (int)opt->iteration_number, rows, fgr_opt_rule().multi_timeout);
+            static const int wide_env = getenv("PCR_FGR_MULTI_WGS") ? atoi(getenv("PCR_FGR_MULTI_WGS")) : 0;      // (diagnostics: 8 .. 32)
+            const int multi_wgs = wide_env >= 1 && wide_env <= FMG_MAX ? wide_env : (ncorr >= FGR_MULTI_WIDE ? FMG_MAX : FMG);
+            if (multi) PCR_LAUNCH(ctx, k_fgr_opt_multi, dim3(multi_wgs), dim3(FMB), 0, ctx->stream, oa, (int)opt->iteration_number, rows, fgr_opt_rule().multi_timeout);
             else if (variant == 0) PCR_LAUNCH(ctx, k_fgr_opt_single<256>, dim3(1), dim3(256), 0, ctx->stream, oa, (int)opt->iteration_number);
             else if (variant == 1) PCR_LAUNCH(ctx, k_fgr_opt_single<FSB>, dim3(1), dim3(FSB), 0, ctx->stream, oa, (int)opt->iteration_number);
             else per_iteration();
@@ -1444,7 +1450,7 @@ int pcr_registro_fgr_group(pcr_context *ctx, pcr_fgr_group_pair *q, int G) {
                 if (v == 0) PCR_LAUNCH(ctx, k_fgr_opt_single_g<256>, dim3(1, m), dim3(256), 0, ctx->stream, doa, iters);
                 else if (v == 1) PCR_LAUNCH(ctx, k_fgr_opt_single_g<FSB>, dim3(1, m), dim3(FSB), 0, ctx->stream, doa, iters);
                 else {
-                    double *rows = arena<double>(ctx, (size_t)m * 2 * FMG * FNVP);
+                    double *rows = arena<double>(ctx, (size_t)m * 2 * FMG_MAX * FNVP);
                     if (!rows) return PCR_ENOMEM;
                     // FMG x m co-resident 512-thread workgroups (at most 8 x 64 of the chip's 1024 slots of that size)
                     PCR_LAUNCH(ctx, k_fgr_opt_multi_g, dim3(FMG, m), dim3(FMB), 0, ctx->stream, doa, iters, rows, fgr_opt_rule().multi_timeout);
