@@ -782,13 +782,20 @@ __device__ static inline void d_fn_exact_min(const FnxArgs &a, int n_rec_cap, co
     }
 }
 // pass 2: smallest row among the records that attain it (exact ties -> smaller index, as the oracle's heap orders them)
-__global__ void __launch_bounds__(256) k_fn_exact_min(FnxArgs a, int n_rec_cap) { d_fn_exact_min(a, n_rec_cap, blockIdx.x * 256 + threadIdx.x); }
+// (a fixed grid strides over the USED part of the pool -- a fifth of its capacity; one thread per slot of the capacity was 80 000 workgroups that exit at once)
+__global__ void __launch_bounds__(256) k_fn_exact_min(FnxArgs a, int n_rec_cap) {
+    const int used = *a.pool_used < n_rec_cap ? *a.pool_used : n_rec_cap;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < used; r += gridDim.x * 256) d_fn_exact_min(a, n_rec_cap, r);
+}
 __device__ static inline void d_fn_exact_arg(const FnxArgs &a, int n_rec_cap, const int r) {
     int q, row;
     if (r >= n_rec_cap || !fn_record(a, r, &q, &row)) return;
     if ((unsigned long long)__double_as_longlong(a.rec_d[r]) == a.best_d[q]) atomicMin(&a.out[a.perm_q ? a.perm_q[q] : q], (int)(a.perm_db ? a.perm_db[row] : row));
 }
-__global__ void __launch_bounds__(256) k_fn_exact_arg(FnxArgs a, int n_rec_cap) { d_fn_exact_arg(a, n_rec_cap, blockIdx.x * 256 + threadIdx.x); }
+__global__ void __launch_bounds__(256) k_fn_exact_arg(FnxArgs a, int n_rec_cap) {
+    const int used = *a.pool_used < n_rec_cap ? *a.pool_used : n_rec_cap;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < used; r += gridDim.x * 256) d_fn_exact_arg(a, n_rec_cap, r);
+}
 // pass 3: zero queries take the first zero row; a query without any record (empty database) gets -1
 __device__ static inline void d_fn_finish(const FnxArgs &a) {
     const int q = blockIdx.x * 256 + threadIdx.x;
@@ -1038,9 +1045,9 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         x.db_first_zero = first_zero + dc; x.Ug = Ug;
         x.pool_used = pool_used; x.chunk_fill = chunk_fill; x.rec_q = rec_q; x.rec_row = rec_row; x.rec_w = rec_w; x.best_d = best_d; x.out = out; x.dbg = dbg;
         x.perm_q = perm[qc]; x.perm_db = perm[dc]; x.rec_d = rec_d;
-        // the record kernels cover the whole pool capacity (the used part is only known on the device); unused slots exit at once
-        PCR_LAUNCH(ctx, k_fn_exact_min, dim3((pool_cap + 255) / 256), dim3(256), 0, ctx->stream, x, pool_cap);
-        PCR_LAUNCH(ctx, k_fn_exact_arg, dim3((pool_cap + 255) / 256), dim3(256), 0, ctx->stream, x, pool_cap);
+        const int xgrid = std::min((pool_cap + 255) / 256, 4096);
+        PCR_LAUNCH(ctx, k_fn_exact_min, dim3(xgrid), dim3(256), 0, ctx->stream, x, pool_cap);
+        PCR_LAUNCH(ctx, k_fn_exact_arg, dim3(xgrid), dim3(256), 0, ctx->stream, x, pool_cap);
         PCR_LAUNCH(ctx, k_fn_finish, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, x);
         if (check) {
             int h[2] = {0, 0}; float hd[2] = {0, 0};
