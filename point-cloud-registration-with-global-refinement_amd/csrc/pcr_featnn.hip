@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(256) k_fn_split_g(const FnSplitDesc *d) { cons
 #ifdef FN_LIST_CAP_OVERRIDE
 #define FN_LIST_CAP FN_LIST_CAP_OVERRIDE
 #else
-#define FN_LIST_CAP 1024
+#define FN_LIST_CAP 512
 #endif
 //                  // steps of one (workgroup, split): capacity of its list
 #define FN_GRAM_SKIP 4                     // the second moments are taken on a quarter of the rows (the axes only have to be good; the means are exact)
@@ -484,6 +484,7 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
     const int s1 = a.pre_mode ? 0 : min(a.step_end, s0 + a.steps_per_split);
     if (!a.pre_mode && s0 >= s1) return;
     __shared__ int slist[FN_LIST_CAP];
+    __shared__ float slw[FN_WG / 64][FN_LIST_CAP];         // box distance of list entry i from wavefront w's queries (pruned form; else zeros are never read)
     __shared__ int n_list_s;
     __shared__ float sD[FN_WG / 64];
     __shared__ unsigned pre_bits[FN_LIST_CAP / 32];
@@ -538,11 +539,25 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
         __syncthreads();
         for (int t = s0 + tid; t < s1; t += FN_WG) {
             bool need = !((pre_bits[(t - s0) >> 5] >> ((t - s0) & 31)) & 1u);
+            float lwv[FN_WG / 64];
+#pragma unroll
+            for (int w = 0; w < FN_WG / 64; w++) lwv[w] = 0.0f;
             if (need && prune) {
                 need = false;
-                for (int w = 0; w < FN_WG / 64; w++) { const int r = bx * (FN_WG / 64) + w; if (r < a.n_qt && a.L[(size_t)r * a.L_stride + t] <= sD[w]) need = true; }
+#pragma unroll
+                for (int w = 0; w < FN_WG / 64; w++) {
+                    const int r = bx * (FN_WG / 64) + w;
+                    lwv[w] = r < a.n_qt ? a.L[(size_t)r * a.L_stride + t] : __builtin_inff();
+                    if (lwv[w] <= sD[w]) need = true;
+                }
             }
-            if (need) slist[atomicAdd(&n_list_s, 1)] = t;
+            if (need) {
+                const int pos = atomicAdd(&n_list_s, 1);
+                slist[pos] = t;
+                if (prune)
+#pragma unroll
+                    for (int w = 0; w < FN_WG / 64; w++) slw[w][pos] = lwv[w];
+            }
         }
     }
     __syncthreads();
@@ -556,8 +571,8 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
     const int st_r = tid / FN_CPR, st_j = tid % FN_CPR;     // r = 0 .. FN_RSTEP - 1
     auto st_dst = [&](int r) { return (r >> 4) * FN_SUB_BYTES + (st_j / FN_NM) * FN_GROUP + (r & 15) * FN_PITCH + (st_j % FN_NM) * 16; };
     struct Slot { uint4 v[FN_NCH]; float nv, nu, lw; };
-    auto fetch = [&](int step, Slot &x) {
-        x.lw = (prune && !a.pre_mode && qt < a.n_qt) ? a.L[(size_t)qt * a.L_stride + step] : 0.0f;
+    auto fetch = [&](int step, float lw, Slot &x) {
+        x.lw = lw;
         const _Float16 *src = a.dbA + ((size_t)step * FN_STEP + st_r) * FN_K + st_j * 8;
 #pragma unroll
         for (int c = 0; c < FN_NCH; c++) x.v[c] = *(const uint4 *)(src + (size_t)c * FN_RSTEP * FN_K);
@@ -584,16 +599,24 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
     // 13.0 before the other changes of the round) leave the time where it is.  A wavefront computes in 62 % of the staged steps of its
     // workgroup, its SIMD partner likewise, and whichever way the waiting is cut the workgroup lasts as long as its busiest wavefront:
     // the matrix pipes idle because the work of a step cannot move between wavefronts (the B operands of a wavefront's 64 queries live
-    // in its registers).  FN_GRP = 1 is the form kept (41 KB of LDS, 184 VGPRs).
+    // in its registers).  FN_GRP = 1 is the form kept.  (Those figures are of the K = 128 kernel with workgroups of 8: 41 KB of LDS, 184 VGPRs.  The
+    // K = 64 form -- 32 KB of LDS, 123 VGPRs, four workgroups of 4 wavefronts per CU -- fills the stalls of one workgroup with the others; its own
+    // phase shares are in DESIGN.md section 8.)
     Slot slot[FN_GRP];
     float lw_now[FN_GRP], lw_next[FN_GRP];
     const int n_groups = (n_list + FN_GRP - 1) / FN_GRP;
+    const bool lw_live = prune && !a.pre_mode;             // (a query tile beyond n_qt got +inf in slw: never computed)
+    auto list_lw = [&](int i) { return lw_live ? slw[wv][i] : 0.0f; };
 #pragma unroll
-    for (int t = 0; t < FN_GRP; t++) { lw_now[t] = 0.0f; lw_next[t] = 0.0f; if (t < n_list) { fetch(slist[t], slot[t]); } }
+    for (int t = 0; t < FN_GRP; t++) { lw_now[t] = 0.0f; lw_next[t] = 0.0f; if (t < n_list) { fetch(slist[t], list_lw(t), slot[t]); } }
 #pragma unroll
     for (int t = 0; t < FN_GRP; t++) if (t < n_list) { stash(t, slot[t]); lw_now[t] = slot[t].lw; }
 #pragma unroll
-    for (int t = 0; t < FN_GRP; t++) if (FN_GRP + t < n_list) fetch(slist[FN_GRP + t], slot[t]);
+    for (int t = 0; t < FN_GRP; t++) if (FN_GRP + t < n_list) fetch(slist[FN_GRP + t], list_lw(FN_GRP + t), slot[t]);
+    // the list entries of the group after next are read from LDS one iteration ahead of their fetch (no LDS round trip in front of the global loads)
+    int pf_step[FN_GRP]; float pf_lw[FN_GRP];
+#pragma unroll
+    for (int t = 0; t < FN_GRP; t++) { const int i = 2 * FN_GRP + t; pf_step[t] = i < n_list ? slist[i] : 0; pf_lw[t] = i < n_list ? list_lw(i) : 0.0f; }
     unsigned long long n_comp = 0;
 #ifdef FN_STAMPS          // diagnostics build (tools/build_variant.sh ... -DFN_STAMPS): shader cycles of a wavefront per phase of the step loop
     unsigned long long tc_bar = 0, tc_fast = 0, tc_cand = 0, tc_stash = 0, tc_fetch = 0, n_hitblk = 0;
@@ -712,8 +735,10 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
         FN_T(const unsigned long long t5 = __builtin_amdgcn_s_memtime(); tc_stash += t5 - t4;)
         if (gi + 2 < n_groups) {
 #pragma unroll
-            for (int t = 0; t < FN_GRP; t++) if ((gi + 2) * FN_GRP + t < n_list) fetch(slist[(gi + 2) * FN_GRP + t], slot[t]);
+            for (int t = 0; t < FN_GRP; t++) if ((gi + 2) * FN_GRP + t < n_list) fetch(pf_step[t], pf_lw[t], slot[t]);
         }
+#pragma unroll
+        for (int t = 0; t < FN_GRP; t++) { const int i = (gi + 3) * FN_GRP + t; pf_step[t] = i < n_list ? slist[i] : 0; pf_lw[t] = i < n_list ? list_lw(i) : 0.0f; }
         FN_T(tc_fetch += __builtin_amdgcn_s_memtime() - t5;)
 #pragma unroll
         for (int t = 0; t < FN_GRP; t++) lw_now[t] = lw_next[t];
