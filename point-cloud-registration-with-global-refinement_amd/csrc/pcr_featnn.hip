@@ -57,7 +57,9 @@
 #ifndef FN_GRP
 #define FN_GRP 1                 // database tiles staged and computed between two workgroup barriers (LDS: 2 x FN_GRP x 18 KB); 2 / 4 measured: no gain, see below
 #endif
+#ifndef FN_QB
 #define FN_QB 4                  // query blocks of 16 per wavefront
+#endif
 #define FN_QPW (16 * FN_QB)      // queries per wavefront
 #define FN_QPG (FN_QPW * (FN_WG / 64))
 #define FN_STEP 64               // database rows per staged step (four 16-row MFMA tiles)

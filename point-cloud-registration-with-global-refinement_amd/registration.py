@@ -252,10 +252,13 @@ def default_group(points_per_cloud: float) -> int:
 
 def default_fgr_group(points_per_cloud: float) -> int:
     """Pairs per lockstep ``registro_FGR`` group (``pcr_pairs_plan.fgr_group``): NCLT-size pairs are ~125 small dependent launches and 8
-    host waits each, which a group shares (16 pairs of 20k points per group); from ~70k points the tile-pruned feature search takes over
-    and pairs run one by one."""
+    host waits each, which a group shares (24 pairs up to 30k points per cloud -- measured on the shipped-size NCLT scans with the K = 64
+    feature screen: 8 / 12 / 16 / 24 pairs x 4 groups in flight = 1762 / 1775 / 1841 / 1885 pairs/s; 16 at 20k-40k by the older rule); from ~70k
+    points the tile-pruned feature search takes over and pairs run one by one."""
     if points_per_cloud >= 70_000:
         return 1
+    if points_per_cloud <= 30_000:
+        return 24
     return max(1, min(16, int(round(320_000 / max(float(points_per_cloud), 1.0)))))
 
 

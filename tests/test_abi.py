@@ -95,7 +95,7 @@ def test_set_option_and_fgr_group_rule():
     with pytest.raises(ValueError):
         P._lib.set_option("no_such_option", 1)
     g = P.registration.default_fgr_group
-    assert [g(n) for n in (5_000, 20_000, 40_000, 69_999, 70_000, 200_000)] == [16, 16, 8, 5, 1, 1]
+    assert [g(n) for n in (5_000, 20_000, 30_000, 40_000, 69_999, 70_000, 200_000)] == [24, 24, 24, 8, 5, 1, 1]
 
 
 def test_profiles_manifest_lists_the_tracked_evidence():

@@ -190,3 +190,42 @@ def test_config2_fgr_variant_global_then_multiscale(P, pair200k):
     res = P.registration.multiscale_gicp(P.PointCloud(p.source), P.PointCloud(p.target), p.voxel_sizes, p.max_distances_script, fgr.transformation, est, crit)
     ang, dt = pose_error(res.transformation, p.T_true)
     assert ang < 2e-3 and dt < 2e-2, (ang, dt)
+
+
+def test_config2_feature_search_is_exact_at_full_size(P, pair200k):
+    """The mutual nearest-feature search of registro_FGR on the FPFH features of the 200 000-point pair (the tile-pruned K = 64 screen, the
+    form config 2's FGR variant runs): against the all-pairs float64 MFMA path it replaced wherever that one is decisive, and -- on 1500
+    sampled queries and on EVERY query where the two paths differ -- against sum_k (a_k - b_k)^2 in float64 over all 200 000 rows in numpy
+    (ties -> the smaller row), which is what the oracle's kd-tree returns.  Bit-exact index work at BASELINE's full size."""
+    import ctypes as C
+    import torch
+    S, T = P.PointCloud(pair200k.source), P.PointCloud(pair200k.target)
+    for c in (S, T):
+        c.estimate_normals(P.KDTreeSearchParamHybrid(0.2, 20))
+    fs = P.registration.compute_fpfh_feature(S, P.KDTreeSearchParamHybrid(1.0, 200))._dev
+    ft = P.registration.compute_fpfh_feature(T, P.KDTreeSearchParamHybrid(1.0, 200))._dev
+    ctx = P._lib.Context.current()
+    res = {}
+    for mode in (0, 1):       # the production choice (pruned screen at this size) / the float64 all-pairs path
+        o10 = torch.full((len(T),), -7, dtype=torch.int32, device="cuda"); o01 = torch.full((len(S),), -7, dtype=torch.int32, device="cuda")
+        ctx.check(ctx.lib.pcr_debug_feature_nn(ctx.handle, C.c_void_p(fs.data_ptr()), C.c_int64(len(S)), C.c_void_p(ft.data_ptr()), C.c_int64(len(T)),
+                                               C.c_void_p(o10.data_ptr()), C.c_void_p(o01.data_ptr()), C.c_int(mode)), "pcr_debug_feature_nn")
+        res[mode] = (o10.cpu().numpy(), o01.cpu().numpy())
+    f0 = fs.cpu().numpy().astype(np.float64); f1 = ft.cpu().numpy().astype(np.float64)
+
+    def exact(db, q):         # as tests/test_gpu_fgr._exact_nn: differences first, squares summed in column order
+        out = np.empty(len(q), np.int64)
+        for s in range(0, len(q), 256):
+            d = np.zeros((min(256, len(q) - s), len(db)))
+            for k in range(db.shape[1]):
+                e = q[s:s + 256, k:k + 1] - db[None, :, k]
+                d += e * e
+            out[s:s + 256] = np.argmin(d, axis=1)
+        return out
+    rng = np.random.default_rng(3)
+    for (got, alt), db, q in (((res[0][0], res[1][0]), f0, f1), ((res[0][1], res[1][1]), f1, f0)):
+        assert (got >= 0).all() and (got < len(db)).all()
+        differ = np.flatnonzero(got != alt)
+        assert len(differ) < 2e-3 * len(q), len(differ)             # the expanded float64 form loses only near-ties
+        sel = np.unique(np.concatenate([differ[:1500], rng.permutation(len(q))[:1500]]))
+        assert np.array_equal(got[sel], exact(db, q[sel])), "the screen's answer is not the exact nearest row"
