@@ -1981,6 +1981,8 @@ int pcr_dev_normals(pcr_context *ctx, DevCloud *c, int search_kind, int knn, dou
 size_t pcr_scratch_bytes_for(int64_t n) {
     // voxel/sort temporaries (2x u64 keys, 2x u32 vals, flags, pos, sort temp) + clouds + boxes, with slack
     // (+ 256 B per point: the k-best rows of a search with k <= 64, pcr_knn_wave.h)
-    return (size_t)(n > 0 ? n : 1) * 576 + pcr_sort_temp_bytes((size_t)(n > 0 ? n : 1)) + (4u << 20);
+    // (+ 84 B per point: the cell hash of a GICP target -- 16 B x next_pow2(2 n) slots, pcr_dev_build_grid_batch -- and the pending-query lists of
+    // the streaming iteration, 20 B per source point; they used to fit only because the filter's scratch had been released by then)
+    return (size_t)(n > 0 ? n : 1) * 660 + pcr_sort_temp_bytes((size_t)(n > 0 ? n : 1)) + (4u << 20);
 }
 
