@@ -861,14 +861,21 @@ struct FnInitDesc { int *pool_used, *chunk_fill; int n_chunks; int *Ug; int n_ug
 __global__ void __launch_bounds__(256) k_fn_init_g(const FnInitDesc *d) { const FnInitDesc a = d[blockIdx.y]; d_fn_init(a.pool_used, a.chunk_fill, a.n_chunks, a.Ug, a.n_ug, a.best_d, a.out, a.n_q, nullptr, nullptr); }
 
 // ------------------------------------------------------------------------------------------------------------------ driver
-size_t pcr_feature_nn_scratch_bytes(int64_t n0, int64_t n1) {
+size_t pcr_feature_nn_scratch_bytes(int64_t n0, int64_t n1, int prune_mode) {
     const size_t p0 = ((size_t)n0 + FN_QPG) / FN_QPG * FN_QPG, p1 = ((size_t)n1 + FN_QPG) / FN_QPG * FN_QPG;
     const size_t per_row = 2 * FN_K * sizeof(_Float16) + 4 * sizeof(float);                 // both forms + the four floats of FnRows
     const size_t per_query = (size_t)FN_POOL_PER_QUERY * 21 + 8 + 4 + 16;                   // records (+ exact distances), best distance, bound, chunk table share
     // tile pruning: principal coordinates, keys / values (in, out) and sort scratch per row; boxes; the (query tile x row tile) bound matrix
     const size_t prune_rows = (p0 + p1) * (FN_D * sizeof(float) + 2 * (8 + 4)) + pcr_sort_temp_bytes(p0 > p1 ? p0 : p1) + (p0 + p1) / 64 * (2 * FN_D * 4 + 64);
     const size_t lmat = (p0 / 64 + 64) * (p1 / 64 + 64) * sizeof(float);
-    return (p0 + p1) * per_row + (p0 > p1 ? p0 : p1) * per_query + (size_t)(FN_WGS_PRUNED + 2048 + (2 + FN_PRE_SPLIT) * ((p0 > p1 ? p0 : p1) / FN_QPG) + 256) * (FN_WG / 64) * FN_CHUNK * 21 + (1u << 22) + prune_rows
+    // chunks the wavefronts of the screen may leave partly filled: workgroups of the widest records pass + those of the pre-pass.  Only pairs the
+    // size rule prunes (or a forced PCR_FEATNN_PRUNE / debug mode) cut the database into FN_WGS_PRUNED workgroups; the others into ~2048-3072
+    static const bool forced = getenv("PCR_FEATNN_PRUNE") && atoi(getenv("PCR_FEATNN_PRUNE")) > 0;
+    const size_t groups = (p0 > p1 ? p0 : p1) / FN_QPG, steps = (p0 > p1 ? p0 : p1) / FN_STEP;
+    const bool may_prune = forced || prune_mode > 0 || (double)n0 * (double)n1 >= 5.0e9;
+    const size_t wide = may_prune ? std::min<size_t>(FN_WGS_PRUNED + groups, groups * std::min<size_t>(256, steps ? steps : 1)) : 3072 + groups;
+    const size_t waves = (wide + (2 + FN_PRE_SPLIT) * groups + 512) * (FN_WG / 64);
+    return (p0 + p1) * per_row + (p0 > p1 ? p0 : p1) * per_query + waves * FN_CHUNK * 21 + (1u << 22) + prune_rows
            + (lmat <= ((size_t)512 << 20) ? lmat : 0) + (1u << 20);
 }
 

@@ -347,7 +347,7 @@ static int feature_nn(pcr_context *ctx, const float *db, int n_db, const float *
 extern "C" int pcr_debug_feature_nn(pcr_context *ctx, const float *f0, int64_t n0, const float *f1, int64_t n1, int32_t *out_1to0, int32_t *out_0to1, int mode) {
     return pcr_api_call(ctx, [&]() -> int {
         if (n0 <= 0 || n1 <= 0 || !f0 || !f1 || !out_1to0 || !out_0to1) return PCR_EINVAL;
-        PCR_TRY(pcr_arena_reserve(ctx, pcr_feature_nn_scratch_bytes(n0, n1) + (size_t)(n0 + n1) * (FK * 16 + 32 * 12 + 64) + (64u << 20)));
+        PCR_TRY(pcr_arena_reserve(ctx, pcr_feature_nn_scratch_bytes(n0, n1, mode == 3 ? 1 : -1) + (size_t)(n0 + n1) * (FK * 16 + 32 * 12 + 64) + (64u << 20)));
         if (mode == 0 || mode == 3 || mode == 4) return pcr_feature_nn_mutual(ctx, f0, (int)n0, f1, (int)n1, out_1to0, out_0to1, mode == 0 ? -1 : (mode == 3 ? 1 : 0));
         if (mode == 2) {
             PCR_LAUNCH(ctx, k_feature_nn, dim3((unsigned)((n1 + FB - 1) / FB)), dim3(FB), 0, ctx->stream, f0, (int)n0, f1, (int)n1, out_1to0);

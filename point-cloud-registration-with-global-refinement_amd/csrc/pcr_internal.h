@@ -245,7 +245,7 @@ int pcr_evaluate_registration_impl(pcr_context *ctx, const float *src_xyz, int64
                                    double max_dist, const double *T, pcr_result *result, int32_t *correspondences);
 
 // ---- feature matching (pcr_featnn.hip): exact nearest feature rows in both directions; PCR_ECAPACITY = values outside the f16 range
-size_t pcr_feature_nn_scratch_bytes(int64_t n0, int64_t n1);
+size_t pcr_feature_nn_scratch_bytes(int64_t n0, int64_t n1, int prune_mode = -1);      // prune_mode as pcr_feature_nn_mutual's (1: forced on)
 int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float *f1, int n1, int32_t *out_1to0, int32_t *out_0to1,
                           int prune_mode /* -1: by size (PCR_FEATNN_PRUNE overrides), 0: off, 1: on */);
 
