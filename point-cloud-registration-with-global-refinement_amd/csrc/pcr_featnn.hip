@@ -1110,8 +1110,9 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
 }
 
 // ---- the mutual search of G pairs through the same launches (lockstep FGR groups).  Only the form WITHOUT tile pruning (every pair under
-// 5e9 row pairs: NCLT-size clouds, where the chain of small launches per pair is the whole cost); per pair the arithmetic, the split of the
-// steps and the pool sizes are exactly those of pcr_feature_nn_mutual, so the matches are the same bits.  Returns PCR_ECAPACITY when a
+// 5e9 row pairs: NCLT-size clouds, where the chain of small launches per pair is the whole cost); per pair the arithmetic is that of
+// pcr_feature_nn_mutual (the steps are cut differently -- the grid is shared by 2 G problems -- but the matches are the exact float64 nearest rows
+// whatever the cut: the same bits).  Returns PCR_ECAPACITY when a
 // pair wants the pruned form or its features leave the f16 range (the caller then runs the pairs one by one); `overflow_dev[g]` = a device
 // int (the words of all pairs lie in ONE array, two per pair, so overflow_dev[0] + 2 g is pair g's) the caller reads with its next read-back: != 0 means the record pool of pair g overflowed (that pair alone is redone on the float64 path).
 int pcr_feature_nn_mutual_batch(pcr_context *ctx, int G, const float *const *f0, const int *n0, const float *const *f1, const int *n1, int32_t *const *out_1to0,

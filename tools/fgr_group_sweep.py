@@ -1,6 +1,6 @@
 """FGR stage (script-1 parameters) on the shipped-size golden NCLT clouds: the 8 golden pairs tiled to 96 pairs, through register_pairs_plan with
 `fgr_group` pairs in lockstep and `inflight` groups in flight; prints pairs/s and the error band against the shipped GICP poses.
-usage: fgr_group_sweep.py "g1xf1,g2xf2,..."   (default: 1x8,8x4,12x4,16x3,16x2,24x2)"""
+usage: fgr_group_sweep.py "g1xf1,g2xf2,..." [tiles=12]   (default: 1x8,8x4,12x4,16x3,16x2,24x2; 8 x tiles pairs per call)"""
 import glob, importlib, os, sys, time
 import numpy as np
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
@@ -9,8 +9,9 @@ import torch
 P = importlib.import_module("point-cloud-registration-with-global-refinement_amd")
 reg = P.registration
 gold = [np.load(f) for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "nclt_pair_*.npz")))]
-work = [(P.PointCloud(g["source"]), P.PointCloud(g["target"]), None) for g in gold] * 12
-truth = [g["T_gicp"] for g in gold] * 12
+TILES = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+work = [(P.PointCloud(g["source"]), P.PointCloud(g["target"]), None) for g in gold] * TILES
+truth = [g["T_gicp"] for g in gold] * TILES
 def err(T, R):
     dR = T[:3, :3].T @ R[:3, :3]
     return float(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))), float(np.linalg.norm(T[:3, 3] - R[:3, 3]))
