@@ -570,7 +570,17 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
     constexpr int FN_CPR = FN_K / 8;                                          // 16-byte chunks per row: k-group j / FN_NM, MFMA j % FN_NM
     constexpr int FN_NCH = FN_STEP * FN_CPR / FN_WG, FN_RSTEP = FN_WG / FN_CPR;   // chunks per thread (K = 64: 1 at 512 threads, 2 at 256), rows per round
     static_assert(FN_NCH >= 1 && FN_NCH * FN_RSTEP == FN_STEP, "staging: the workgroup must cover a step in whole rounds");
+#ifndef FN_STASH_REMAP
+#define FN_STASH_REMAP 1
+#endif
+#if FN_STASH_REMAP && FN_K == 64
+    // K = 64 (8 chunks per row): the two 32-lane halves of a wavefront write k-groups {0, 1} and {2, 3} of 8 rows each.  With lane = (row, chunk) in
+    // plain order all four k-groups met in one half, and groups g and g + 2 share LDS banks at the 40-byte pitch (2 x 640 B = 0 mod 256):
+    // SQ_LDS_BANK_CONFLICT 1.55e9 -> 0.52e9 cycles per six calls at 200k x 200k rows, 7.36 -> 7.24 ms
+    const int st_r = (tid >> 6) * 8 + ((lane >> 2) & 7), st_j = (lane >> 5) * 4 + (lane & 3);
+#else
     const int st_r = tid / FN_CPR, st_j = tid % FN_CPR;     // r = 0 .. FN_RSTEP - 1
+#endif
     auto st_dst = [&](int r) { return (r >> 4) * FN_SUB_BYTES + (st_j / FN_NM) * FN_GROUP + (r & 15) * FN_PITCH + (st_j % FN_NM) * 16; };
     struct Slot { uint4 v[FN_NCH]; float nv, nu, lw; };
     auto fetch = [&](int step, float lw, Slot &x) {
