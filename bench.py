@@ -375,6 +375,9 @@ def main(argv=None) -> int:
                          "fraction_of_queries_searched_again": (solo[11] / (alg_bytes / 48.0)) if alg_bytes else None,
                          "measured_on": "up to 4 extra single-pair steps after the timed region (same process, HIP events on the launch stream)",
                          "live_launches": live, "launches_issued_timed_region": issued,
+                         "noop_launch_fraction": {"one_pair_at_a_time": (1.0 - solo[13] / solo[5]) if solo[5] else None, "timed_region": (1.0 - prof[13] / prof[5]) if prof[5] else None,
+                                                  "what": "launches of the loop that found their problem(s) converged and returned at once (a chunk of launches is queued before the state of the one before it is read back; "
+                                                          "the chunk length shrinks from 8 to 4 and 2 as the changes of fitness and RMSE approach the criteria)"},
                          "path": {"algorithmic_bytes_per_pair": path_bytes, "achieved": path_gbs, "unit": "GB/s", "frac": path_gbs / HBM_PEAK_GBS,
                                   "what": "SURVEY 8d's byte model of the whole pair (sum over clouds and scales of 12 N0 + 44 D + 36 C, plus 48 C_source (I + 1) per scale) x this run's pairs/s per GPU, "
                                           "over the HBM peak: the kernel figure above is one launch of the hot loop alone"}},

@@ -1983,6 +1983,7 @@ size_t pcr_scratch_bytes_for(int64_t n) {
     // (+ 256 B per point: the k-best rows of a search with k <= 64, pcr_knn_wave.h)
     // (+ 84 B per point: the cell hash of a GICP target -- 16 B x next_pow2(2 n) slots, pcr_dev_build_grid_batch -- and the pending-query lists of
     // the streaming iteration, 20 B per source point; they used to fit only because the filter's scratch had been released by then)
-    return (size_t)(n > 0 ? n : 1) * 660 + pcr_sort_temp_bytes((size_t)(n > 0 ? n : 1)) + (4u << 20);
+    // (+ 16 B per point: the list certificates of the cell-hash GICP searches, int4 per source point)
+    return (size_t)(n > 0 ? n : 1) * 676 + pcr_sort_temp_bytes((size_t)(n > 0 ? n : 1)) + (4u << 20);
 }
 

@@ -7,6 +7,11 @@
 // Reference behaviour: Open3D RegistrationGeneralizedICP / RegistrationICP /
 // TransformationEstimationForGeneralizedICP::ComputeTransformation as called at ALL_FUNCTIONS.py:304-311 and
 // 2_MGICP_refinement_in_NCLT_dataset.py:155-162.
+// Floating-point contraction per SOURCE EXPRESSION only (the command line's default for HIP, "fast", lets the back end fuse a multiply with an add
+// of another statement, and whether it does depends on the code around it: the float64 linearisation inlined into the fused kernel with its
+// inputs already in registers came out with other fused pairs than the same function in k_icp_lin -- poses 1e-7 apart under L1, where the
+// kernel forms are promised to give the same bits).  Before the includes: the helpers inlined into these kernels follow the same rule.
+#pragma clang fp contract(on)
 #include <cmath>
 #include <cstring>
 #include <cstdio>
@@ -37,6 +42,7 @@ struct IcpState {
     unsigned long long t_live;  // sum over live launches of (last workgroup's exit stamp - t_start)
     unsigned long long t_dbg[4]; // diagnostic stamps (sum): wg0 after search, wg0 after reduce, last wg entering tail, last wg after partial sums
     unsigned long long searched; // queries whose certificate did not hold, summed over the launches after the cold one (bench: fraction searched)
+    double dfit, drmse;         // |change| of fitness / rmse at the most recent launch (what the criteria test): the host sizes the next chunk of launches by them
 };
 
 struct IcpArgs {
@@ -45,7 +51,8 @@ struct IcpArgs {
     const float4 *tgt_pts, *tgt_nrm; OctView tgt; const int *nt_ptr;
     GridView grid;                               // cell hash of the target (grid.tab == nullptr: search the octree)
     int32_t *match; int src_cap;
-    float4 *ref; int32_t *rbest;                 // per source point: position and margin / nearest point of its last search (skip certificate)
+    float4 *ref; int32_t *rbest;                 // per source point: position and margin / nearest point of its last search (skip certificate, tree-walk form)
+    int4 *clist;                                 // cell-hash form: the PCR_NN_K nearest target points of the last search (list certificate); ref.w = distance of the next one
     float4 *pend_q; int32_t *pend_i; int *pend_n; // streaming iteration of large clouds: this launch's pending queries (position + hint, point), their count
     float r2s, rs_minus_r;                       // search cap (r + g)^2 of the certificate mode and g = the unmatched margin
     int verify;                                  // diagnostics (PCR_ICP_VERIFY): search certified queries too and report disagreements
@@ -65,7 +72,7 @@ struct IcpInit { double T[16]; };
 __device__ static inline void d_icp_init(IcpState *st, const IcpInit &in) {
     if (threadIdx.x == 0) {
         for (int k = 0; k < 16; k++) st->T[k] = in.T[k];
-        st->fitness = 0; st->rmse = 0; st->count = 0; st->iter = 0; st->launches = 0; st->done = 0; st->converged = 0; st->ticket = 0; st->ns = 0; st->t_start = 0; st->t_live = 0; st->searched = 0; for (int k = 0; k < 4; k++) st->t_dbg[k] = 0;
+        st->fitness = 0; st->rmse = 0; st->count = 0; st->iter = 0; st->launches = 0; st->done = 0; st->converged = 0; st->ticket = 0; st->ns = 0; st->t_start = 0; st->t_live = 0; st->searched = 0; st->dfit = 1e300; st->drmse = 1e300; for (int k = 0; k < 4; k++) st->t_dbg[k] = 0;
         for (int k = 0; k < NVP; k++) st->sums[k] = 0;
     }
 }
@@ -140,6 +147,42 @@ __device__ static inline int oct_nn_query(const OctView &t, const OctMeta &m, Oc
                     [](int, int) { return false; }, ol, oct, ob, visits);
     *d1_out = bestd; *d2_out = secd;
     return best;
+}
+
+// ---- LIST CERTIFICATE of the cell-hash searches (grid_nn_query8).  The last search of the query, at position ref.xyz, found the listed K
+// nearest target points and D = ref.w, the distance of the (K+1)-th (or the search cap when fewer lie inside it): every point NOT listed
+// is at least D - delta away from the query now, delta = |q - ref| (triangle inequality).  So while the nearest LISTED point is closer
+// than that, it is the exact nearest neighbour (ties inside the list -> lower index, as in a search; a tie with an unlisted point is
+// excluded by the strict test and the slack); when even D - delta lies beyond the float32 radius and no listed point is nearer, the
+// query is unmatched; otherwise it must be searched again.  Returns 1 (decided: *cand = the neighbour, or -1) or 0 (search).
+// The test needs K gathered points per query and launch, one dependent load after the record -- against a search it is one round trip
+// instead of four or five, and (d5 - d1) / 2 of room instead of (d2 - d1) / 2: 0.3 instead of 0.1 voxels on a planar patch.
+__device__ static inline void icp_list_load(const float4 *__restrict__ tgt_pts, const int4 lst, float4 (&tp)[PCR_NN_K]) {
+    const int ids[PCR_NN_K] = {lst.x, lst.y, lst.z, lst.w};
+#pragma unroll
+    for (int k = 0; k < PCR_NN_K; k++) tp[k] = tgt_pts[ids[k] >= 0 ? ids[k] : 0];
+}
+__device__ static inline int icp_list_decide(float qx, float qy, float qz, const float4 refv, const int4 lst, const float4 (&tp)[PCR_NN_K], float r2f, int *cand, float4 *cand_pt) {
+    const int ids[PCR_NN_K] = {lst.x, lst.y, lst.z, lst.w};
+    const float delta = sqrtf(pcr_d2(qx - refv.x, qy - refv.y, qz - refv.z));
+    const float slack = 2e-5f + 1e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz));
+    const float room = refv.w - delta - slack;
+    float best = 3.4e38f; int bi = -1; float4 bp = tp[0];
+#pragma unroll
+    for (int k = 0; k < PCR_NN_K; k++) {
+        const float c = pcr_d2(tp[k].x - qx, tp[k].y - qy, tp[k].z - qz);
+        if (ids[k] >= 0 && (c < best || (c == best && ids[k] < bi))) { best = c; bi = ids[k]; bp = tp[k]; }
+    }
+    *cand = -1; *cand_pt = bp;
+    if (!(room > 0.0f)) return 0;
+    const float room2 = room * room;
+    if (bi >= 0 && best < room2) { *cand = bi; return 1; }
+    return room2 > r2f ? 1 : 0;
+}
+__device__ static inline int icp_list_eval(const float4 *__restrict__ tgt_pts, float qx, float qy, float qz, const float4 refv, const int4 lst, float r2f, int *cand) {
+    float4 tp[PCR_NN_K], bp;
+    icp_list_load(tgt_pts, lst, tp);
+    return icp_list_decide(qx, qy, qz, refv, lst, tp, r2f, cand, &bp);
 }
 
 __device__ static inline double icp_weight(int loss, double k, double r) {
@@ -265,6 +308,24 @@ __device__ static bool icp_ldlt6_pivoted(const double *S, const double *b6, doub
     return ok;
 }
 
+// what a search leaves for the launches after it: the certificate of the query (list form for the cell-hash searches, margin form for
+// the tree walks) and its match / start hint
+static_assert(PCR_NN_K == 4, "the list certificate is an int4 record");
+template <bool GRID>
+__device__ static inline void icp_store_cert(const IcpArgs &a, int qi, float qx, float qy, float qz, int best, const int (&nnk)[PCR_NN_K], float d1, float d2, int start_pt) {
+    if (GRID) {
+        a.ref[qi] = make_float4(qx, qy, qz, sqrtf(d2));          // d2 = squared distance of the first point NOT listed (or the search cap)
+        a.clist[qi] = make_int4(nnk[0], nnk[1], nnk[2], nnk[3]);
+    } else {
+        const float slack = 2e-5f + 1e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz));
+        // nothing within the (enlarged) search cap: still nothing within max_dist while the query moves by less than the gap
+        const float margin = best >= 0 ? 0.5f * (sqrtf(d2) - sqrtf(d1)) - slack : a.rs_minus_r - slack;
+        a.ref[qi] = make_float4(qx, qy, qz, margin > 0.0f ? margin : 0.0f);
+        a.rbest[qi] = best;
+    }
+    a.match[qi] = best >= 0 ? best : -(start_pt + 2);
+}
+
 // ---- kernel 1 of an iteration: exact 1-NN of every transformed source point, ONE query per octet (32 per
 // workgroup).  Latency-bound pointer chasing, so it runs at full occupancy (few registers, many wavefronts).
 template <bool GRID>
@@ -282,7 +343,8 @@ __device__ static inline void d_icp_nn(const IcpArgs &a) {
     const float4 pf = a.src_pts[ic];
     const int mraw = a.match[ic];
     const float4 refv = a.ref ? a.ref[ic] : make_float4(0, 0, 0, 0);
-    const int rb = a.rbest ? a.rbest[ic] : -1;
+    int rb = (!GRID && a.rbest) ? a.rbest[ic] : -1;
+    const int4 lst = (GRID && a.ref) ? a.clist[ic] : make_int4(-1, -1, -1, -1);
     double T[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) T[k] = st->T[k];
@@ -313,10 +375,13 @@ __device__ static inline void d_icp_nn(const IcpArgs &a) {
         // margin = (d2 - d1)/2 - slack.  While the query has moved by less than the margin since then, rb is still its
         // unique nearest point (triangle inequality) and no search is needed; k_icp_iter re-tests the radius in float64.
         const float ex = qx - refv.x, ey = qy - refv.y, ez = qz - refv.z;
-        const bool certified = launches > 0 && a.ref && !a.dbg_visits && refv.w > 0.0f && pcr_d2(ex, ey, ez) < refv.w * refv.w;
+        bool certified = launches > 0 && a.ref && !a.dbg_visits && refv.w > 0.0f;
+        if (GRID) { if (certified) certified = icp_list_eval(a.tgt_pts, qx, qy, qz, refv, lst, a.r2f, &rb) != 0; }   // list certificate: rb = the decided neighbour (or -1)
+        else certified = certified && pcr_d2(ex, ey, ez) < refv.w * refv.w;
         need = nt > 0 && (!certified || a.verify);
         cert_flag = certified;
         if (certified && ol == 0 && rb >= 0 && mraw != rb) a.match[i] = rb;     // k_icp_iter may have turned it into a hint (beyond max_dist)
+        if (GRID && certified && ol == 0 && rb < 0 && mraw >= 0) a.match[i] = -1;   // decided unmatched after having been matched
     }
     // ---- compact the workgroup's pending queries to the front: wavefronts left without work retire at once
     {
@@ -335,8 +400,8 @@ __device__ static inline void d_icp_nn(const IcpArgs &a) {
     int qi = 0;
     if (live) { const float4 r = rec_q[ob]; qx = r.x; qy = r.y; qz = r.z; hint = __float_as_int(r.w); qi = rec_i[ob]; }
     int visits = 0, start_pt = 0; float d1 = 0, d2 = 0;
-    int best;
-    if (GRID) { best = grid_nn_query8(a.grid, a.tgt_pts, live, qx, qy, qz, a.ref ? a.r2s : a.r2f, ol, &d1, &d2); start_pt = hint >= 0 ? hint : 0; }
+    int best; int nnk[PCR_NN_K];
+    if (GRID) { grid_nn_query8<PCR_NN_K>(a.grid, a.tgt_pts, live, qx, qy, qz, a.ref ? a.r2s : a.r2f, ol, nnk, &d1, &d2); best = nnk[0]; start_pt = hint >= 0 ? hint : 0; }
     else best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.ref ? a.r2s : a.r2f, hint, ol, oct, ob, &start_pt, a.dbg_visits ? &visits : nullptr, &d1, &d2);
     if (a.verify && ol == 0 && live && rec_c[ob] != -2) {
         const int claim = rec_c[ob];
@@ -346,7 +411,10 @@ __device__ static inline void d_icp_nn(const IcpArgs &a) {
     }
     if (ol == 0 && live) {
         a.match[qi] = a.dbg_visits ? visits : (best >= 0 ? best : -(start_pt + 2));
-        if (a.ref) {
+        if (a.ref && GRID) {
+            a.ref[qi] = make_float4(qx, qy, qz, sqrtf(d2));          // d2 = squared distance of the first point NOT listed (or the cap)
+            a.clist[qi] = make_int4(nnk[0], nnk[1], nnk[2], nnk[3]);
+        } else if (a.ref) {
             const float slack = 2e-5f + 1e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz));
             // nothing within the (enlarged) search cap: still nothing within max_dist while the query moves by less than the gap
             const float margin = best >= 0 ? 0.5f * (sqrtf(d2) - sqrtf(d1)) - slack : a.rs_minus_r - slack;
@@ -388,7 +456,8 @@ __device__ static inline void d_icp_ab(const IcpArgs &a) {
     const float4 pf = a.src_pts[ic];
     const int mraw = a.match[ic];
     const float4 refv = a.ref[ic];
-    const int rb = a.rbest[ic];
+    int rb = GRID ? -1 : a.rbest[ic];
+    const int4 lst = GRID ? a.clist[ic] : make_int4(-1, -1, -1, -1);
     double T[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) T[k] = st->T[k];
@@ -410,9 +479,12 @@ __device__ static inline void d_icp_ab(const IcpArgs &a) {
             qz = (float)(T[8] * px + T[9] * py + T[10] * pz + T[11]);
             hint = mraw >= 0 ? mraw : (mraw <= -2 ? -(mraw + 2) : -1);
             const float ex = qx - refv.x, ey = qy - refv.y, ez = qz - refv.z;
-            const bool certified = refv.w > 0.0f && pcr_d2(ex, ey, ez) < refv.w * refv.w;
+            bool certified = refv.w > 0.0f;
+            if (GRID) { if (certified) certified = icp_list_eval(a.tgt_pts, qx, qy, qz, refv, lst, a.r2f, &rb) != 0; }
+            else certified = certified && pcr_d2(ex, ey, ez) < refv.w * refv.w;
             need = nt > 0 && !certified;
             if (certified && rb >= 0 && mraw != rb) a.match[i] = rb;     // k_icp_iter may have turned it into a hint (beyond max_dist)
+            if (GRID && certified && rb < 0 && mraw >= 0) a.match[i] = -1;
         }
         const unsigned long long nbm = __ballot(need);
         int base = 0;
@@ -433,16 +505,10 @@ __device__ static inline void d_icp_ab(const IcpArgs &a) {
         float qx = 0, qy = 0, qz = 0; int hint = -1, qi = 0;
         if (live) { const float4 r = rec_q[e]; qx = r.x; qy = r.y; qz = r.z; hint = __float_as_int(r.w); qi = rec_i[e]; }
         int start_pt = 0; float d1 = 0, d2 = 0;
-        int best;
-        if (GRID) { best = grid_nn_query8(a.grid, a.tgt_pts, live, qx, qy, qz, a.r2s, ol, &d1, &d2); start_pt = hint >= 0 ? hint : 0; }
+        int best; int nnk[PCR_NN_K];
+        if (GRID) { grid_nn_query8<PCR_NN_K>(a.grid, a.tgt_pts, live, qx, qy, qz, a.r2s, ol, nnk, &d1, &d2); best = nnk[0]; start_pt = hint >= 0 ? hint : 0; }
         else best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.r2s, hint, ol, oct, ob, &start_pt, nullptr, &d1, &d2);
-        if (ol == 0 && live) {
-            const float slack = 2e-5f + 1e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz));
-            const float margin = best >= 0 ? 0.5f * (sqrtf(d2) - sqrtf(d1)) - slack : a.rs_minus_r - slack;
-            a.ref[qi] = make_float4(qx, qy, qz, margin > 0.0f ? margin : 0.0f);
-            a.rbest[qi] = best;
-            a.match[qi] = best >= 0 ? best : -(start_pt + 2);
-        }
+        if (ol == 0 && live) icp_store_cert<GRID>(a, qi, qx, qy, qz, best, nnk, d1, d2, start_pt);
     }
 }
 template <bool GRID> __global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_icp_ab(IcpArgs a) { d_icp_ab<GRID>(a); }
@@ -453,6 +519,7 @@ template <bool GRID> __global__ void __launch_bounds__(ICP_BS) __attribute__((am
 // of a region (per-workgroup lists left 32 octets to 16 % of 256 points on average and 8 rounds to a tile that had moved).
 // k_icp_lin zeroes the count for the next launch.
 #define CERT_BS 1024      // one atomic on the list's count per WORKGROUP: 25 000 wavefronts adding to one address took longer than the searches
+template <bool GRID>
 __global__ void __launch_bounds__(CERT_BS) k_icp_cert(IcpArgs a) {
     IcpState *st = a.state;
     __shared__ int wave_n[CERT_BS / 64];
@@ -465,7 +532,8 @@ __global__ void __launch_bounds__(CERT_BS) k_icp_cert(IcpArgs a) {
     const float4 pf = a.src_pts[ic];
     const int mraw = a.match[ic];
     const float4 refv = a.ref[ic];
-    const int rb = a.rbest[ic];
+    int rb = GRID ? -1 : a.rbest[ic];
+    const int4 lst = GRID ? a.clist[ic] : make_int4(-1, -1, -1, -1);
     double T[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) T[k] = st->T[k];
@@ -481,9 +549,12 @@ __global__ void __launch_bounds__(CERT_BS) k_icp_cert(IcpArgs a) {
         qz = (float)(T[8] * px + T[9] * py + T[10] * pz + T[11]);
         hint = mraw >= 0 ? mraw : (mraw <= -2 ? -(mraw + 2) : -1);
         const float ex = qx - refv.x, ey = qy - refv.y, ez = qz - refv.z;
-        const bool certified = refv.w > 0.0f && pcr_d2(ex, ey, ez) < refv.w * refv.w;
+        bool certified = refv.w > 0.0f;
+        if (GRID) { if (certified) certified = icp_list_eval(a.tgt_pts, qx, qy, qz, refv, lst, a.r2f, &rb) != 0; }
+        else certified = certified && pcr_d2(ex, ey, ez) < refv.w * refv.w;
         need = nt > 0 && !certified;
         if (certified && rb >= 0 && mraw != rb) a.match[i] = rb;     // k_icp_lin may have turned it into a hint (beyond max_dist)
+        if (GRID && certified && rb < 0 && mraw >= 0) a.match[i] = -1;
     }
     const unsigned long long nbm = __ballot(need);
     if (lane == 0) wave_n[wv] = __builtin_popcountll(nbm);
@@ -522,26 +593,21 @@ __global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 
         float qx = 0, qy = 0, qz = 0; int hint = -1, qi = 0;
         if (live) { const float4 r = a.pend_q[e]; qx = r.x; qy = r.y; qz = r.z; hint = __float_as_int(r.w); qi = a.pend_i[e]; }
         int start_pt = 0; float d1 = 0, d2 = 0;
-        int best;
-        if (GRID) { best = grid_nn_query8(a.grid, a.tgt_pts, live, qx, qy, qz, a.r2s, ol, &d1, &d2); start_pt = hint >= 0 ? hint : 0; }
+        int best; int nnk[PCR_NN_K];
+        if (GRID) { grid_nn_query8<PCR_NN_K>(a.grid, a.tgt_pts, live, qx, qy, qz, a.r2s, ol, nnk, &d1, &d2); best = nnk[0]; start_pt = hint >= 0 ? hint : 0; }
         else best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.r2s, hint, ol, oct, ob, &start_pt, nullptr, &d1, &d2);
-        if (ol == 0 && live) {
-            const float slack = 2e-5f + 1e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz));
-            const float margin = best >= 0 ? 0.5f * (sqrtf(d2) - sqrtf(d1)) - slack : a.rs_minus_r - slack;
-            a.ref[qi] = make_float4(qx, qy, qz, margin > 0.0f ? margin : 0.0f);
-            a.rbest[qi] = best;
-            a.match[qi] = best >= 0 ? best : -(start_pt + 2);
-        }
+        if (ol == 0 && live) icp_store_cert<GRID>(a, qi, qx, qy, qz, best, nnk, d1, d2, start_pt);
     }
 }
 
 // ---- one correspondence in float64: accumulates its 30 sums into acc[]; `cand` = candidate target point (or < 0)
+struct IcpPre { float4 pf, sn, tf, tn; };    // the inputs of a correspondence already in registers (fused kernel: gathered under its certificate phase)
 template <int MODE>
-__device__ static inline void icp_point(const IcpArgs &a, const double *T, int i, int ns, int cand_in, double *acc) {
+__device__ static inline void icp_point(const IcpArgs &a, const double *T, int i, int ns, int cand_in, double *acc, const IcpPre *pre = nullptr) {
     double qx = 0, qy = 0, qz = 0;
     int cand = -1;
     {
-        const float4 pf = a.src_pts[i];
+        const float4 pf = pre ? pre->pf : a.src_pts[i];
         const double px = pf.x, py = pf.y, pz = pf.z;
         qx = T[0] * px + T[1] * py + T[2] * pz + T[3];
         qy = T[4] * px + T[5] * py + T[6] * pz + T[7];
@@ -554,7 +620,7 @@ __device__ static inline void icp_point(const IcpArgs &a, const double *T, int i
     if (i < ns && cand >= 0) {
         int best = cand;
         {
-            const float4 tf = a.tgt_pts[best];
+            const float4 tf = pre ? pre->tf : a.tgt_pts[best];
             const double dx = qx - (double)tf.x, dy = qy - (double)tf.y, dz = qz - (double)tf.z;
             const double d2 = dx * dx + dy * dy + dz * dz;
             if (d2 < a.max_dist2) {
@@ -580,7 +646,7 @@ __device__ static inline void icp_point(const IcpArgs &a, const double *T, int i
                         icp_sym3_inv_sqrt(M6, W);
                     } else {
                     // effective covariance normals: C = I - a m m^T, m = e1 when n.x < -0.99 (Open3D GetRotationFromE1ToX)
-                    const float4 sn = a.src_nrm[i], tn = a.tgt_nrm[best];
+                    const float4 sn = pre ? pre->sn : a.src_nrm[i], tn = pre ? pre->tn : a.tgt_nrm[best];
                     double sx = sn.x, sy = sn.y, sz = sn.z, tx = tn.x, ty = tn.y, tz = tn.z;
                     if (sx < -0.99) { sx = 1; sy = 0; sz = 0; }
                     if (tx < -0.99) { tx = 1; ty = 0; tz = 0; }
@@ -644,7 +710,8 @@ __device__ static inline void icp_point(const IcpArgs &a, const double *T, int i
 // ---- workgroup reduction of acc[], write-through partial row + ticket, and -- in the last-arriving workgroup -- the end of
 // the iteration: gather the rows, fixed-order sums, convergence test, 6x6 solve, pose update.  BS = workgroup size.
 template <int MODE, int BS>
-__device__ static inline void icp_finish(const IcpArgs &a, IcpState *st, const double *T, double *acc, int nb, int ns, int launches, unsigned long long t_entry, int row, unsigned long long t_phase = 0) {
+__device__ static inline void icp_finish(const IcpArgs &a, IcpState *st, const double *T, double *acc, int nb, int ns, int launches, unsigned long long t_entry, int row,
+                                         unsigned long long t_p = 0, unsigned long long t_a = 0, unsigned long long t_b = 0) {
     __shared__ double red[BS / 16][NVP];           // one row per 16-lane DPP row
     __shared__ double fin[16][NVP];
     __shared__ int is_last;
@@ -666,8 +733,12 @@ __device__ static inline void icp_finish(const IcpArgs &a, IcpState *st, const d
         __hip_atomic_store(&a.partials[(size_t)row * NVP + threadIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (threadIdx.x == 63) {   // diagnostics in the two padding columns: ticks to end-of-search / end-of-reduction
+        // PCR_ICP_PHASE = phase + 16 * mean: column 31 <- this workgroup's ticks from its entry to the end of phase 1 prologue / 2 certificates /
+        // 3 searches / 4 linearisation / 5 row sums (0: to here); gathered as the maximum over the workgroups, or their mean with + 16
+        const int ph = a.dbg_phase & 15;
+        const unsigned long long t_sel = ph == 1 ? t_p : ph == 2 ? t_a : ph == 3 ? t_b : ph == 4 ? t_search : ph == 5 ? t_ws - t_entry : wall_clock64() - t_entry;
         __hip_atomic_store(&a.partials[(size_t)row * NVP + 30], (double)t_search, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&a.partials[(size_t)row * NVP + 31], (double)(a.dbg_phase ? t_phase : wall_clock64() - t_entry), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.partials[(size_t)row * NVP + 31], (double)t_sel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its stores ...
     const unsigned long long t_drain = wall_clock64();
@@ -705,7 +776,7 @@ __device__ static inline void icp_finish(const IcpArgs &a, IcpState *st, const d
                 v[r] = x.d;
             }
 #pragma unroll
-            for (int r = 0; r < 20; r++) { const double x = b0 + chunk + NCH * r < nb ? v[r] : 0.0; s = vcol < NV ? s + x : fmax(s, x); }
+            for (int r = 0; r < 20; r++) { const double x = b0 + chunk + NCH * r < nb ? v[r] : 0.0; s = (vcol < NV || (vcol == 31 && a.dbg_phase >= 16)) ? s + x : fmax(s, x); }
         }
         fin[chunk][vcol] = s;
     }
@@ -714,25 +785,35 @@ __device__ static inline void icp_finish(const IcpArgs &a, IcpState *st, const d
     if (threadIdx.x < NVP) {
         double s = 0;
 #pragma unroll
-        for (int c = 0; c < BS / 32; c++) s = threadIdx.x < NV ? s + fin[c][threadIdx.x] : fmax(s, fin[c][threadIdx.x]);
+        for (int c = 0; c < BS / 32; c++) s = (threadIdx.x < NV || (threadIdx.x == 31 && a.dbg_phase >= 16)) ? s + fin[c][threadIdx.x] : fmax(s, fin[c][threadIdx.x]);
         fin[0][threadIdx.x] = s;
         st->sums[threadIdx.x] = s;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {
+        // The end of the iteration on the first WAVEFRONT: every lane runs the same scalar work on the same sums (no extra time), so that the
+        // three sine / cosine pairs of the pose update -- two thirds of this tail's dependent instructions when one lane computed them one
+        // after the other -- are taken by three lanes at once; lane 0 alone writes the state.
+        const bool lead = threadIdx.x == 0;
         const unsigned long long t0k = st->t_start;    // stamped by k_icp_nn (previous kernel)
-        st->t_dbg[3] += wall_clock64() - t0k;
-        st->t_dbg[0] += (unsigned long long)fin[0][30]; st->t_dbg[1] += (unsigned long long)fin[0][31];
-        if (wl) wl[7] = wall_clock64();
+        if (lead) {
+            st->t_dbg[3] += wall_clock64() - t0k;
+            st->t_dbg[0] += (unsigned long long)fin[0][30]; st->t_dbg[1] += (unsigned long long)(a.dbg_phase >= 16 ? fin[0][31] / nb : fin[0][31]);
+            if (wl) wl[7] = wall_clock64();
+        }
         const double *S = fin[0];
         const long long count = (long long)(S[29] + 0.5);
         const double fit = ns > 0 ? (double)count / (double)ns : 0.0;
         const double rmse = count > 0 ? sqrt(S[28] / (double)count) : 0.0;
+        const double fit_prev = st->fitness, rmse_prev = st->rmse; const int iter_prev = st->iter;
         bool stop = false, conv = false;
         if (a.single) stop = true;
-        else if (launches > 0 && fabs(st->fitness - fit) < a.rel_fit && fabs(st->rmse - rmse) < a.rel_rmse) { stop = true; conv = true; }
-        else if (st->iter >= a.max_it) stop = true;
-        st->fitness = fit; st->rmse = rmse; st->count = count;
+        else if (launches > 0 && fabs(fit_prev - fit) < a.rel_fit && fabs(rmse_prev - rmse) < a.rel_rmse) { stop = true; conv = true; }
+        else if (iter_prev >= a.max_it) stop = true;
+        if (lead) {
+            st->dfit = launches > 0 ? fabs(fit_prev - fit) : 1e300; st->drmse = launches > 0 ? fabs(rmse_prev - rmse) : 1e300;
+            st->fitness = fit; st->rmse = rmse; st->count = count;
+        }
         if (!stop && (MODE == ICP_MODE_GICP || MODE == ICP_MODE_GICP_COV)) {
             double U[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
             if (count > 0) {
@@ -740,39 +821,53 @@ __device__ static inline void icp_finish(const IcpArgs &a, IcpState *st, const d
 #pragma unroll
                 for (int p = 0; p < 6; p++) nb6[p] = -S[21 + p];
                 bool solved = icp_ldlt6_fast(S, nb6, x);
-                if (!solved) {                         // rare: indefinite / semi-definite system
+                if (!solved) {                         // rare: indefinite / semi-definite system (wave-uniform: every lane saw the same sums)
                     double *rhs = &fin[1][0];          // LDS copies (dynamic indexing must not touch scratch)
                     double *sol = &fin[2][0];
-                    for (int p = 0; p < 6; p++) rhs[p] = -S[21 + p];
-                    solved = icp_ldlt6_pivoted(S, rhs, sol, ldl_w, ldl_perm);
+                    if (lead) {
+                        for (int p = 0; p < 6; p++) rhs[p] = -S[21 + p];
+                        sol[6] = icp_ldlt6_pivoted(S, rhs, sol, ldl_w, ldl_perm) ? 1.0 : 0.0;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    solved = sol[6] != 0.0;
                     for (int p = 0; p < 6; p++) x[p] = sol[p];
                 }
                 if (solved) {
-                    const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]), sg = sin(x[2]);
+                    // lane j < 3 takes angle j; the six values come back by readlane
+                    const int lj = threadIdx.x;
+                    const double ang = lj == 0 ? x[0] : (lj == 1 ? x[1] : x[2]);
+                    union { double d; int i[2]; } sv, cv, t;
+                    sv.d = sin(ang); cv.d = cos(ang);
+                    auto from = [&](const decltype(sv) &v, int l) { t.i[0] = __builtin_amdgcn_readlane(v.i[0], l); t.i[1] = __builtin_amdgcn_readlane(v.i[1], l); return t.d; };
+                    const double sa = from(sv, 0), ca = from(cv, 0), sb = from(sv, 1), cb = from(cv, 1), sg = from(sv, 2), cg = from(cv, 2);
                     U[0] = cg * cb; U[1] = cg * sb * sa - sg * ca; U[2] = cg * sb * ca + sg * sa; U[3] = x[3];
                     U[4] = sg * cb; U[5] = sg * sb * sa + cg * ca; U[6] = sg * sb * ca - cg * sa; U[7] = x[4];
                     U[8] = -sb;     U[9] = cb * sa;                U[10] = cb * ca;               U[11] = x[5];
                 }
             }
-            if (wl) wl[8] = wall_clock64();
-            double Tn[16];
-            for (int r = 0; r < 4; r++)
-                for (int c = 0; c < 4; c++) {
-                    double s = 0;
-                    for (int k = 0; k < 4; k++) s += U[r * 4 + k] * (k < 3 ? T[k * 4 + c] : (c == 3 ? 1.0 : 0.0));
-                    Tn[r * 4 + c] = s;
-                }
-            for (int k = 0; k < 16; k++) st->T[k] = Tn[k];
-            st->iter = st->iter + 1;
+            if (wl && lead) wl[8] = wall_clock64();
+            if (lead) {
+                double Tn[16];
+                for (int r = 0; r < 4; r++)
+                    for (int c = 0; c < 4; c++) {
+                        double s = 0;
+                        for (int k = 0; k < 4; k++) s += U[r * 4 + k] * (k < 3 ? T[k * 4 + c] : (c == 3 ? 1.0 : 0.0));
+                        Tn[r * 4 + c] = s;
+                    }
+                for (int k = 0; k < 16; k++) st->T[k] = Tn[k];
+                st->iter = iter_prev + 1;
+            }
         }
-        st->launches = launches + 1;
-        st->converged = conv ? 1 : 0;
-        __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        st->ns = ns;
-        st->t_live += wall_clock64() - t0k;
-        if (a.stamps_it && launches < ICP_STAMP_LAUNCHES)
-            a.stamps_it[12 * ((size_t)launches * gridDim.x * (BS / 64) + (size_t)blockIdx.x * (BS / 64)) + 3] = wall_clock64();
-        st->done = stop ? 1 : 0;          // visible to the next launch through the kernel boundary
+        if (lead) {
+            st->launches = launches + 1;
+            st->converged = conv ? 1 : 0;
+            __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st->ns = ns;
+            st->t_live += wall_clock64() - t0k;
+            if (a.stamps_it && launches < ICP_STAMP_LAUNCHES)
+                a.stamps_it[12 * ((size_t)launches * gridDim.x * (BS / 64) + (size_t)blockIdx.x * (BS / 64)) + 3] = wall_clock64();
+            st->done = stop ? 1 : 0;          // visible to the next launch through the kernel boundary
+        }
     }
 }
 
@@ -863,12 +958,15 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
     const int per = (nb + 7) >> 3;
     const int bid = (int)(blockIdx.x >> 3) < per ? (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3) : nb;
     const int tile0 = (bid < nb ? bid : 0) * TILE_PTS;
-    float4 pf[PPL], refv[PPL]; int mraw[PPL], rb[PPL];
+    float4 pf[PPL], refv[PPL]; int mraw[PPL], rb[PPL]; int4 lst[PPL];
+    IcpPre pre[PPL];                            // phase C's inputs, requested as early as they are known
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
         const int i = tile0 + p * FUSED_BS + tid;
         const int ic = (i < a.src_cap && p * FUSED_BS + tid < TILE_PTS) ? i : 0;
-        pf[p] = a.src_pts[ic]; mraw[p] = a.match[ic]; refv[p] = a.ref[ic]; rb[p] = a.rbest[ic];
+        pf[p] = a.src_pts[ic]; mraw[p] = a.match[ic]; refv[p] = a.ref[ic];
+        if (GRID) { lst[p] = a.clist[ic]; rb[p] = -1; } else { rb[p] = a.rbest[ic]; lst[p] = make_int4(-1, -1, -1, -1); }
+        pre[p].pf = pf[p]; pre[p].sn = a.src_nrm[ic];
     }
     double T[12];
 #pragma unroll
@@ -882,7 +980,19 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
     if (tid < (int)(sizeof(OctMeta) / 4)) ((int *)&m)[tid] = mword;
     if (tid == 0) n_rec = 0;
     __syncthreads();
-    // ---- phase A: per point -- certificate or a place in the pending list
+    const unsigned long long t_p = wall_clock64() - t_entry;
+    // ---- phase A: per point -- certificate or a place in the pending list.  The listed points of ALL the lane's queries are requested first
+    // (one round trip for the lane), and the moment a neighbour is decided its normal is requested for phase C.
+    float4 ltp[PPL][PCR_NN_K];
+    if (GRID) {
+#pragma unroll
+        for (int p = 0; p < PPL; p++) {
+            // (records beyond the cloud's count are never written: their indices are whatever the arena held)
+            if (!(p * FUSED_BS + tid < TILE_PTS && tile0 + p * FUSED_BS + tid < ns)) lst[p] = make_int4(-1, -1, -1, -1);
+            icp_list_load(a.tgt_pts, lst[p], ltp[p]);
+        }
+    }
+    int pre_c[PPL];
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
         const int i = tile0 + p * FUSED_BS + tid;
@@ -890,6 +1000,7 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
         bool need = false;
         int cand = -1;
         float qx = 0, qy = 0, qz = 0; int hint = -1;
+        pre_c[p] = -1;
         if (mine && i < ns) {
             const double px = pf[p].x, py = pf[p].y, pz = pf[p].z;
             qx = (float)(T[0] * px + T[1] * py + T[2] * pz + T[3]);
@@ -897,9 +1008,16 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
             qz = (float)(T[8] * px + T[9] * py + T[10] * pz + T[11]);
             hint = mraw[p] >= 0 ? mraw[p] : (mraw[p] <= -2 ? -(mraw[p] + 2) : -1);
             const float ex = qx - refv[p].x, ey = qy - refv[p].y, ez = qz - refv[p].z;
-            const bool certified = refv[p].w > 0.0f && pcr_d2(ex, ey, ez) < refv[p].w * refv[p].w;
+            bool certified = refv[p].w > 0.0f;
+            if (GRID) { if (certified) certified = icp_list_decide(qx, qy, qz, refv[p], lst[p], ltp[p], a.r2f, &rb[p], &pre[p].tf) != 0; }
+            else certified = certified && pcr_d2(ex, ey, ez) < refv[p].w * refv[p].w;
             need = nt > 0 && !certified;
             cand = certified ? rb[p] : -1;                 // rb < 0: certified unmatched
+            if (GRID && certified && rb[p] < 0 && mraw[p] >= 0) a.match[i] = -1;      // decided unmatched after having been matched
+            if (cand >= 0) {
+                if (!GRID) pre[p].tf = a.tgt_pts[cand];
+                pre[p].tn = a.tgt_nrm[cand]; pre_c[p] = cand;
+            }
         }
         const unsigned long long nbm = __ballot(need);
         int base = 0;
@@ -917,22 +1035,43 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
     // per-lane scans, 47 us against 27 us per launch at the coarsest scale)
     const int npend = n_rec;
     if (tid == 0 && npend > 0) atomicAdd(&st->searched, (unsigned long long)npend);
-    for (int e0 = 0; e0 < npend; e0 += OPB) {
+    // a handful of pending queries (the usual case): a WAVEFRONT per query -- all eight cells of its block at once, two round trips
+    const bool few = GRID && npend <= 2 * (FUSED_BS / 64);
+    if (GRID && few) {
+        for (int e = tid >> 6; e < npend; e += FUSED_BS / 64) {
+            const float4 r = rec_q[e]; const int l = rec_l[e];
+            float d1 = 0, d2 = 0; int nnk[PCR_NN_K];
+            grid_nn_query64<PCR_NN_K>(a.grid, a.tgt_pts, r.x, r.y, r.z, a.r2s, lane, nnk, &d1, &d2);
+            if (lane == 0) {
+                const int qi = tile0 + l;
+                a.ref[qi] = make_float4(r.x, r.y, r.z, sqrtf(d2));
+                a.clist[qi] = make_int4(nnk[0], nnk[1], nnk[2], nnk[3]);
+                if (nnk[0] < 0) { const int hint = __float_as_int(r.w); a.match[qi] = -((hint >= 0 ? hint : 0) + 2); }
+                cand_l[l] = nnk[0];
+            }
+        }
+    }
+    for (int e0 = 0; e0 < (few ? 0 : npend); e0 += OPB) {
         const int e = e0 + ob;
         const bool live = e < npend;
         if (__ballot(live) == 0ull) continue;
         float qx = 0, qy = 0, qz = 0; int hint = -1, l = 0;
         if (live) { const float4 r = rec_q[e]; qx = r.x; qy = r.y; qz = r.z; hint = __float_as_int(r.w); l = rec_l[e]; }
         int start_pt = 0; float d1 = 0, d2 = 0;
-        int best;
-        if (GRID) { best = grid_nn_query8(a.grid, a.tgt_pts, live, qx, qy, qz, a.r2s, ol, &d1, &d2); start_pt = hint >= 0 ? hint : 0; }
+        int best; int nnk[PCR_NN_K];
+        if (GRID) { grid_nn_query8<PCR_NN_K>(a.grid, a.tgt_pts, live, qx, qy, qz, a.r2s, ol, nnk, &d1, &d2); best = nnk[0]; start_pt = hint >= 0 ? hint : 0; }
         else best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.r2s, hint, ol, oct, ob, &start_pt, nullptr, &d1, &d2);
         if (ol == 0 && live) {
             const int qi = tile0 + l;
-            const float slack = 2e-5f + 1e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz));
-            const float margin = best >= 0 ? 0.5f * (sqrtf(d2) - sqrtf(d1)) - slack : a.rs_minus_r - slack;
-            a.ref[qi] = make_float4(qx, qy, qz, margin > 0.0f ? margin : 0.0f);
-            a.rbest[qi] = best;
+            if (GRID) {
+                a.ref[qi] = make_float4(qx, qy, qz, sqrtf(d2));
+                a.clist[qi] = make_int4(nnk[0], nnk[1], nnk[2], nnk[3]);
+            } else {
+                const float slack = 2e-5f + 1e-6f * (fabsf(qx) + fabsf(qy) + fabsf(qz));
+                const float margin = best >= 0 ? 0.5f * (sqrtf(d2) - sqrtf(d1)) - slack : a.rs_minus_r - slack;
+                a.ref[qi] = make_float4(qx, qy, qz, margin > 0.0f ? margin : 0.0f);
+                a.rbest[qi] = best;
+            }
             if (best < 0) a.match[qi] = -(start_pt + 2);       // next launch's start hint
             cand_l[l] = best;
         }
@@ -949,10 +1088,11 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
         if (p * FUSED_BS + tid < TILE_PTS && i < ns) {
             const int c = cand_l[p * FUSED_BS + tid];
             if (c >= 0 && c != mraw[p]) a.match[i] = c;
-            icp_point<ICP_MODE_GICP>(a, T, i, ns, c, acc);
+            if (c >= 0 && c != pre_c[p]) { pre[p].tf = a.tgt_pts[c]; pre[p].tn = a.tgt_nrm[c]; }      // searched in phase B
+            icp_point<ICP_MODE_GICP>(a, T, i, ns, c, acc, &pre[p]);
         }
     }
-    icp_finish<ICP_MODE_GICP, FUSED_BS>(a, st, T, acc, nb, ns, launches, t_entry, bid, a.dbg_phase == 1 ? t_a : t_b);
+    icp_finish<ICP_MODE_GICP, FUSED_BS>(a, st, T, acc, nb, ns, launches, t_entry, bid, t_p, t_a, t_b);
 }
 template <int TILE_PTS, bool GRID> __global__ void __launch_bounds__(FUSED_BS) k_icp_fused(IcpArgs a) { d_icp_fused<TILE_PTS, GRID>(a); }
 // (the problem's arguments are copied out of the device buffer ONCE, by scalar loads, like by-value kernel arguments: read through the
@@ -996,6 +1136,17 @@ static int fused_tile_points(const pcr_context *ctx, int cap, int G) {
 
 // PCR_ICP_GRID=0: every correspondence search over the octree (the independent check of tests/test_gpu_gicp.py::test_switches_do_not_change_the_result)
 static bool icp_use_grid() { static const bool on = !(getenv("PCR_ICP_GRID") && atoi(getenv("PCR_ICP_GRID")) == 0); return on; }
+// The search cap of the certificate mode is r + g.  With the cell hash the cap costs nothing up to what the level's cells cover (edge >= 2.04 cap,
+// pcr_grid_level_for), and the room of a certificate is bounded by it: a query with fewer than K + 1 target points inside the cap -- every
+// unmatched one: 45 % of the finest scale -- carries D = cap, i.e. g of room, and with g = 2.5 cm it was searched again every few launches.
+// So once the level is known, g grows to what its cells allow (at most r itself).
+static double icp_gap_for_level(const DevCloud *tgt, int L, double max_dist, double g) {
+    if (L < 0) return g;
+    const double cap_max = 0.49 * (double)tgt->key_unit[0] * (double)(1 << L) * (1.0 - 2e-3);
+    double gl = cap_max - max_dist;
+    if (gl > max_dist) gl = max_dist;
+    return gl > g ? gl : g;
+}
 static void fill_args(IcpArgs &a, const DevCloud *src, const DevCloud *tgt, double max_dist, const pcr_gicp_params *p,
                       int32_t *match, IcpState *st, double *partials, int single) {
     a.src_pts = src->pts; a.src_nrm = src->nrm; a.ns_ptr = src->n;
@@ -1016,7 +1167,7 @@ static void fill_args(IcpArgs &a, const DevCloud *src, const DevCloud *tgt, doub
     a.dbg_visits = (single && getenv("PCR_DEBUG_VISITS")) ? 1 : 0;
     a.dbg_phase = getenv("PCR_ICP_PHASE") ? atoi(getenv("PCR_ICP_PHASE")) : 0;
     a.stamps_nn = nullptr; a.stamps_it = nullptr;
-    a.ref = nullptr; a.rbest = nullptr;
+    a.ref = nullptr; a.rbest = nullptr; a.clist = nullptr;
     memset(&a.grid, 0, sizeof a.grid); a.grid.L = -1;
 }
 
@@ -1031,6 +1182,24 @@ static void state_to_result(const IcpState &s, pcr_result *out) {
     for (int k = 0; k < 16; k++) out->transformation[k] = s.T[k];
     out->fitness = s.fitness; out->inlier_rmse = s.rmse; out->n_correspondences = s.count;
     out->iterations = s.iter; out->converged = s.converged;
+}
+
+// Length of the next chunk of launches.  A chunk is queued before the state of the one before it has come back, so after convergence the
+// rest of the current chunk and all of the next are launches that return at once (4.4 us each: with chunks of 8 a third of all launches of a
+// pair run alone).  Once the last changes of fitness and RMSE are within a small factor of the criteria the loop is about to stop: short chunks.
+// Measured (48 pairs of 200k points): lockstep groups, four in flight: 26 % -> 13 % of the launches return at once, 692 -> 695 pairs/s (nothing:
+// the other groups' kernels fill those slots either way); ONE pair at a time: 34 % -> 26 %, but 244 -> 236 pairs/s -- every chunk boundary is a
+// ~10 us gap on the one stream there is, and short chunks have more of them than they save in 4.4-us launches.  So: on for groups, off
+// for the one-pair loop (PCR_ICP_CHUNK_ADAPT = 0 / 1 forces either).
+static int icp_next_chunk(const IcpState &s, double rel_fit, double rel_rmse, int chunk, bool group) {
+    static const int forced = getenv("PCR_ICP_CHUNK_ADAPT") ? atoi(getenv("PCR_ICP_CHUNK_ADAPT")) : -1;
+    const bool adaptive = forced < 0 ? group : forced != 0;
+    if (!adaptive || s.launches < 2 || !(rel_rmse > 0.0)) return chunk;
+    const double quantum = s.ns > 0 ? 1.0 / (double)s.ns : 0.0;           // the fitness moves in steps of one correspondence
+    const double fit_tol = rel_fit > quantum ? rel_fit : quantum;
+    if (s.dfit <= 2.5 * fit_tol && s.drmse <= 30.0 * rel_rmse) return chunk < 2 ? chunk : 2;
+    if (s.dfit <= 8.5 * fit_tol && s.drmse <= 300.0 * rel_rmse) return chunk < 4 ? chunk : 4;
+    return chunk;
 }
 
 int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, double max_dist, const double *T0,
@@ -1057,8 +1226,8 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     if (!st || !partials || !match) return PCR_ENOMEM;
     IcpArgs a; memset(&a, 0, sizeof a); fill_args(a, src, tgt, max_dist, p, match, st, partials, 0);
     if (use_skip && max_dist < 1e15) {
-        a.ref = arena<float4>(ctx, cap); a.rbest = arena<int32_t>(ctx, cap);
-        if (!a.ref || !a.rbest) return PCR_ENOMEM;
+        a.ref = arena<float4>(ctx, cap); a.rbest = arena<int32_t>(ctx, cap); a.clist = arena<int4>(ctx, cap);
+        if (!a.ref || !a.rbest || !a.clist) return PCR_ENOMEM;
         // certificate mode searches a slightly larger ball (r + g): a query with nothing inside it stays unmatched, without
         // a search, until it has moved by g; candidates between r and r + g are rejected by k_icp_iter's float64 radius test
         static const double gfrac = getenv("PCR_ICP_GAP") ? atof(getenv("PCR_ICP_GAP")) : 0.25;
@@ -1077,6 +1246,10 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     if (icp_use_grid() && !use_cov) {       // cell hash of the target for radii of a few voxels (pcr_octree.h GridView); the octree serves the others
         const int L = pcr_grid_level_for(tgt, std::sqrt((double)(a.ref ? a.r2s : a.r2f)));
         PCR_TRY(pcr_dev_build_grid_batch(ctx, &tgt, &L, 1, &a.grid));
+        if (a.ref && a.grid.tab) {
+            const double rs = max_dist + icp_gap_for_level(tgt, L, max_dist, (double)a.rs_minus_r);
+            a.r2s = (float)(rs * rs * (1.0 + 1e-6)); a.rs_minus_r = (float)(rs - max_dist);
+        }
     }
     const bool grid = a.grid.tab != nullptr;
     IcpInit in; memcpy(in.T, T0, sizeof in.T);
@@ -1101,7 +1274,8 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     const bool fused = use_fused && a.ref && !use_cov && !stamp_path && nbf <= 4096 && !stream;
     auto enqueue = [&](int launch_index) {
         if (launch_index > 0 && stream && a.pend_n) {
-            PCR_LAUNCH(ctx, k_icp_cert, dim3((cap + CERT_BS - 1) / CERT_BS), dim3(CERT_BS), 0, ctx->stream, a);
+            if (grid) PCR_LAUNCH(ctx, k_icp_cert<true>, dim3((cap + CERT_BS - 1) / CERT_BS), dim3(CERT_BS), 0, ctx->stream, a);
+            else PCR_LAUNCH(ctx, k_icp_cert<false>, dim3((cap + CERT_BS - 1) / CERT_BS), dim3(CERT_BS), 0, ctx->stream, a);
             if (grid) PCR_LAUNCH(ctx, k_icp_search<true>, dim3(nbsearch), dim3(ICP_BS), 0, ctx->stream, a);
             else PCR_LAUNCH(ctx, k_icp_search<false>, dim3(nbsearch), dim3(ICP_BS), 0, ctx->stream, a);
             PCR_LAUNCH(ctx, k_icp_lin, dim3(nblin), dim3(LIN_BS), 0, ctx->stream, a);
@@ -1123,48 +1297,49 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
         else if (stamp_path) PCR_LAUNCH(ctx, k_icp_iter<ICP_MODE_GICP>, dim3(nbmax), dim3(LIN_BS), 0, ctx->stream, a);
         else PCR_LAUNCH(ctx, k_icp_lin, dim3(nblin), dim3(LIN_BS), 0, ctx->stream, a);
     };
-    hipGraphExec_t chunk_exec[2] = {nullptr, nullptr};          // [0]: the chunk that starts with launch 0, [1]: every later chunk
-    if (use_graph && !stamp_path) {
-        for (int which = 0; which < 2; which++) {
-            std::string key((const char *)&a, sizeof a);
-            const int extra[7] = {nbnn, nbmax, use_cov ? 1 : 0, CHUNK, fused ? nbf + (tile_pts << 16) : (stream ? -nblin : 0), which, grid ? 1 : 0};
-            key.append((const char *)extra, sizeof extra);
-            for (auto &g : ctx->icp_graphs) if (g.key == key) { chunk_exec[which] = g.exec; break; }
-            if (!chunk_exec[which]) {
-                hipGraph_t graph = nullptr;
-                PCR_HIP_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-                for (int k = 0; k < CHUNK; k++) enqueue(which == 0 ? k : CHUNK + k);
-                PCR_HIP_CHECK(ctx, hipStreamEndCapture(ctx->stream, &graph));
-                PCR_HIP_CHECK(ctx, hipGraphInstantiate(&chunk_exec[which], graph, nullptr, nullptr, 0));
-                (void)hipGraphDestroy(graph);
-                if (ctx->icp_graphs.size() >= 32) {           // evict the oldest entry this call does not use itself
-                    size_t victim = 0;
-                    while (victim < ctx->icp_graphs.size() && ctx->icp_graphs[victim].exec == chunk_exec[0]) victim++;
-                    if (victim < ctx->icp_graphs.size()) {
-                        (void)hipGraphExecDestroy(ctx->icp_graphs[victim].exec);
-                        if (ctx->icp_graphs[victim].graph) (void)hipGraphDestroy(ctx->icp_graphs[victim].graph);
-                        ctx->icp_graphs.erase(ctx->icp_graphs.begin() + victim);
-                    }
-                }
-                { IcpGraph e; e.key = std::move(key); e.exec = chunk_exec[which]; ctx->icp_graphs.push_back(std::move(e)); }
-            }
+    // graph of a chunk of `len` launches: which = 0 starts with launch 0 (cold search + linearisation), which = 1 holds later launches only
+    auto graph_for = [&](int which, int len, hipGraphExec_t *out) -> int {
+        *out = nullptr;
+        if (!use_graph || stamp_path) return PCR_OK;
+        std::string key((const char *)&a, sizeof a);
+        const int extra[7] = {nbnn, nbmax, use_cov ? 1 : 0, len, fused ? nbf + (tile_pts << 16) : (stream ? -nblin : 0), which, grid ? 1 : 0};
+        key.append((const char *)extra, sizeof extra);
+        for (auto &g : ctx->icp_graphs) if (g.key == key) { *out = g.exec; return PCR_OK; }
+        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+        PCR_HIP_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        for (int k = 0; k < len; k++) enqueue(which == 0 ? k : len + k);
+        PCR_HIP_CHECK(ctx, hipStreamEndCapture(ctx->stream, &graph));
+        PCR_HIP_CHECK(ctx, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        if (ctx->icp_graphs.size() >= 48) {           // evict the oldest entry (the stream is drained first: a replay of it may still be queued)
+            PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipGraphExecDestroy(ctx->icp_graphs[0].exec);
+            if (ctx->icp_graphs[0].graph) (void)hipGraphDestroy(ctx->icp_graphs[0].graph);
+            ctx->icp_graphs.erase(ctx->icp_graphs.begin());
         }
-    }
+        { IcpGraph e; e.key = std::move(key); e.exec = exec; ctx->icp_graphs.push_back(std::move(e)); }
+        *out = exec;
+        return PCR_OK;
+    };
     IcpState *slots = (IcpState *)ctx->pinned;      // two read-back slots
-    int launched = 0, cur = 0, prev = -1, n_chunks = 0;
+    int launched = 0, cur = 0, prev = -1, n_chunks = 0, next_len = CHUNK;
+    std::vector<int> chunk_first, chunk_last;
     IcpState fin; bool have = false;
     for (;;) {
         const bool enq = launched < total;
         if (enq) {
-            const int c = total - launched < CHUNK ? total - launched : CHUNK;
+            const int want = launched == 0 ? CHUNK : next_len;
+            const int c = total - launched < want ? total - launched : want;
             if (ctx->profiling) {
                 while ((int)ctx->prof_events.size() < 2 * (n_chunks + 1)) { hipEvent_t e; PCR_HIP_CHECK(ctx, hipEventCreate(&e)); ctx->prof_events.push_back(e); }
                 PCR_HIP_CHECK(ctx, hipEventRecord(ctx->prof_events[2 * n_chunks], ctx->stream));
             }
-            hipGraphExec_t ge = chunk_exec[launched == 0 ? 0 : 1];
-            if (ge && c == CHUNK) PCR_HIP_CHECK(ctx, hipGraphLaunch(ge, ctx->stream));
+            hipGraphExec_t ge = nullptr;
+            if (c == want) PCR_TRY(graph_for(launched == 0 ? 0 : 1, c, &ge));      // (a ragged last chunk before max_iteration is launched directly)
+            if (ge) PCR_HIP_CHECK(ctx, hipGraphLaunch(ge, ctx->stream));
             else for (int k = 0; k < c; k++) enqueue(launched + k);
             if (ctx->profiling) PCR_HIP_CHECK(ctx, hipEventRecord(ctx->prof_events[2 * n_chunks + 1], ctx->stream));
+            chunk_first.push_back(launched); chunk_last.push_back(launched + c);
             n_chunks++;
             launched += c;
             PCR_HIP_CHECK(ctx, hipMemcpyAsync(&slots[cur], st, sizeof(IcpState), hipMemcpyDeviceToHost, ctx->stream));
@@ -1173,6 +1348,7 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
         if (prev >= 0) {
             PCR_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev[prev]));
             if (slots[prev].done) { fin = slots[prev]; have = true; break; }
+            next_len = icp_next_chunk(slots[prev], a.rel_fit, a.rel_rmse, CHUNK, false);
         }
         if (!enq) break;
         prev = cur; cur ^= 1;
@@ -1183,7 +1359,7 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     if (ctx->profiling) {
         // chunks whose launches were all live (before 'done'): HIP-event time / launches = launch-to-launch period
         for (int c = 0; c < n_chunks; c++) {
-            const int first = c * CHUNK, last = first + CHUNK < total ? first + CHUNK : total;
+            const int first = chunk_first[c], last = chunk_last[c];
             if (last <= fin.launches) {
                 float ms = 0;
                 PCR_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->prof_events[2 * c], ctx->prof_events[2 * c + 1]));
@@ -1193,8 +1369,8 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
         ctx->prof[2] += (double)fin.t_live * 0.01;            // 100 MHz ticks -> microseconds
         ctx->prof[3] += fin.launches;
         ctx->prof[4] += 48.0 * (double)fin.ns * (double)fin.launches;   // 48 B per source point per launch
-        ctx->prof[5] += launched;
-        ctx->prof[6] += (double)fin.t_dbg[0] * 0.01; ctx->prof[7] += (double)fin.t_dbg[3] * 0.01;
+        ctx->prof[5] += launched; ctx->prof[13] += fin.launches;          // issued / live launches of the loop: the rest returned at once
+        ctx->prof[6] += (double)fin.t_dbg[0] * 0.01; ctx->prof[7] += (double)fin.t_dbg[3] * 0.01; ctx->prof[14] += (double)fin.t_dbg[1] * 0.01;
         ctx->prof[11] += (double)fin.searched;
         if (getenv("PCR_DEBUG_STAMPS")) fprintf(stderr, "icp stamps (us/launch): slowest-wg search %.1f slowest-wg reduce %.1f (unused %.1f) sums-done %.1f end %.1f (launches %d ns %d)\n", fin.t_dbg[0] * 0.01 / fin.launches, fin.t_dbg[1] * 0.01 / fin.launches, fin.t_dbg[2] * 0.01 / fin.launches, fin.t_dbg[3] * 0.01 / fin.launches, fin.t_live * 0.01 / fin.launches, fin.launches, fin.ns);
     }
@@ -1246,8 +1422,8 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
         IcpArgs &a = args[g]; memset(&a, 0, sizeof a);
         const double max_dist = max_dists[g];
         fill_args(a, src[g], tgt[g], max_dist, p, match, st + g, partials, 0);
-        a.ref = arena<float4>(ctx, cap); a.rbest = arena<int32_t>(ctx, cap);
-        if (!a.ref || !a.rbest) return PCR_ENOMEM;
+        a.ref = arena<float4>(ctx, cap); a.rbest = arena<int32_t>(ctx, cap); a.clist = arena<int4>(ctx, cap);
+        if (!a.ref || !a.rbest || !a.clist) return PCR_ENOMEM;
         double gg = gfrac * max_dist; gg = gg < 0.01 ? 0.01 : (gg > 0.05 ? 0.05 : gg);
         const double rs = max_dist + gg;
         a.r2s = (float)(rs * rs * (1.0 + 1e-6)); a.rs_minus_r = (float)gg;
@@ -1263,6 +1439,11 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
             PCR_TRY(pcr_dev_build_grid_batch(ctx, tgt, levels.data(), G, views.data()));
             for (int g = 0; g < G; g++) { args[g].grid = views[g]; grid = grid_ok = true; }
             for (int g = 0; g < G; g++) grid = grid && views[g].tab != nullptr;
+            if (grid)
+                for (int g = 0; g < G; g++) {
+                    const double rs = max_dists[g] + icp_gap_for_level(tgt[g], levels[g], max_dists[g], (double)args[g].rs_minus_r);
+                    args[g].r2s = (float)(rs * rs * (1.0 + 1e-6)); args[g].rs_minus_r = (float)(rs - max_dists[g]);
+                }
         }
     }
     if (nbf > 4096) { ctx->err = "GICP group: cloud too large for the fused iteration kernel"; return PCR_EINVAL; }
@@ -1301,99 +1482,102 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
     // One captured chunk per launch FORM (group size, kernel forms, tile, chunk length): what differs from call to call -- the
     // grid widths and, for the by-value kernels, the argument batch -- is patched into the instantiated graph's kernel nodes
     // (hipGraphExecKernelNodeSetParams), so circuits whose clouds differ in size do not pay a capture + instantiate per call.
-    hipGraphExec_t chunk_exec[2] = {nullptr, nullptr};
-    if (use_graph) {
-        const void *dargs_v = dargs;
-        std::string now;
-        { const int w[3] = {nbnn, nbmax, nbf}; now.assign((const char *)w, sizeof w); if (byval) now.append((const char *)&hb, sizeof hb); }
-        for (int which = 0; which < 2; which++) {
-            const long long kv[6] = {0x47525550ll /* "GRUP" */, G + (grid ? 1000 : 0) + (use_fused_g ? 0 : 2000) + (byval ? 4000 : 0), tile_pts, CHUNK, which, (long long)(uintptr_t)dargs_v};
-            std::string key((const char *)kv, sizeof kv);
-            IcpGraph *hit = nullptr;
-            for (auto &gr : ctx->icp_graphs) if (gr.key == key) { hit = &gr; break; }
-            if (!hit) {
-                IcpGraph e; e.key = key;
-                // (the graph objects belong to `e` until it is stored: an early error return below must not leak them)
-                struct Owner { IcpGraph *g; ~Owner() { if (g) { if (g->exec) (void)hipGraphExecDestroy(g->exec); if (g->graph) (void)hipGraphDestroy(g->graph); } } } owner{&e};
-                PCR_HIP_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-                for (int k = 0; k < CHUNK; k++) enqueue(which == 0 ? k : CHUNK + k);
-                PCR_HIP_CHECK(ctx, hipStreamEndCapture(ctx->stream, &e.graph));
-                PCR_HIP_CHECK(ctx, hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
-                // the captured chunk is a chain: walk it from its root so that nodes[] is in launch order
-                size_t nr = 1; hipGraphNode_t node = nullptr;
-                PCR_HIP_CHECK(ctx, hipGraphGetRootNodes(e.graph, &node, &nr));
-                if (nr != 1) { ctx->err = "GICP group: captured chunk has more than one root"; return PCR_EHIP; }
-                while (node) {
-                    hipGraphNodeType nt;
-                    PCR_HIP_CHECK(ctx, hipGraphNodeGetType(node, &nt));
-                    if (nt != hipGraphNodeTypeKernel) { ctx->err = "GICP group: captured chunk holds a node that is not a kernel"; return PCR_EHIP; }
-                    e.nodes.push_back(node);
-                    size_t nd = 0;
-                    PCR_HIP_CHECK(ctx, hipGraphNodeGetDependentNodes(node, nullptr, &nd));
-                    if (nd == 0) break;
-                    if (nd != 1) { ctx->err = "GICP group: captured chunk is not a chain"; return PCR_EHIP; }
-                    hipGraphNode_t next = nullptr;
-                    PCR_HIP_CHECK(ctx, hipGraphNodeGetDependentNodes(node, &next, &nd));
-                    node = next;
-                }
-                {   // launch order of a chunk: launch 0 is search + linearisation (two kernels), every later launch one fused kernel (or the same two)
-                    size_t expect = 0;
-                    for (int k = 0; k < CHUNK; k++) expect += ((which == 0 ? k : CHUNK + k) > 0 && use_fused_g) ? 1 : 2;
-                    if (e.nodes.size() != expect) { ctx->err = "GICP group: captured chunk does not match its launch list"; return PCR_EHIP; }
-                }
-                e.baked = now;
-                if (ctx->icp_graphs.size() >= 32) {
-                    size_t victim = 0;
-                    while (victim < ctx->icp_graphs.size() && ctx->icp_graphs[victim].exec == chunk_exec[0]) victim++;
-                    if (victim < ctx->icp_graphs.size()) {
-                        (void)hipGraphExecDestroy(ctx->icp_graphs[victim].exec);
-                        if (ctx->icp_graphs[victim].graph) (void)hipGraphDestroy(ctx->icp_graphs[victim].graph);
-                        ctx->icp_graphs.erase(ctx->icp_graphs.begin() + victim);
-                    }
-                }
-                owner.g = nullptr;                            // stored: the context owns the graph from here on
-                ctx->icp_graphs.push_back(std::move(e));
-                hit = &ctx->icp_graphs.back();
-            } else if (hit->baked != now) {
-                // launch order of a chunk (enqueue above): launch 0 is search + iteration, every later launch one fused kernel
-                size_t i = 0;
-                for (int k = 0; k < CHUNK; k++) {
-                    const int launch_index = which == 0 ? k : CHUNK + k;
-                    const bool one = launch_index > 0 && use_fused_g;
-                    for (int part = 0; part < (one ? 1 : 2); part++, i++) {
-                        if (i >= hit->nodes.size()) { ctx->err = "GICP group: captured chunk shorter than its launch list"; return PCR_EHIP; }
-                        hipKernelNodeParams np;
-                        PCR_HIP_CHECK(ctx, hipGraphKernelNodeGetParams(hit->nodes[i], &np));
-                        void *kp[1];
-                        if (one) { np.gridDim = dim3(nbf, G); kp[0] = byval ? (void *)&hb : (void *)&dargs_v; }
-                        else { np.gridDim = part == 0 ? dim3(nbnn, G) : dim3(nbmax, G); kp[0] = (void *)&dargs_v; }
-                        np.kernelParams = kp; np.extra = nullptr;
-                        PCR_HIP_CHECK(ctx, hipGraphExecKernelNodeSetParams(hit->exec, hit->nodes[i], &np));
-                    }
-                }
-                hit->baked = now;
+    const void *dargs_v = dargs;
+    std::string now;
+    { const int w[3] = {nbnn, nbmax, nbf}; now.assign((const char *)w, sizeof w); if (byval) now.append((const char *)&hb, sizeof hb); }
+    auto graph_for = [&](int which, int len, hipGraphExec_t *out) -> int {
+        *out = nullptr;
+        if (!use_graph) return PCR_OK;
+        const long long kv[6] = {0x47525550ll /* "GRUP" */, G + (grid ? 1000 : 0) + (use_fused_g ? 0 : 2000) + (byval ? 4000 : 0), tile_pts, len, which, (long long)(uintptr_t)dargs_v};
+        std::string key((const char *)kv, sizeof kv);
+        IcpGraph *hit = nullptr;
+        for (auto &gr : ctx->icp_graphs) if (gr.key == key) { hit = &gr; break; }
+        if (!hit) {
+            IcpGraph e; e.key = key;
+            // (the graph objects belong to `e` until it is stored: an early error return below must not leak them)
+            struct Owner { IcpGraph *g; ~Owner() { if (g) { if (g->exec) (void)hipGraphExecDestroy(g->exec); if (g->graph) (void)hipGraphDestroy(g->graph); } } } owner{&e};
+            PCR_HIP_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            for (int k = 0; k < len; k++) enqueue(which == 0 ? k : len + k);
+            PCR_HIP_CHECK(ctx, hipStreamEndCapture(ctx->stream, &e.graph));
+            PCR_HIP_CHECK(ctx, hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
+            // the captured chunk is a chain: walk it from its root so that nodes[] is in launch order
+            size_t nr = 1; hipGraphNode_t node = nullptr;
+            PCR_HIP_CHECK(ctx, hipGraphGetRootNodes(e.graph, &node, &nr));
+            if (nr != 1) { ctx->err = "GICP group: captured chunk has more than one root"; return PCR_EHIP; }
+            while (node) {
+                hipGraphNodeType nt;
+                PCR_HIP_CHECK(ctx, hipGraphNodeGetType(node, &nt));
+                if (nt != hipGraphNodeTypeKernel) { ctx->err = "GICP group: captured chunk holds a node that is not a kernel"; return PCR_EHIP; }
+                e.nodes.push_back(node);
+                size_t nd = 0;
+                PCR_HIP_CHECK(ctx, hipGraphNodeGetDependentNodes(node, nullptr, &nd));
+                if (nd == 0) break;
+                if (nd != 1) { ctx->err = "GICP group: captured chunk is not a chain"; return PCR_EHIP; }
+                hipGraphNode_t next = nullptr;
+                PCR_HIP_CHECK(ctx, hipGraphNodeGetDependentNodes(node, &next, &nd));
+                node = next;
             }
-            chunk_exec[which] = hit->exec;
+            {   // launch order of a chunk: launch 0 is search + linearisation (two kernels), every later launch one fused kernel (or the same two)
+                size_t expect = 0;
+                for (int k = 0; k < len; k++) expect += ((which == 0 ? k : len + k) > 0 && use_fused_g) ? 1 : 2;
+                if (e.nodes.size() != expect) { ctx->err = "GICP group: captured chunk does not match its launch list"; return PCR_EHIP; }
+            }
+            e.baked = now;
+            if (ctx->icp_graphs.size() >= 48) {           // evict the oldest entry (the stream is drained first: a replay of it may still be queued)
+                PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                (void)hipGraphExecDestroy(ctx->icp_graphs[0].exec);
+                if (ctx->icp_graphs[0].graph) (void)hipGraphDestroy(ctx->icp_graphs[0].graph);
+                ctx->icp_graphs.erase(ctx->icp_graphs.begin());
+            }
+            owner.g = nullptr;                            // stored: the context owns the graph from here on
+            ctx->icp_graphs.push_back(std::move(e));
+            hit = &ctx->icp_graphs.back();
+        } else if (hit->baked != now) {
+            // One captured chunk per launch FORM (group size, kernel forms, tile, chunk length): what differs from call to call -- the
+            // grid widths and, for the by-value kernels, the argument batch -- is patched into the instantiated graph's kernel nodes
+            // (hipGraphExecKernelNodeSetParams), so circuits whose clouds differ in size do not pay a capture + instantiate per call.
+            size_t i = 0;
+            for (int k = 0; k < len; k++) {
+                const int launch_index = which == 0 ? k : len + k;
+                const bool one = launch_index > 0 && use_fused_g;
+                for (int part = 0; part < (one ? 1 : 2); part++, i++) {
+                    if (i >= hit->nodes.size()) { ctx->err = "GICP group: captured chunk shorter than its launch list"; return PCR_EHIP; }
+                    hipKernelNodeParams np;
+                    PCR_HIP_CHECK(ctx, hipGraphKernelNodeGetParams(hit->nodes[i], &np));
+                    void *kp[1];
+                    if (one) { np.gridDim = dim3(nbf, G); kp[0] = byval ? (void *)&hb : (void *)&dargs_v; }
+                    else { np.gridDim = part == 0 ? dim3(nbnn, G) : dim3(nbmax, G); kp[0] = (void *)&dargs_v; }
+                    np.kernelParams = kp; np.extra = nullptr;
+                    PCR_HIP_CHECK(ctx, hipGraphExecKernelNodeSetParams(hit->exec, hit->nodes[i], &np));
+                }
+            }
+            hit->baked = now;
         }
-    }
+        *out = hit->exec;
+        return PCR_OK;
+    };
     // two read-back slots of G states each in the pinned window
     const size_t slot_bytes = sizeof(IcpState) * (size_t)G;
     if (2 * slot_bytes > ctx->pinned_cap) { ctx->err = "GICP group: pinned window too small"; return PCR_ENOMEM; }
     IcpState *slots[2] = {(IcpState *)ctx->pinned, (IcpState *)(ctx->pinned + slot_bytes)};
-    int launched = 0, cur = 0, prev = -1, n_chunks = 0;
+    int launched = 0, cur = 0, prev = -1, n_chunks = 0, next_len = CHUNK;
+    std::vector<int> chunk_first, chunk_last;
     std::vector<IcpState> fin((size_t)G); bool have = false;
     for (;;) {
         const bool enq = launched < total;
         if (enq) {
-            const int c = total - launched < CHUNK ? total - launched : CHUNK;
+            const int want = launched == 0 ? CHUNK : next_len;
+            const int c = total - launched < want ? total - launched : want;
             if (ctx->profiling) {
                 while ((int)ctx->prof_events.size() < 2 * (n_chunks + 1)) { hipEvent_t e; PCR_HIP_CHECK(ctx, hipEventCreate(&e)); ctx->prof_events.push_back(e); }
                 PCR_HIP_CHECK(ctx, hipEventRecord(ctx->prof_events[2 * n_chunks], ctx->stream));
             }
-            hipGraphExec_t ge = chunk_exec[launched == 0 ? 0 : 1];
-            if (ge && c == CHUNK) PCR_HIP_CHECK(ctx, hipGraphLaunch(ge, ctx->stream));
+            hipGraphExec_t ge = nullptr;
+            if (c == want) PCR_TRY(graph_for(launched == 0 ? 0 : 1, c, &ge));
+            if (ge) PCR_HIP_CHECK(ctx, hipGraphLaunch(ge, ctx->stream));
             else for (int k = 0; k < c; k++) enqueue(launched + k);
             if (ctx->profiling) PCR_HIP_CHECK(ctx, hipEventRecord(ctx->prof_events[2 * n_chunks + 1], ctx->stream));
+            chunk_first.push_back(launched); chunk_last.push_back(launched + c);
             n_chunks++;
             launched += c;
             PCR_HIP_CHECK(ctx, hipMemcpyAsync(slots[cur], st, slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -1404,6 +1588,9 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
             bool all = true;
             for (int g = 0; g < G; g++) all = all && slots[prev][g].done;
             if (all) { memcpy(fin.data(), slots[prev], slot_bytes); have = true; break; }
+            next_len = 1;                               // the group goes on until its last pair has stopped: the chunk that pair asks for
+            for (int g = 0; g < G; g++)
+                if (!slots[prev][g].done) { const int l = icp_next_chunk(slots[prev][g], args[g].rel_fit, args[g].rel_rmse, CHUNK, true); next_len = l > next_len ? l : next_len; }
         }
         if (!enq) break;
         prev = cur; cur ^= 1;
@@ -1414,7 +1601,7 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
         int longest = 0;
         for (int g = 0; g < G; g++) longest = fin[g].launches > longest ? fin[g].launches : longest;
         for (int c = 0; c < n_chunks; c++) {
-            const int first = c * CHUNK, last = first + CHUNK < total ? first + CHUNK : total;
+            const int first = chunk_first[c], last = chunk_last[c];
             if (last <= longest) {
                 float ms = 0;
                 PCR_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->prof_events[2 * c], ctx->prof_events[2 * c + 1]));
@@ -1425,8 +1612,14 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
             ctx->prof[2] += (double)fin[g].t_live * 0.01; ctx->prof[3] += fin[g].launches;
             ctx->prof[4] += 48.0 * (double)fin[g].ns * (double)fin[g].launches;
             ctx->prof[11] += (double)fin[g].searched;
+            ctx->prof[6] += (double)fin[g].t_dbg[0] * 0.01; ctx->prof[7] += (double)fin[g].t_dbg[3] * 0.01; ctx->prof[14] += (double)fin[g].t_dbg[1] * 0.01;
         }
-        ctx->prof[5] += launched;
+        ctx->prof[5] += launched; ctx->prof[13] += longest;                // issued / live launches of the GROUP's loop (live: some pair still iterating)
+        if (getenv("PCR_DEBUG_STAMPS")) {
+            double l = 0, t0 = 0, t1 = 0, t3 = 0, tl = 0;
+            for (int g = 0; g < G; g++) { l += fin[g].launches; t0 += fin[g].t_dbg[0] * 0.01; t1 += fin[g].t_dbg[1] * 0.01; t3 += fin[g].t_dbg[3] * 0.01; tl += fin[g].t_live * 0.01; }
+            fprintf(stderr, "icp group stamps (us/launch, mean over %d pairs): slowest-wg A+B+C %.1f phase %.1f sums-done %.1f end %.1f (pair-launches %.0f ns %d)\n", G, t0 / l, t1 / l, t3 / l, tl / l, l, fin[0].ns);
+        }
     }
     for (int g = 0; g < G; g++) {
         state_to_result(fin[g], &out[g]);

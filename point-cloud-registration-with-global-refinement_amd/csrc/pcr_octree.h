@@ -222,21 +222,49 @@ __device__ static inline int2 pcr_grid_lookup(const GridView &g, unsigned mask, 
 // cell and the neighbour on the NEARER side, i.e. the 2 x 2 x 2 block of cells around q: lane b of the octet looks up the cell whose
 // offset bits are b (bit set = the neighbour along that axis; lane 0 = q's own cell) -- one lookup per lane, one round trip for the
 // block -- and then the octet scans the cells TOGETHER, own cell first, face / edge / corner neighbours after it, 8 PCR_GRID8_PPS consecutive
-// points per step (that many coalesced loads per lane in flight); a cell is skipped when the ball of the octet's second-nearest distance so far does not
+// points per step (that many coalesced loads per lane in flight); a cell is skipped when the ball that must still be searched does not
 // reach its cube.  Against the first form of this search (27 cells of edge >= r: 4 lookups and up to 8 scattered point loads per lane
-// and step, most lanes without work): a third of the load instructions and of the VALU work per query.  Same answers as the tree walk
-// (ties -> lower index).
+// and step, most lanes without work): a third of the load instructions and of the VALU work per query.
+//
+// Round 5: the search returns the K NEAREST points (ordered by distance; the first with ties -> lower index, exactly the answer of the
+// tree walk) and the squared distance of the (K+1)-th (r2cap when fewer lie inside the cap).  That is the query's LIST CERTIFICATE
+// (pcr_gicp.hip, icp_list_eval): while the query has moved by delta and its nearest LISTED point is closer than D_{K+1} - delta, that
+// point is its exact nearest neighbour -- decided from K gathered points, without a search.  The (d2 - d1) / 2 margin of the rounds
+// before lost ~8 % of the queries per launch to a search again (the same chronic near-bisector queries every launch); (d5 - d1) / 2 is three
+// times wider and has no mass near zero.  Every lane keeps its own K+1 smallest, sorted (an insertion is a compare-select chain run only
+// for points under the lane's (K+1)-th); the octet merges by K pops of the smallest head.
 #ifndef PCR_GRID8_PPS
 #define PCR_GRID8_PPS 8      // points per lane and step of a cell scan (loads in flight)
 #endif
+#define PCR_NN_K 4           // listed neighbours of a certificate (int4 record)
 template <int K> __device__ static inline int pcr_octet_bcast(int v, int ol) {       // value of octet lane K in all 8 lanes
     const int q = pcr_dpp_i<(K & 3) * 0x55>(v);                                     // quad_perm [K&3 x 4]
     const int h = pcr_dpp_i<PCR_DPP_HMIRROR>(q);
     return ((ol >> 2) == (K >> 2)) ? q : h;
 }
-__device__ static inline int grid_nn_query8(const GridView &g, const float4 *__restrict__ pts, bool live, float qx, float qy, float qz, float r2cap, int ol,
-                                            float *d1_out, float *d2_out) {
-    float d = r2cap, dd = r2cap; int id = -1;
+__device__ static inline int pcr_octet_min_i(int v) {
+    v = min(v, pcr_dpp_i<PCR_DPP_XOR1>(v)); v = min(v, pcr_dpp_i<PCR_DPP_XOR2>(v)); v = min(v, pcr_dpp_i<PCR_DPP_HMIRROR>(v));
+    return v;
+}
+// sorted insertion of (du, idx) into the lane's K+1 smallest: strict order by distance, the head also by index among equal distances
+template <int K> __device__ static inline void pcr_nn_insert(float (&d)[K + 1], int (&id)[K], float du, int idx) {
+    float cd = du; int ci = idx;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const bool lt = cd < d[k] || (k == 0 && cd == d[k] && ci < id[k]);
+        const float td = lt ? d[k] : cd; const int ti = lt ? id[k] : ci;
+        d[k] = lt ? cd : d[k]; id[k] = lt ? ci : id[k];
+        cd = td; ci = ti;
+    }
+    d[K] = fminf(d[K], cd);
+}
+template <int K>
+__device__ static inline void grid_nn_query8(const GridView &g, const float4 *__restrict__ pts, bool live, float qx, float qy, float qz, float r2cap, int ol,
+                                             int (&out_id)[K], float *d1_out, float *dnext_out) {
+    float d[K + 1]; int id[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { d[k] = r2cap; id[k] = -1; }
+    d[K] = r2cap;
     const unsigned mask = g.mask;
     int rng = 0;                                    // the lane's cell: first point | count << 22 (0: absent, empty or out of reach)
     float gx2 = 0.0f, gy2 = 0.0f, gz2 = 0.0f;       // squared gap between q and the neighbour cell, per axis (the same in all lanes of the octet)
@@ -257,7 +285,7 @@ __device__ static inline int grid_nn_query8(const GridView &g, const float4 *__r
             rng = r.y > 0 ? (r.x | (r.y << 22)) : 0;
         }
     }
-    float bound = r2cap;
+    float bound = r2cap;                            // upper bound of the octet's (K+1)-th smallest squared distance: what a cell must be nearer than
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const float g2k = ((k & 1) ? gx2 : 0.0f) + ((k & 2) ? gy2 : 0.0f) + ((k & 4) ? gz2 : 0.0f);
@@ -279,25 +307,109 @@ __device__ static inline int grid_nn_query8(const GridView &g, const float4 *__r
             for (int u = 0; u < PCR_GRID8_PPS; u++) {
                 const int j = j0 + u * OCT + ol;
                 const float du = pcr_d2(pp[u].x - qx, pp[u].y - qy, pp[u].z - qz);
-                if (j < cnt) {
-                    if (du < d || (du == d && first + j < id)) { dd = d; d = du; id = first + j; }
-                    else dd = fminf(dd, du);
-                }
+                if (j < cnt && (du < d[K] || (du == d[0] && first + j < id[0]))) pcr_nn_insert<K>(d, id, du, first + j);
             }
         }
-        // octet-wide second-nearest so far: the winner lane's runner-up or another lane's best
-        const float m1 = pcr_octet_min(d);
-        const unsigned hold = (unsigned)(__ballot(d == m1) >> (threadIdx.x & 56)) & 0xffu;
-        const bool winner = ol == (int)__builtin_ctz(hold | 0x100u);
-        bound = pcr_octet_min(winner ? dd : d);
+        // octet-wide bound: K rounds of "the lanes holding the smallest head drop it" on a copy of the distances, then the smallest head left
+        // is the (K+1)-th smallest or later (lanes tying for a head drop together): an upper bound, which is all the pruning needs
+        {
+            float h[K + 1];
+#pragma unroll
+            for (int t = 0; t <= K; t++) h[t] = d[t];
+#pragma unroll
+            for (int rd = 0; rd < K; rd++) {
+                const float m = pcr_octet_min(h[0]);
+                const bool pop = h[0] == m && m < r2cap;
+#pragma unroll
+                for (int t = 0; t < K; t++) h[t] = pop ? h[t + 1] : h[t];
+                h[K] = pop ? r2cap : h[K];
+            }
+            bound = pcr_octet_min(h[0]);
+        }
     }
-    const float dmin = pcr_octet_min(d);
-    int cand = (d == dmin && id >= 0) ? id : 0x7fffffff;
-    cand = min(cand, pcr_dpp_i<PCR_DPP_XOR1>(cand)); cand = min(cand, pcr_dpp_i<PCR_DPP_XOR2>(cand)); cand = min(cand, pcr_dpp_i<PCR_DPP_HMIRROR>(cand));
-    const float sec = pcr_octet_min(id == cand ? dd : d);
-    if (cand == 0x7fffffff) { *d1_out = r2cap; *d2_out = r2cap; return -1; }
-    *d1_out = dmin; *d2_out = sec;
-    return cand;
+    // merge: K pops of the octet's smallest head (ties -> lower index), then the smallest head left is the (K+1)-th squared distance
+    float d1 = r2cap;
+#pragma unroll
+    for (int rd = 0; rd < K; rd++) {
+        const float m = pcr_octet_min(d[0]);
+        const int w = pcr_octet_min_i((d[0] == m && id[0] >= 0) ? id[0] : 0x7fffffff);
+        const bool pop = d[0] == m && id[0] == w && w != 0x7fffffff;
+        out_id[rd] = w != 0x7fffffff ? w : -1;
+        if (rd == 0) d1 = m;
+#pragma unroll
+        for (int t = 0; t + 1 < K; t++) { d[t] = pop ? d[t + 1] : d[t]; id[t] = pop ? id[t + 1] : id[t]; }
+        d[K - 1] = pop ? d[K] : d[K - 1]; id[K - 1] = pop ? -1 : id[K - 1];
+        d[K] = pop ? r2cap : d[K];
+    }
+    *d1_out = d1;
+    *dnext_out = pcr_octet_min(d[0]);
+}
+
+// The same search with ONE QUERY PER WAVEFRONT (wave-uniform query): the eight 8-lane groups of the wavefront take the eight cells of the
+// block at once -- group b looks cell b up and scans it, 64 points per step -- so a search is one lookup and (cells of up to 64 points) one
+// scan step, where the octet form walks the cells one after the other with the bound between them.  For workgroups with a handful of
+// pending queries (the usual case since the list certificates: 0.3 % of the queries are searched again per launch): a wavefront per query
+// has the answer after two round trips, an octet per query after four or five.  Same list (the head exactly: ties -> lower index) and
+// the same (K+1)-th distance as grid_nn_query8.
+__device__ static inline int pcr_wave_min_i(int v) {          // over all 64 lanes, result in every lane (DPP inside the rows, permlane swaps across)
+    v = min(v, pcr_dpp_i<PCR_DPP_XOR1>(v)); v = min(v, pcr_dpp_i<PCR_DPP_XOR2>(v)); v = min(v, pcr_dpp_i<PCR_DPP_HMIRROR>(v)); v = min(v, pcr_dpp_i<PCR_DPP_MIRROR>(v));
+    unsigned o; unsigned a = pcr_swap16((unsigned)v, &o);
+    v = min((int)a, (int)o);
+    a = pcr_swap32((unsigned)v, &o);
+    return min((int)a, (int)o);
+}
+template <int K>
+__device__ static inline void grid_nn_query64(const GridView &g, const float4 *__restrict__ pts, float qx, float qy, float qz, float r2cap, int lane,
+                                              int (&out_id)[K], float *d1_out, float *dnext_out) {
+    const int b = lane >> 3, ol = lane & 7;
+    float d[K + 1]; int id[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { d[k] = r2cap; id[k] = -1; }
+    d[K] = r2cap;
+    int first = 0, cnt = 0;
+    {
+        const float fx = (qx - g.org[0]) * g.inv_unit[0], fy = (qy - g.org[1]) * g.inv_unit[1], fz = (qz - g.org[2]) * g.inv_unit[2];
+        const int cx = (int)floorf(fx) >> g.L, cy = (int)floorf(fy) >> g.L, cz = (int)floorf(fz) >> g.L;
+        const float lox = qx - (g.org[0] + (float)cx * g.cell[0]), loy = qy - (g.org[1] + (float)cy * g.cell[1]), loz = qz - (g.org[2] + (float)cz * g.cell[2]);
+        const float slack = 2e-3f * g.cell[0];
+        const bool upx = lox + lox > g.cell[0], upy = loy + loy > g.cell[1], upz = loz + loz > g.cell[2];
+        const float ax = fmaxf((upx ? g.cell[0] - lox : lox) - slack, 0.0f), ay = fmaxf((upy ? g.cell[1] - loy : loy) - slack, 0.0f),
+                    az = fmaxf((upz ? g.cell[2] - loz : loz) - slack, 0.0f);
+        const int x = cx + ((b & 1) ? (upx ? 1 : -1) : 0), y = cy + ((b & 2) ? (upy ? 1 : -1) : 0), z = cz + ((b & 4) ? (upz ? 1 : -1) : 0);
+        const float g2 = ((b & 1) ? ax * ax : 0.0f) + ((b & 2) ? ay * ay : 0.0f) + ((b & 4) ? az * az : 0.0f);
+        const int lim = (1 << 21) >> g.L;
+        if (g2 < r2cap && x >= 0 && y >= 0 && z >= 0 && x < lim && y < lim && z < lim) {
+            const int2 r = pcr_grid_lookup(g, g.mask, x, y, z);
+            first = r.x; cnt = r.y > 0 ? r.y : 0;
+        }
+    }
+    for (int j0 = 0; __ballot(j0 < cnt) != 0ull; j0 += PCR_GRID8_PPS * OCT) {
+        float4 pp[PCR_GRID8_PPS];
+#pragma unroll
+        for (int u = 0; u < PCR_GRID8_PPS; u++) { const int j = j0 + u * OCT + ol; pp[u] = pts[first + (j < cnt ? j : 0)]; }
+#pragma unroll
+        for (int u = 0; u < PCR_GRID8_PPS; u++) {
+            const int j = j0 + u * OCT + ol;
+            const float du = pcr_d2(pp[u].x - qx, pp[u].y - qy, pp[u].z - qz);
+            if (j < cnt && (du < d[K] || (du == d[0] && first + j < id[0]))) pcr_nn_insert<K>(d, id, du, first + j);
+        }
+    }
+    // merge over the 64 lanes: K pops of the smallest head (ties -> lower index); distances are >= 0, so they order like their bit patterns
+    float d1 = r2cap;
+#pragma unroll
+    for (int rd = 0; rd < K; rd++) {
+        const float m = __int_as_float(pcr_wave_min_i(__float_as_int(d[0])));
+        const int w = pcr_wave_min_i((d[0] == m && id[0] >= 0) ? id[0] : 0x7fffffff);
+        const bool pop = d[0] == m && id[0] == w && w != 0x7fffffff;
+        out_id[rd] = w != 0x7fffffff ? w : -1;
+        if (rd == 0) d1 = m;
+#pragma unroll
+        for (int t = 0; t + 1 < K; t++) { d[t] = pop ? d[t + 1] : d[t]; id[t] = pop ? id[t + 1] : id[t]; }
+        d[K - 1] = pop ? d[K] : d[K - 1]; id[K - 1] = pop ? -1 : id[K - 1];
+        d[K] = pop ? r2cap : d[K];
+    }
+    *d1_out = d1;
+    *dnext_out = __int_as_float(pcr_wave_min_i(__float_as_int(d[0])));
 }
 
 // greedy nearest-box descent from the root (cold start of a 1-NN query): returns a leaf id (octet-uniform)

@@ -129,8 +129,12 @@ def assert_reference_fixed_point(oracle, src_xyz, tgt_xyz, voxel, max_dist, T_de
     o = {k: max(x[k] for x in os_) for k in ("dfit", "drmse", "step_rad", "step_m")}
     print(f"fixed point {what}: device end pose -> next reference step {d['step_rad']:.1e} rad {d['step_m']:.1e} m, dfit {d['dfit']:.1e} drmse {d['drmse']:.1e};"
           f" oracle end pose(s, {len(poses)}) -> {o['step_rad']:.1e} rad {o['step_m']:.1e} m, dfit {o['dfit']:.1e} drmse {o['drmse']:.1e}  (n {d['n_src']})")
-    slack_fit = 3.0 / max(d["n_src"], 1)
-    assert d["dfit"] <= max(1e-6 + slack_fit, 3.0 * o["dfit"]), (what, d, o)
+    # Rim flips of one more step are a COUNT (a handful out of ~1e5 correspondences: on the 200k-point pairs the oracle's own end poses show 1, 1
+    # and 4 of them, a device end pose 0, 2 and 5): the device is held to the oracle's count plus three standard deviations of a count of that
+    # size plus the three float32-rim flips, not to three times a sample of one
+    flips_o = o["dfit"] * max(d["n_src"], 1)
+    slack_fit = (3.0 + 3.0 * np.sqrt(flips_o + 1.0)) / max(d["n_src"], 1)
+    assert d["dfit"] <= max(1e-6 + slack_fit, 3.0 * o["dfit"], o["dfit"] + slack_fit), (what, d, o)
     # a correspondence entering or leaving at the rim (d = max_dist) moves the RMSE by (max_dist^2 - rmse^2) / (2 rmse n_corr): that much per flip is not motion
     flips = round(d["dfit"] * d["n_src"])
     per_flip = max_dist * max_dist / (2.0 * max(d["rmse"], 1e-9) * max(d["fitness"] * d["n_src"], 1.0))

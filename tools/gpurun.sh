@@ -1,7 +1,7 @@
 #!/bin/bash
 # gpurun with a pre-flight: rebuild the in-tree library (the GPU box runs the snapshot's .so) and refuse to go when it does not build.
 # usage: tools/gpurun.sh <tag> <steps-file> [timeout]
-set -e
+set -e -o pipefail
 cd "$(dirname "$0")/.."
 bash point-cloud-registration-with-global-refinement_amd/csrc/build.sh 2>&1 | grep -v "warning\|^ \|^$\|generated" | tail -3
 make -s -C oracle > /dev/null 2>&1 || true

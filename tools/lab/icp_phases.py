@@ -1,0 +1,38 @@
+"""Diagnostic: where a launch of the fused GICP iteration kernel spends its time.  Runs the default bench workload's pairs (a) one pair at a
+time, (b) one lockstep group of six alone, (c) four groups in flight, once per value of PCR_ICP_PHASE (phase p: ticks from a workgroup's
+entry to the end of 1 prologue / 2 certificates / 3 searches / 4 linearisation / 5 row sums; mean over the workgroups with + 16, else the maximum)."""
+import ctypes, importlib, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+P = importlib.import_module("point-cloud-registration-with-global-refinement_amd")
+syn = importlib.import_module("point-cloud-registration-with-global-refinement_amd.synthetic")
+lib = importlib.import_module("point-cloud-registration-with-global-refinement_amd._lib").load()
+reg = P.registration
+base = [syn.make_pair(200000, index=i) for i in range(4)]
+pairs = [syn.derive_pair(base[i % 4], i // 4) if i >= 4 else base[i] for i in range(24)] if hasattr(syn, "derive_pair") else base * 6
+clouds = [(P.PointCloud(p.source), P.PointCloud(p.target)) for p in pairs]
+est = reg.TransformationEstimationForGeneralizedICP(reg.L1Loss()); crit = reg.ICPConvergenceCriteria(1e-6, 1e-6, 100)
+def prof(enable=None, reset=False):
+    out = (ctypes.c_double * 16)()
+    lib.pcr_pool_profile(ctypes.c_int(0), ctypes.c_int(-1 if enable is None else int(enable)), out, ctypes.c_int(int(reset)))
+    return [out[k] for k in range(16)]
+def run(n, inflight, group):
+    batch = [(clouds[i][0], clouds[i][1], pairs[i].T_init) for i in range(n)]
+    p0 = pairs[0]
+    return reg.register_pairs_plan(batch, "gicp", p0.voxel_sizes, p0.max_distances_script, est, crit, 30, 1.0, 20, inflight=inflight, with_correspondences=True, group=group)
+names = {1: "prologue", 2: "certificates", 3: "searches", 4: "linearisation", 5: "row sums", 0: "published"}
+for label, n, inflight, group in (("one pair at a time", 4, 1, 1), ("one group of 6 alone", 6, 1, 6), ("4 groups of 6 in flight", 24, 4, 6)):
+    run(n, inflight, group)
+    for mean in (16, 0):
+        row = []
+        for ph in (1, 2, 3, 4, 5, 0):
+            os.environ["PCR_ICP_PHASE"] = str(ph + mean)
+            prof(enable=1, reset=True)
+            run(n, inflight, group)
+            torch.cuda.synchronize()
+            q = prof(enable=0, reset=True)
+            live = q[3]
+            row.append(f"{names[ph]} {q[14] / live:.1f}")
+            extra = f"| A+B+C slowest {q[6] / live:.1f}, sums gathered {q[7] / live:.1f}, in-kernel {q[2] / live:.1f}, events {1e3 * q[0] / q[1] if q[1] else 0:.1f} us/launch, searched {q[11] / (q[4] / 48):.4f}"
+        print(f"{label:26s} {'mean over workgroups' if mean else 'slowest workgroup':22s}: " + ", ".join(row) + " " + extra, flush=True)
