@@ -53,7 +53,6 @@ struct IcpArgs {
     int32_t *match; int src_cap;
     float4 *ref; int32_t *rbest;                 // per source point: position and margin / nearest point of its last search (skip certificate, tree-walk form)
     int4 *clist;                                 // cell-hash form: the PCR_NN_K nearest target points of the last search (list certificate); ref.w = distance of the next one
-    float4 *pend_q; int32_t *pend_i; int *pend_n; // streaming iteration of large clouds: this launch's pending queries (position + hint, point), their count
     float r2s, rs_minus_r;                       // search cap (r + g)^2 of the certificate mode and g = the unmatched margin
     int verify;                                  // diagnostics (PCR_ICP_VERIFY): search certified queries too and report disagreements
     IcpState *state;
@@ -434,172 +433,6 @@ template <bool GRID> __global__ void __launch_bounds__(ICP_BS) __attribute__((am
 // group form (lockstep group of pairs, blockIdx.y = pair; arguments in device memory)
 template <bool GRID> __global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_icp_nn_g(const IcpArgs *__restrict__ a) { d_icp_nn<GRID>(a[blockIdx.y]); }
 
-// ---- large clouds (icp_stream_min() points and more): the iteration as TWO streaming kernels.  k_icp_ab = phases A and B of the fused
-// kernel below without its float64 part: one source point per LANE for the certificate test (the cold kernel above spends an octet on
-// it), the workgroup's pending queries compacted in LDS, its 32 octets search them; 64 VGPRs = 8 wavefronts per SIMD where the fused
-// kernel's 122 leave 4, and k_icp_iter follows with one 512-point tile per workgroup.  At 0.5-1.6M source points a launch of the fused
-// kernel is 2-3 rounds of workgroups that mostly wait on dependent loads; the two kernel boundaries cost less than that.
-template <bool GRID>
-__device__ static inline void d_icp_ab(const IcpArgs &a) {
-    IcpState *st = a.state;
-    constexpr int OPB = ICP_BS / OCT;
-    __shared__ OctMeta m;
-    __shared__ OctStack<OPB> stk;
-    __shared__ float4 rec_q[ICP_BS];
-    __shared__ int rec_i[ICP_BS];
-    __shared__ int n_rec;
-    const int done = st->done;
-    const int ns = *a.ns_ptr, nt = *a.nt_ptr;
-    const int tid = threadIdx.x, lane = tid & 63, oct = lane >> 3, ol = lane & 7, ob = tid >> 3;
-    const int i = blockIdx.x * ICP_BS + tid;
-    const int ic = i < a.src_cap ? i : 0;
-    const float4 pf = a.src_pts[ic];
-    const int mraw = a.match[ic];
-    const float4 refv = a.ref[ic];
-    int rb = GRID ? -1 : a.rbest[ic];
-    const int4 lst = GRID ? a.clist[ic] : make_int4(-1, -1, -1, -1);
-    double T[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) T[k] = st->T[k];
-    int mword = 0;
-    if (tid < (int)(sizeof(OctMeta) / 4)) mword = ((const int *)a.tgt.meta)[tid];
-    if (done) return;
-    if ((int)blockIdx.x * ICP_BS >= ns) return;
-    if (blockIdx.x == 0 && tid == 0) st->t_start = wall_clock64();
-    if (tid < (int)(sizeof(OctMeta) / 4)) ((int *)&m)[tid] = mword;
-    if (tid == 0) n_rec = 0;
-    __syncthreads();
-    {
-        bool need = false;
-        float qx = 0, qy = 0, qz = 0; int hint = -1;
-        if (i < ns) {
-            const double px = pf.x, py = pf.y, pz = pf.z;
-            qx = (float)(T[0] * px + T[1] * py + T[2] * pz + T[3]);
-            qy = (float)(T[4] * px + T[5] * py + T[6] * pz + T[7]);
-            qz = (float)(T[8] * px + T[9] * py + T[10] * pz + T[11]);
-            hint = mraw >= 0 ? mraw : (mraw <= -2 ? -(mraw + 2) : -1);
-            const float ex = qx - refv.x, ey = qy - refv.y, ez = qz - refv.z;
-            bool certified = refv.w > 0.0f;
-            if (GRID) { if (certified) certified = icp_list_eval(a.tgt_pts, qx, qy, qz, refv, lst, a.r2f, &rb) != 0; }
-            else certified = certified && pcr_d2(ex, ey, ez) < refv.w * refv.w;
-            need = nt > 0 && !certified;
-            if (certified && rb >= 0 && mraw != rb) a.match[i] = rb;     // k_icp_iter may have turned it into a hint (beyond max_dist)
-            if (GRID && certified && rb < 0 && mraw >= 0) a.match[i] = -1;
-        }
-        const unsigned long long nbm = __ballot(need);
-        int base = 0;
-        if (lane == 0 && nbm != 0ull) base = atomicAdd(&n_rec, __builtin_popcountll(nbm));
-        base = __builtin_amdgcn_readfirstlane(base);            // (lane 0 holds it; no ds_bpermute round trip)
-        if (need) {
-            const int slot = base + __builtin_popcountll(nbm & ((1ull << lane) - 1ull));
-            rec_q[slot] = make_float4(qx, qy, qz, __int_as_float(hint)); rec_i[slot] = i;
-        }
-    }
-    __syncthreads();
-    const int npend = n_rec;
-    if (tid == 0 && npend > 0) atomicAdd(&st->searched, (unsigned long long)npend);
-    for (int e0 = 0; e0 < npend; e0 += OPB) {
-        const int e = e0 + ob;
-        const bool live = e < npend;
-        if (__ballot(live) == 0ull) continue;
-        float qx = 0, qy = 0, qz = 0; int hint = -1, qi = 0;
-        if (live) { const float4 r = rec_q[e]; qx = r.x; qy = r.y; qz = r.z; hint = __float_as_int(r.w); qi = rec_i[e]; }
-        int start_pt = 0; float d1 = 0, d2 = 0;
-        int best; int nnk[PCR_NN_K];
-        if (GRID) { grid_nn_query8<PCR_NN_K>(a.grid, a.tgt_pts, live, qx, qy, qz, a.r2s, ol, nnk, &d1, &d2); best = nnk[0]; start_pt = hint >= 0 ? hint : 0; }
-        else best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.r2s, hint, ol, oct, ob, &start_pt, nullptr, &d1, &d2);
-        if (ol == 0 && live) icp_store_cert<GRID>(a, qi, qx, qy, qz, best, nnk, d1, d2, start_pt);
-    }
-}
-template <bool GRID> __global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_icp_ab(IcpArgs a) { d_icp_ab<GRID>(a); }
-
-// The same in two kernels with ONE list for the whole cloud (PCR_ICP_COMPACT, default for the streaming form): k_icp_cert tests the
-// certificates, one point per lane, and appends the pending queries to a.pend_q / a.pend_i (one atomic per wavefront); k_icp_search
-// serves the list one query per octet with a fixed grid striding over it -- every wavefront full whatever the share of pending queries
-// of a region (per-workgroup lists left 32 octets to 16 % of 256 points on average and 8 rounds to a tile that had moved).
-// k_icp_lin zeroes the count for the next launch.
-#define CERT_BS 1024      // one atomic on the list's count per WORKGROUP: 25 000 wavefronts adding to one address took longer than the searches
-template <bool GRID>
-__global__ void __launch_bounds__(CERT_BS) k_icp_cert(IcpArgs a) {
-    IcpState *st = a.state;
-    __shared__ int wave_n[CERT_BS / 64];
-    __shared__ int wg_base;
-    const int done = st->done;
-    const int ns = *a.ns_ptr, nt = *a.nt_ptr;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int i = blockIdx.x * CERT_BS + tid;
-    const int ic = i < a.src_cap ? i : 0;
-    const float4 pf = a.src_pts[ic];
-    const int mraw = a.match[ic];
-    const float4 refv = a.ref[ic];
-    int rb = GRID ? -1 : a.rbest[ic];
-    const int4 lst = GRID ? a.clist[ic] : make_int4(-1, -1, -1, -1);
-    double T[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) T[k] = st->T[k];
-    if (done) return;
-    if ((int)blockIdx.x * CERT_BS >= ns) return;
-    if (blockIdx.x == 0 && tid == 0) st->t_start = wall_clock64();
-    bool need = false;
-    float qx = 0, qy = 0, qz = 0; int hint = -1;
-    if (i < ns) {
-        const double px = pf.x, py = pf.y, pz = pf.z;
-        qx = (float)(T[0] * px + T[1] * py + T[2] * pz + T[3]);
-        qy = (float)(T[4] * px + T[5] * py + T[6] * pz + T[7]);
-        qz = (float)(T[8] * px + T[9] * py + T[10] * pz + T[11]);
-        hint = mraw >= 0 ? mraw : (mraw <= -2 ? -(mraw + 2) : -1);
-        const float ex = qx - refv.x, ey = qy - refv.y, ez = qz - refv.z;
-        bool certified = refv.w > 0.0f;
-        if (GRID) { if (certified) certified = icp_list_eval(a.tgt_pts, qx, qy, qz, refv, lst, a.r2f, &rb) != 0; }
-        else certified = certified && pcr_d2(ex, ey, ez) < refv.w * refv.w;
-        need = nt > 0 && !certified;
-        if (certified && rb >= 0 && mraw != rb) a.match[i] = rb;     // k_icp_lin may have turned it into a hint (beyond max_dist)
-        if (GRID && certified && rb < 0 && mraw >= 0) a.match[i] = -1;
-    }
-    const unsigned long long nbm = __ballot(need);
-    if (lane == 0) wave_n[wv] = __builtin_popcountll(nbm);
-    __syncthreads();
-    if (tid == 0) {
-        int tot = 0;
-        for (int w = 0; w < CERT_BS / 64; w++) { const int c = wave_n[w]; wave_n[w] = tot; tot += c; }
-        wg_base = tot > 0 ? atomicAdd(a.pend_n, tot) : 0;
-    }
-    __syncthreads();
-    if (need) {
-        const int slot = wg_base + wave_n[wv] + __builtin_popcountll(nbm & ((1ull << lane) - 1ull));
-        a.pend_q[slot] = make_float4(qx, qy, qz, __int_as_float(hint)); a.pend_i[slot] = i;
-    }
-}
-template <bool GRID>
-__global__ void __launch_bounds__(ICP_BS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_icp_search(IcpArgs a) {
-    IcpState *st = a.state;
-    constexpr int OPB = ICP_BS / OCT;
-    __shared__ OctMeta m;
-    __shared__ OctStack<OPB> stk;
-    const int done = st->done;
-    const int npend = *a.pend_n;
-    const int tid = threadIdx.x, lane = tid & 63, oct = lane >> 3, ol = lane & 7, ob = tid >> 3;
-    int mword = 0;
-    if (tid < (int)(sizeof(OctMeta) / 4)) mword = ((const int *)a.tgt.meta)[tid];
-    if (done) return;
-    if ((int)blockIdx.x * OPB >= npend) return;
-    if (blockIdx.x == 0 && tid == 0) atomicAdd(&st->searched, (unsigned long long)npend);
-    if (tid < (int)(sizeof(OctMeta) / 4)) ((int *)&m)[tid] = mword;
-    __syncthreads();
-    for (int e0 = blockIdx.x * OPB; e0 < npend; e0 += gridDim.x * OPB) {
-        const int e = e0 + ob;
-        const bool live = e < npend;
-        if (__ballot(live) == 0ull) continue;
-        float qx = 0, qy = 0, qz = 0; int hint = -1, qi = 0;
-        if (live) { const float4 r = a.pend_q[e]; qx = r.x; qy = r.y; qz = r.z; hint = __float_as_int(r.w); qi = a.pend_i[e]; }
-        int start_pt = 0; float d1 = 0, d2 = 0;
-        int best; int nnk[PCR_NN_K];
-        if (GRID) { grid_nn_query8<PCR_NN_K>(a.grid, a.tgt_pts, live, qx, qy, qz, a.r2s, ol, nnk, &d1, &d2); best = nnk[0]; start_pt = hint >= 0 ? hint : 0; }
-        else best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.r2s, hint, ol, oct, ob, &start_pt, nullptr, &d1, &d2);
-        if (ol == 0 && live) icp_store_cert<GRID>(a, qi, qx, qy, qz, best, nnk, d1, d2, start_pt);
-    }
-}
-
 // ---- one correspondence in float64: accumulates its 30 sums into acc[]; `cand` = candidate target point (or < 0)
 struct IcpPre { float4 pf, sn, tf, tn; };    // the inputs of a correspondence already in registers (fused kernel: gathered under its certificate phase)
 template <int MODE>
@@ -910,7 +743,6 @@ __device__ static inline void d_icp_lin(const IcpArgs &a) {
 #pragma unroll
     for (int k = 0; k < 12; k++) T[k] = st->T[k];
     if (done) return;
-    if (a.pend_n && blockIdx.x == 0 && threadIdx.x == 0) *a.pend_n = 0;        // the list of k_icp_cert / k_icp_search is consumed
     int nb = (ns + LIN_BS - 1) / LIN_BS;
     if (nb < 1) nb = 1;
     if ((int)blockIdx.x >= nb) return;
@@ -1210,13 +1042,9 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     ArenaMark mark(ctx);
     const int cap = src->cap > 0 ? src->cap : 1;
     static const bool use_skip = !(getenv("PCR_ICP_SKIP") && atoi(getenv("PCR_ICP_SKIP")) == 0);
-    // PCR_ICP_STREAM_MIN: source points from which an iteration is k_icp_ab + k_icp_iter instead of the fused kernel (0 = never)
-    static const int stream_min = getenv("PCR_ICP_STREAM_MIN") ? atoi(getenv("PCR_ICP_STREAM_MIN")) : 400000;
     const int nblin = (cap + LIN_BS - 1) / LIN_BS;                  // k_icp_lin: one tile per workgroup
-    const bool stream = stream_min > 0 && cap >= stream_min && use_skip && max_dist < 1e15 && !use_cov && !getenv("PCR_ICP_STAMPS");
     const int nbmax = nblin < LIN_MAX_BLOCKS ? nblin : LIN_MAX_BLOCKS;
-    const int nbnn = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT), nbab = (cap + ICP_BS - 1) / ICP_BS;
-    const int nbsearch = nbnn < 2048 ? nbnn : 2048;                 // k_icp_search: a fixed grid strides over the pending list (8 workgroups of 4 wavefronts per CU)
+    const int nbnn = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT);
     const int tile_pts = fused_tile_points(ctx, cap, 1);
     const int nbf = ((cap + tile_pts - 1) / tile_pts + 7) & ~7;      // workgroups of the fused kernel: one per tile of source points, a multiple of 8 (XCD order)
     IcpState *st = arena<IcpState>(ctx, 1);
@@ -1235,13 +1063,6 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
         const double rs = max_dist + g;
         a.r2s = (float)(rs * rs * (1.0 + 1e-6)); a.rs_minus_r = (float)g;
         a.verify = getenv("PCR_ICP_VERIFY") ? 1 : 0;
-        // PCR_ICP_COMPACT=0: the streaming form with per-workgroup pending lists (k_icp_ab) instead of one list for the cloud
-        static const bool compact = !(getenv("PCR_ICP_COMPACT") && atoi(getenv("PCR_ICP_COMPACT")) == 0);
-        if (stream && compact) {
-            a.pend_q = arena<float4>(ctx, cap); a.pend_i = arena<int32_t>(ctx, cap); a.pend_n = arena<int>(ctx, 1);
-            if (!a.pend_q || !a.pend_i || !a.pend_n) return PCR_ENOMEM;
-            PCR_HIP_CHECK(ctx, hipMemsetAsync(a.pend_n, 0, sizeof(int), ctx->stream));
-        }
     }
     if (icp_use_grid() && !use_cov) {       // cell hash of the target for radii of a few voxels (pcr_octree.h GridView); the octree serves the others
         const int L = pcr_grid_level_for(tgt, std::sqrt((double)(a.ref ? a.r2s : a.r2f)));
@@ -1271,22 +1092,11 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     static const bool use_graph = !(getenv("PCR_ICP_GRAPH") && atoi(getenv("PCR_ICP_GRAPH")) == 0);
     static const bool use_fused = !(getenv("PCR_ICP_FUSED") && atoi(getenv("PCR_ICP_FUSED")) == 0);
     // launch 0 of a scale searches every query (cold): two kernels at full occupancy; later launches: the fused kernel
-    const bool fused = use_fused && a.ref && !use_cov && !stamp_path && nbf <= 4096 && !stream;
+    // (round 5: also for the 0.5-1.6M-point scales of config 5, which ran three streaming kernels per iteration -- certificates, one pending
+    // list for the cloud, tile linearisation -- while 17 % of their queries were searched again per launch; with list certificates it is 3 %
+    // and the one kernel is the faster form there too: 167 against 184 us per launch, 26.7 against 26.4 pairs/s.  The streaming kernels are gone.)
+    const bool fused = use_fused && a.ref && !use_cov && !stamp_path && nbf <= 4096;
     auto enqueue = [&](int launch_index) {
-        if (launch_index > 0 && stream && a.pend_n) {
-            if (grid) PCR_LAUNCH(ctx, k_icp_cert<true>, dim3((cap + CERT_BS - 1) / CERT_BS), dim3(CERT_BS), 0, ctx->stream, a);
-            else PCR_LAUNCH(ctx, k_icp_cert<false>, dim3((cap + CERT_BS - 1) / CERT_BS), dim3(CERT_BS), 0, ctx->stream, a);
-            if (grid) PCR_LAUNCH(ctx, k_icp_search<true>, dim3(nbsearch), dim3(ICP_BS), 0, ctx->stream, a);
-            else PCR_LAUNCH(ctx, k_icp_search<false>, dim3(nbsearch), dim3(ICP_BS), 0, ctx->stream, a);
-            PCR_LAUNCH(ctx, k_icp_lin, dim3(nblin), dim3(LIN_BS), 0, ctx->stream, a);
-            return;
-        }
-        if (launch_index > 0 && stream) {
-            if (grid) PCR_LAUNCH(ctx, k_icp_ab<true>, dim3(nbab), dim3(ICP_BS), 0, ctx->stream, a);
-            else PCR_LAUNCH(ctx, k_icp_ab<false>, dim3(nbab), dim3(ICP_BS), 0, ctx->stream, a);
-            PCR_LAUNCH(ctx, k_icp_lin, dim3(nblin), dim3(LIN_BS), 0, ctx->stream, a);
-            return;
-        }
         if (fused && launch_index > 0) {
             PCR_FUSED_LAUNCH(ctx, k_icp_fused, grid, tile_pts, dim3(nbf), a);
             return;
@@ -1302,7 +1112,7 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
         *out = nullptr;
         if (!use_graph || stamp_path) return PCR_OK;
         std::string key((const char *)&a, sizeof a);
-        const int extra[7] = {nbnn, nbmax, use_cov ? 1 : 0, len, fused ? nbf + (tile_pts << 16) : (stream ? -nblin : 0), which, grid ? 1 : 0};
+        const int extra[7] = {nbnn, nbmax, use_cov ? 1 : 0, len, fused ? nbf + (tile_pts << 16) : 0, which, grid ? 1 : 0};
         key.append((const char *)extra, sizeof extra);
         for (auto &g : ctx->icp_graphs) if (g.key == key) { *out = g.exec; return PCR_OK; }
         hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;

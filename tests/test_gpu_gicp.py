@@ -280,14 +280,11 @@ def test_register_pairs_ragged_sizes_stress(P, small_pair):
 
 def test_switches_do_not_change_the_result():
     """Every execution switch (merged voxel pass, batched SOR chain, fused iteration kernel, skip certificates, hipGraph replay, ring
-    depth, lanes, cell hash or octree for the correspondence search, streaming or fused iteration) only changes HOW the same arithmetic is scheduled: pose bits, iteration counts and cloud counts are identical."""
+    depth, lanes, cell hash or octree for the correspondence search) only changes HOW the same arithmetic is scheduled: pose bits, iteration counts and cloud counts are identical."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     variants = [{}, {"PCR_VOXEL_MERGED": "0"}, {"PCR_SOR_BATCH": "0"}, {"PCR_ICP_FUSED": "0"}, {"PCR_ICP_SKIP": "0"}, {"PCR_ICP_GRAPH": "0"},
                 {"PCR_ICP_GRID": "0"}, {"PCR_ICP_GRID": "0", "PCR_ICP_FUSED": "0"},      # correspondence search over the octree instead of the cell hash
-                {"PCR_ICP_STREAM_MIN": "1000"},                                          # the two streaming kernels of large clouds (k_icp_ab + k_icp_lin) instead of the fused one
-                {"PCR_ICP_STREAM_MIN": "1000", "PCR_ICP_GRID": "0"},
-                {"PCR_ICP_STREAM_MIN": "1000", "PCR_ICP_COMPACT": "0"},                  # ... with per-workgroup pending lists (k_icp_ab) instead of one list for the cloud
                 {"PCR_PIPELINE": "1", "PCR_LANES": "1"}, {"PCR_VOXEL_MERGED": "0", "PCR_ICP_FUSED": "0", "PCR_ICP_GRAPH": "0", "PCR_PIPELINE": "2"}]
     lines = []
     for env in variants:
