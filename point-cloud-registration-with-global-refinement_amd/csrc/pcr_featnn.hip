@@ -1043,7 +1043,7 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         a.pool_used = pool_used; a.pool_cap = pool_cap; a.chunk_fill = chunk_fill; a.rec_q = rec_q; a.rec_row = rec_row; a.rec_w = rec_w; a.flags = flags;
         a.L = nullptr; a.L_stride = 0; a.n_qt = 0; a.prelist = nullptr; a.pre_mode = 0; a.n_bound = 0; a.xcd_chunk = 0; a.stats = nullptr;
         unsigned long long *stats = nullptr;
-        if (check) { stats = arena<unsigned long long>(ctx, 16); if (!stats) return PCR_ENOMEM; PCR_HIP_CHECK(ctx, hipMemsetAsync(stats, 0, 128, ctx->stream)); a.stats = stats; }
+        if (check || ctx->profiling) { stats = arena<unsigned long long>(ctx, 16); if (!stats) return PCR_ENOMEM; PCR_HIP_CHECK(ctx, hipMemsetAsync(stats, 0, 128, ctx->stream)); a.stats = stats; }
         if (prune) {
             const int nqt = (nq + 63) / 64, nbt = steps;
             float *L = arena<float>(ctx, (size_t)nqt * nbt);
@@ -1093,6 +1093,12 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         PCR_LAUNCH(ctx, k_fn_exact_min, dim3(xgrid), dim3(256), 0, ctx->stream, x, pool_cap);
         PCR_LAUNCH(ctx, k_fn_exact_arg, dim3(xgrid), dim3(256), 0, ctx->stream, x, pool_cap);
         PCR_LAUNCH(ctx, k_fn_finish, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, x);
+        if (ctx->profiling && !check) {     // bench.py: (wavefront, 64-row step) pairs the screen computed, of all -- what it executes of the all-pairs flops
+            unsigned long long hs[4] = {0, 0, 0, 0};
+            PCR_HIP_CHECK(ctx, hipMemcpyAsync(hs, stats, 32, hipMemcpyDeviceToHost, ctx->stream));
+            PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->prof[12] += (double)hs[1]; ctx->prof[15] += (double)groups * (FN_WG / 64) * (double)steps;
+        }
         if (check) {
             int h[2] = {0, 0}; float hd[2] = {0, 0};
             PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h[0], pool_used, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

@@ -36,12 +36,18 @@ def block_bounds(costs, world_size: int) -> list:
             lo = mid + 1
     b = cuts(lo)
     b = b[:-1] + [P] * (W + 1 - (len(b) - 1))                   # fewer than W blocks: the rest are empty for now
-    changed = True
-    while changed:                                              # an empty block takes the last pair of a predecessor that holds several
-        changed = False                                         # (one pair costs at most max(c) <= lo: the optimum stays)
-        for r in range(W - 1, 0, -1):
-            if b[r] == b[r + 1] and b[r] - b[r - 1] >= 2:
-                b[r] -= 1; changed = True
+    # An empty block (the greedy cut leaves them at the back) takes a pair from the nearest block before it that holds several: every cut
+    # between the two moves one pair to the left, the one-pair blocks in between pass their pair on (one pair costs at most max(c) <= lo:
+    # the optimum stays).  [1, 1, 1, 3] on 3 ranks: greedy [0, 3, 4, 4] -> [0, 2, 3, 4].
+    while True:
+        empty = next((r for r in range(W - 1, 0, -1) if b[r] == b[r + 1]), None)
+        if empty is None:
+            break
+        donor = next((j for j in range(empty - 1, -1, -1) if b[j + 1] - b[j] >= 2), None)
+        if donor is None:
+            break                                               # fewer pairs than ranks: some blocks stay empty
+        for k in range(donor + 1, empty + 1):
+            b[k] -= 1
     return b
 
 

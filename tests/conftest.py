@@ -141,3 +141,41 @@ def assert_reference_fixed_point(oracle, src_xyz, tgt_xyz, voxel, max_dist, T_de
     assert d["drmse"] <= max(5e-6 + flips * per_flip, 3.0 * o["drmse"]), (what, d, o, flips, per_flip)
     assert d["step_rad"] <= max(TOL_RAD / 4, 3.0 * o["step_rad"]) and d["step_m"] <= max(TOL_M / 4, 3.0 * o["step_m"]), (what, d, o)
     return d, o
+
+
+def assert_fpfh_explained(dev, ref, what="FPFH"):
+    """Device FPFH rows against the oracle's on the same float32 points and normals: >= 99.9 % of the entries agree to 1e-3 relative, and every
+    entry that does not is ONE pair feature voting in an adjacent bin of the same 11-bin histogram (circularly adjacent for the angle feature
+    f0): inside each of the three histograms of a point the difference carries no mass and moves it only between neighbouring bins."""
+    assert dev.shape == ref.shape
+    blocks = dev.reshape(-1, 3, 11).sum(2)
+    has = ref.sum(1) > 0
+    assert np.allclose(blocks[has], 200.0, atol=2e-3)
+    assert (np.abs(dev[~has]).sum(1) == 0).all()
+    # a pair feature sitting exactly on a histogram edge may vote one bin over: rare, bounded
+    close = np.abs(dev - ref) <= 1e-3 * (1.0 + np.abs(ref))
+    assert close.mean() > 0.999, close.mean()
+    assert (np.abs(dev - ref).max(axis=1) < 5.0).mean() > 0.9999
+    # ... and that is ALL the mismatching entries are.  For a vote of weight w cast one bin over, the difference is (+w, -w) in neighbouring
+    # bins: its running sum is w in one bin, so L1(running sum) = L1(difference) / 2; a vote that landed g bins away would give g times that.
+    diff = (dev - ref).reshape(-1, 3, 11)
+    bad = ~close.reshape(-1, 3, 11).all(axis=2)                       # (point, histogram) pairs with a mismatching entry
+    print(f"{what}: {int((~close).sum())} of {close.size} entries differ by more than 1e-3 relative; {int(bad.sum())} histograms affected")
+    assert bad.mean() < 0.02, bad.mean()                                 # (on the golden pairs there are none at all)
+    if not bad.any():
+        return
+    d = diff[bad]
+    l1 = np.abs(d).sum(1)
+    assert (np.abs(d.sum(1)) <= 1e-3 * (1.0 + l1)).all()                # mass conserved inside the histogram
+    run = np.abs(np.cumsum(d, axis=1)).sum(1)
+    # f0 is an ANGLE (atan2 in [-pi, pi], histogram 0): its first and last bin are neighbours too -- a pair feature at +-pi is on an edge
+    wrap = d.copy()
+    is_f0 = np.nonzero(bad)[1] == 0
+    wrap[is_f0] = np.roll(d[is_f0], 5, axis=1)                          # bins 0 and 10 become 5 and 4
+    run_w = np.abs(np.cumsum(wrap, axis=1)).sum(1)
+    run = np.where(is_f0, np.minimum(run, run_w), run)
+    for k in range(min(3, len(d))):
+        print("   mismatching histogram", int(np.nonzero(bad)[1][k]), "bins", np.nonzero(np.abs(d[k]) > 1e-3 * (1 + np.abs(d[k]).max()))[0], "values", d[k][np.abs(d[k]) > 1e-6].round(4))
+    adjacent = run <= 0.5 * l1 * (1.0 + 1e-3) + 1e-3
+    assert adjacent.mean() > 0.98, adjacent.mean()                      # adjacent bins only ...
+    assert (run <= l1 * (1.0 + 1e-3) + 1e-3).all(), float((run / np.maximum(l1, 1e-12)).max())     # ... but for two chained edge votes in one histogram

@@ -60,3 +60,13 @@ def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
     """`python bench.py --gpus 2` (no torchrun around it): bench.py starts the ranks itself; both share device 0 here."""
     d = _run(["--gpus", "2", "--steps", "1", "--warmup", "1", "--pairs-per-step", "4", "--no-cpu-baseline"], env={"PCR_BENCH_REHEARSE": "1"})
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["config"]["gathered_records"] == 8
+
+
+def test_bench_config3_two_rank_rehearsal_on_one_gpu():
+    """`bench.py --gpus 2 --config3`: BASELINE config 3's block as a strong-scaling run -- two ranks (both on device 0, gloo) take cost-balanced
+    blocks of the tiled golden NCLT pairs, each runs ONE fgr+gicp plan, one all-gather; every pose reaches the reference's shipped GICP pose."""
+    d = _run(["--gpus", "2", "--config3", "--config3-tiles", "3", "--warmup", "1"], env={"PCR_BENCH_REHEARSE": "1"})
+    c = d["config"]
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["dry_run"] is False
+    assert c["pairs"] == 24 and c["gathered_records"] == 24 and c["tables_identical"] is True and c["poses_valid"] is True
+    assert sum(r["pairs"] for r in c["per_rank"]) == 24 and all(r["wall_s"] > 0 and r["upload_s"] > 0 for r in c["per_rank"])

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import pkg, pose_error
+from conftest import assert_fpfh_explained, pkg, pose_error
 
 pytestmark = pytest.mark.gpu
 
@@ -27,41 +27,7 @@ def test_fpfh_matches_oracle(P, oracle, fgr_inputs):
     for pc, feat in fgr_inputs:
         pts, nrm = pc.points, pc.normals
         ref = oracle.compute_fpfh(pts, nrm, oracle.SEARCH_HYBRID, 200, 1.0)          # same float32 points / normals
-        dev = feat.data.T
-        assert dev.shape == ref.shape
-        blocks = dev.reshape(-1, 3, 11).sum(2)
-        has = ref.sum(1) > 0
-        assert np.allclose(blocks[has], 200.0, atol=2e-3)
-        assert (np.abs(dev[~has]).sum(1) == 0).all()
-        # a pair feature sitting exactly on a histogram edge may vote one bin over: rare, bounded
-        close = np.abs(dev - ref) <= 1e-3 * (1.0 + np.abs(ref))
-        assert close.mean() > 0.999, close.mean()
-        assert (np.abs(dev - ref).max(axis=1) < 5.0).mean() > 0.9999
-        # ... and that is ALL the mismatching entries are: inside each of the three 11-bin histograms of a point the difference
-        # device - oracle carries no mass (the votes are the same votes) and moves it only between ADJACENT bins.  For a vote of weight
-        # w cast one bin over, the difference is (+w, -w) in neighbouring bins: its running sum is w in one bin, so
-        # L1(running sum) = L1(difference) / 2; a vote that landed g bins away would give g times that.
-        diff = (dev - ref).reshape(-1, 3, 11)
-        bad = ~close.reshape(-1, 3, 11).all(axis=2)                       # (point, histogram) pairs with a mismatching entry
-        print(f"FPFH: {int((~close).sum())} of {close.size} entries differ by more than 1e-3 relative; {int(bad.sum())} histograms affected")
-        assert bad.mean() < 0.02, bad.mean()                                 # (on the golden pairs there are none at all)
-        if not bad.any():
-            continue
-        d = diff[bad]
-        l1 = np.abs(d).sum(1)
-        assert (np.abs(d.sum(1)) <= 1e-3 * (1.0 + l1)).all()                # mass conserved inside the histogram
-        run = np.abs(np.cumsum(d, axis=1)).sum(1)
-        # f0 is an ANGLE (atan2 in [-pi, pi], histogram 0): its first and last bin are neighbours too -- a pair feature at +-pi is on an edge
-        wrap = d.copy()
-        is_f0 = np.nonzero(bad)[1] == 0
-        wrap[is_f0] = np.roll(d[is_f0], 5, axis=1)                          # bins 0 and 10 become 5 and 4
-        run_w = np.abs(np.cumsum(wrap, axis=1)).sum(1)
-        run = np.where(is_f0, np.minimum(run, run_w), run)
-        for k in range(min(3, len(d))):
-            print("   mismatching histogram", int(np.nonzero(bad)[1][k]), "bins", np.nonzero(np.abs(d[k]) > 1e-3 * (1 + np.abs(d[k]).max()))[0], "values", d[k][np.abs(d[k]) > 1e-6].round(4))
-        adjacent = run <= 0.5 * l1 * (1.0 + 1e-3) + 1e-3
-        assert adjacent.mean() > 0.98, adjacent.mean()                      # adjacent bins only ...
-        assert (run <= l1 * (1.0 + 1e-3) + 1e-3).all(), float((run / np.maximum(l1, 1e-12)).max())     # ... but for two chained edge votes in one histogram
+        assert_fpfh_explained(feat.data.T, ref)
 
 
 def test_fpfh_errors(P, small_pair):

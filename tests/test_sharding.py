@@ -172,3 +172,40 @@ def test_bench_rank_that_fails_before_init_ends_the_job_nonzero():
     assert out.returncode != 0
     assert not [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
     assert time.time() - t0 < 300
+
+
+def test_bench_config3_dry_run_at_world_8():
+    """`bench.py --gpus 8 --config3` without a GPU (PCR_BENCH_DRYRUN=1): the strong-scaling mode of BASELINE config 3's block -- eight ranks cut
+    the 96 tiled golden pairs into contiguous cost-balanced blocks, each packs its block's records, ONE all-gather leaves the ordered table on
+    every rank (digest check), and the line carries every rank's pairs, points, wall, upload and gather time."""
+    import json
+    import subprocess
+    env = dict(_clean_env(), PCR_BENCH_DRYRUN="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--config3"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["n_ranks_seen"] == 8 and d["dry_run"] is True and d["scaling"] == "strong" and d["value"] == 0.0
+    c = d["config"]
+    assert c["pairs"] == 96 and c["gathered_records"] == 96 and c["tables_identical"] is True
+    assert len(c["per_rank"]) == 8 and sum(r["pairs"] for r in c["per_rank"]) == 96 and all(r["pairs"] > 0 for r in c["per_rank"])
+    assert c["load_balance_max_over_mean_points"] < 1.1, c["load_balance_max_over_mean_points"]
+    for r in c["per_rank"]:
+        for k in ("wall_s", "upload_s", "gather_s", "points"):
+            assert k in r
+
+
+def test_block_bounds_moves_pairs_through_one_pair_blocks():
+    """Round-4 advisor finding: [1, 1, 1, 3] on three ranks used to leave the last rank empty ([0, 3, 4, 4]): an empty block now takes a pair
+    from the nearest block before it that holds several, the one-pair blocks in between passing theirs on; the largest block cost stays optimal."""
+    from importlib import import_module
+    sh = import_module("point-cloud-registration-with-global-refinement_amd.sharding")
+    assert sh.block_bounds([1, 1, 1, 3], 3) == [0, 2, 3, 4]
+    assert sh.block_bounds([5, 1, 1, 1, 1], 4) == [0, 1, 3, 4, 5]
+    assert sh.block_bounds([1, 1], 4) == [0, 1, 2, 2, 2]              # fewer pairs than ranks: the last ranks stay empty
+    for costs, w in (([1, 1, 1, 1, 9], 3), ([3] * 6, 3), ([2, 7, 1, 8, 2, 8, 1, 8], 4)):
+        b = sh.block_bounds(costs, w)
+        assert b[0] == 0 and b[-1] == len(costs) and all(b[i] <= b[i + 1] for i in range(w))
+        assert all(b[i] < b[i + 1] for i in range(w)), (costs, b)      # nobody empty while there are pairs enough
+        assert list(sh.partition(len(costs), w, w - 1, costs))[-1] == len(costs) - 1      # the closure pair falls to the last rank
