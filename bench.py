@@ -639,6 +639,8 @@ def extras(args, P, syn, reg, est, crit, pairs, clouds, run_batch, pool_prof, po
                 e.append((float(np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1))), float(np.linalg.norm(r.transformation[:3, 3] - Tg[:3, 3]))))
             return e
         nc = {}
+        for k_ in ("fgr_group_pairs_redone_alone", "fgr_group_barrier_timeouts", "fgr_group_pool_overflows"):
+            P._lib.counter(k_, True)
         for stage, tol in (("gicp", (2e-3, 2e-2)), ("fgr", (3e-2, 0.5))):
             run_small(stage); torch.cuda.synchronize(); t0 = time.perf_counter()
             r = run_small(stage); torch.cuda.synchronize()
@@ -674,6 +676,7 @@ def extras(args, P, syn, reg, est, crit, pairs, clouds, run_batch, pool_prof, po
                                            "groups": {"gicp_group": reg.balanced_group(reg.default_group(npts), m, args.inflight), "fgr_group": reg.balanced_group(reg.default_fgr_group(npts), m, args.inflight),
                                                       "groups_in_flight": args.inflight, "how": "register_pairs_plan(group=None, fgr_group=None): sized by the clouds, whole rounds of the workers (both divide the 96 pairs)"},
                                            "with_correspondences": True,
+                                           "fgr_group_fallbacks_in_these_runs": {k: P._lib.counter(k, True) for k in ("fgr_group_pairs_redone_alone", "fgr_group_barrier_timeouts", "fgr_group_pool_overflows")},
                                            "what": "BASELINE config 3's per-GPU building block on the reference's own NCLT scans (8 golden pairs tiled to 96 per call): script-1 FGR stage, "
                                                    "script-2 five-scale GICP stage from the shipped FGR poses, and both as one plan; poses checked against the shipped GICP poses; correspondence sets "
                                                    "returned, as the reference's result objects hold them (tools/fgr_group_sweep.py and tools/gicp_nclt_sweep.py time the stages without them)"}

@@ -202,7 +202,7 @@ typedef struct {
     int32_t group;                                      /* > 1 (stages GICP and FGR + GICP, whose FGR part stays pair by pair): `group` consecutive pairs run in LOCKSTEP through the same
                                                            launches (blockIdx.y = pair: preprocessing batched over clouds and scales, one GICP loop per
                                                            scale for the whole group); `inflight` then counts groups.  Same per-pair arithmetic as the
-                                                           pair-by-pair path; <= 32.  Every unit of such a plan -- a ragged last group of ONE pair too --
+                                                           pair-by-pair path; at most 24 (larger values are clamped).  Every unit of such a plan -- a ragged last group of ONE pair too --
                                                            runs the GROUP forms of the kernels (one-query-per-lane k-NN, 1024-point iteration tiles),
                                                            so a pair's bits do not depend on how the batch was cut */
     int32_t pair_forms;                                 /* != 0: the kernel forms are chosen by the PAIR alone (group forms iff both clouds hold fewer than
@@ -283,6 +283,11 @@ int pcr_debug_feature_nn(pcr_context *ctx, const float *f0, int64_t n0, const fl
  * (clouds the batched preprocessing declines: config 5) starts after ALL preprocessing enqueued so far has finished, so that HIP-event times
  * per launch are the iteration kernels' own.  Returns PCR_EINVAL for an unknown name. */
 int pcr_set_option(const char *name, long long value);
+/* Process-wide event counters (value, or -1 for an unknown name; reset != 0 clears it): how often a lockstep registro_FGR group fell back to
+ * the one-pair path for one of its pairs -- "fgr_group_barrier_timeouts" (the co-resident optimiser workgroups of the group did not all get a
+ * slot in time), "fgr_group_pool_overflows" (record pool of the feature screen), "fgr_group_pairs_redone_alone" (all causes).  The results are
+ * the same bits either way; the throughput is not (bench.py prints them next to the NCLT stages). */
+long long pcr_counter(const char *name, int reset);
 
 #ifdef __cplusplus
 }

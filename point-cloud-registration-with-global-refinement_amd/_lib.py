@@ -73,7 +73,7 @@ EXPORTS = [
     "pcr_registration_generalized_icp", "pcr_multiscale_gicp", "pcr_evaluate_registration", "pcr_information_matrix",
     "pcr_compute_fpfh_feature", "pcr_registration_fgr", "pcr_debug_knn", "pcr_debug_gicp_linearize",
     "pcr_profile_enable", "pcr_profile_read", "pcr_registration_generalized_icp_cov", "pcr_register_pairs", "pcr_pool_profile",
-    "pcr_registro_fgr", "pcr_register_pairs_plan", "pcr_debug_feature_nn", "pcr_set_option",
+    "pcr_registro_fgr", "pcr_register_pairs_plan", "pcr_debug_feature_nn", "pcr_set_option", "pcr_counter",
 ]
 
 _lib = None
@@ -114,6 +114,16 @@ def load():
                 lib.pcr_set_option.argtypes = [C.c_char_p, C.c_longlong]
             _lib = lib
     return _lib
+
+
+def counter(name: str, reset: bool = False) -> int:
+    """Process-wide event counter of the library (``pcr_counter``, include/pcr_hip.h), e.g. ``counter("fgr_group_barrier_timeouts")``."""
+    lib = load()
+    lib.pcr_counter.argtypes = [C.c_char_p, C.c_int]; lib.pcr_counter.restype = C.c_longlong
+    v = int(lib.pcr_counter(name.encode(), int(bool(reset))))
+    if v < 0:
+        raise ValueError(f"pcr_counter: unknown counter {name!r}")
+    return v
 
 
 def set_option(name: str, value: int) -> None:

@@ -24,6 +24,15 @@ PcrOptions &pcr_options() {
     });
     return o;
 }
+PcrCounters &pcr_counters() { static PcrCounters c; return c; }
+extern "C" long long pcr_counter(const char *name, int reset) {
+    if (!name) return -1;
+    PcrCounters &c = pcr_counters();
+    std::atomic<long long> *v = !strcmp(name, "fgr_group_barrier_timeouts") ? &c.fgr_group_barrier_timeouts : !strcmp(name, "fgr_group_pool_overflows") ? &c.fgr_group_pool_overflows
+                               : !strcmp(name, "fgr_group_pairs_redone_alone") ? &c.fgr_group_pairs_redone_alone : nullptr;
+    if (!v) return -1;
+    return reset ? v->exchange(0) : v->load();
+}
 extern "C" int pcr_set_option(const char *name, long long value) {
     if (!name) return PCR_EINVAL;
     PcrOptions &o = pcr_options();
@@ -985,7 +994,7 @@ extern "C" int pcr_register_pairs_plan(int device, pcr_pair_ex *pairs, int n_pai
                             }
                             const int rc = pcr_api_call(ctx, [&]() -> int { return pcr_registro_fgr_group(ctx, q.data(), (int)m); });
                             if (rc == PCR_EHIP) { rc_group = rc; break; }
-                            if (rc == PCR_OK) for (size_t t = 0; t < m; t++) fgr_done[take[t0 + t]] = q[t].status == PCR_OK;
+                            if (rc == PCR_OK) for (size_t t = 0; t < m; t++) { fgr_done[take[t0 + t]] = q[t].status == PCR_OK; if (q[t].status == 1) pcr_counters().fgr_group_pairs_redone_alone++; }
                         }
                     }
                     for (int k = 0; k < cnt && rc_group == PCR_OK; k++) {
@@ -1043,7 +1052,7 @@ extern "C" int pcr_register_pairs_plan(int device, pcr_pair_ex *pairs, int n_pai
                     for (int k = 0; k < cnt; k++) { pairs[i + k].base.status = rc; failed++; snprintf(pairs[i + k].base.error, sizeof pairs[i + k].base.error, "%s", ctx->err.c_str()); }
                     return rc;
                 }
-                if (rc == PCR_OK) for (size_t t = 0; t < take.size(); t++) if (q[t].status == PCR_OK) { done[take[t]] = 1; pairs[i + take[t]].base.status = PCR_OK; }
+                if (rc == PCR_OK) for (size_t t = 0; t < take.size(); t++) { if (q[t].status == PCR_OK) { done[take[t]] = 1; pairs[i + take[t]].base.status = PCR_OK; } else if (q[t].status == 1) pcr_counters().fgr_group_pairs_redone_alone++; }
             }
             for (int k = 0; k < cnt; k++) {
                 if (done[k]) continue;

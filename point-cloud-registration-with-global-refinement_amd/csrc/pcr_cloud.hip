@@ -1638,6 +1638,7 @@ struct NflArgs {
     int k_list, k_nrm;
     const float4 *prior; float4 *normals;            // cleaned order
     uint8_t *todo; int *todo_count;
+    int *piece_list, *piece_count;                   // optional: first point (un-cleaned index) of every 8-point piece that holds a todo point -- the work list of the fallback search
 };
 struct NflBatch { NflArgs a[PCR_MAX_BATCH]; };
 // A wavefront serves 64 points: octet o takes points base + 8 o + r in rounds r = 0..7 (list filtering, farthest-survivor drops, raw
@@ -1650,6 +1651,7 @@ __device__ static inline void d_normals_from_lists(const NflArgs &a) {
     if (base >= n) return;
     double my_cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, my_c = 0;      // raw moments of the point this lane solves (the divisions wait until all 64 lanes have one)
     bool my_exact = false; int my_j = 0;
+    bool piece_todo = false;                                        // (octet-uniform) one of the octet's 8 points -- the piece [base + 8 o, + 8) -- needs the search
 #pragma unroll 1
     for (int r = 0; r < OCT; r++) {
         const int i = base + oct_id * OCT + r;
@@ -1673,6 +1675,7 @@ __device__ static inline void d_normals_from_lists(const NflArgs &a) {
             a.todo[j] = exact ? 0 : 1;
             if (!exact) atomicAdd(a.todo_count, 1);
         }
+        piece_todo = piece_todo || (act && !exact);
         // drop the farthest survivors until k_nrm remain (octet arg-max rounds; octets that are done idle along)
         int excess = exact ? vc - a.k_nrm : 0;
         while (__ballot(excess > 0) != 0ull) {
@@ -1706,6 +1709,9 @@ __device__ static inline void d_normals_from_lists(const NflArgs &a) {
             for (int t = 0; t < 9; t++) my_cu[t] = cu[t];
         }
     }
+    // the fallback search serves exactly the listed pieces (k_knn_list, hard_piece): the full-range launch with the todo mask started a wavefront
+    // per 8 points of the whole cloud to find the ~2 % that hold one (8.9 % of the headline run's kernel time)
+    if (a.piece_list && piece_todo && ol == 0) a.piece_list[atomicAdd(a.piece_count, 1)] = base + oct_id * OCT;
     if (!my_exact) return;
     double myC[6] = {1, 0, 0, 1, 0, 1};
     if (my_c >= 3.0) {                                  // (the nine float64 divisions once per wavefront, not once per round under a one-lane-in-eight branch)
@@ -1819,6 +1825,9 @@ static int sor_batch(pcr_context *ctx, SorProblem *pr, int count, int nb_neighbo
     struct { CompactArgs *a; } mb{mbv.data()}; struct { NflArgs *a; } nb_{nbv.data()};
     std::vector<int> capsv((size_t)count); int *caps = capsv.data(); int m = 0;
     bool any_todo = false, fuse_all = true;
+    // work lists of the fallback normals (pieces of 8 points that hold a todo point, filled by k_normals_from_lists): one counter per problem, zeroed together
+    int *piece_counts = (fallback_here && normal_k > 0 && normal_k <= 32) ? arena<int>(ctx, count) : nullptr;
+    if (piece_counts) PCR_HIP_CHECK(ctx, hipMemsetAsync(piece_counts, 0, sizeof(int) * (size_t)count, ctx->stream));
     for (int k = 0; k < count; k++) {
         SorProblem &q = pr[k];
         const DevCloud *in = q.in; DevCloud *out = q.out;
@@ -1865,6 +1874,12 @@ static int sor_batch(pcr_context *ctx, SorProblem *pr, int count, int nb_neighbo
                 b.t = oct_view(in); b.n_ptr = in->n; b.k = normal_k; b.prior = q.prior_out; b.normals = out->nrm_final; b.todo = fuse ? q.todo_out : nullptr;
                 b.keep = flags; b.pos = pos; b.seed_span = -1;
                 knn_radius(b, PCR_SEARCH_KNN, 0);
+                if (fuse && piece_counts) {
+                    int *pl = arena<int>(ctx, (size_t)in->cap / OCT + 1);
+                    if (!pl) return PCR_ENOMEM;
+                    nb_.a[m].piece_list = pl; nb_.a[m].piece_count = piece_counts + m;
+                    b.hard_list = pl; b.hard_count = piece_counts + m; b.hard_piece = 1;
+                }
             }
         } else fuse_all = false;
         caps[m] = in->cap;
@@ -1887,7 +1902,12 @@ static int sor_batch(pcr_context *ctx, SorProblem *pr, int count, int nb_neighbo
         if (fuse_all) PCR_TRY(PCR_BATCH_LAUNCH(ctx, NflBatch, k_normals_from_lists_batch, k_normals_from_lists_batchp, nb_.a, m, dim3((unsigned)(((size_t)mc + KNN_BS - 1) / KNN_BS), m), dim3(KNN_BS)));
         else for (int k = 0; k < m; k++) if (nb_.a[k].pts) PCR_LAUNCH(ctx, k_normals_from_lists, dim3((unsigned)(((size_t)caps[k] + KNN_BS - 1) / KNN_BS)), dim3(KNN_BS), 0, ctx->stream, nb_.a[k]);
         if (fallback_here && normal_k > 0) {
-            if (normal_k <= 32) PCR_TRY(launch_knn_batch<KNN_MODE_NORMALS>(ctx, fb.a, caps, m));
+            bool listed = fuse_all && piece_counts != nullptr;
+            for (int k = 0; k < m; k++) listed = listed && fb.a[k].hard_list != nullptr;
+            if (listed) {       // every problem's todo points come as a list of pieces: the octet kernel's list form, a fixed small grid striding over them
+                const dim3 grid(knn_list_grid(mc), m), block(KNN_BS);
+                PCR_TRY(PCR_BATCH_LAUNCH(ctx, KnnBatch, (k_knn_list_batch<KNN_MODE_NORMALS, 4>), (k_knn_list_batchp<KNN_MODE_NORMALS, 4>), fb.a, m, grid, block));
+            } else if (normal_k <= 32) PCR_TRY(launch_knn_batch<KNN_MODE_NORMALS>(ctx, fb.a, caps, m));
             else for (int k = 0; k < m; k++) { DevCloud tmp; tmp.cap = caps[k]; PCR_TRY(launch_knn<KNN_MODE_NORMALS>(ctx, &tmp, fb.a[k])); }
         }
     }

@@ -1371,7 +1371,7 @@ int pcr_registro_fgr_group(pcr_context *ctx, pcr_fgr_group_pair *q, int G) {
         PCR_HIP_CHECK(ctx, hipMemcpyAsync(ncross.data(), counts_all, sizeof(int) * (size_t)G, hipMemcpyDeviceToHost, ctx->stream));
         PCR_HIP_CHECK(ctx, hipMemcpyAsync(hflags.data(), overflow_dev[0], sizeof(int) * (size_t)2 * G, hipMemcpyDeviceToHost, ctx->stream));
         PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        for (int g = 0; g < G; g++) { overflow[g] = hflags[2 * g]; if (overflow[g]) q[g].status = 1; }        // record pool exhausted: that pair alone takes the float64 path
+        for (int g = 0; g < G; g++) { overflow[g] = hflags[2 * g]; if (overflow[g]) { q[g].status = 1; pcr_counters().fgr_group_pool_overflows++; } }        // record pool exhausted: that pair alone takes the float64 path
     }
     // ---- tuple test (wait 4: the accepted counts)
     std::vector<int32_t *> corr((size_t)G, nullptr); std::vector<int64_t> ncorr((size_t)G, 0);
@@ -1431,9 +1431,13 @@ int pcr_registro_fgr_group(pcr_context *ctx, pcr_fgr_group_pair *q, int G) {
             FgrOptArgs oa;
             oa.pq = pq; oa.stride = stride; oa.ncorr = (int)ncorr[g]; oa.st = st[g]; oa.partials = partials;
             oa.decrease_mu = opt.decrease_mu; oa.max_corr_dist = opt.maximum_correspondence_distance; oa.division_factor = opt.division_factor;
-            const int variant = fgr_opt_variant(ncorr[g]);
+            int variant = fgr_opt_variant(ncorr[g]);
+            // the group's multi-workgroup launch has FMG workgroups per pair; the one-pair path takes FMG_MAX from FGR_MULTI_WIDE correspondences (or what
+            // PCR_FGR_MULTI_WGS says): other rows, another summation order.  Such a pair goes the one-pair way, so that "group = pair by pair" holds
+            // for explicit tuple counts beyond the reference's 0.2 n as well (round-4 advisor finding)
+            if (variant == 2 && (ncorr[g] >= FGR_MULTI_WIDE || getenv("PCR_FGR_MULTI_WGS"))) variant = 3;
             if (variant < 3) cls[variant].push_back(oa);
-            else { q[g].status = 1; pd.pop_back(); st[g] = nullptr; continue; }              // one launch per iteration: the one-pair path
+            else { q[g].status = 1; pd.pop_back(); st[g] = nullptr; continue; }              // one launch per iteration / wide form: the one-pair path
             who.push_back(g);
             max_corr = (int)ncorr[g] > max_corr ? (int)ncorr[g] : max_corr;
         }
@@ -1458,7 +1462,7 @@ int pcr_registro_fgr_group(pcr_context *ctx, pcr_fgr_group_pair *q, int G) {
             }
             PCR_HIP_CHECK(ctx, hipMemcpyAsync(hst.data(), st_all, sizeof(FgrState) * (size_t)G, hipMemcpyDeviceToHost, ctx->stream));
             PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-            for (int g : who) if (hst[g].failed) q[g].status = 1;                             // barrier timeout: the one-pair path reruns it launch by launch
+            for (int g : who) if (hst[g].failed) { q[g].status = 1; pcr_counters().fgr_group_barrier_timeouts++; }     // barrier timeout: the one-pair path reruns it launch by launch (counted: pcr_counter)
         }
     }
     // ---- GetTransformationOriginalScale + inverse per pair (host), then evaluate_registration of all pairs (wait 6)

@@ -11,6 +11,9 @@
 // process-wide switches (pcr_set_option, include/pcr_hip.h): latched from the environment once, atomics afterwards
 struct PcrOptions { std::atomic<int> knn_wave{-1}, knnw_budget{80}, fence_prep{0}; };
 PcrOptions &pcr_options();
+// process-wide event counters (pcr_counter, include/pcr_hip.h): how often a slow fall-back was taken -- invisible in the results, which are the same bits
+struct PcrCounters { std::atomic<long long> fgr_group_barrier_timeouts{0}, fgr_group_pool_overflows{0}, fgr_group_pairs_redone_alone{0}; };
+PcrCounters &pcr_counters();
 #define PCR_GROUP_FORMS_MAX_POINTS 400000      // pcr_pairs_plan.pair_forms: pairs with both clouds under this take the group forms of the kernels
 
 
