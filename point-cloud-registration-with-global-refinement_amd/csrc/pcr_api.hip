@@ -533,12 +533,11 @@ static int multiscale_batched(pcr_context *ctx, const float *src_xyz, const floa
         DevCloud *vp[8];
         for (int s = 0; s < n_scales; s++) vp[s] = &vox[s];
         PCR_TRY(pcr_dev_build_bvh_batch(ctx, vp, n_scales));
-        PCR_TRY(pcr_dev_sor_batch(ctx, ins, outs, n_scales, sor_k, sor_std, normal_k, priors, todos, todo_counts, cnt_in, cnt_kept, !need_tree));
+        // (round 5: the incomplete normal lists of the TARGETS are searched over the voxel trees too, through the piece lists of the filter pass -- they
+        // used to wait for the cleaned trees and run as a full-range launch with a todo mask)
+        PCR_TRY(pcr_dev_sor_batch(ctx, ins, outs, n_scales, sor_k, sor_std, normal_k, priors, todos, todo_counts, cnt_in, cnt_kept, true));
         for (int s = 0; s < n_scales; s++) { for (int d = 0; d < 3; d++) { clean[which][s].key_org[d] = tmp[s].key_org[d]; clean[which][s].key_unit[d] = tmp[s].key_unit[d]; } clean[which][s].voxel_lattice = tmp[s].voxel_lattice; }
-        if (need_tree) {
-            PCR_TRY(pcr_dev_build_bvh_batch(ctx, trees, n_scales));
-            PCR_TRY(pcr_dev_normals_knn_batch(ctx, trees, n_scales, normal_k, priors, nouts, todos));
-        }
+        if (need_tree) PCR_TRY(pcr_dev_build_bvh_batch(ctx, trees, n_scales));
         PCR_HIP_CHECK(ctx, hipEventRecord(ctx->lane_ev[which], ctx->stream));
         return PCR_OK;
     };
@@ -637,14 +636,13 @@ static int multiscale_group(pcr_context *ctx, pcr_pair_ex *const *px, int G, con
         for (size_t k = 0; k < vp.size(); k++) vp[k] = &vox[k];
         PCR_TRY(pcr_dev_build_bvh_batch(ctx, vp.data(), (int)vp.size()));
     }
-    for (int which = 0; which < 2; which++) {            // sources: incomplete normal lists searched over the voxel trees; targets: over their own trees below
+    {   // the filter chains of ALL clouds and scales of the group as one batch (round 5: sources and targets were two batches -- twice the launches, and
+        // twice the tails of the list-driven searches); incomplete normal lists are searched over the voxel trees (piece lists of the filter pass)
         std::vector<const DevCloud *> ins; std::vector<DevCloud *> outs; std::vector<const float4 *> pr; std::vector<uint8_t *> td; std::vector<int *> tc, ci, ck;
-        for (int g = 0; g < G; g++)
-            for (int s = 0; s < n_scales; s++) {
-                const size_t k = (size_t)(2 * g + which) * n_scales + s;
-                ins.push_back(&vox[k]); outs.push_back(&tmp[k]); pr.push_back(priors[k]); td.push_back(todos[k]); tc.push_back(tcs[k]); ci.push_back(cin[k]); ck.push_back(ckept[k]);
-            }
-        PCR_TRY(pcr_dev_sor_batch(ctx, ins.data(), outs.data(), (int)ins.size(), sor_k, sor_std, normal_k, pr.data(), td.data(), tc.data(), ci.data(), ck.data(), which == 0));
+        for (size_t k = 0; k < (size_t)C * n_scales; k++) {
+            ins.push_back(&vox[k]); outs.push_back(&tmp[k]); pr.push_back(priors[k]); td.push_back(todos[k]); tc.push_back(tcs[k]); ci.push_back(cin[k]); ck.push_back(ckept[k]);
+        }
+        PCR_TRY(pcr_dev_sor_batch(ctx, ins.data(), outs.data(), (int)ins.size(), sor_k, sor_std, normal_k, pr.data(), td.data(), tc.data(), ci.data(), ck.data(), true));
     }
     for (size_t k = 0; k < clean.size(); k++) { for (int d = 0; d < 3; d++) { clean[k].key_org[d] = tmp[k].key_org[d]; clean[k].key_unit[d] = tmp[k].key_unit[d]; } clean[k].voxel_lattice = tmp[k].voxel_lattice; }
     {
@@ -655,7 +653,6 @@ static int multiscale_group(pcr_context *ctx, pcr_pair_ex *const *px, int G, con
                 trees.push_back(&clean[k]); pr.push_back(priors[k]); no.push_back(clean[k].nrm); td.push_back(todos[k]);
             }
         PCR_TRY(pcr_dev_build_bvh_batch(ctx, trees.data(), (int)trees.size()));
-        PCR_TRY(pcr_dev_normals_knn_batch(ctx, trees.data(), (int)trees.size(), normal_k, pr.data(), no.data(), td.data()));
     }
     // ---- the GICP loops, one lockstep loop per scale
     std::vector<double> T((size_t)G * 16), md((size_t)G);
