@@ -281,7 +281,9 @@ int pcr_debug_feature_nn(pcr_context *ctx, const float *f0, int64_t n0, const fl
  * 1 the one-query-per-lane kernel for every search that fits it; "knnw_budget": candidate batches a wavefront of that kernel takes before
  * it hands its queries over; "fence_prep": measurement only -- with profiling on, every scale's GICP loop of the pipelined multiscale path
  * (clouds the batched preprocessing declines: config 5) starts after ALL preprocessing enqueued so far has finished, so that HIP-event times
- * per launch are the iteration kernels' own.  Returns PCR_EINVAL for an unknown name. */
+ * per launch are the iteration kernels' own; "icp_phase", "icp_verify", "debug_stamps", "debug_visits": diagnostics of the GICP loop and the searches
+ * (phase stamps of the fused iteration kernel, re-search of certified queries, per-call stamp print-outs, visit counts instead of results).
+ * Returns PCR_EINVAL for an unknown name. */
 int pcr_set_option(const char *name, long long value);
 /* Process-wide event counters (value, or -1 for an unknown name; reset != 0 clears it): how often a lockstep registro_FGR group fell back to
  * the one-pair path for one of its pairs -- "fgr_group_barrier_timeouts" (the co-resident optimiser workgroups of the group did not all get a

@@ -21,6 +21,10 @@ PcrOptions &pcr_options() {
         if (const char *e = getenv("PCR_KNN_WAVE")) o.knn_wave = atoi(e);
         if (const char *e = getenv("PCR_KNNW_BUDGET")) o.knnw_budget = atoi(e);
         if (const char *e = getenv("PCR_FENCE_PREP")) o.fence_prep = atoi(e);
+        if (const char *e = getenv("PCR_ICP_PHASE")) o.icp_phase = atoi(e);
+        if (getenv("PCR_ICP_VERIFY")) o.icp_verify = 1;
+        if (getenv("PCR_DEBUG_STAMPS")) o.debug_stamps = 1;
+        if (const char *e = getenv("PCR_DEBUG_VISITS")) o.debug_visits = atoi(e) ? atoi(e) : 1;
     });
     return o;
 }
@@ -39,6 +43,10 @@ extern "C" int pcr_set_option(const char *name, long long value) {
     if (!strcmp(name, "knn_wave")) { o.knn_wave = (int)value; return PCR_OK; }
     if (!strcmp(name, "knnw_budget")) { o.knnw_budget = (int)value; return PCR_OK; }
     if (!strcmp(name, "fence_prep")) { o.fence_prep = (int)value; return PCR_OK; }
+    if (!strcmp(name, "icp_phase")) { o.icp_phase = (int)value; return PCR_OK; }
+    if (!strcmp(name, "icp_verify")) { o.icp_verify = (int)value; return PCR_OK; }
+    if (!strcmp(name, "debug_stamps")) { o.debug_stamps = (int)value; return PCR_OK; }
+    if (!strcmp(name, "debug_visits")) { o.debug_visits = (int)value; return PCR_OK; }
     return PCR_EINVAL;
 }
 
@@ -437,7 +445,7 @@ extern "C" int pcr_debug_gicp_linearize(pcr_context *ctx, const float *src_xyz, 
     if (!match) return PCR_ENOMEM;
     PCR_TRY(pcr_dev_linearize_once(ctx, &s, &t, max_dist, T, params, JTJ36, JTr6, stats3, match));
     if (match_out) {
-        PCR_LAUNCH(ctx, k_match_unpermute, dim3((unsigned)((n_src + 255) / 256)), dim3(256), 0, ctx->stream, match, sperm, tperm, (int)n_src, match_out, getenv("PCR_DEBUG_VISITS") ? 1 : 0);
+        PCR_LAUNCH(ctx, k_match_unpermute, dim3((unsigned)((n_src + 255) / 256)), dim3(256), 0, ctx->stream, match, sperm, tperm, (int)n_src, match_out, pcr_options().debug_visits.load(std::memory_order_relaxed) ? 1 : 0);
         PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     }
     return PCR_OK;

@@ -1465,7 +1465,7 @@ int pcr_dev_knn_debug(pcr_context *ctx, const DevCloud *c, int k, double radius,
     a.t = oct_view(c); a.n_ptr = c->n; a.k = k;
     knn_radius(a, radius > 0 ? PCR_SEARCH_HYBRID : PCR_SEARCH_KNN, radius);
     if (radius > 0) a.r2cap_f = (float)(radius * radius);
-    a.dbg_idx = idx; a.dbg_d2 = d2; a.dbg_cnt = counts; a.dbg_visits = getenv("PCR_DEBUG_VISITS") ? atoi(getenv("PCR_DEBUG_VISITS")) : 0;
+    a.dbg_idx = idx; a.dbg_d2 = d2; a.dbg_cnt = counts; a.dbg_visits = pcr_options().debug_visits.load(std::memory_order_relaxed);
     return launch_knn<KNN_MODE_DEBUG>(ctx, c, a);
 }
 
@@ -1929,9 +1929,6 @@ int pcr_dev_sor_batch(pcr_context *ctx, const DevCloud *const *ins, DevCloud *co
     return sor_batch(ctx, p, count, nb_neighbors, std_ratio, normal_k, fallback_here);
 }
 // k-NN normals of `count` clouds over their own trees in one launch (todo masks optional): the incomplete lists of the cleaned targets
-int pcr_dev_normals_knn_batch(pcr_context *ctx, DevCloud *const *cs, int count, int knn, const float4 *const *priors, float4 *const *normals_out, const uint8_t *const *todos) {
-    return pcr_dev_normals_batch(ctx, cs, count, PCR_SEARCH_KNN, knn, 0.0, priors, normals_out, todos);
-}
 int pcr_dev_normals_batch(pcr_context *ctx, DevCloud *const *cs, int count, int search_kind, int knn, double radius, const float4 *const *priors, float4 *const *normals_out,
                           const uint8_t *const *todos) {
     if (search_kind != PCR_SEARCH_KNN && search_kind != PCR_SEARCH_HYBRID) { ctx->err = "normals batch: KNN or Hybrid search"; return PCR_EINVAL; }

@@ -996,8 +996,8 @@ static void fill_args(IcpArgs &a, const DevCloud *src, const DevCloud *tgt, doub
     a.loss = p ? p->loss : 0; a.loss_k = p ? p->loss_k : 1.0; a.a = 1.0 - (p ? p->epsilon : 1e-3);
     a.rel_fit = p ? p->relative_fitness : 1e-6; a.rel_rmse = p ? p->relative_rmse : 1e-6; a.max_it = p ? p->max_iteration : 30;
     a.single = single;
-    a.dbg_visits = (single && getenv("PCR_DEBUG_VISITS")) ? 1 : 0;
-    a.dbg_phase = getenv("PCR_ICP_PHASE") ? atoi(getenv("PCR_ICP_PHASE")) : 0;
+    a.dbg_visits = (single && pcr_options().debug_visits.load(std::memory_order_relaxed)) ? 1 : 0;      // (diagnostic switches: pcr_set_option, latched from the environment once)
+    a.dbg_phase = pcr_options().icp_phase.load(std::memory_order_relaxed);
     a.stamps_nn = nullptr; a.stamps_it = nullptr;
     a.ref = nullptr; a.rbest = nullptr; a.clist = nullptr;
     memset(&a.grid, 0, sizeof a.grid); a.grid.L = -1;
@@ -1062,7 +1062,7 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
         double g = gfrac * max_dist; g = g < 0.01 ? 0.01 : (g > 0.05 ? 0.05 : g);
         const double rs = max_dist + g;
         a.r2s = (float)(rs * rs * (1.0 + 1e-6)); a.rs_minus_r = (float)g;
-        a.verify = getenv("PCR_ICP_VERIFY") ? 1 : 0;
+        a.verify = pcr_options().icp_verify.load(std::memory_order_relaxed) ? 1 : 0;
     }
     if (icp_use_grid() && !use_cov) {       // cell hash of the target for radii of a few voxels (pcr_octree.h GridView); the octree serves the others
         const int L = pcr_grid_level_for(tgt, std::sqrt((double)(a.ref ? a.r2s : a.r2f)));
@@ -1075,7 +1075,7 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     const bool grid = a.grid.tab != nullptr;
     IcpInit in; memcpy(in.T, T0, sizeof in.T);
     PCR_LAUNCH(ctx, k_icp_init, dim3(1), dim3(64), 0, ctx->stream, st, in);
-    const char *stamp_path = getenv("PCR_ICP_STAMPS");          // diagnostics only
+    static const char *const stamp_path = getenv("PCR_ICP_STAMPS");          // diagnostics only (latched once)
     const size_t sw_nn = (size_t)ICP_STAMP_LAUNCHES * nbnn * (ICP_BS / 64) * 2, sw_it = (size_t)ICP_STAMP_LAUNCHES * nbmax * (LIN_BS / 64) * 12;
     if (stamp_path) {
         if (hipMalloc(&a.stamps_nn, sw_nn * 8) != hipSuccess || hipMalloc(&a.stamps_it, sw_it * 8) != hipSuccess) return PCR_ENOMEM;
@@ -1182,7 +1182,7 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
         ctx->prof[5] += launched; ctx->prof[13] += fin.launches;          // issued / live launches of the loop: the rest returned at once
         ctx->prof[6] += (double)fin.t_dbg[0] * 0.01; ctx->prof[7] += (double)fin.t_dbg[3] * 0.01; ctx->prof[14] += (double)fin.t_dbg[1] * 0.01;
         ctx->prof[11] += (double)fin.searched;
-        if (getenv("PCR_DEBUG_STAMPS")) fprintf(stderr, "icp stamps (us/launch): slowest-wg search %.1f slowest-wg reduce %.1f (unused %.1f) sums-done %.1f end %.1f (launches %d ns %d)\n", fin.t_dbg[0] * 0.01 / fin.launches, fin.t_dbg[1] * 0.01 / fin.launches, fin.t_dbg[2] * 0.01 / fin.launches, fin.t_dbg[3] * 0.01 / fin.launches, fin.t_live * 0.01 / fin.launches, fin.launches, fin.ns);
+        if (pcr_options().debug_stamps.load(std::memory_order_relaxed)) fprintf(stderr, "icp stamps (us/launch): slowest-wg search %.1f slowest-wg reduce %.1f (unused %.1f) sums-done %.1f end %.1f (launches %d ns %d)\n", fin.t_dbg[0] * 0.01 / fin.launches, fin.t_dbg[1] * 0.01 / fin.launches, fin.t_dbg[2] * 0.01 / fin.launches, fin.t_dbg[3] * 0.01 / fin.launches, fin.t_live * 0.01 / fin.launches, fin.launches, fin.ns);
     }
     if (stamp_path) {
         unsigned long long *h = (unsigned long long *)malloc((sw_nn + sw_it) * 8);
@@ -1425,7 +1425,7 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
             ctx->prof[6] += (double)fin[g].t_dbg[0] * 0.01; ctx->prof[7] += (double)fin[g].t_dbg[3] * 0.01; ctx->prof[14] += (double)fin[g].t_dbg[1] * 0.01;
         }
         ctx->prof[5] += launched; ctx->prof[13] += longest;                // issued / live launches of the GROUP's loop (live: some pair still iterating)
-        if (getenv("PCR_DEBUG_STAMPS")) {
+        if (pcr_options().debug_stamps.load(std::memory_order_relaxed)) {
             double l = 0, t0 = 0, t1 = 0, t3 = 0, tl = 0;
             for (int g = 0; g < G; g++) { l += fin[g].launches; t0 += fin[g].t_dbg[0] * 0.01; t1 += fin[g].t_dbg[1] * 0.01; t3 += fin[g].t_dbg[3] * 0.01; tl += fin[g].t_live * 0.01; }
             fprintf(stderr, "icp group stamps (us/launch, mean over %d pairs): slowest-wg A+B+C %.1f phase %.1f sums-done %.1f end %.1f (pair-launches %.0f ns %d)\n", G, t0 / l, t1 / l, t3 / l, tl / l, l, fin[0].ns);

@@ -1,7 +1,7 @@
 """Diagnostic: node/leaf visit counts of the GICP 1-NN walk per source point (PCR_DEBUG_VISITS=1)."""
 import ctypes as C, importlib, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("PCR_DEBUG_VISITS", "1")
 import torch
 P = importlib.import_module("point-cloud-registration-with-global-refinement_amd")

@@ -1,7 +1,7 @@
 """Debug helper: HIP vs oracle on the Facade golden pair, element-wise pose differences per scale."""
 import os, sys, importlib
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 P = importlib.import_module("point-cloud-registration-with-global-refinement_amd")
 from oracle import oracle

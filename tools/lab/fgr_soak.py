@@ -5,7 +5,7 @@ usage: fgr_soak.py [repetitions=20] [inflight=4]"""
 import glob, importlib, os, sys, time
 import numpy as np
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 P = importlib.import_module("point-cloud-registration-with-global-refinement_amd")
 reg = P.registration

@@ -2,7 +2,7 @@
 usage: group_check.py [points] [group] [inflight]"""
 import importlib, os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 P = importlib.import_module("point-cloud-registration-with-global-refinement_amd")
 syn = importlib.import_module("point-cloud-registration-with-global-refinement_amd.synthetic")

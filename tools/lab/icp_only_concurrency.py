@@ -2,7 +2,7 @@
 import importlib, os, sys, threading, time
 import numpy as np
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 P = importlib.import_module("point-cloud-registration-with-global-refinement_amd")
 syn = importlib.import_module("point-cloud-registration-with-global-refinement_amd.synthetic")

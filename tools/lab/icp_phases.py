@@ -27,7 +27,7 @@ for label, n, inflight, group in (("one pair at a time", 4, 1, 1), ("one group o
     for mean in (16, 0):
         row = []
         for ph in (1, 2, 3, 4, 5, 0):
-            os.environ["PCR_ICP_PHASE"] = str(ph + mean)
+            P._lib.set_option("icp_phase", ph + mean)
             prof(enable=1, reset=True)
             run(n, inflight, group)
             torch.cuda.synchronize()

@@ -1,7 +1,7 @@
 """Diagnostic: per-wavefront timeline of the GICP iteration kernels (PCR_ICP_STAMPS) for the config-2 pair."""
 import importlib, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 OUT = "/tmp/icp_stamps.bin"
 if os.path.exists(OUT): os.remove(OUT)
 os.environ["PCR_ICP_STAMPS"] = OUT

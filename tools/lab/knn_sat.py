@@ -1,7 +1,7 @@
 """The exact 30-NN search with the chip saturated: 8 shifted copies of the 0.1 m voxel grid of the bench cloud in ONE cloud (1.4 M queries),
 wavefront kernel against octet kernel.  Run under rocprofv3 --kernel-trace --stats and read the kernels' durations.  usage: knn_sat.py [k] [copies]"""
 import importlib, os, sys, time, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 P = importlib.import_module("point-cloud-registration-with-global-refinement_amd")
 syn = importlib.import_module("point-cloud-registration-with-global-refinement_amd.synthetic")

@@ -2,7 +2,7 @@
 distribution and placement per XCD for the SOR search of each scale of the config-2 target cloud."""
 import importlib, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 OUT = "/tmp/knn_stamps.bin"
 os.environ["PCR_KNN_STAMPS"] = OUT
 import torch

@@ -2,7 +2,7 @@
 (leaks or a growing arena would show as shrinking free memory or falling throughput)."""
 import importlib, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import torch
 P = importlib.import_module("point-cloud-registration-with-global-refinement_amd")

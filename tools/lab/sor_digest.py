@@ -2,7 +2,7 @@
 one-query-per-lane k-NN kernel (option knn_wave = 1) -- to compare library builds across processes (PCR_HIP_SO)."""
 import hashlib, importlib, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 P = importlib.import_module("point-cloud-registration-with-global-refinement_amd")
 syn = importlib.import_module("point-cloud-registration-with-global-refinement_amd.synthetic")
 p = syn.make_pair(200000)
