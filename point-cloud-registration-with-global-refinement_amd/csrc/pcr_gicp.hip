@@ -404,7 +404,10 @@ __device__ static inline void d_icp_nn(const IcpArgs &a) {
     else best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.ref ? a.r2s : a.r2f, hint, ol, oct, ob, &start_pt, a.dbg_visits ? &visits : nullptr, &d1, &d2);
     if (a.verify && ol == 0 && live && rec_c[ob] != -2) {
         const int claim = rec_c[ob];
-        const bool bad = claim >= 0 ? best != claim : (best >= 0 && d1 < a.r2f);
+        // (a decided neighbour may have drifted beyond the search cap r + g -- it is beyond r then, and the search finds nothing: no contradiction)
+        bool beyond = false;
+        if (claim >= 0 && best < 0) { const float4 cp = a.tgt_pts[claim]; beyond = pcr_d2(cp.x - qx, cp.y - qy, cp.z - qz) >= (a.ref ? a.r2s : a.r2f); }
+        const bool bad = claim >= 0 ? (best != claim && !beyond) : (best >= 0 && d1 < a.r2f);
         if (bad) printf("certificate violated: launch %d query %d claim %d found %d d1 %.6f d2 %.6f ref margin %.6f moved %.6f\n", launches, qi, claim, best, sqrtf(d1), sqrtf(d2),
                         a.ref[qi].w, sqrtf(pcr_d2(qx - a.ref[qi].x, qy - a.ref[qi].y, qz - a.ref[qi].z)));
     }
@@ -761,7 +764,20 @@ __global__ void __launch_bounds__(LIN_BS) __attribute__((amdgpu_waves_per_eu(4, 
 // one correspondence per lane in float64 -> reduction / ticket / last-workgroup finish as in k_icp_iter.  Halves the
 // launches of the loop (the in-flight throughput is bound by the dispatch rate of small dependent kernels, ~90k/s
 // system-wide) and removes the match[] round trip between the two kernels.
+#ifndef FUSED_BS
 #define FUSED_BS 512
+#endif
+#ifdef FUSED_WAVES
+#define FUSED_OCC __attribute__((amdgpu_waves_per_eu(FUSED_WAVES, FUSED_WAVES)))
+#else
+#define FUSED_OCC
+#endif
+// a wave-uniform double held in SGPRs (the pose: twelve doubles every lane loaded into 24 VGPRs of its own)
+__device__ static inline double icp_uniform(double v) {
+    union { double d; int i[2]; } u; u.d = v;
+    u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]); u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+    return u.d;
+}
 // PPL = source points per lane (PCR_ICP_PPL, default 1).  The kernel is latency-bound (dependent loads, publish -> ticket -> gather), so
 // its wavefronts mostly wait, and at one point per lane a 160k-point launch is 312 workgroups of 8 wavefronts at 122 VGPRs -- 61 % of
 // the chip's wavefront slots for ONE pair's iteration.  Two / four points per lane (half / a quarter of the wavefronts, partial rows
@@ -807,6 +823,8 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
     if (tid < (int)(sizeof(OctMeta) / 4)) mword = ((const int *)a.tgt.meta)[tid];
     if (done) return;
     if (bid >= nb) return;
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = icp_uniform(T[k]);
     const unsigned long long t_entry = wall_clock64();
     if (bid == 0 && tid == 0) st->t_start = t_entry;
     if (tid < (int)(sizeof(OctMeta) / 4)) ((int *)&m)[tid] = mword;
@@ -926,15 +944,15 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
     }
     icp_finish<ICP_MODE_GICP, FUSED_BS>(a, st, T, acc, nb, ns, launches, t_entry, bid, t_p, t_a, t_b);
 }
-template <int TILE_PTS, bool GRID> __global__ void __launch_bounds__(FUSED_BS) k_icp_fused(IcpArgs a) { d_icp_fused<TILE_PTS, GRID>(a); }
+template <int TILE_PTS, bool GRID> __global__ void __launch_bounds__(FUSED_BS) FUSED_OCC k_icp_fused(IcpArgs a) { d_icp_fused<TILE_PTS, GRID>(a); }
 // (the problem's arguments are copied out of the device buffer ONCE, by scalar loads, like by-value kernel arguments: read through the
 // pointer wherever they are used they sat in VGPRs -- 146-162 instead of 122, one workgroup per CU instead of two)
-template <int TILE_PTS, bool GRID> __global__ void __launch_bounds__(FUSED_BS) k_icp_fused_g(const IcpArgs *__restrict__ a) { d_icp_fused<TILE_PTS, GRID>(a[blockIdx.y]); }
+template <int TILE_PTS, bool GRID> __global__ void __launch_bounds__(FUSED_BS) FUSED_OCC k_icp_fused_g(const IcpArgs *__restrict__ a) { d_icp_fused<TILE_PTS, GRID>(a[blockIdx.y]); }
 // groups of up to ICP_BYVAL problems: the argument structs travel BY VALUE in the kernel arguments (scalar loads on demand, 123 VGPRs = two
 // workgroups per CU; read through a device pointer the fields sit in VGPRs: 147-150, one workgroup per CU)
 #define ICP_BYVAL 8
 struct IcpArgsB { IcpArgs a[ICP_BYVAL]; };
-template <int TILE_PTS, bool GRID> __global__ void __launch_bounds__(FUSED_BS) k_icp_fused_b(IcpArgsB b) { d_icp_fused<TILE_PTS, GRID>(b.a[blockIdx.y]); }
+template <int TILE_PTS, bool GRID> __global__ void __launch_bounds__(FUSED_BS) FUSED_OCC k_icp_fused_b(IcpArgsB b) { d_icp_fused<TILE_PTS, GRID>(b.a[blockIdx.y]); }
 
 // Source points per workgroup of the fused kernel (PCR_ICP_TILE = 128 ... 2048; PCR_ICP_PPL = 1 / 2 / 4 is the older spelling of
 // 512 / 1024 / 2048).  The workgroup's 64 octets serve its pending queries 64 at a time, so a 512-point tile whose certificates do not

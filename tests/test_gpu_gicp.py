@@ -293,6 +293,12 @@ def test_switches_do_not_change_the_result():
         lines.append([l for l in out.stdout.splitlines() if l.startswith("GICP ")][-1])
     for env, line in zip(variants[1:], lines[1:]):
         assert line == lines[0], (env, line[:80], lines[0][:80])
+    # the list certificates (round 5) checked from inside: with PCR_ICP_VERIFY every query a certificate decides is searched anyway (two-kernel form) and
+    # a decision the search does not confirm is reported by the kernel; none may be, and the result is the same bits
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gicp_pose.py")], env=dict(os.environ, PCR_ICP_FUSED="0", PCR_ICP_VERIFY="1"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "certificate violated" not in out.stdout and "certificate violated" not in out.stderr, out.stdout[-2000:]
+    assert [l for l in out.stdout.splitlines() if l.startswith("GICP ")][-1] == lines[0]
     # clouds that carry normals (averaged per voxel, orientation prior of the estimated ones): merged and per-scale voxel passes agree
     with_n = []
     for env in ({"GICP_POSE_WITH_NORMALS": "1"}, {"GICP_POSE_WITH_NORMALS": "1", "PCR_VOXEL_MERGED": "0"}):
