@@ -964,9 +964,12 @@ static int fused_tile_points(const pcr_context *ctx, int cap, int G) {
     static const int fixed = getenv("PCR_ICP_TILE") ? atoi(getenv("PCR_ICP_TILE")) : (getenv("PCR_ICP_PPL") ? FUSED_BS * atoi(getenv("PCR_ICP_PPL")) : 0);
     int t = fixed;
     if (t <= 0) {
-        t = (G > 1 || ctx->group_forms) ? 1024 : (cap >= 40000 ? 256 : 512);      // group_forms: a unit of a lockstep-group plan, whatever its size
+        // group_forms: a unit of a lockstep-group plan, whatever its size.  One pair: 256 from 40k points (the slowest workgroup's search sets the
+        // launch), 1024 from 400k (round 5, config 5's 0.5-1.6M-point scales: the launch is several rounds of workgroups and fewer, fatter ones win:
+        // 568 against 617 us per launch in flight, 26.0 against 24.9 pairs/s; 2048: 603 / 25.4)
+        t = (G > 1 || ctx->group_forms) ? 1024 : (cap >= 400000 ? 1024 : (cap >= 40000 ? 256 : 512));
     }
-    t = t >= 2048 ? 2048 : (t >= 1024 ? 1024 : (t >= 512 ? 512 : (t >= 256 ? 256 : 128)));
+    t = t >= 2048 ? 2048 : (t >= 1024 ? 1024 : (t >= 512 ? 512 : 256));
     // the last workgroup of the fused kernel gathers one partial row per tile: at most 4096 of them (2M-point clouds of config 5: tiles of 512)
     while (t < 2048 && (cap + t - 1) / t > 4088) t *= 2;
     return t;
@@ -974,7 +977,6 @@ static int fused_tile_points(const pcr_context *ctx, int cap, int G) {
 #define PCR_FUSED_LAUNCH_(ctx, KERNEL, GRID, tile, grid, arg)                                                          \
     do {                                                                                                               \
         switch (tile) {                                                                                                \
-            case 128: PCR_LAUNCH(ctx, (KERNEL<128, GRID>), grid, dim3(FUSED_BS), 0, (ctx)->stream, arg); break;        \
             case 256: PCR_LAUNCH(ctx, (KERNEL<256, GRID>), grid, dim3(FUSED_BS), 0, (ctx)->stream, arg); break;        \
             case 1024: PCR_LAUNCH(ctx, (KERNEL<1024, GRID>), grid, dim3(FUSED_BS), 0, (ctx)->stream, arg); break;      \
             case 2048: PCR_LAUNCH(ctx, (KERNEL<2048, GRID>), grid, dim3(FUSED_BS), 0, (ctx)->stream, arg); break;      \

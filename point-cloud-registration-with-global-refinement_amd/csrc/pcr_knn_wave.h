@@ -324,6 +324,22 @@ __device__ static inline void d_knn_wave(const KnnArgs &a) {
     // pass 1: distances only; every candidate that beats the bound of some lane is logged for pass 2
     int nlog = 0;
     const kw_f2 qx2 = {q.x, q.x}, qy2 = {q.y, q.y}, qz2 = {q.z, q.z};
+    // x replaces the largest entry when it is smaller, else the chain leaves the list as it is; entries are >= 0 or -1, so they order like
+    // their bit patterns (integer min / max: no NaN canonicalisation).  (A lambda of its own since round 5: written out inside the four-way
+    // unrolled step the same chain cost the 30-NN instance 12 spilled VGPRs, so 3.)
+    auto insert = [&](const float d2) {
+        const float x = __int_as_float(min(__float_as_int(d2), __float_as_int(sd[0])));
+        if (K == 1) sd[0] = x;
+        else {
+            float nd[K];
+            nd[0] = __int_as_float(max(__float_as_int(x), __float_as_int(sd[1])));
+#pragma unroll
+            for (int s = 1; s + 1 < K; s++) nd[s] = __builtin_amdgcn_fmed3f(x, sd[s], sd[s + 1]);
+            nd[K - 1] = __int_as_float(min(__float_as_int(x), __float_as_int(sd[K - 1])));
+#pragma unroll
+            for (int s = 0; s < K; s++) sd[s] = nd[s];
+        }
+    };
     auto scan1 = [&](int nb) {
 #if KW_STEP == 2         // two candidates per step: 16 VGPRs of read-ahead instead of 32
         float2 nX = *(const float2 *)&sh.stage.x[0], nY = *(const float2 *)&sh.stage.y[0], nZ = *(const float2 *)&sh.stage.z[0];
@@ -360,19 +376,7 @@ __device__ static inline void d_knn_wave(const KnnArgs &a) {
                 if (STATS) st1.events++;
                 sh.log[nlog < KwShared<K>::LOG ? nlog : KwShared<K>::LOG - 1] = i4[u];      // all lanes, one address, one value
                 nlog = __builtin_amdgcn_readfirstlane(nlog + 1);
-                // x replaces the largest entry when it is smaller, else the chain leaves the list as it is; entries are >= 0 or -1, so
-                // they order like their bit patterns (integer min / max: no NaN canonicalisation)
-                const float x = __int_as_float(min(__float_as_int(d2), __float_as_int(sd[0])));
-                if (K == 1) sd[0] = x;
-                else {
-                    float nd[K];
-                    nd[0] = __int_as_float(max(__float_as_int(x), __float_as_int(sd[1])));
-#pragma unroll
-                    for (int s = 1; s + 1 < K; s++) nd[s] = __builtin_amdgcn_fmed3f(x, sd[s], sd[s + 1]);
-                    nd[K - 1] = __int_as_float(min(__float_as_int(x), __float_as_int(sd[K - 1])));
-#pragma unroll
-                    for (int s = 0; s < K; s++) sd[s] = nd[s];
-                }
+                insert(d2);
             }
             }
         }

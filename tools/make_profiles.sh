@@ -4,8 +4,8 @@
 #   profiles/rNN_pmc_hbm_traffic.csv      per-kernel HBM traffic from separate --pmc passes (FETCH_SIZE, WRITE_SIZE, TCC hit/miss)
 #   profiles/rNN_traffic.json             the same numbers keyed by kernel (bench.py reads it for roofline.traffic)
 #   profiles/rNN_config5_kernel_stats.csv / rNN_nclt_kernel_stats.csv: the same summary for config 5 (2M points, 5 scales) and NCLT-size pairs
-# usage: tools/make_profiles.sh r04
-TAG=${1:-r04}
+# usage: tools/make_profiles.sh r05
+TAG=${1:-r05}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out/profiles_$TAG
@@ -15,6 +15,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- p
 cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$ROOT/profiles/${TAG}_bench_kernel_stats.csv"
 python3 "$ROOT/tools/icp_gap_hist.py" "$OUT/stats" "$ROOT/profiles/${TAG}_icp_gaps_inflight.txt" > /dev/null
 python3 "$ROOT/tools/trace_overview.py" "$OUT/stats" 0.4 > "$ROOT/profiles/${TAG}_trace_overview_inflight.txt"
+python3 "$ROOT/tools/trace_bins.py" "$OUT/stats" > "$ROOT/profiles/${TAG}_timeline_bins.txt"
 # config 2's FGR variant (registro_FGR + the same GICP): kernel summary of the same command the bench line of that variant comes from
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/fgr" -o run -- python3 "$ROOT/bench.py" --variant fgr --no-cpu-baseline --steps 1 --warmup 1 --pairs-per-step 16 > "$OUT/bench_fgr.log" 2> "$OUT/bench_fgr.err" || exit 1
 cp "$(find "$OUT/fgr" -name '*kernel_stats.csv' | head -1)" "$ROOT/profiles/${TAG}_fgr_kernel_stats.csv"
@@ -58,6 +59,7 @@ def norm(name):                      # whatever the tile, the search form and th
     if name.startswith("void k_knn_wave_batchp<0, 30>"): return "k_knn_wave_batchp<SOR,30>"
     if name.startswith("void k_knn_list_batchp<0, 4>"): return "k_knn_list_batchp<SOR,4>"
     if name.startswith("void k_knn_batchp<1, 4>"): return "k_knn_batchp<NORMALS,4>"
+    if name.startswith("void k_knn_list_batchp<1, 4>"): return "k_knn_list_batchp<NORMALS,4>"
     return {"void k_icp_iter<0>(IcpArgs)": "k_icp_iter<GICP>", "void k_knn_batch<0, 4>(KnnBatch)": "k_knn_batch<SOR,4>", "void k_knn_batch<1, 4>(KnnBatch)": "k_knn_batch<NORMALS,4>",
             "k_normals_from_lists_batch(NflBatch)": "k_normals_from_lists_batch", "k_grid_build(GridBuildDesc const*)": "k_grid_build"}.get(name, name.split("(")[0])
 def load(pat):
@@ -70,7 +72,7 @@ def load(pat):
     return d
 rows, js = [], {}
 for group_form, names in ((False, ["k_icp_fused", "k_icp_nn", "k_icp_iter<GICP>", "k_knn_batch<SOR,4>", "k_knn_batch<NORMALS,4>", "k_normals_from_lists_batch", "k_grid_build", "k_rs_scatter"]),
-                          (True, ["k_icp_fused", "k_knn_wave_batchp<SOR,30>", "k_knn_list_batchp<SOR,4>", "k_knn_batchp<NORMALS,4>", "k_normals_from_lists_batchp", "k_icp_nn_g", "k_icp_lin_g"])):
+                          (True, ["k_icp_fused", "k_knn_wave_batchp<SOR,30>", "k_knn_list_batchp<SOR,4>", "k_knn_list_batchp<NORMALS,4>", "k_normals_from_lists_batchp", "k_icp_nn_g", "k_icp_lin_g"])):
   pre = "pmcg_" if group_form else "pmc_"
   fetch, write, tcc = load(pre + "FETCH_SIZE"), load(pre + "WRITE_SIZE"), load(pre + "TCC_HIT_sum_TCC_MISS_sum")
   for name in names:
