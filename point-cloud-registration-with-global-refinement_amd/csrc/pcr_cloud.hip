@@ -847,11 +847,23 @@ int pcr_dev_build_bvh(pcr_context *ctx, DevCloud *c) { return pcr_dev_build_bvh_
 // ====================================================================== cell hash of a voxel-lattice cloud (pcr_octree.h GridView)
 // One thread per point: the first point of a level-L Morton cell counts the cell's points (<= 8^L: the lattice holds one point per
 // voxel) and inserts (code -> first, count) by linear probing.  blockIdx.y picks the cloud.
-struct GridBuildDesc { const uint64_t *keys; const int *n; GridEntry *tab; unsigned mask; int shift; };
-__global__ void __launch_bounds__(BS) k_grid_build(const GridBuildDesc *descs) {
+struct GridBuildDesc { const uint64_t *keys; const int *n; GridEntry *tab; unsigned *dmask; unsigned max_slots; int shift; };
+// the table of a cloud is as large as its point COUNT asks for (pcr_grid_slots), inside the allocation its capacity asked for: cleared here, mask left for the searches
+__global__ void __launch_bounds__(BS) k_grid_clear(const GridBuildDesc *descs) {
     const GridBuildDesc d = descs[blockIdx.y];
-    const int n = *d.n, i = blockIdx.x * BS + threadIdx.x;
+    const int n = *d.n;
+    unsigned slots = pcr_grid_slots((unsigned)(n > 0 ? n : 0)); slots = slots < d.max_slots ? slots : d.max_slots;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *d.dmask = slots - 1;
+    const unsigned long long ff = 0xffffffffffffffffull;
+    ulonglong2 *t2 = (ulonglong2 *)d.tab;
+    for (unsigned i = blockIdx.x * BS + threadIdx.x; i < slots; i += gridDim.x * BS) t2[i] = make_ulonglong2(ff, ff);
+}
+__global__ void __launch_bounds__(BS) k_grid_build(const GridBuildDesc *descs) {
+    const GridBuildDesc dd = descs[blockIdx.y];
+    const int n = *dd.n, i = blockIdx.x * BS + threadIdx.x;
     if (i >= n) return;
+    unsigned slots = pcr_grid_slots((unsigned)n); slots = slots < dd.max_slots ? slots : dd.max_slots;
+    struct { const uint64_t *keys; GridEntry *tab; unsigned mask; int shift; } d = {dd.keys, dd.tab, slots - 1, dd.shift};
     const unsigned long long code = d.keys[i] >> d.shift;
     if (i > 0 && (d.keys[i - 1] >> d.shift) == code) return;
     int j = i + 1;
@@ -877,7 +889,7 @@ int pcr_grid_level_for(const DevCloud *c, double search_radius) {
 int pcr_dev_build_grid_batch(pcr_context *ctx, const DevCloud *const *cs, const int *levels, int count, GridView *views) {
     std::vector<GridBuildDesc> d; int max_cap = 0;
     size_t total_slots = 0;
-    auto slots_of = [](const DevCloud *c) { unsigned s = 64; while (s < (unsigned)c->cap * 2u && s < (1u << 30)) s <<= 1; return s; };      // load factor <= 0.5
+    auto slots_of = [](const DevCloud *c) { return pcr_grid_slots((unsigned)c->cap); };      // the allocation: what the capacity could need (load factor <= 0.5)
     for (int k = 0; k < count; k++) {
         std::memset(&views[k], 0, sizeof(GridView)); views[k].L = -1;
         if (levels[k] < 0 || cs[k]->cap <= 0 || !cs[k]->voxel_lattice) continue;
@@ -885,21 +897,25 @@ int pcr_dev_build_grid_batch(pcr_context *ctx, const DevCloud *const *cs, const 
     }
     if (total_slots == 0) return PCR_OK;
     GridEntry *tab = arena<GridEntry>(ctx, total_slots);
-    if (!tab) return PCR_ENOMEM;
-    PCR_HIP_CHECK(ctx, hipMemsetAsync(tab, 0xff, total_slots * sizeof(GridEntry), ctx->stream));
+    unsigned *dmasks = arena<unsigned>(ctx, (size_t)count);
+    if (!tab || !dmasks) return PCR_ENOMEM;
     size_t off = 0;
     for (int k = 0; k < count; k++) {
         const DevCloud *c = cs[k];
         if (levels[k] < 0 || c->cap <= 0 || !c->voxel_lattice) continue;
         const unsigned slots = slots_of(c);
         GridView &g = views[k];
-        g.tab = tab + off; g.mask = slots - 1; g.L = levels[k];
+        g.tab = tab + off; g.dmask = dmasks + k; g.L = levels[k];
         for (int a = 0; a < 3; a++) { g.org[a] = c->key_org[a]; g.inv_unit[a] = 1.0f / c->key_unit[a]; g.cell[a] = c->key_unit[a] * (float)(1 << levels[k]); }
-        d.push_back(GridBuildDesc{c->keys, c->n, tab + off, slots - 1, 3 * levels[k]});
+        d.push_back(GridBuildDesc{c->keys, c->n, tab + off, dmasks + k, slots, 3 * levels[k]});
         off += slots; max_cap = c->cap > max_cap ? c->cap : max_cap;
     }
     const GridBuildDesc *dd = pcr_desc_upload(ctx, d.data(), (int)d.size());
     if (!dd) return PCR_ENOMEM;
+    {   // clear: a grid-stride launch over what the COUNT needs (a quarter of a 2M-capacity table for a 460k-point scale)
+        const unsigned gx = (unsigned)((2 * (size_t)max_cap + BS - 1) / BS);
+        PCR_LAUNCH(ctx, k_grid_clear, dim3(gx < 2048u ? gx : 2048u, (unsigned)d.size()), dim3(BS), 0, ctx->stream, dd);
+    }
     PCR_LAUNCH(ctx, k_grid_build, dim3((unsigned)((max_cap + BS - 1) / BS), (unsigned)d.size()), dim3(BS), 0, ctx->stream, dd);
     return PCR_OK;
 }

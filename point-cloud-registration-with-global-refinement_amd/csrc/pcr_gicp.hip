@@ -349,6 +349,7 @@ __device__ static inline void d_icp_nn(const IcpArgs &a) {
     for (int k = 0; k < 12; k++) T[k] = st->T[k];
     int mword = 0;
     if (threadIdx.x < (int)(sizeof(OctMeta) / 4)) mword = ((const int *)a.tgt.meta)[threadIdx.x];
+    const unsigned gmask = GRID ? *a.grid.dmask : 0u;          // (the cell hash's size lives on the device: requested with everything else)
     if (done) return;
     if ((int)blockIdx.x * OPB >= ns) return;
     const unsigned long long t_wave0 = wall_clock64();
@@ -400,7 +401,7 @@ __device__ static inline void d_icp_nn(const IcpArgs &a) {
     if (live) { const float4 r = rec_q[ob]; qx = r.x; qy = r.y; qz = r.z; hint = __float_as_int(r.w); qi = rec_i[ob]; }
     int visits = 0, start_pt = 0; float d1 = 0, d2 = 0;
     int best; int nnk[PCR_NN_K];
-    if (GRID) { grid_nn_query8<PCR_NN_K>(a.grid, a.tgt_pts, live, qx, qy, qz, a.ref ? a.r2s : a.r2f, ol, nnk, &d1, &d2); best = nnk[0]; start_pt = hint >= 0 ? hint : 0; }
+    if (GRID) { grid_nn_query8<PCR_NN_K>(a.grid, gmask, a.tgt_pts, live, qx, qy, qz, a.ref ? a.r2s : a.r2f, ol, nnk, &d1, &d2); best = nnk[0]; start_pt = hint >= 0 ? hint : 0; }
     else best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.ref ? a.r2s : a.r2f, hint, ol, oct, ob, &start_pt, a.dbg_visits ? &visits : nullptr, &d1, &d2);
     if (a.verify && ol == 0 && live && rec_c[ob] != -2) {
         const int claim = rec_c[ob];
@@ -821,6 +822,7 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
     for (int k = 0; k < 12; k++) T[k] = st->T[k];
     int mword = 0;
     if (tid < (int)(sizeof(OctMeta) / 4)) mword = ((const int *)a.tgt.meta)[tid];
+    const unsigned gmask = GRID ? *a.grid.dmask : 0u;
     if (done) return;
     if (bid >= nb) return;
 #pragma unroll
@@ -891,7 +893,7 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
         for (int e = tid >> 6; e < npend; e += FUSED_BS / 64) {
             const float4 r = rec_q[e]; const int l = rec_l[e];
             float d1 = 0, d2 = 0; int nnk[PCR_NN_K];
-            grid_nn_query64<PCR_NN_K>(a.grid, a.tgt_pts, r.x, r.y, r.z, a.r2s, lane, nnk, &d1, &d2);
+            grid_nn_query64<PCR_NN_K>(a.grid, gmask, a.tgt_pts, r.x, r.y, r.z, a.r2s, lane, nnk, &d1, &d2);
             if (lane == 0) {
                 const int qi = tile0 + l;
                 a.ref[qi] = make_float4(r.x, r.y, r.z, sqrtf(d2));
@@ -909,7 +911,7 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
         if (live) { const float4 r = rec_q[e]; qx = r.x; qy = r.y; qz = r.z; hint = __float_as_int(r.w); l = rec_l[e]; }
         int start_pt = 0; float d1 = 0, d2 = 0;
         int best; int nnk[PCR_NN_K];
-        if (GRID) { grid_nn_query8<PCR_NN_K>(a.grid, a.tgt_pts, live, qx, qy, qz, a.r2s, ol, nnk, &d1, &d2); best = nnk[0]; start_pt = hint >= 0 ? hint : 0; }
+        if (GRID) { grid_nn_query8<PCR_NN_K>(a.grid, gmask, a.tgt_pts, live, qx, qy, qz, a.r2s, ol, nnk, &d1, &d2); best = nnk[0]; start_pt = hint >= 0 ? hint : 0; }
         else best = oct_nn_query<OPB>(a.tgt, m, stk, live, qx, qy, qz, a.r2s, hint, ol, oct, ob, &start_pt, nullptr, &d1, &d2);
         if (ol == 0 && live) {
             const int qi = tile0 + l;

@@ -196,10 +196,13 @@ __device__ static inline void oct_search(const OctView &t, const OctMeta &m, Oct
 struct GridEntry { unsigned long long code; int first, count; };     // 16 B: one load per probe; code 0xffff... = empty slot
 struct GridView {
     const GridEntry *tab;
-    unsigned mask; int L;
+    const unsigned *dmask; int L;             // slots - 1 of the table, ON THE DEVICE: the table is sized by the cloud's point COUNT (round 5), which only the device knows
+                                              //   (sized by the capacity, a 1.6M-point scale of a 2M-point cloud cleared 64 MB per call: 4.5 % of config 5's kernel time)
     float org[3], inv_unit[3], cell[3];       // lattice origin, 1 / voxel, cell edge (voxel * 2^L)
 };
 #define PCR_GRID_EMPTY 0xffffffffffffffffull
+// slots of the table of a cloud of n points: the power of two from 2 n (load <= 0.5), at least 64; the same rule in k_grid_clear, k_grid_build and the host's allocation
+__host__ __device__ static inline unsigned pcr_grid_slots(unsigned n) { unsigned s = 64; while (s < n * 2u && s < (1u << 30)) s <<= 1; return s; }
 __host__ __device__ static inline unsigned pcr_grid_hash(unsigned long long code, unsigned mask) {
     return (unsigned)((code * 0x9E3779B97F4A7C15ull) >> 40) & mask;
 }
@@ -259,13 +262,12 @@ template <int K> __device__ static inline void pcr_nn_insert(float (&d)[K + 1], 
     d[K] = fminf(d[K], cd);
 }
 template <int K>
-__device__ static inline void grid_nn_query8(const GridView &g, const float4 *__restrict__ pts, bool live, float qx, float qy, float qz, float r2cap, int ol,
+__device__ static inline void grid_nn_query8(const GridView &g, const unsigned mask, const float4 *__restrict__ pts, bool live, float qx, float qy, float qz, float r2cap, int ol,
                                              int (&out_id)[K], float *d1_out, float *dnext_out) {
     float d[K + 1]; int id[K];
 #pragma unroll
     for (int k = 0; k < K; k++) { d[k] = r2cap; id[k] = -1; }
     d[K] = r2cap;
-    const unsigned mask = g.mask;
     int rng = 0;                                    // the lane's cell: first point | count << 22 (0: absent, empty or out of reach)
     float gx2 = 0.0f, gy2 = 0.0f, gz2 = 0.0f;       // squared gap between q and the neighbour cell, per axis (the same in all lanes of the octet)
     if (live) {
@@ -359,7 +361,7 @@ __device__ static inline int pcr_wave_min_i(int v) {          // over all 64 lan
     return min((int)a, (int)o);
 }
 template <int K>
-__device__ static inline void grid_nn_query64(const GridView &g, const float4 *__restrict__ pts, float qx, float qy, float qz, float r2cap, int lane,
+__device__ static inline void grid_nn_query64(const GridView &g, const unsigned mask, const float4 *__restrict__ pts, float qx, float qy, float qz, float r2cap, int lane,
                                               int (&out_id)[K], float *d1_out, float *dnext_out) {
     const int b = lane >> 3, ol = lane & 7;
     float d[K + 1]; int id[K];
@@ -379,7 +381,7 @@ __device__ static inline void grid_nn_query64(const GridView &g, const float4 *_
         const float g2 = ((b & 1) ? ax * ax : 0.0f) + ((b & 2) ? ay * ay : 0.0f) + ((b & 4) ? az * az : 0.0f);
         const int lim = (1 << 21) >> g.L;
         if (g2 < r2cap && x >= 0 && y >= 0 && z >= 0 && x < lim && y < lim && z < lim) {
-            const int2 r = pcr_grid_lookup(g, g.mask, x, y, z);
+            const int2 r = pcr_grid_lookup(g, mask, x, y, z);
             first = r.x; cnt = r.y > 0 ? r.y : 0;
         }
     }
