@@ -557,8 +557,18 @@ __device__ static inline void icp_finish(const IcpArgs &a, IcpState *st, const d
     const unsigned long long t_search = wall_clock64() - t_entry;
     // ---- workgroup reduction: DPP butterfly inside every 16-lane row (no LDS crossbar), then the 64 rows in order
     const int lane = threadIdx.x & 63;
+#ifdef ICP_ROWSUM_FULL
 #pragma unroll
     for (int k = 0; k < NV; k++) { const double s = pcr_row16_sum(acc[k]); if ((lane & 15) == 0) red[threadIdx.x >> 4][k] = s; }
+#else
+    {   // halving butterfly (pcr_device.h): lane r of a row ends with the sums of values r and 16 + r -- the same bits as pcr_row16_sum, 218 instead of 384 instructions
+        double lo, hi;
+        pcr_row16_sum_halving<NV>(acc, lane, &lo, &hi);
+        const int r = lane & 15;
+        red[threadIdx.x >> 4][r] = lo;
+        if (16 + r < NV) red[threadIdx.x >> 4][16 + r] = hi;
+    }
+#endif
     const unsigned long long t_ws = wall_clock64();
     __syncthreads();
     if (threadIdx.x < NV) {
