@@ -766,15 +766,19 @@ __device__ static inline void d_oct_level_boxes(const OctMeta *__restrict__ meta
     if (__ballot(live) == 0ull) return;
     oct_node_box(*meta, child, boxes, up, li, j, live, threadIdx.x & 7, pinfo, l1);
 }
-// remaining (small) levels in ONE workgroup of 1024 threads = 128 octets, level by level
+// remaining (small) levels in ONE workgroup per tree, level by level.  OCT_UPPER_BS threads = that / 8 octets per round.  (Round 5: 256 threads instead of
+// 1024.  A 1024-thread workgroup needs a CU with sixteen free wavefront slots at once; next to the other groups' 9-ms k-NN launches it waited for one:
+// 0.9 ms on average and up to 11 ms for ~30 us of work, 5.3 % of the headline run's kernel time and every group's chain held up twice.)
+#define OCT_UPPER_BS 256
 __device__ static inline void d_oct_upper_boxes(const OctMeta *__restrict__ meta, const int *__restrict__ child, float4 *__restrict__ boxes, int4 *__restrict__ up, int first_li) {
     __shared__ OctMeta m;
     if (threadIdx.x == 0) m = *meta;
     __syncthreads();
+    constexpr int OPR = OCT_UPPER_BS / OCT;
     for (int li = first_li; li < m.nl; li++) {
-        const int rounds = (m.cnt[li] + 127) / 128;
+        const int rounds = (m.cnt[li] + OPR - 1) / OPR;
         for (int r = 0; r < rounds; r++) {
-            const int j = r * 128 + (threadIdx.x >> 3);
+            const int j = r * OPR + (threadIdx.x >> 3);
             oct_node_box(m, child, boxes, up, li, j, j < m.cnt[li], threadIdx.x & 7);
         }
         __threadfence_block();
@@ -801,13 +805,13 @@ __global__ void __launch_bounds__(256) k_oct_meta(OctBuildBatch b) { dd_oct_meta
 __global__ void __launch_bounds__(BS) k_oct_apply(OctBuildBatch b) { dd_oct_apply(b.a[blockIdx.y]); }
 __global__ void __launch_bounds__(BS) k_oct_leaf_boxes(OctBuildBatch b) { dd_oct_leaf(b.a[blockIdx.y]); }
 __global__ void __launch_bounds__(BS) k_oct_level_boxes(OctBuildBatch b) { dd_oct_level1(b.a[blockIdx.y]); }
-__global__ void __launch_bounds__(1024) k_oct_upper_boxes(OctBuildBatch b) { dd_oct_upper(b.a[blockIdx.y]); }
+__global__ void __launch_bounds__(OCT_UPPER_BS) k_oct_upper_boxes(OctBuildBatch b) { dd_oct_upper(b.a[blockIdx.y]); }
 __global__ void __launch_bounds__(BS) k_oct_lstar_p(const OctBuildDesc *a) { dd_oct_lstar(a[blockIdx.y]); }
 __global__ void __launch_bounds__(256) k_oct_meta_p(const OctBuildDesc *a) { dd_oct_meta(a[blockIdx.y]); }
 __global__ void __launch_bounds__(BS) k_oct_apply_p(const OctBuildDesc *a) { dd_oct_apply(a[blockIdx.y]); }
 __global__ void __launch_bounds__(BS) k_oct_leaf_boxes_p(const OctBuildDesc *a) { dd_oct_leaf(a[blockIdx.y]); }
 __global__ void __launch_bounds__(BS) k_oct_level_boxes_p(const OctBuildDesc *a) { dd_oct_level1(a[blockIdx.y]); }
-__global__ void __launch_bounds__(1024) k_oct_upper_boxes_p(const OctBuildDesc *a) { dd_oct_upper(a[blockIdx.y]); }
+__global__ void __launch_bounds__(OCT_UPPER_BS) k_oct_upper_boxes_p(const OctBuildDesc *a) { dd_oct_upper(a[blockIdx.y]); }
 
 int pcr_dev_build_bvh_batch(pcr_context *ctx, DevCloud *const *cs, int count) {
     if (count < 1) return PCR_OK;
@@ -839,7 +843,7 @@ int pcr_dev_build_bvh_batch(pcr_context *ctx, DevCloud *const *cs, int count) {
     PCR_TRY(PCR_BATCH_LAUNCH(ctx, OctBuildBatch, k_oct_leaf_boxes, k_oct_leaf_boxes_p, b.data(), m, dim3(max_nbl, m), dim3(BS)));
     PCR_TRY(PCR_BATCH_LAUNCH(ctx, OctBuildBatch, k_oct_level_boxes, k_oct_level_boxes_p, b.data(), m, dim3(max_nbl, m), dim3(BS)));
     // levels >= 2 (n/64 nodes and fewer) in ONE workgroup per tree, level by level: a launch less than one grid per level
-    PCR_TRY(PCR_BATCH_LAUNCH(ctx, OctBuildBatch, k_oct_upper_boxes, k_oct_upper_boxes_p, b.data(), m, dim3(1, m), dim3(1024)));
+    PCR_TRY(PCR_BATCH_LAUNCH(ctx, OctBuildBatch, k_oct_upper_boxes, k_oct_upper_boxes_p, b.data(), m, dim3(1, m), dim3(OCT_UPPER_BS)));
     return PCR_OK;
 }
 int pcr_dev_build_bvh(pcr_context *ctx, DevCloud *c) { return pcr_dev_build_bvh_batch(ctx, &c, 1); }
