@@ -51,6 +51,8 @@ struct IcpArgs {
     const float4 *tgt_pts, *tgt_nrm; OctView tgt; const int *nt_ptr;
     GridView grid;                               // cell hash of the target (grid.tab == nullptr: search the octree)
     int32_t *match; int src_cap;
+    int tile_rt;                                 // fused kernel: source points per workgroup of THIS problem when smaller than the kernel's tile (0: the kernel's): a launch of a lockstep
+                                                 //   group has one kernel form, its pairs their own tile by their own size (same bits however the batch is cut)
     float4 *ref; int32_t *rbest;                 // per source point: position and margin / nearest point of its last search (skip certificate, tree-walk form)
     int4 *clist;                                 // cell-hash form: the PCR_NN_K nearest target points of the last search (list certificate); ref.w = distance of the next one
     float r2s, rs_minus_r;                       // search cap (r + g)^2 of the certificate mode and g = the unmatched margin
@@ -813,16 +815,17 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
     // part of the target tree instead of all of it (the grid is a multiple of 8 and covers 8 per; rows of the partial sums stay in tile
     // order: same arithmetic)
     const int ns = *a.ns_ptr, nt = *a.nt_ptr;
-    const int nb = (ns + TILE_PTS - 1) / TILE_PTS > 0 ? (ns + TILE_PTS - 1) / TILE_PTS : 1;
+    const int tile = (a.tile_rt > 0 && a.tile_rt < TILE_PTS) ? a.tile_rt : TILE_PTS;      // (kernel argument: uniform)
+    const int nb = (ns + tile - 1) / tile > 0 ? (ns + tile - 1) / tile : 1;
     const int per = (nb + 7) >> 3;
     const int bid = (int)(blockIdx.x >> 3) < per ? (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3) : nb;
-    const int tile0 = (bid < nb ? bid : 0) * TILE_PTS;
+    const int tile0 = (bid < nb ? bid : 0) * tile;
     float4 pf[PPL], refv[PPL]; int mraw[PPL], rb[PPL]; int4 lst[PPL];
     IcpPre pre[PPL];                            // phase C's inputs, requested as early as they are known
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
         const int i = tile0 + p * FUSED_BS + tid;
-        const int ic = (i < a.src_cap && p * FUSED_BS + tid < TILE_PTS) ? i : 0;
+        const int ic = (i < a.src_cap && p * FUSED_BS + tid < tile) ? i : 0;
         pf[p] = a.src_pts[ic]; mraw[p] = a.match[ic]; refv[p] = a.ref[ic];
         if (GRID) { lst[p] = a.clist[ic]; rb[p] = -1; } else { rb[p] = a.rbest[ic]; lst[p] = make_int4(-1, -1, -1, -1); }
         pre[p].pf = pf[p]; pre[p].sn = a.src_nrm[ic];
@@ -850,7 +853,7 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
 #pragma unroll
         for (int p = 0; p < PPL; p++) {
             // (records beyond the cloud's count are never written: their indices are whatever the arena held)
-            if (!(p * FUSED_BS + tid < TILE_PTS && tile0 + p * FUSED_BS + tid < ns)) lst[p] = make_int4(-1, -1, -1, -1);
+            if (!(p * FUSED_BS + tid < tile && tile0 + p * FUSED_BS + tid < ns)) lst[p] = make_int4(-1, -1, -1, -1);
             icp_list_load(a.tgt_pts, lst[p], ltp[p]);
         }
     }
@@ -858,7 +861,7 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
         const int i = tile0 + p * FUSED_BS + tid;
-        const bool mine = p * FUSED_BS + tid < TILE_PTS;
+        const bool mine = p * FUSED_BS + tid < tile;
         bool need = false;
         int cand = -1;
         float qx = 0, qy = 0, qz = 0; int hint = -1;
@@ -947,7 +950,7 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
 #pragma unroll
     for (int p = 0; p < PPL; p++) {
         const int i = tile0 + p * FUSED_BS + tid;
-        if (p * FUSED_BS + tid < TILE_PTS && i < ns) {
+        if (p * FUSED_BS + tid < tile && i < ns) {
             const int c = cand_l[p * FUSED_BS + tid];
             if (c >= 0 && c != mraw[p]) a.match[i] = c;
             if (c >= 0 && c != pre_c[p]) { pre[p].tf = a.tgt_pts[c]; pre[p].tn = a.tgt_nrm[c]; }      // searched in phase B
@@ -985,6 +988,14 @@ static int fused_tile_points(const pcr_context *ctx, int cap, int G) {
     // the last workgroup of the fused kernel gathers one partial row per tile: at most 4096 of them (2M-point clouds of config 5: tiles of 512)
     while (t < 2048 && (cap + t - 1) / t > 4088) t *= 2;
     return t;
+}
+// Tile of a pair in the GROUP forms (round 5): 512 points up to 40k source points -- the NCLT scans: five scales of 5-20k points, where a launch is one
+// round of a few workgroups and halving their work shortens it (script-2 stage on the shipped scans, groups of 8 x 4: 1590-1780 -> 1900-2020 pairs/s) --
+// else the kernel's 1024 (50k points: 1892 against 1841 with 512; 100k: 1197 against 1164; 200k: 698 against 672).  By the PAIR alone.
+static int icp_group_tile(int cap, int kernel_tile) {
+    static const bool fixed = getenv("PCR_ICP_TILE") || getenv("PCR_ICP_PPL");
+    if (fixed || kernel_tile != 1024) return 0;
+    return cap < 40000 ? 512 : 0;
 }
 #define PCR_FUSED_LAUNCH_(ctx, KERNEL, GRID, tile, grid, arg)                                                          \
     do {                                                                                                               \
@@ -1078,13 +1089,15 @@ int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, dou
     const int nbmax = nblin < LIN_MAX_BLOCKS ? nblin : LIN_MAX_BLOCKS;
     const int nbnn = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT);
     const int tile_pts = fused_tile_points(ctx, cap, 1);
-    const int nbf = ((cap + tile_pts - 1) / tile_pts + 7) & ~7;      // workgroups of the fused kernel: one per tile of source points, a multiple of 8 (XCD order)
+    const int tile_eff = (ctx->group_forms && icp_group_tile(cap, tile_pts)) ? icp_group_tile(cap, tile_pts) : tile_pts;
+    const int nbf = ((cap + tile_eff - 1) / tile_eff + 7) & ~7;      // workgroups of the fused kernel: one per tile of source points, a multiple of 8 (XCD order)
     IcpState *st = arena<IcpState>(ctx, 1);
     const int rows = nblin > nbf ? nblin : nbf;
     double *partials = arena<double>(ctx, (size_t)rows * NVP);
     int32_t *match = match_dev ? match_dev : arena<int32_t>(ctx, cap);
     if (!st || !partials || !match) return PCR_ENOMEM;
     IcpArgs a; memset(&a, 0, sizeof a); fill_args(a, src, tgt, max_dist, p, match, st, partials, 0);
+    a.tile_rt = ctx->group_forms ? icp_group_tile(cap, tile_pts) : 0;
     if (use_skip && max_dist < 1e15) {
         a.ref = arena<float4>(ctx, cap); a.rbest = arena<int32_t>(ctx, cap); a.clist = arena<int4>(ctx, cap);
         if (!a.ref || !a.rbest || !a.clist) return PCR_ENOMEM;
@@ -1256,7 +1269,8 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
     for (int g = 0; g < G; g++) {
         const int cap = src[g]->cap > 0 ? src[g]->cap : 1;
         const int m_ = (cap + LIN_BS - 1) / LIN_BS;                      // k_icp_lin_g: one 512-point tile per workgroup
-        const int n_ = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT), f_ = ((cap + tile_pts - 1) / tile_pts + 7) & ~7;
+        const int tile_g = icp_group_tile(cap, tile_pts) ? icp_group_tile(cap, tile_pts) : tile_pts;
+        const int n_ = (cap + ICP_BS / OCT - 1) / (ICP_BS / OCT), f_ = ((cap + tile_g - 1) / tile_g + 7) & ~7;
         nbmax = m_ > nbmax ? m_ : nbmax; nbnn = n_ > nbnn ? n_ : nbnn; nbf = f_ > nbf ? f_ : nbf;
         double *partials = arena<double>(ctx, (size_t)(m_ > f_ ? m_ : f_) * NVP);
         int32_t *match = (match_dev && match_dev[g]) ? match_dev[g] : arena<int32_t>(ctx, cap);
@@ -1264,6 +1278,7 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
         IcpArgs &a = args[g]; memset(&a, 0, sizeof a);
         const double max_dist = max_dists[g];
         fill_args(a, src[g], tgt[g], max_dist, p, match, st + g, partials, 0);
+        a.tile_rt = icp_group_tile(cap, tile_pts);
         a.ref = arena<float4>(ctx, cap); a.rbest = arena<int32_t>(ctx, cap); a.clist = arena<int4>(ctx, cap);
         if (!a.ref || !a.rbest || !a.clist) return PCR_ENOMEM;
         double gg = gfrac * max_dist; gg = gg < 0.01 ? 0.01 : (gg > 0.05 ? 0.05 : gg);

@@ -241,15 +241,17 @@ def registro_fgr(source: PointCloud, target: PointCloud, voxel_size: float, use_
 
 def default_group(points_per_cloud: float) -> int:
     """Pairs per lockstep GICP group for clouds of this size: about 1.2M points per group, at most 8 (the by-value argument batch
-    of ``k_icp_fused_b``; larger groups take the by-pointer kernel).  Measured on one MI355X, 4 groups in flight, 3-scale
-    GICP stage, pair by pair -> groups: 200k-point pairs 340 -> 530 pairs/s (groups of 6), 100k 440 -> 850 (8), 50k 540 -> 1360 (8),
-    20k-point subsamples 680 -> 2460 (8; 2590 with 16).  On the reference's own scans (shipped-size NCLT pairs, ~28k points, the five-scale
-    stage of script 2, pairs in random order) groups of 6 / 8 / 10 / 12 / 16 give 1323 / 1640 / 1457 / 1430 / 1315 pairs/s
-    (``tools/gicp_nclt_sweep.py``): 8 it is, also for the smallest clouds (round 4; 16 before)."""
+    of ``k_icp_fused_b``; larger groups take the by-pointer kernel) -- 24 up to 40k points per cloud (round 5, below).  Measured on one
+    MI355X, 4 groups in flight, 3-scale GICP stage, pair by pair -> groups: 200k-point pairs 340 -> 530 pairs/s (groups of 6), 100k
+    440 -> 850 (8), 50k 540 -> 1360 (8) (round 3/4 numbers; HISTORY.md)."""
     if points_per_cloud >= 400_000:           # PCR_GROUP_FORMS_MAX_POINTS: such pairs run one by one with the single-pair kernel forms
         return 1
     g = int(round(1_200_000 / max(float(points_per_cloud), 1.0)))
-    return max(1, min(8, g))
+    # Round 5: up to 24 pairs (the library's limit) for clouds up to 40k points -- the reference's NCLT scans.  The by-pointer kernel of groups beyond 8
+    # holds 117 VGPRs now (146 before: one workgroup per CU, which is why 8 was the rule) and such pairs take 512-point tiles: script-2 stage on the
+    # shipped-size scans, tiled and in three random orders, 8 / 12 / 16 / 24 pairs x 4 groups in flight = 1970 / 2530 / 2390 / 2920 pairs/s
+    # (tools/gicp_nclt_sweep.py).  From 50k points the group size makes no difference (8 / 12 / 24: 1892 / 1874 / 1918 pairs/s at 50k, 1197 / 1199 / 1196 at 100k).
+    return max(1, min(24 if points_per_cloud <= 40_000 else 8, g))
 
 
 def default_fgr_group(points_per_cloud: float) -> int:

@@ -75,11 +75,11 @@ def test_io_roundtrip(tmp_path):
 
 def test_default_group_rule():
     """``register_pairs_plan(group=None)``: about 1.2M points per lockstep group, at most 8 pairs (the by-value argument batch of the fused
-    iteration kernel holds 8; measured best on the shipped-size NCLT scans too), pair by pair from 400k-point clouds up (the size from
-    which `pcr_pairs_plan.pair_forms` runs a pair alone with the single-pair kernel forms: configs 4 and 5)."""
+    iteration kernel) -- 24, the library's limit, for clouds up to 40k points (round 5: the reference's NCLT scans) --, pair by pair from
+    400k-point clouds up (the size from which `pcr_pairs_plan.pair_forms` runs a pair alone with the single-pair kernel forms: configs 4 and 5)."""
     g = pkg().registration.default_group
-    assert [g(n) for n in (20_000, 50_000, 100_000, 200_000, 399_999, 400_000, 2_000_000)] == [8, 8, 8, 6, 3, 1, 1]
-    assert g(0) == 8 and g(1e9) == 1
+    assert [g(n) for n in (20_000, 40_000, 50_000, 100_000, 200_000, 399_999, 400_000, 2_000_000)] == [24, 24, 8, 8, 6, 3, 1, 1]
+    assert g(0) == 24 and g(1e9) == 1
     # ... rounded so that the groups of a batch fill whole rounds of the workers in flight
     b = pkg().registration.balanced_group
     assert [b(16, 96, 4), b(6, 48, 4), b(16, 192, 4), b(16, 20, 4), b(1, 100, 4), b(6, 48, 1)] == [12, 6, 16, 16, 1, 6]
