@@ -573,8 +573,7 @@ static int multiscale_batched(pcr_context *ctx, const float *src_xyz, const floa
     }
     if (tl) { ctx->prof[11] += t_enq - t_entry; ctx->prof[12] += t_prep - t_enq; ctx->prof[13] += now() - t_prep; ctx->prof[15] += 1.0; }
     if (correspondences) {
-        int64_t nc = 0;
-        PCR_TRY(pcr_dev_compact_matches(ctx, match, clean[0][n_scales - 1].n, clean[0][n_scales - 1].cap, nullptr, nullptr, correspondences, &nc));
+        PCR_TRY(pcr_dev_compact_matches(ctx, match, clean[0][n_scales - 1].n, clean[0][n_scales - 1].cap, nullptr, nullptr, correspondences, nullptr));      // (the count is the result's n_correspondences: no read-back)
     }
     int h[32];
     PCR_HIP_CHECK(ctx, hipMemcpyAsync(h, cnt4, 4 * n_scales * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -677,12 +676,16 @@ static int multiscale_group(pcr_context *ctx, pcr_pair_ex *const *px, int G, con
         PCR_TRY(pcr_dev_gicp_group(ctx, G, ss.data(), tt.data(), md.data(), T.data(), params, res.data(), match.data()));
         for (int g = 0; g < G; g++) { px[g]->base.records[s].icp = res[g]; memcpy(&T[16 * g], res[g].transformation, 16 * sizeof(double)); }
     }
-    for (int g = 0; g < G; g++)
-        if (px[g]->base.correspondences) {
-            int64_t nc = 0;
-            const DevCloud &last = clean[(size_t)(2 * g) * n_scales + n_scales - 1];
-            PCR_TRY(pcr_dev_compact_matches(ctx, match[g], last.n, last.cap, nullptr, nullptr, px[g]->base.correspondences, &nc));
-        }
+    {   // correspondence sets of the group's pairs in three batched launches and no read-back (round 5: three launches and a host wait PER PAIR cost the
+        // script-2 stage on the NCLT scans a fifth of its rate)
+        std::vector<const int32_t *> mm; std::vector<const int *> nn; std::vector<int> cc; std::vector<int32_t *> oo;
+        for (int g = 0; g < G; g++)
+            if (px[g]->base.correspondences) {
+                const DevCloud &last = clean[(size_t)(2 * g) * n_scales + n_scales - 1];
+                mm.push_back(match[g]); nn.push_back(last.n); cc.push_back(last.cap); oo.push_back((int32_t *)px[g]->base.correspondences);
+            }
+        if (!mm.empty()) PCR_TRY(pcr_dev_compact_matches_batch(ctx, (int)mm.size(), mm.data(), nn.data(), cc.data(), oo.data()));
+    }
     std::vector<int> h((size_t)C * n_scales * 2);
     PCR_HIP_CHECK(ctx, hipMemcpyAsync(h.data(), cnt, sizeof(int) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
     PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -807,8 +810,7 @@ static int multiscale_gicp_impl(pcr_context *ctx, const float *src_xyz, const fl
         records[s].n_voxel[0] = h[0]; records[s].n_voxel[1] = h[1]; records[s].n_clean[0] = h[2]; records[s].n_clean[1] = h[3];
         memcpy(T, records[s].icp.transformation, sizeof T);
         if (s == n_scales - 1 && correspondences) {
-            int64_t nc = 0;
-            PCR_TRY(pcr_dev_compact_matches(ctx, match, cs[r].n, cs[r].cap, nullptr, nullptr, correspondences, &nc));
+                PCR_TRY(pcr_dev_compact_matches(ctx, match, cs[r].n, cs[r].cap, nullptr, nullptr, correspondences, nullptr));      // (the count is the result's n_correspondences: no read-back)
         }
         // the block of scale s is free again (its GICP has been waited for): prepare the next scale not yet enqueued
         if (prepared < n_scales) { PCR_TRY(enqueue_prep(prepared)); prepared++; }

@@ -1493,12 +1493,15 @@ int pcr_registro_fgr_group(pcr_context *ctx, pcr_fgr_group_pair *q, int G) {
             if (!match[g]) return PCR_ENOMEM;
         }
         PCR_TRY(pcr_dev_evaluate_group(ctx, G, ss.data(), tt.data(), p0.option.maximum_correspondence_distance, T.data(), res.data(), match.data()));
+        std::vector<const int32_t *> mm; std::vector<const int *> nn; std::vector<int> cc; std::vector<int32_t *> oo; std::vector<const uint32_t *> sp, tp;
         for (int g = 0; g < G; g++) {
             if (q[g].status != PCR_OK) continue;
             *q[g].result = res[g];
             for (int k = 0; k < 16; k++) q[g].result->transformation[k] = T[16 * g + k];
-            if (q[g].correspondences) PCR_TRY(pcr_dev_compact_matches(ctx, match[g], c[2 * g].n, c[2 * g].cap, perm[2 * g], perm[2 * g + 1], q[g].correspondences, nullptr));
+            if (q[g].correspondences) { mm.push_back(match[g]); nn.push_back(c[2 * g].n); cc.push_back(c[2 * g].cap); oo.push_back((int32_t *)q[g].correspondences); sp.push_back(perm[2 * g]); tp.push_back(perm[2 * g + 1]); }
         }
+        // the correspondence sets of the group in three batched launches (they were three per pair)
+        if (!mm.empty()) PCR_TRY(pcr_dev_compact_matches_batch(ctx, (int)mm.size(), mm.data(), nn.data(), cc.data(), oo.data(), sp.data(), tp.data()));
     }
     return PCR_OK;
 }

@@ -1583,6 +1583,40 @@ __global__ void __launch_bounds__(256) k_match_emit(const int32_t *__restrict__ 
     corr[2 * (size_t)o + 1] = tperm ? (int32_t)tperm[t] : t;
 }
 
+// the same for `count` clouds in three batched launches (blockIdx.y = cloud; indices in the clouds' own order), counts not read back
+struct MatchBatchDesc { const int32_t *match; const int *n; uint8_t *flags; const int *pos; int32_t *corr; const uint32_t *sperm, *tperm; };      // (perms: back to the caller's point order, or null)
+__global__ void __launch_bounds__(256) k_match_flags_g(const MatchBatchDesc *d) { const MatchBatchDesc a = d[blockIdx.y]; const int i = blockIdx.x * 256 + threadIdx.x; if (i < *a.n) a.flags[i] = a.match[i] >= 0 ? 1 : 0; }
+__global__ void __launch_bounds__(256) k_match_emit_g(const MatchBatchDesc *d) {
+    const MatchBatchDesc a = d[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= *a.n || !a.flags[i]) return;
+    const int o = a.pos[i];
+    const int t = a.match[i];
+    a.corr[2 * (size_t)o] = a.sperm ? (int32_t)a.sperm[i] : i; a.corr[2 * (size_t)o + 1] = a.tperm ? (int32_t)a.tperm[t] : t;
+}
+int pcr_dev_compact_matches_batch(pcr_context *ctx, int count, const int32_t *const *match, const int *const *n, const int *cap, int32_t *const *corr_out,
+                                  const uint32_t *const *src_perm, const uint32_t *const *tgt_perm) {
+    ArenaMark mark(ctx);
+    std::vector<MatchBatchDesc> d((size_t)count); std::vector<uint8_t *> flags((size_t)count); std::vector<int *> pos((size_t)count), total((size_t)count);
+    int mc = 1;
+    int *totals = arena<int>(ctx, count);
+    if (!totals) return PCR_ENOMEM;
+    for (int k = 0; k < count; k++) {
+        const int c = cap[k] > 0 ? cap[k] : 1;
+        flags[k] = arena<uint8_t>(ctx, c); pos[k] = arena<int>(ctx, c); total[k] = totals + k;
+        if (!flags[k] || !pos[k]) return PCR_ENOMEM;
+        d[k] = MatchBatchDesc{match[k], n[k], flags[k], pos[k], corr_out[k], src_perm ? src_perm[k] : nullptr, tgt_perm ? tgt_perm[k] : nullptr};
+        mc = c > mc ? c : mc;
+    }
+    const MatchBatchDesc *dd = pcr_desc_upload(ctx, d.data(), count);
+    if (!dd) return PCR_ENOMEM;
+    const dim3 grid((unsigned)((mc + 255) / 256), (unsigned)count);
+    PCR_LAUNCH(ctx, k_match_flags_g, grid, dim3(256), 0, ctx->stream, dd);
+    PCR_TRY(pcr_dev_flag_scan_batch(ctx, count, flags.data(), n, cap, pos.data(), total.data()));
+    PCR_LAUNCH(ctx, k_match_emit_g, grid, dim3(256), 0, ctx->stream, dd);
+    return PCR_OK;
+}
+
 int pcr_dev_compact_matches(pcr_context *ctx, const int32_t *match, const int *n, int cap, const uint32_t *src_perm,
                             const uint32_t *tgt_perm, int32_t *corr_out, int64_t *n_corr) {
     if (cap <= 0) { if (n_corr) *n_corr = 0; return PCR_OK; }

@@ -221,6 +221,8 @@ int pcr_dev_knn_debug(pcr_context *ctx, const DevCloud *c, int k, double radius,
 int pcr_read_count(pcr_context *ctx, const int *dev_n, int64_t *out);
 // pos[i] = number of set flags before i, *total_dev = number of set flags (n from device pointer or n_cap)
 int pcr_dev_flag_scan(pcr_context *ctx, const uint8_t *flags, const int *n_ptr, int n_cap, int *pos, int *total_dev);
+int pcr_dev_compact_matches_batch(pcr_context *ctx, int count, const int32_t *const *match, const int *const *n, const int *cap, int32_t *const *corr_out,
+                                  const uint32_t *const *src_perm = nullptr, const uint32_t *const *tgt_perm = nullptr);
 // gather helpers between caller order and Morton order
 int pcr_dev_scatter_rows_f4_to_f3(pcr_context *ctx, const float4 *src_sorted, const uint32_t *perm, const int *n, int cap, float *dst_packed);
 int pcr_dev_pack_f4_to_f3(pcr_context *ctx, const float4 *src, const int *n, int cap, float *dst_packed);
