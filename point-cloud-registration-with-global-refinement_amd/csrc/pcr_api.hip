@@ -25,6 +25,8 @@ PcrOptions &pcr_options() {
         if (getenv("PCR_ICP_VERIFY")) o.icp_verify = 1;
         if (getenv("PCR_DEBUG_STAMPS")) o.debug_stamps = 1;
         if (const char *e = getenv("PCR_DEBUG_VISITS")) o.debug_visits = atoi(e) ? atoi(e) : 1;
+        if (const char *e = getenv("PCR_SPFH_FLOAT64")) o.spfh_float64 = atoi(e);
+        if (const char *e = getenv("PCR_RADIUS_LIST_SELECT")) o.radius_list_select = atoi(e);
     });
     return o;
 }
@@ -47,6 +49,9 @@ extern "C" int pcr_set_option(const char *name, long long value) {
     if (!strcmp(name, "icp_verify")) { o.icp_verify = (int)value; return PCR_OK; }
     if (!strcmp(name, "debug_stamps")) { o.debug_stamps = (int)value; return PCR_OK; }
     if (!strcmp(name, "debug_visits")) { o.debug_visits = (int)value; return PCR_OK; }
+    if (!strcmp(name, "spfh_float64")) { o.spfh_float64 = (int)value; return PCR_OK; }
+    if (!strcmp(name, "radius_list_select")) { o.radius_list_select = (int)value; return PCR_OK; }
+    if (!strcmp(name, "arena_poison")) { o.arena_poison = (int)value; return PCR_OK; }
     return PCR_EINVAL;
 }
 
@@ -133,6 +138,9 @@ extern "C" const char *pcr_last_error(const pcr_context *ctx) { return ctx ? ctx
 
 int pcr_arena_reserve(pcr_context *ctx, size_t bytes) {
     ctx->arena_off = 0;
+    if (const int poison = pcr_options().arena_poison.load(std::memory_order_relaxed)) {      // diagnostic: a read of scratch nobody wrote shows as a result that follows the pattern
+        if (ctx->arena) { PCR_HIP_CHECK(ctx, hipDeviceSynchronize()); PCR_HIP_CHECK(ctx, hipMemset(ctx->arena, poison & 0xff, ctx->arena_cap)); }
+    }
     if (bytes <= ctx->arena_cap) return PCR_OK;
     PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->arena) { PCR_HIP_CHECK(ctx, hipFree(ctx->arena)); ctx->arena = nullptr; ctx->arena_cap = 0; }

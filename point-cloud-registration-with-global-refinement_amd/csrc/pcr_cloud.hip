@@ -1563,13 +1563,38 @@ __global__ void __launch_bounds__(KNN_BS) k_radius_moments(RadArgs a) {
 struct RadListArgs {
     OctView t; const int *n_ptr; float r2f; int k;
     int32_t *idx; int32_t *cnt;                  // rows of k int32 per query; entries per row (-1: row in the k-best kernel's slot layout, scan all k)
-    int *over_list, *over_count;                 // first queries of the 8-query pieces with an overfull ball
+    int *over_list, *over_count;                 // first queries of the 8-query pieces left to the k-best kernel
+    int select;                                  // 1: overfull balls are finished here (threshold selection); 0: every overfull piece goes to the k-best kernel
 };
+// Round 5: an OVERFULL ball (23 % of the balls of a 175k-point cloud at r = 1 m, max_nn = 200) no longer goes through the k-best kernel's
+// 25-slot sorted insertion.  FPFH needs the SET of the k nearest, not their order: the first walk also counts the in-ball points of each
+// query in RL_BINS bins of d^2 (LDS), the bin B in which the count passes k is read off, and a second walk -- bounded by that bin's upper edge --
+// appends every point of the bins below B and collects the points of bin B (a dozen) into LDS, of which the k - below smallest complete the
+// row -- smallest by (float64 d^2, caller index), the order of the reference's k-d tree (oracle/kdtree.c cmp_item), so that a tie at the k-th
+// place falls as it does there (the k-best kernel keeps the first one its walk meets).  Both walks test the same float32 expressions, so they see the same points.  A boundary bin of more than RL_EDGE points
+// (many equal distances) sends the piece to the k-best kernel as before.
+#define RL_BINS 64
+#define RL_EDGE 40
+// squared distance as the reference's k-d tree forms it (float64 differences of the float32 coordinates, products and sums rounded one by one)
+__device__ static inline double pcr_d2_f64_unfused(const float4 q, const float4 p) {
+#pragma clang fp contract(off)
+    const double ex = (double)q.x - (double)p.x, ey = (double)q.y - (double)p.y, ez = (double)q.z - (double)p.z;
+    double d2 = ex * ex;
+    d2 += ey * ey;
+    d2 += ez * ez;
+    return d2;
+}
 __device__ static inline void d_radius_list(const RadListArgs &a) {
     constexpr int OPB = KNN_BS / OCT;
     __shared__ OctMeta m;
     __shared__ OctGroupStack gstk[KNN_BS / 64];
+    __shared__ int hist[OPB][RL_BINS];
+    __shared__ double edge_d2[OPB][RL_EDGE];     // the boundary bin's points: float64 distance (as the reference's k-d tree orders them),
+    __shared__ int2 edge_id[OPB][RL_EDGE];       //   (caller index, index in Morton order)
+    __shared__ int nedge[OPB];
     if (threadIdx.x == 0) m = *a.t.meta;
+    for (int b = threadIdx.x; b < OPB * RL_BINS; b += KNN_BS) (&hist[0][0])[b] = 0;
+    if (threadIdx.x < OPB) nedge[threadIdx.x] = 0;
     __syncthreads();
     const int n = m.n;
     const int lane = threadIdx.x & 63, oct = lane >> 3, ol = lane & 7, ob = threadIdx.x >> 3;
@@ -1578,26 +1603,81 @@ __device__ static inline void d_radius_list(const RadListArgs &a) {
     if (__ballot(live) == 0ull) return;
     const float4 q = a.t.pts[live ? qi : 0];
     int32_t *const row = a.idx + (size_t)(live ? qi : 0) * a.k;
+    const float bin_scale = (float)RL_BINS / a.r2f;
+    const bool select = a.select != 0;
     int cnt = 0;                                 // octet-uniform
     auto visit = [&](int first, int count) {
         for (int base = first; base < first + count; base += OCT) {
             const int idx = base + ol;
-            bool hit = false;
-            if (live && cnt <= a.k && idx < first + count) {
+            bool hit = false; float d2 = 0.0f;
+            if (live && (select || cnt <= a.k) && idx < first + count) {
                 const float4 p = a.t.pts[idx];
-                hit = pcr_d2(p.x - q.x, p.y - q.y, p.z - q.z) < a.r2f;
+                d2 = pcr_d2(p.x - q.x, p.y - q.y, p.z - q.z);
+                hit = d2 < a.r2f;
             }
             const unsigned mask = (unsigned)(__ballot(hit) >> (oct * 8)) & 0xffu;
             const int pos = cnt + __builtin_popcount(mask & ((1u << ol) - 1u));
             if (hit && pos < a.k) row[pos] = idx;
+            if (hit && select) { const int b = (int)(d2 * bin_scale); atomicAdd(&hist[ob][b < RL_BINS ? b : RL_BINS - 1], 1); }
             cnt += __builtin_popcount(mask);
         }
     };
     const int g0 = blockIdx.x * OPB + (threadIdx.x >> 6) * OCT;
-    // a ball that is overfull already needs nothing more from the walk: its bound drops to nothing
-    oct_search_group(a.t, m, gstk[threadIdx.x >> 6], live, a.t.leaf_of[g0 < n ? g0 : 0], q.x, q.y, q.z, [&]() { return cnt > a.k ? -1.0f : a.r2f; }, visit,
+    const int leaf0 = a.t.leaf_of[g0 < n ? g0 : 0];
+    // (without the selection a ball that is overfull already needs nothing more from the walk: its bound drops to nothing)
+    oct_search_group(a.t, m, gstk[threadIdx.x >> 6], live, leaf0, q.x, q.y, q.z, [&]() { return (!select && cnt > a.k) ? -1.0f : a.r2f; }, visit,
                      [](int, int) { return false; }, ol, nullptr);
-    const bool over = __ballot(live && cnt > a.k) != 0ull;                 // (a wavefront = one piece of 8 queries)
+    const bool mine = live && cnt > a.k;                                   // octet-uniform
+    bool over = __ballot(mine) != 0ull;                                    // (a wavefront = one piece of 8 queries)
+    if (over && select) {
+        // the bin in which the count passes k (octet-uniform: every lane reads the octet's 64 counters)
+        int B = 0, below = 0;
+        if (mine) {
+            for (int b = 0; b < RL_BINS; b++) { const int h = hist[ob][b]; if (below + h >= a.k) { B = b; break; } below += h; }
+        }
+        const float bound2 = mine ? fminf(a.r2f, (float)(B + 1) / bin_scale * 1.0001f) : -1.0f;
+        int cnt2 = 0;
+        auto visit2 = [&](int first, int count) {
+            for (int base = first; base < first + count; base += OCT) {
+                const int idx = base + ol;
+                bool lo = false, eq = false; float d2 = 0.0f;
+                if (mine && idx < first + count) {
+                    const float4 p = a.t.pts[idx];
+                    d2 = pcr_d2(p.x - q.x, p.y - q.y, p.z - q.z);
+                    if (d2 < a.r2f) { int b = (int)(d2 * bin_scale); b = b < RL_BINS ? b : RL_BINS - 1; lo = b < B; eq = b == B; }
+                }
+                const unsigned mask = (unsigned)(__ballot(lo) >> (oct * 8)) & 0xffu;
+                const int pos = cnt2 + __builtin_popcount(mask & ((1u << ol) - 1u));
+                if (lo && pos < below) row[pos] = idx;
+                cnt2 += __builtin_popcount(mask);
+                if (eq) {
+                    const int e = atomicAdd(&nedge[ob], 1);
+                    if (e < RL_EDGE) {
+                        const float4 p = a.t.pts[idx];
+                        edge_d2[ob][e] = pcr_d2_f64_unfused(q, p); edge_id[ob][e] = make_int2(__float_as_int(p.w), idx);
+                    }
+                }
+            }
+        };
+        oct_search_group(a.t, m, gstk[threadIdx.x >> 6], mine, leaf0, q.x, q.y, q.z, [&]() { return bound2; }, visit2,
+                         [](int, int) { return false; }, ol, nullptr);
+        const int ne = mine ? nedge[ob] : 0;
+        const bool spill = ne > RL_EDGE;
+        over = __ballot(spill) != 0ull;                                    // such a piece is the k-best kernel's
+        if (!over && mine) {
+            const int need = a.k - below;                                  // 1 <= need <= ne
+            for (int e = ol; e < ne; e += OCT) {
+                const double md = edge_d2[ob][e]; const int2 mi = edge_id[ob][e];
+                int rank = 0;
+                for (int f = 0; f < ne; f++) {
+                    const double od = edge_d2[ob][f]; const int2 oi = edge_id[ob][f];
+                    rank += (od < md || (od == md && (oi.x < mi.x || (oi.x == mi.x && oi.y < mi.y)))) ? 1 : 0;
+                }
+                if (rank < need) row[below + rank] = mi.y;
+            }
+            cnt = a.k;
+        }
+    }
     if (live && ol == 0) a.cnt[qi] = over ? -1 : cnt;
     if (over && lane == 0) a.over_list[atomicAdd(a.over_count, 1)] = g0;
 }
@@ -1619,6 +1699,7 @@ int pcr_dev_radius_lists_batch(pcr_context *ctx, const DevCloud *const *cs, int 
         RadListArgs r;
         r.t = oct_view(cs[c]); r.n_ptr = cs[c]->n; r.r2f = (float)(radius * radius); r.k = k; r.idx = idx[c]; r.cnt = cnt[c];
         r.over_list = arena<int>(ctx, (size_t)cs[c]->cap / OCT + 1); r.over_count = counts + c;
+        r.select = pcr_options().radius_list_select.load(std::memory_order_relaxed);
         if (!r.over_list) return PCR_ENOMEM;
         ra.push_back(r);
         KnnArgs a; std::memset(&a, 0, sizeof a);                        // the k-best search of pcr_dev_knn_debug, over the listed pieces only

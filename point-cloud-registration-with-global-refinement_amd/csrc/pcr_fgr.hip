@@ -23,6 +23,10 @@ __device__ static inline int bin11(double x) {
 
 // Open3D ComputePairFeatures(p1,n1,p2,n2) -> the three histogram bins (degenerate pairs vote in the bins of f = 0)
 __device__ static inline void pair_bins(const double *p1, const double *n1, const double *p2, const double *n2, int *b0, int *b1, int *b2) {
+    // Products and sums rounded one by one, as the x86 build of Open3D (and the oracle) rounds them: a direction exactly along the frame's
+    // normal gives v = 0 -- the degenerate vote in the bins of f = 0 -- only if dy * az - dz * ay cancels as two rounded products do; a fused
+    // multiply-add leaves a residue of 1e-17 there and the vote lands three bins away (seen at 200k points: 26 histograms of 400 000).
+#pragma clang fp contract(off)
     double dx = p2[0] - p1[0], dy = p2[1] - p1[1], dz = p2[2] - p1[2];
     double f0 = 0, f1 = 0, f2 = 0;
     const double len = sqrt(dx * dx + dy * dy + dz * dz);
@@ -50,44 +54,130 @@ __device__ static inline void pair_bins(const double *p1, const double *n1, cons
     *b2 = bin11(11.0 * (f2 + 1.0) * 0.5) + 22;
 }
 
+// The same three bins from float arithmetic, or `false` when float cannot decide them: a bin coordinate within SPFH_MARGIN of a bin
+// edge (float error here: <= 1e-4 of a bin under the two conditioning guards), the two angles too close to order, a direction nearly
+// parallel to the frame's normal, the second normal nearly parallel to the frame's v.  The caller then evaluates pair_bins (float64),
+// so the histogram is the float64 one bin for bin ("spfh_float64" = 1 evaluates every pair that way: tests compare the two).
+#define SPFH_MARGIN 1e-3f
+__device__ static inline bool pair_bins_fast(const float4 p1, const float4 n1, const float4 p2, const float4 n2, int *b0, int *b1, int *b2) {
+    float dx = p2.x - p1.x, dy = p2.y - p1.y, dz = p2.z - p1.z;
+    const float l2 = dx * dx + dy * dy + dz * dz;
+    if (!(l2 > 1e-20f)) return false;
+    const float il = __builtin_amdgcn_rsqf(l2);
+    const float a1 = (n1.x * dx + n1.y * dy + n1.z * dz) * il, a2 = (n2.x * dx + n2.y * dy + n2.z * dz) * il;
+    const float fa1 = fabsf(a1), fa2 = fabsf(a2);
+    if (fabsf(fa1 - fa2) < 1e-5f) return false;
+    const bool sw = fa1 < fa2;           // acos|angle1| > acos|angle2|
+    const float ax = sw ? n2.x : n1.x, ay = sw ? n2.y : n1.y, az = sw ? n2.z : n1.z;
+    const float bx = sw ? n1.x : n2.x, by = sw ? n1.y : n2.y, bz = sw ? n1.z : n2.z;
+    if (sw) { dx = -dx; dy = -dy; dz = -dz; }
+    const float g2 = sw ? -a2 : a1;
+    float vx = dy * az - dz * ay, vy = dz * ax - dx * az, vz = dx * ay - dy * ax;
+    const float vn2 = vx * vx + vy * vy + vz * vz;
+    if (!(vn2 * il * il > 0.01f)) return false;
+    const float iv = __builtin_amdgcn_rsqf(vn2);
+    vx *= iv; vy *= iv; vz *= iv;
+    const float wx = ay * vz - az * vy, wy = az * vx - ax * vz, wz = ax * vy - ay * vx;
+    const float f1 = vx * bx + vy * by + vz * bz;
+    const float y = wx * bx + wy * by + wz * bz, x = ax * bx + ay * by + az * bz;
+    if (!(x * x + y * y > 0.01f)) return false;
+    const float c0 = atan2f(y, x) * (float)(5.5 / PI_D) + 5.5f, c1 = 5.5f * f1 + 5.5f, c2 = 5.5f * g2 + 5.5f;
+    const float r0 = rintf(c0), r1 = rintf(c1), r2 = rintf(c2);
+    if (fabsf(c0 - r0) < SPFH_MARGIN) return false;                              // 0 and 11 are edges too: the angle wraps there
+    if (fabsf(c1 - r1) < SPFH_MARGIN && r1 >= 1.0f && r1 <= 10.0f) return false;
+    if (fabsf(c2 - r2) < SPFH_MARGIN && r2 >= 1.0f && r2 <= 10.0f) return false;
+    const int h0 = (int)floorf(c0), h1 = (int)floorf(c1), h2 = (int)floorf(c2);
+    *b0 = h0 < 0 ? 0 : (h0 > 10 ? 10 : h0);
+    *b1 = (h1 < 0 ? 0 : (h1 > 10 ? 10 : h1)) + 11;
+    *b2 = (h2 < 0 ? 0 : (h2 > 10 ? 10 : h2)) + 22;
+    return true;
+}
+
+// SPFH of a point as it is kept between the two kernels: the 33 bin COUNTS (<= max_nn <= 200: a byte each) and 100 / (m - 1); the value
+// Open3D holds, (double)count * inc, is formed where it is used (the same product, the same bits) -- 48 B per neighbour gathered by the
+// FPFH pass instead of 264.
+struct __attribute__((aligned(16))) SpfhRow { uint8_t bins[40]; double inc; };
+static_assert(sizeof(SpfhRow) == 48, "SpfhRow");
+
 struct FpfhArgs {
     const float4 *pts, *nrm; const int *n_ptr;
     const int32_t *nbr; int k; double r2;       // neighbour lists (sorted-cloud indices, -1 padded)
     const int32_t *cnt;                         // optional: entries of each row (pcr_dev_radius_lists_batch; -1 or null: all k slots)
-    double *spfh;                               // n x 33
+    SpfhRow *spfh;                              // n rows
     const uint32_t *perm; float *feat;          // output rows in caller order
+    int float64_only;                           // option "spfh_float64"
+    int *verify;
 };
 
+#define SPFH_QUEUE 256
 __device__ static inline void d_spfh(const FpfhArgs &a) {
     __shared__ int hist[FB / OCT][33];
+    __shared__ unsigned queue[SPFH_QUEUE];       // pairs float could not decide: (octet << 16 | slot), evaluated in float64 by the whole workgroup
+    __shared__ int nqueue;
     const int n = *a.n_ptr;
     const int ol = threadIdx.x & 7, ob = threadIdx.x >> 3;
     const int qi = blockIdx.x * (FB / OCT) + ob;
     for (int b = ol; b < 33; b += OCT) hist[ob][b] = 0;
+    if (threadIdx.x == 0) nqueue = 0;
     __syncthreads();
     int cnt = 0;
     if (qi < n) {
         const float4 pf = a.pts[qi], nf = a.nrm[qi];
-        const double p1[3] = {pf.x, pf.y, pf.z}, n1[3] = {nf.x, nf.y, nf.z};
         const int kk = a.cnt ? (a.cnt[qi] < 0 ? a.k : a.cnt[qi]) : a.k;
         for (int slot = ol; slot < kk; slot += OCT) {
             const int id = a.nbr[(size_t)qi * a.k + slot];
             if (id < 0 || id == qi) continue;
             const float4 qf = a.pts[id], mf = a.nrm[id];
-            const double p2[3] = {qf.x, qf.y, qf.z}, n2[3] = {mf.x, mf.y, mf.z};
-            const double dx = p2[0] - p1[0], dy = p2[1] - p1[1], dz = p2[2] - p1[2];
+            const double dx = (double)qf.x - (double)pf.x, dy = (double)qf.y - (double)pf.y, dz = (double)qf.z - (double)pf.z;
             if (!(dx * dx + dy * dy + dz * dz < a.r2)) continue;
-            int b0, b1, b2;
-            pair_bins(p1, n1, p2, n2, &b0, &b1, &b2);
-            atomicAdd(&hist[ob][b0], 1); atomicAdd(&hist[ob][b1], 1); atomicAdd(&hist[ob][b2], 1);
             cnt++;
+            int b0, b1, b2;
+            if (a.verify) {                       // option "spfh_float64" = 2: both ways, disagreements counted, the float64 bins kept
+                const double p1[3] = {pf.x, pf.y, pf.z}, n1[3] = {nf.x, nf.y, nf.z}, p2[3] = {qf.x, qf.y, qf.z}, n2[3] = {mf.x, mf.y, mf.z};
+                pair_bins(p1, n1, p2, n2, &b0, &b1, &b2);
+                int c0, c1, c2;
+                if (pair_bins_fast(pf, nf, qf, mf, &c0, &c1, &c2) && (c0 != b0 || c1 != b1 || c2 != b2)) {
+                    const int at = atomicAdd(a.verify, 1);
+                    if (at < 32) {
+                        int d0, d1, d2; const bool again = pair_bins_fast(pf, nf, qf, mf, &d0, &d1, &d2);
+                        float *r = reinterpret_cast<float *>(a.verify) + 16 + at * 32;
+                        r[0] = pf.x; r[1] = pf.y; r[2] = pf.z; r[3] = nf.x; r[4] = nf.y; r[5] = nf.z; r[6] = qf.x; r[7] = qf.y; r[8] = qf.z; r[9] = mf.x; r[10] = mf.y; r[11] = mf.z;
+                        r[12] = (float)b0; r[13] = (float)b1; r[14] = (float)b2; r[15] = (float)c0; r[16] = (float)c1; r[17] = (float)c2;
+                        r[18] = again ? (float)d0 : -1.0f; r[19] = (float)d1; r[20] = (float)d2; r[21] = (float)qi; r[22] = (float)id; r[23] = (float)slot;
+                    }
+                }
+            } else
+            if (a.float64_only || !pair_bins_fast(pf, nf, qf, mf, &b0, &b1, &b2)) {
+#ifdef SPFH_NO_QUEUE
+                const int at = SPFH_QUEUE;
+#else
+                const int at = a.float64_only ? SPFH_QUEUE : atomicAdd(&nqueue, 1);
+#endif
+                if (at < SPFH_QUEUE) { queue[at] = (unsigned)ob << 16 | (unsigned)slot; continue; }
+                const double p1[3] = {pf.x, pf.y, pf.z}, n1[3] = {nf.x, nf.y, nf.z}, p2[3] = {qf.x, qf.y, qf.z}, n2[3] = {mf.x, mf.y, mf.z};
+                pair_bins(p1, n1, p2, n2, &b0, &b1, &b2);
+            }
+            atomicAdd(&hist[ob][b0], 1); atomicAdd(&hist[ob][b1], 1); atomicAdd(&hist[ob][b2], 1);
         }
     }
     cnt = pcr_octet_sum_i(cnt);
     __syncthreads();
+    const int nq = nqueue < SPFH_QUEUE ? nqueue : SPFH_QUEUE;
+    for (int e = threadIdx.x; e < nq; e += FB) {
+        const int eo = (int)(queue[e] >> 16), slot = (int)(queue[e] & 0xffffu);
+        const int q2 = blockIdx.x * (FB / OCT) + eo;
+        const int id = a.nbr[(size_t)q2 * a.k + slot];
+        const float4 pf = a.pts[q2], nf = a.nrm[q2], qf = a.pts[id], mf = a.nrm[id];
+        const double p1[3] = {pf.x, pf.y, pf.z}, n1[3] = {nf.x, nf.y, nf.z}, p2[3] = {qf.x, qf.y, qf.z}, n2[3] = {mf.x, mf.y, mf.z};
+        int b0, b1, b2;
+        pair_bins(p1, n1, p2, n2, &b0, &b1, &b2);
+        atomicAdd(&hist[eo][b0], 1); atomicAdd(&hist[eo][b1], 1); atomicAdd(&hist[eo][b2], 1);
+    }
+    __syncthreads();
     if (qi < n) {
-        const double inc = cnt > 0 ? 100.0 / (double)cnt : 0.0;       // 100 / (m - 1), m counts the point itself
-        for (int b = ol; b < 33; b += OCT) a.spfh[(size_t)qi * 33 + b] = (double)hist[ob][b] * inc;
+        SpfhRow *row = a.spfh + qi;
+        for (int b = ol; b < 40; b += OCT) row->bins[b] = b < 33 ? (uint8_t)hist[ob][b] : (uint8_t)0;
+        if (ol == 0) row->inc = cnt > 0 ? 100.0 / (double)cnt : 0.0;       // 100 / (m - 1), m counts the point itself
     }
 }
 
@@ -113,9 +203,15 @@ __device__ static inline void d_fpfh(const FpfhArgs &a) {
             cnt++;
             if (d2 == 0.0) continue;
             const double inv = 1.0 / d2;
-            const double *s = a.spfh + (size_t)id * 33;
+            const uint4 *rw = reinterpret_cast<const uint4 *>(a.spfh + id);
+            const uint4 w0 = rw[0], w1 = rw[1], w2 = rw[2];
+            const unsigned bw[9] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x};
+            union { unsigned u[2]; double d; } ic; ic.u[0] = w2.z; ic.u[1] = w2.w;
 #pragma unroll
-            for (int j = 0; j < 33; j++) acc[j] += s[j] * inv;
+            for (int j = 0; j < 33; j++) {
+                const double sj = (double)((bw[j >> 2] >> (8 * (j & 3))) & 0xffu) * ic.d;      // the SPFH value (d_spfh)
+                acc[j] += sj * inv;
+            }
         }
     }
     // octet sums by DPP (pcr_octet_sum: the same pairwise tree as a xor-1 / 2 / 4 butterfly, so the same bits): the butterfly by
@@ -132,7 +228,7 @@ __device__ static inline void d_fpfh(const FpfhArgs &a) {
 #pragma unroll
             for (int g = 0; g < 3; g++) if (sum[g] != 0.0) sum[g] = 100.0 / sum[g];
 #pragma unroll
-            for (int j = 0; j < 33; j++) out[j] = (float)(acc[j] * sum[j / 11] + a.spfh[(size_t)qi * 33 + j]);
+            for (int j = 0; j < 33; j++) out[j] = (float)(acc[j] * sum[j / 11] + (double)a.spfh[qi].bins[j] * a.spfh[qi].inc);
         } else {
 #pragma unroll
             for (int j = 0; j < 33; j++) out[j] = 0.0f;
@@ -153,7 +249,7 @@ static int fpfh_of_cloud(pcr_context *ctx, const DevCloud &c, const uint32_t *pe
     if (n == 0) return PCR_OK;
     ArenaMark mark(ctx);
     int32_t *nbr = arena<int32_t>(ctx, (size_t)n * knn);
-    double *spfh = arena<double>(ctx, (size_t)n * 33);
+    SpfhRow *spfh = arena<SpfhRow>(ctx, (size_t)n);
     if (!nbr || !spfh) return PCR_ENOMEM;
     int32_t *ncnt = nullptr;
     if (search_kind == PCR_SEARCH_HYBRID) {      // every point inside the ball, appended; the k nearest only where a ball is overfull
@@ -169,10 +265,29 @@ static int fpfh_of_cloud(pcr_context *ctx, const DevCloud &c, const uint32_t *pe
     FpfhArgs a;
     a.pts = c.pts; a.nrm = c.nrm; a.n_ptr = c.n; a.nbr = nbr; a.k = knn; a.cnt = ncnt;
     a.r2 = search_kind == PCR_SEARCH_HYBRID ? radius * radius : 1e300;
-    a.spfh = spfh; a.perm = perm; a.feat = feat33;
+    a.spfh = spfh; a.perm = perm; a.feat = feat33; a.float64_only = pcr_options().spfh_float64.load(std::memory_order_relaxed);
+    a.verify = nullptr;
+    if (a.float64_only == 2) {
+        a.verify = arena<int>(ctx, 16 + 32 * 32);
+        if (!a.verify) return PCR_ENOMEM;
+        PCR_HIP_CHECK(ctx, hipMemsetAsync(a.verify, 0, sizeof(int) * (16 + 32 * 32), ctx->stream));
+    }
     const dim3 grid((unsigned)(((size_t)n * OCT + FB - 1) / FB));
     PCR_LAUNCH(ctx, k_spfh, grid, dim3(FB), 0, ctx->stream, a);
     PCR_LAUNCH(ctx, k_fpfh, grid, dim3(FB), 0, ctx->stream, a);
+    if (a.verify) {
+        std::vector<int> rec(16 + 32 * 32);
+        PCR_HIP_CHECK(ctx, hipMemcpyAsync(rec.data(), a.verify, sizeof(int) * rec.size(), hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        const int bad = rec[0];
+        for (int e = 0; e < bad && e < 32; e++) {
+            const float *r = reinterpret_cast<const float *>(rec.data()) + 16 + e * 32;
+            fprintf(stderr, "SPFHBAD");
+            for (int j = 0; j < 24; j++) fprintf(stderr, " %.9g", r[j]);
+            fprintf(stderr, "\n");
+        }
+        if (bad) { ctx->err = "spfh_float64 = 2: " + std::to_string(bad) + " pairs whose float bins differ from the float64 bins"; return PCR_EINVAL; }
+    }
     return PCR_OK;
 }
 
@@ -1270,11 +1385,11 @@ int pcr_registro_fgr_group(pcr_context *ctx, pcr_fgr_group_pair *q, int G) {
         for (int k = 0; k < C; k++) {
             cp[k] = &c[k];
             nbr[k] = arena<int32_t>(ctx, (size_t)n[k] * p0.feature_max_nn); ncnt[k] = arena<int32_t>(ctx, n[k]);
-            double *spfh = arena<double>(ctx, (size_t)n[k] * 33);
+            SpfhRow *spfh = arena<SpfhRow>(ctx, (size_t)n[k]);
             if (!nbr[k] || !ncnt[k] || !spfh) return PCR_ENOMEM;
             FpfhArgs &a = fa[k];
             a.pts = c[k].pts; a.nrm = c[k].nrm; a.n_ptr = c[k].n; a.nbr = nbr[k]; a.k = p0.feature_max_nn; a.r2 = p0.feature_radius * p0.feature_radius; a.cnt = ncnt[k];
-            a.spfh = spfh; a.perm = perm[k]; a.feat = feat[k];
+            a.spfh = spfh; a.perm = perm[k]; a.feat = feat[k]; a.float64_only = pcr_options().spfh_float64.load(std::memory_order_relaxed) == 1; a.verify = nullptr;
             nmax = n[k] > nmax ? n[k] : nmax;
         }
         PCR_TRY(pcr_dev_radius_lists_batch(ctx, cp.data(), C, p0.feature_max_nn, p0.feature_radius, nbr.data(), ncnt.data()));

@@ -30,6 +30,23 @@ def test_fpfh_matches_oracle(P, oracle, fgr_inputs):
         assert_fpfh_explained(feat.data.T, ref)
 
 
+def test_fpfh_float_filter_gives_the_float64_histograms(P, fgr_inputs):
+    """The SPFH pass decides a pair's three bins in float where float can (pair_bins_fast: margins to the bin edges, conditioning guards) and in
+    float64 otherwise; option "spfh_float64" evaluates every pair in float64.  Same histograms -> the same feature bits."""
+    from importlib import import_module
+    lib = import_module(P.__name__ + "._lib")
+    for pc, feat in fgr_inputs:
+        lib.set_option("spfh_float64", 1)
+        try:
+            ref = P.registration.compute_fpfh_feature(pc, P.KDTreeSearchParamHybrid(radius=1.0, max_nn=200))
+            ref_knn = P.registration.compute_fpfh_feature(pc, P.KDTreeSearchParamKNN(100))
+        finally:
+            lib.set_option("spfh_float64", 0)
+        assert np.array_equal(np.asarray(feat.data), np.asarray(ref.data))
+        got_knn = P.registration.compute_fpfh_feature(pc, P.KDTreeSearchParamKNN(100))
+        assert np.array_equal(np.asarray(got_knn.data), np.asarray(ref_knn.data))
+
+
 def test_fpfh_errors(P, small_pair):
     pc = P.PointCloud(small_pair["source"][:100])
     with pytest.raises(RuntimeError):

@@ -253,6 +253,19 @@ def test_config2_fpfh_matches_oracle_at_full_size(P, oracle, fgr_inputs_200k):
         assert_fpfh_explained(feat.data.T, ref, what=f"FPFH at 200k points, cloud {k}")
 
 
+def test_config2_fpfh_float_filter_at_full_size(P, fgr_inputs_200k):
+    """At 200k points too the float-filtered SPFH pass gives the histograms of the all-float64 pass: identical feature bits (70 M pairs)."""
+    from importlib import import_module
+    lib = import_module(P.__name__ + "._lib")
+    for pc, feat in fgr_inputs_200k:
+        lib.set_option("spfh_float64", 1)
+        try:
+            ref = P.registration.compute_fpfh_feature(pc, P.KDTreeSearchParamHybrid(radius=1.0, max_nn=200))
+        finally:
+            lib.set_option("spfh_float64", 0)
+        assert np.array_equal(np.asarray(feat.data), np.asarray(ref.data))
+
+
 def test_config2_fgr_matches_oracle_on_the_devices_features_at_full_size(P, oracle, fgr_inputs_200k, pair200k):
     """registration_fgr_based_on_feature_matching on the 200k-point pair -- tile-pruned f16 screen + float64 re-check, cross check, tuple test, 300 GNC
     steps, the path config 2's FGR variant runs -- against oracle.registration_fgr on the DEVICE's features with the same counter-based sampler:

@@ -5,7 +5,8 @@
 set -e
 cd "$(dirname "$0")/../point-cloud-registration-with-global-refinement_amd/csrc"
 NAME=$1; UNIT=$2; FLAGS=$3
-hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -w $FLAGS -c $UNIT.hip -o /tmp/${UNIT}_$NAME.o
+extra=""; [ $UNIT = pcr_fgr ] && extra="-fno-slp-vectorize"       # (as csrc/build.sh)
+hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -w $extra $FLAGS -c $UNIT.hip -o /tmp/${UNIT}_$NAME.o
 objs=""
 for f in pcr_sort pcr_cloud pcr_gicp pcr_featnn pcr_fgr pcr_api; do
   if [ $f = $UNIT ]; then objs="$objs /tmp/${UNIT}_$NAME.o"; else objs="$objs $f.o"; fi
