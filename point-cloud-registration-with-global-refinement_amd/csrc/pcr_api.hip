@@ -27,6 +27,7 @@ PcrOptions &pcr_options() {
         if (const char *e = getenv("PCR_DEBUG_VISITS")) o.debug_visits = atoi(e) ? atoi(e) : 1;
         if (const char *e = getenv("PCR_SPFH_FLOAT64")) o.spfh_float64 = atoi(e);
         if (const char *e = getenv("PCR_RADIUS_LIST_SELECT")) o.radius_list_select = atoi(e);
+        if (const char *e = getenv("PCR_FEATNN_MUTUAL")) o.featnn_mutual = atoi(e);
     });
     return o;
 }
@@ -52,6 +53,7 @@ extern "C" int pcr_set_option(const char *name, long long value) {
     if (!strcmp(name, "spfh_float64")) { o.spfh_float64 = (int)value; return PCR_OK; }
     if (!strcmp(name, "radius_list_select")) { o.radius_list_select = (int)value; return PCR_OK; }
     if (!strcmp(name, "arena_poison")) { o.arena_poison = (int)value; return PCR_OK; }
+    if (!strcmp(name, "featnn_mutual")) { o.featnn_mutual = (int)value; return PCR_OK; }
     return PCR_EINVAL;
 }
 

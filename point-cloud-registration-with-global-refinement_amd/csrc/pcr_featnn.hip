@@ -465,6 +465,8 @@ struct FnnArgs {
                                                                    //   (atomicMin on the order-preserving int image) when it ends
     // record pool: chunk c holds records [c * FN_CHUNK, +chunk_fill[c]); pool_used counts allocated records; flags[0] = overflow
     int *pool_used; int pool_cap; int *chunk_fill; int *rec_q; int *rec_row; float *rec_w; int *flags;
+    int seeded = 0;                                                // 1 (second direction of a MUTUAL search): Ug comes seeded by k_fn_seed; a query still at +inf cannot be
+                                                                   //   a mutual match and produces no candidates
 };
 
 // ---- the screen.  grid = (query groups of 512, splits of the database)
@@ -506,6 +508,7 @@ __device__ static inline void d_feature_nn_screen(const FnnArgs &a) {
         cq[b] = (q < a.n_q && !known) ? a.q_cq[qc] : -__builtin_inff();
         nqv[b] = fabsf(nr);
         U[b] = fn_unord(a.Ug[qc]);                        // what the pre-pass has established
+        if (a.seeded && U[b] == __builtin_inff()) cq[b] = -__builtin_inff();
         thrh[b] = -0.5f * (U[b] + cq[b]);
     }
     // D = the largest (upper bound of the best squared distance) over the wavefront's live queries: a tile whose box is farther than
@@ -870,6 +873,33 @@ __global__ void __launch_bounds__(256) k_fn_init(int *pool_used, int *chunk_fill
 struct FnInitDesc { int *pool_used, *chunk_fill; int n_chunks; int *Ug; int n_ug; unsigned long long *best_d; int32_t *out; int n_q; };
 __global__ void __launch_bounds__(256) k_fn_init_g(const FnInitDesc *d) { const FnInitDesc a = d[blockIdx.y]; d_fn_init(a.pool_used, a.chunk_fill, a.n_chunks, a.Ug, a.n_ug, a.best_d, a.out, a.n_q, nullptr, nullptr); }
 
+// ---- mutual search, second direction (round 5).  FGR keeps a pair (i, j) only if j is the nearest row of i AND i the nearest row of j
+// (cross check, pcr_fgr.hip k_cross_flags), so once the first direction has given every j its nearest i, the second direction matters only
+// for the rows i that some j points at, and for those an upper bound of the answer is known: the exact distance of that j.  k_fn_seed writes
+// it into the bound array -- U = d* - |x_i|^2 in the screen's units, rounded up: every row at distance <= d* (the true nearest row of i and
+// its exact ties) passes the candidate test L(b) < U + 2 E_q, since L(b) <= d_b - |x_i|^2 + E_q -- and the screen starts with its FINAL bounds:
+// no pre-passes, and the tile lists keep only the tiles within those bounds.  Rows nobody points at stay at +inf and are dead.
+struct FnSeedArgs {
+    const int32_t *out_prev; const unsigned long long *best_prev; const uint32_t *perm_prev; int n_prev;      // first direction: answers (original indices), exact distances (screen order)
+    const uint32_t *inv_cur; const float *q_nrm_cur; int *Ug;                                                 // second direction: original row -> screen query, |x|^2, bounds
+};
+__global__ void __launch_bounds__(256) k_fn_invperm(const uint32_t *__restrict__ perm, int n, uint32_t *__restrict__ inv) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) inv[perm[i]] = (uint32_t)i;
+}
+__global__ void __launch_bounds__(256) k_fn_seed(FnSeedArgs a) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.n_prev) return;
+    const int oi = a.out_prev[a.perm_prev ? a.perm_prev[s] : (uint32_t)s];
+    if (oi < 0) return;
+    const unsigned long long bits = a.best_prev[s];
+    const double d = bits == ~0ull ? 0.0 : __longlong_as_double((long long)bits);      // (no record but an answer: an all-zero row matched to the first all-zero row)
+    const int pos = a.inv_cur ? (int)a.inv_cur[oi] : oi;
+    const double nq = fabs((double)a.q_nrm_cur[pos]), ds = d * (FN_SCALE * FN_SCALE);
+    const float u = (float)(ds - nq + 2.0e-6 * (ds + nq) + 1.0e-6);
+    atomicMin(&a.Ug[pos], fn_ord(fn_add_up(u, 0.0f)));
+}
+
 // ------------------------------------------------------------------------------------------------------------------ driver
 size_t pcr_feature_nn_scratch_bytes(int64_t n0, int64_t n1, int prune_mode) {
     const size_t p0 = ((size_t)n0 + FN_QPG) / FN_QPG * FN_QPG, p1 = ((size_t)n1 + FN_QPG) / FN_QPG * FN_QPG;
@@ -885,15 +915,16 @@ size_t pcr_feature_nn_scratch_bytes(int64_t n0, int64_t n1, int prune_mode) {
     const bool may_prune = forced || prune_mode > 0 || (double)n0 * (double)n1 >= 5.0e9;
     const size_t wide = may_prune ? std::min<size_t>(FN_WGS_PRUNED + groups, groups * std::min<size_t>(256, steps ? steps : 1)) : 3072 + groups;
     const size_t waves = (wide + (2 + FN_PRE_SPLIT) * groups + 512) * (FN_WG / 64);
-    return (p0 + p1) * per_row + (p0 > p1 ? p0 : p1) * per_query + waves * FN_CHUNK * 21 + (1u << 22) + prune_rows
+    return (p0 + p1) * (per_row + 12) + (p0 > p1 ? p0 : p1) * per_query + waves * FN_CHUNK * 21 + (1u << 22) + prune_rows
            + (lmat <= ((size_t)512 << 20) ? lmat : 0) + (1u << 20);
 }
 
 // For every row of cloud 1 its exact nearest row of cloud 0 (out_1to0, n1 entries) and vice versa (out_0to1, n0 entries).
 // f0 / f1: device float32 (n x 33).  Scratch from the arena above the current mark.  PCR_ECAPACITY: feature values outside the
 // f16 range or record pool exhausted -- the caller takes the all-pairs float64 path.
-int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float *f1, int n1, int32_t *out_1to0, int32_t *out_0to1, int prune_mode) {
+int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float *f1, int n1, int32_t *out_1to0, int32_t *out_0to1, int prune_mode, int mutual_only) {
     if (n0 <= 0 || n1 <= 0) return PCR_OK;
+    if (!pcr_options().featnn_mutual.load(std::memory_order_relaxed)) mutual_only = 0;      // (test switch: both directions in full)
     ArenaMark mark(ctx);
     const float *f[2] = {f0, f1}; const int n[2] = {n0, n1}; int np[2];
     _Float16 *A[2], *B[2]; FnRows rows[2];
@@ -995,7 +1026,19 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
     }
     float *dbg = nullptr;
     if (check) { dbg = arena<float>(ctx, 2); if (!dbg) return PCR_ENOMEM; }
+    // mutual_only: out_0to1 is complete only where it can matter to the cross check (-1 elsewhere); the first direction's exact distances stay
+    unsigned long long *best_first = nullptr; uint32_t *inv0 = nullptr;
+    if (mutual_only) {
+        best_first = arena<unsigned long long>(ctx, n[1]);
+        if (!best_first) return PCR_ENOMEM;
+        if (perm[0]) {
+            inv0 = arena<uint32_t>(ctx, n[0]);
+            if (!inv0) return PCR_ENOMEM;
+            PCR_LAUNCH(ctx, k_fn_invperm, dim3((n[0] + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t *)perm[0], n[0], inv0);
+        }
+    }
     for (int dir = 0; dir < 2; dir++) {
+        const bool seeded = mutual_only && dir == 1;
         const int qc = dir == 0 ? 1 : 0, dc = 1 - qc;                          // dir 0: queries = cloud 1, database = cloud 0
         int32_t *out = dir == 0 ? out_1to0 : out_0to1;
         ArenaMark m2(ctx);
@@ -1028,7 +1071,7 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         int *pool_used = arena<int>(ctx, 1), *chunk_fill = arena<int>(ctx, pool_cap / FN_CHUNK);
         int *rec_q = arena<int>(ctx, pool_cap), *rec_row = arena<int>(ctx, pool_cap); float *rec_w = arena<float>(ctx, pool_cap);
         int *Ug = arena<int>(ctx, nqp);
-        unsigned long long *best_d = arena<unsigned long long>(ctx, nq);
+        unsigned long long *best_d = (mutual_only && dir == 0) ? best_first : arena<unsigned long long>(ctx, nq);
         double *rec_d = arena<double>(ctx, pool_cap);
         if (!pool_used || !chunk_fill || !rec_q || !rec_row || !rec_w || !Ug || !best_d || !rec_d) return PCR_ENOMEM;
         {
@@ -1042,9 +1085,26 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         a.db_first_zero = first_zero + dc; a.Ug = Ug;
         a.pool_used = pool_used; a.pool_cap = pool_cap; a.chunk_fill = chunk_fill; a.rec_q = rec_q; a.rec_row = rec_row; a.rec_w = rec_w; a.flags = flags;
         a.L = nullptr; a.L_stride = 0; a.n_qt = 0; a.prelist = nullptr; a.pre_mode = 0; a.n_bound = 0; a.xcd_chunk = 0; a.stats = nullptr;
+        a.seeded = seeded ? 1 : 0;
+        if (seeded) {
+            FnSeedArgs sa;
+            sa.out_prev = out_1to0; sa.best_prev = best_first; sa.perm_prev = perm[1]; sa.n_prev = n[1]; sa.inv_cur = inv0; sa.q_nrm_cur = rows[0].nrm; sa.Ug = Ug;
+            PCR_LAUNCH(ctx, k_fn_seed, dim3((n[1] + 255) / 256), dim3(256), 0, ctx->stream, sa);
+        }
         unsigned long long *stats = nullptr;
         if (check || ctx->profiling) { stats = arena<unsigned long long>(ctx, 16); if (!stats) return PCR_ENOMEM; PCR_HIP_CHECK(ctx, hipMemsetAsync(stats, 0, 128, ctx->stream)); a.stats = stats; }
-        if (prune) {
+        if (prune && seeded) {      // the bounds are final already: one pass over the tiles within them
+            const int nqt = (nq + 63) / 64, nbt = steps;
+            float *L = arena<float>(ctx, (size_t)nqt * nbt);
+            if (!L) return PCR_ENOMEM;
+            PCR_LAUNCH(ctx, k_fn_boxlb, dim3((nbt + 255) / 256, nqt), dim3(256), 0, ctx->stream, (const float *)blo[qc], (const float *)bhi[qc], tile_stride[qc],
+                       (const float *)blo[dc], (const float *)bhi[dc], tile_stride[dc], nbt, eps2, L, nbt);
+            a.L = L; a.L_stride = nbt; a.n_qt = nqt; a.prelist = nullptr;
+            a.pre_mode = 0; a.step0 = 0; a.steps_per_split = sps; a.step_end = steps;
+            a.xcd_chunk = FN_XCD_ORDER ? (groups + 7) / 8 : 0;
+            PCR_LAUNCH(ctx, k_feature_nn_screen<false>, dim3(a.xcd_chunk > 0 ? 8 * a.xcd_chunk : groups, splits), dim3(FN_WG), 0, ctx->stream, a);
+            a.xcd_chunk = 0;
+        } else if (prune) {
             const int nqt = (nq + 63) / 64, nbt = steps;
             float *L = arena<float>(ctx, (size_t)nqt * nbt);
             int *prelist = arena<int>(ctx, (size_t)groups * FN_NPRE);
@@ -1079,7 +1139,7 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
             {
                 const int pre_b = steps < 64 ? steps : 64, pb_splits = pre_b < 8 ? pre_b : 8, pb_sps = (pre_b + pb_splits - 1) / pb_splits;
                 a.step0 = 0; a.steps_per_split = pb_sps; a.step_end = pre_b;
-                PCR_LAUNCH(ctx, k_feature_nn_screen<true>, dim3(groups, pb_splits), dim3(FN_WG), 0, ctx->stream, a);
+                if (!seeded) PCR_LAUNCH(ctx, k_feature_nn_screen<true>, dim3(groups, pb_splits), dim3(FN_WG), 0, ctx->stream, a);
                 a.step0 = 0; a.steps_per_split = sps_all; a.step_end = steps;
                 PCR_LAUNCH(ctx, k_feature_nn_screen<false>, dim3(groups, splits_all), dim3(FN_WG), 0, ctx->stream, a);
             }

@@ -66,8 +66,11 @@ __device__ static inline bool pair_bins_fast(const float4 p1, const float4 n1, c
     const float il = __builtin_amdgcn_rsqf(l2);
     const float a1 = (n1.x * dx + n1.y * dy + n1.z * dz) * il, a2 = (n2.x * dx + n2.y * dy + n2.z * dz) * il;
     const float fa1 = fabsf(a1), fa2 = fabsf(a2);
-    if (fabsf(fa1 - fa2) < 1e-5f) return false;
-    const bool sw = fa1 < fa2;           // acos|angle1| > acos|angle2|
+    // (equal normals -- the (0, 0, 1) of points without a neighbourhood, by the hundred on sparse scans: the float64 angles are the same
+    // expression of the same operands, equal, and the frame stays with the first point)
+    const bool same = n1.x == n2.x && n1.y == n2.y && n1.z == n2.z;
+    if (!same && fabsf(fa1 - fa2) < 1e-5f) return false;
+    const bool sw = !same && fa1 < fa2;  // acos|angle1| > acos|angle2|
     const float ax = sw ? n2.x : n1.x, ay = sw ? n2.y : n1.y, az = sw ? n2.z : n1.z;
     const float bx = sw ? n1.x : n2.x, by = sw ? n1.y : n2.y, bz = sw ? n1.z : n2.z;
     if (sw) { dx = -dx; dy = -dy; dz = -dz; }
@@ -107,10 +110,84 @@ struct FpfhArgs {
     const uint32_t *perm; float *feat;          // output rows in caller order
     int float64_only;                           // option "spfh_float64"
     int *verify;
+    // float pass (k_spfh_fast): the pairs float cannot decide go to a queue of (point, slot), which k_spfh_slow evaluates in float64 and adds to
+    // the byte counters; a queue that overflowed (slow_count > slow_cap) makes k_spfh redo every row in float64 (only_if_over points at the count)
+    uint2 *slowq; int *slow_count; int slow_cap;
+    const int *only_if_over; int over_cap;
 };
+
+// The float pass: light enough in registers for eight wavefronts per SIMD (the gathers of a lane's neighbours are a chain of dependent
+// loads: the pass is bound by how many of them are in flight; with the float64 evaluation inline the kernel held 178 VGPRs, two wavefronts).
+#define SPFH_WGQ 192
+__device__ static inline void d_spfh_fast(const FpfhArgs &a) {
+    __shared__ int hist[FB / OCT][33];
+    __shared__ unsigned wgq[SPFH_WGQ];          // the workgroup's undecided pairs (octet << 16 | slot): ONE reservation in the global queue per workgroup
+    __shared__ int nwgq, wgq_base;
+    const int n = *a.n_ptr;
+    const int ol = threadIdx.x & 7, ob = threadIdx.x >> 3;
+    const int qi = blockIdx.x * (FB / OCT) + ob;
+    for (int b = ol; b < 33; b += OCT) hist[ob][b] = 0;
+    if (threadIdx.x == 0) nwgq = 0;
+    __syncthreads();
+    int cnt = 0;
+    if (qi < n) {
+        const float4 pf = a.pts[qi], nf = a.nrm[qi];
+        const int kk = a.cnt ? (a.cnt[qi] < 0 ? a.k : a.cnt[qi]) : a.k;
+        for (int slot = ol; slot < kk; slot += OCT) {
+            const int id = a.nbr[(size_t)qi * a.k + slot];
+            if (id < 0 || id == qi) continue;
+            const float4 qf = a.pts[id], mf = a.nrm[id];
+            const double dx = (double)qf.x - (double)pf.x, dy = (double)qf.y - (double)pf.y, dz = (double)qf.z - (double)pf.z;
+            if (!(dx * dx + dy * dy + dz * dz < a.r2)) continue;
+            cnt++;
+            int b0, b1, b2;
+            if (!pair_bins_fast(pf, nf, qf, mf, &b0, &b1, &b2)) {
+                const int lq = atomicAdd(&nwgq, 1);
+                if (lq < SPFH_WGQ) wgq[lq] = (unsigned)ob << 16 | (unsigned)slot;
+                else { const int at = atomicAdd(a.slow_count, 1); if (at < a.slow_cap) a.slowq[at] = make_uint2((unsigned)qi, (unsigned)slot); }
+                continue;
+            }
+            atomicAdd(&hist[ob][b0], 1); atomicAdd(&hist[ob][b1], 1); atomicAdd(&hist[ob][b2], 1);
+        }
+    }
+    cnt = pcr_octet_sum_i(cnt);
+    __syncthreads();
+    const int nl = nwgq < SPFH_WGQ ? nwgq : SPFH_WGQ;
+    if (threadIdx.x == 0 && nl > 0) wgq_base = atomicAdd(a.slow_count, nl);
+    if (qi < n) {
+        SpfhRow *row = a.spfh + qi;
+        for (int b = ol; b < 40; b += OCT) row->bins[b] = b < 33 ? (uint8_t)hist[ob][b] : (uint8_t)0;
+        if (ol == 0) row->inc = cnt > 0 ? 100.0 / (double)cnt : 0.0;       // 100 / (m - 1), m counts the point itself
+    }
+    if (nl == 0) return;
+    __syncthreads();
+    for (int e = threadIdx.x; e < nl; e += FB) {
+        const int at = wgq_base + e;
+        if (at < a.slow_cap) a.slowq[at] = make_uint2((unsigned)(blockIdx.x * (FB / OCT)) + (wgq[e] >> 16), wgq[e] & 0xffffu);
+    }
+}
+__device__ static inline void d_spfh_slow(const FpfhArgs &a) {
+    const int total = *a.slow_count;
+    if (total > a.slow_cap) return;                    // k_spfh redoes everything
+    for (int e = blockIdx.x * FB + threadIdx.x; e < total; e += gridDim.x * FB) {
+        const uint2 w = a.slowq[e];
+        const int q2 = (int)w.x, id = a.nbr[(size_t)q2 * a.k + w.y];
+        const float4 pf = a.pts[q2], nf = a.nrm[q2], qf = a.pts[id], mf = a.nrm[id];
+        const double p1[3] = {pf.x, pf.y, pf.z}, n1[3] = {nf.x, nf.y, nf.z}, p2[3] = {qf.x, qf.y, qf.z}, n2[3] = {mf.x, mf.y, mf.z};
+        int b0, b1, b2;
+        pair_bins(p1, n1, p2, n2, &b0, &b1, &b2);
+        unsigned *words = reinterpret_cast<unsigned *>(a.spfh[q2].bins);       // byte counters (<= 200 each): +1 in byte b of its 32-bit word
+        atomicAdd(words + (b0 >> 2), 1u << (8 * (b0 & 3))); atomicAdd(words + (b1 >> 2), 1u << (8 * (b1 & 3))); atomicAdd(words + (b2 >> 2), 1u << (8 * (b2 & 3)));
+    }
+}
+__global__ void __launch_bounds__(FB) k_spfh_fast(FpfhArgs a) { d_spfh_fast(a); }
+__global__ void __launch_bounds__(FB) k_spfh_slow(FpfhArgs a) { d_spfh_slow(a); }
+__global__ void __launch_bounds__(FB) k_spfh_fast_g(const FpfhArgs *a) { d_spfh_fast(a[blockIdx.y]); }
+__global__ void __launch_bounds__(FB) k_spfh_slow_g(const FpfhArgs *a) { d_spfh_slow(a[blockIdx.y]); }
 
 #define SPFH_QUEUE 256
 __device__ static inline void d_spfh(const FpfhArgs &a) {
+    if (a.only_if_over && *a.only_if_over <= a.over_cap) return;         // (the float pass and its queue did the work)
     __shared__ int hist[FB / OCT][33];
     __shared__ unsigned queue[SPFH_QUEUE];       // pairs float could not decide: (octet << 16 | slot), evaluated in float64 by the whole workgroup
     __shared__ int nqueue;
@@ -265,7 +342,8 @@ static int fpfh_of_cloud(pcr_context *ctx, const DevCloud &c, const uint32_t *pe
     FpfhArgs a;
     a.pts = c.pts; a.nrm = c.nrm; a.n_ptr = c.n; a.nbr = nbr; a.k = knn; a.cnt = ncnt;
     a.r2 = search_kind == PCR_SEARCH_HYBRID ? radius * radius : 1e300;
-    a.spfh = spfh; a.perm = perm; a.feat = feat33; a.float64_only = pcr_options().spfh_float64.load(std::memory_order_relaxed);
+    const int spfh_mode = pcr_options().spfh_float64.load(std::memory_order_relaxed);       // 0 product, 1 all float64, 2 both + compare, 3 product with a 16-entry queue (the overflow path)
+    a.spfh = spfh; a.perm = perm; a.feat = feat33; a.float64_only = spfh_mode == 3 ? 0 : spfh_mode;
     a.verify = nullptr;
     if (a.float64_only == 2) {
         a.verify = arena<int>(ctx, 16 + 32 * 32);
@@ -273,6 +351,16 @@ static int fpfh_of_cloud(pcr_context *ctx, const DevCloud &c, const uint32_t *pe
         PCR_HIP_CHECK(ctx, hipMemsetAsync(a.verify, 0, sizeof(int) * (16 + 32 * 32), ctx->stream));
     }
     const dim3 grid((unsigned)(((size_t)n * OCT + FB - 1) / FB));
+    a.slowq = nullptr; a.slow_count = nullptr; a.slow_cap = 0; a.only_if_over = nullptr; a.over_cap = 0;
+    if (a.float64_only == 0) {
+        a.slow_cap = spfh_mode == 3 ? 16 : (int)std::min<int64_t>(8 * n, 1 << 28);
+        a.slowq = arena<uint2>(ctx, (size_t)a.slow_cap); a.slow_count = arena<int>(ctx, 1);
+        if (!a.slowq || !a.slow_count) return PCR_ENOMEM;
+        PCR_HIP_CHECK(ctx, hipMemsetAsync(a.slow_count, 0, sizeof(int), ctx->stream));
+        PCR_LAUNCH(ctx, k_spfh_fast, grid, dim3(FB), 0, ctx->stream, a);
+        PCR_LAUNCH(ctx, k_spfh_slow, dim3(std::min<unsigned>(grid.x, 1024u)), dim3(FB), 0, ctx->stream, a);
+        a.only_if_over = a.slow_count; a.over_cap = a.slow_cap; a.float64_only = 1;
+    }
     PCR_LAUNCH(ctx, k_spfh, grid, dim3(FB), 0, ctx->stream, a);
     PCR_LAUNCH(ctx, k_fpfh, grid, dim3(FB), 0, ctx->stream, a);
     if (a.verify) {
@@ -1022,7 +1110,7 @@ static int fgr_pose(pcr_context *ctx, const float *src_xyz, const float *src_fea
         // the all-pairs float64 MFMA path (also taken for feature values outside the f16 range), PCR_FEATURE_NN_BRUTE the float32 one
         static const bool nn_f64 = getenv("PCR_FEATURE_NN") && !strcmp(getenv("PCR_FEATURE_NN"), "f64");
         int nn_rc = PCR_ECAPACITY;
-        if (!nn_f64 && !getenv("PCR_FEATURE_NN_BRUTE") && nPti >= 64 && nPtj >= 64) nn_rc = pcr_feature_nn_mutual(ctx, fi, nPti, fj, nPtj, j_to_i, i_to_j, -1);
+        if (!nn_f64 && !getenv("PCR_FEATURE_NN_BRUTE") && nPti >= 64 && nPtj >= 64) nn_rc = pcr_feature_nn_mutual(ctx, fi, nPti, fj, nPtj, j_to_i, i_to_j, -1, 1);      // (only the cross check below reads the two lists)
         if (nn_rc == PCR_ECAPACITY) {
             PCR_TRY(feature_nn(ctx, fi, nPti, fj, nPtj, j_to_i));
             PCR_TRY(feature_nn(ctx, fj, nPtj, fi, nPti, i_to_j));
@@ -1390,12 +1478,26 @@ int pcr_registro_fgr_group(pcr_context *ctx, pcr_fgr_group_pair *q, int G) {
             FpfhArgs &a = fa[k];
             a.pts = c[k].pts; a.nrm = c[k].nrm; a.n_ptr = c[k].n; a.nbr = nbr[k]; a.k = p0.feature_max_nn; a.r2 = p0.feature_radius * p0.feature_radius; a.cnt = ncnt[k];
             a.spfh = spfh; a.perm = perm[k]; a.feat = feat[k]; a.float64_only = pcr_options().spfh_float64.load(std::memory_order_relaxed) == 1; a.verify = nullptr;
+            a.slowq = nullptr; a.slow_count = nullptr; a.slow_cap = 0; a.only_if_over = nullptr; a.over_cap = 0;
+            if (!a.float64_only) {
+                a.slow_cap = pcr_options().spfh_float64.load(std::memory_order_relaxed) == 3 ? 16 : (int)std::min<int64_t>(8 * n[k], 1 << 28);
+                a.slowq = arena<uint2>(ctx, (size_t)a.slow_cap); a.slow_count = arena<int>(ctx, 1);
+                if (!a.slowq || !a.slow_count) return PCR_ENOMEM;
+                PCR_HIP_CHECK(ctx, hipMemsetAsync(a.slow_count, 0, sizeof(int), ctx->stream));
+            }
             nmax = n[k] > nmax ? n[k] : nmax;
         }
         PCR_TRY(pcr_dev_radius_lists_batch(ctx, cp.data(), C, p0.feature_max_nn, p0.feature_radius, nbr.data(), ncnt.data()));
         const FpfhArgs *dfa = pcr_desc_upload(ctx, fa.data(), C);
         if (!dfa) return PCR_ENOMEM;
         const dim3 grid((unsigned)(((size_t)nmax * OCT + FB - 1) / FB), C);
+        if (!fa[0].float64_only) {      // float pass, its queue in float64, and (only for a queue that overflowed) every row again in float64
+            PCR_LAUNCH(ctx, k_spfh_fast_g, grid, dim3(FB), 0, ctx->stream, dfa);
+            PCR_LAUNCH(ctx, k_spfh_slow_g, dim3(std::min<unsigned>(grid.x, 256u), C), dim3(FB), 0, ctx->stream, dfa);
+            for (int k = 0; k < C; k++) { fa[k].only_if_over = fa[k].slow_count; fa[k].over_cap = fa[k].slow_cap; fa[k].float64_only = 1; }
+            dfa = pcr_desc_upload(ctx, fa.data(), C);
+            if (!dfa) return PCR_ENOMEM;
+        }
         PCR_LAUNCH(ctx, k_spfh_g, grid, dim3(FB), 0, ctx->stream, dfa);
         PCR_LAUNCH(ctx, k_fpfh_g, grid, dim3(FB), 0, ctx->stream, dfa);
     }

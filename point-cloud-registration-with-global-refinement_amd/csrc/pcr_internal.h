@@ -9,7 +9,7 @@
 #include "../../include/pcr_hip.h"
 
 // process-wide switches (pcr_set_option, include/pcr_hip.h): latched from the environment once, atomics afterwards
-struct PcrOptions { std::atomic<int> knn_wave{-1}, knnw_budget{80}, fence_prep{0}, icp_phase{0}, icp_verify{0}, debug_stamps{0}, debug_visits{0}, spfh_float64{0}, radius_list_select{1}, arena_poison{0}; };
+struct PcrOptions { std::atomic<int> knn_wave{-1}, knnw_budget{80}, fence_prep{0}, icp_phase{0}, icp_verify{0}, debug_stamps{0}, debug_visits{0}, spfh_float64{0}, radius_list_select{1}, arena_poison{0}, featnn_mutual{1}; };
 PcrOptions &pcr_options();
 // process-wide event counters (pcr_counter, include/pcr_hip.h): how often a slow fall-back was taken -- invisible in the results, which are the same bits
 struct PcrCounters { std::atomic<long long> fgr_group_barrier_timeouts{0}, fgr_group_pool_overflows{0}, fgr_group_pairs_redone_alone{0}; };
@@ -251,7 +251,8 @@ int pcr_evaluate_registration_impl(pcr_context *ctx, const float *src_xyz, int64
 // ---- feature matching (pcr_featnn.hip): exact nearest feature rows in both directions; PCR_ECAPACITY = values outside the f16 range
 size_t pcr_feature_nn_scratch_bytes(int64_t n0, int64_t n1, int prune_mode = -1);      // prune_mode as pcr_feature_nn_mutual's (1: forced on)
 int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float *f1, int n1, int32_t *out_1to0, int32_t *out_0to1,
-                          int prune_mode /* -1: by size (PCR_FEATNN_PRUNE overrides), 0: off, 1: on */);
+                          int prune_mode /* -1: by size (PCR_FEATNN_PRUNE overrides), 0: off, 1: on */,
+                          int mutual_only = 0 /* 1: out_0to1 is only needed where the cross check can keep it (-1 elsewhere): second direction seeded by the first */);
 
 int pcr_feature_nn_mutual_batch(pcr_context *ctx, int G, const float *const *f0, const int *n0, const float *const *f1, const int *n1, int32_t *const *out_1to0,
                                 int32_t *const *out_0to1, const int **overflow_dev);

@@ -31,8 +31,8 @@ def test_fpfh_matches_oracle(P, oracle, fgr_inputs):
 
 
 def test_fpfh_float_filter_gives_the_float64_histograms(P, fgr_inputs):
-    """The SPFH pass decides a pair's three bins in float where float can (pair_bins_fast: margins to the bin edges, conditioning guards) and in
-    float64 otherwise; option "spfh_float64" evaluates every pair in float64.  Same histograms -> the same feature bits."""
+    """The SPFH pass decides a pair's three bins in float where float can (pair_bins_fast: margins to the bin edges, conditioning guards) and queues
+    the other pairs for a float64 pass; option "spfh_float64" = 1 evaluates every pair in float64.  Same histograms -> the same feature bits."""
     from importlib import import_module
     lib = import_module(P.__name__ + "._lib")
     for pc, feat in fgr_inputs:
@@ -45,6 +45,12 @@ def test_fpfh_float_filter_gives_the_float64_histograms(P, fgr_inputs):
         assert np.array_equal(np.asarray(feat.data), np.asarray(ref.data))
         got_knn = P.registration.compute_fpfh_feature(pc, P.KDTreeSearchParamKNN(100))
         assert np.array_equal(np.asarray(got_knn.data), np.asarray(ref_knn.data))
+        lib.set_option("spfh_float64", 3)            # a 16-entry queue: it overflows, and every row is done again in float64
+        try:
+            over = P.registration.compute_fpfh_feature(pc, P.KDTreeSearchParamHybrid(radius=1.0, max_nn=200))
+        finally:
+            lib.set_option("spfh_float64", 0)
+        assert np.array_equal(np.asarray(over.data), np.asarray(ref.data))
 
 
 def test_fpfh_errors(P, small_pair):
@@ -71,6 +77,25 @@ def test_fgr_matches_oracle_on_identical_features(P, oracle, fgr_inputs, small_p
         # and both sit in the statistical band around the shipped FGR pose
         a, d = pose_error(res.transformation, small_pair["T_fgr"])
         assert a < 3e-2 and d < 0.5, (a, d)
+
+
+def test_fgr_seeded_second_direction_gives_the_full_search_result(P, fgr_inputs):
+    """The cross check keeps (i, j) only if each is the other's nearest row, so the second direction of the feature search runs only for the rows
+    the first direction points at, under the bound the first direction found (pcr_featnn.hip k_fn_seed).  Option "featnn_mutual" = 0 searches
+    both directions in full: same mutual matches -> the same result, bit for bit."""
+    from importlib import import_module
+    lib = import_module(P.__name__ + "._lib")
+    (src, fs), (tgt, ft) = fgr_inputs
+    n_pontos = int((len(src) + len(tgt)) / 2)
+    opt = P.registration.FastGlobalRegistrationOption(1.4, True, True, 0.2, 300, 0.95, int(n_pontos * 0.2), seed=77)
+    res = P.registration.registration_fgr_based_on_feature_matching(src, tgt, fs, ft, opt)
+    lib.set_option("featnn_mutual", 0)
+    try:
+        ref = P.registration.registration_fgr_based_on_feature_matching(src, tgt, fs, ft, opt)
+    finally:
+        lib.set_option("featnn_mutual", 1)
+    assert np.array_equal(res.transformation, ref.transformation) and res.fitness == ref.fitness and res.inlier_rmse == ref.inlier_rmse
+    assert np.array_equal(res.correspondence_set, ref.correspondence_set)
 
 
 def test_fgr_with_features_that_overflow_the_record_pool(P, oracle, fgr_inputs):

@@ -282,3 +282,13 @@ def test_config2_fgr_matches_oracle_on_the_devices_features_at_full_size(P, orac
     assert abs(res.fitness - ref.fitness) < 1e-9
     a, d = pose_error(res.transformation, pair200k.T_true)
     assert a < 5e-3 and d < 5e-2, (a, d)                               # and it is a registration: within FGR's band of the planted motion
+    # the second direction of the search ran seeded by the first (rows nobody points at skipped, final bounds from the start: k_fn_seed); with both
+    # directions in full ("featnn_mutual" = 0) the mutual matches are the same -> the same bits
+    from importlib import import_module
+    lib = import_module(P.__name__ + "._lib")
+    lib.set_option("featnn_mutual", 0)
+    try:
+        full = P.registration.registration_fgr_based_on_feature_matching(src, tgt, fs, ft, opt)
+    finally:
+        lib.set_option("featnn_mutual", 1)
+    assert np.array_equal(res.transformation, full.transformation) and res.fitness == full.fitness
