@@ -866,7 +866,7 @@ __device__ static inline void d_fn_init(int *pool_used, int *chunk_fill, int n_c
     if (i == 0) { *pool_used = 0; if (first_zero) { first_zero[0] = 0x7fffffff; first_zero[1] = 0x7fffffff; flags[0] = 0; flags[1] = 0; } }
     if (i < n_chunks) chunk_fill[i] = 0;
     if (i < n_ug) Ug[i] = 0x7f800000;                      // +inf
-    if (i < n_q) { best_d[i] = ~0ull; out[i] = 0x7fffffff; }
+    if (i < n_q) { best_d[i] = ~0ull; if (out) out[i] = 0x7fffffff; }
 }
 __global__ void __launch_bounds__(256) k_fn_init(int *pool_used, int *chunk_fill, int n_chunks, int *Ug, int n_ug, unsigned long long *best_d, int32_t *out, int n_q,
                                                  int *first_zero, int *flags) { d_fn_init(pool_used, chunk_fill, n_chunks, Ug, n_ug, best_d, out, n_q, first_zero, flags); }
@@ -900,6 +900,28 @@ __global__ void __launch_bounds__(256) k_fn_seed(FnSeedArgs a) {
     atomicMin(&a.Ug[pos], fn_ord(fn_add_up(u, 0.0f)));
 }
 
+// The live rows of the second direction as a query set of their own (same order): B operands, norms, bounds, the map to the original row.
+struct FnCompactArgs {
+    const int *seedU; const uint8_t *live; const int *cpos; int n;        // per screen position of the cloud: seeded bound, live flag, position among the live rows
+    const _Float16 *B; const float *nrm, *cq; const uint32_t *perm;       // the full query set (perm null: identity)
+    _Float16 *Bc; float *nrm_c, *cq_c; uint32_t *perm_c; int *Ug_c; int32_t *out;
+};
+__global__ void __launch_bounds__(256) k_fn_live(const int *__restrict__ seedU, int n, uint8_t *__restrict__ live) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) live[i] = seedU[i] != 0x7f800000 ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_fn_compact(FnCompactArgs a) {      // 8 lanes per row: 16 bytes of the 128-byte B row each
+    const int i = blockIdx.x * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
+    if (i >= a.n || !a.live[i]) return;
+    const int c = a.cpos[i];
+    static_assert(FN_K * sizeof(_Float16) == 128, "k_fn_compact copies 128-byte rows");
+    reinterpret_cast<uint4 *>(a.Bc + (size_t)c * FN_K)[part] = reinterpret_cast<const uint4 *>(a.B + (size_t)i * FN_K)[part];
+    if (part == 0) {
+        const uint32_t o = a.perm ? a.perm[i] : (uint32_t)i;
+        a.nrm_c[c] = a.nrm[i]; a.cq_c[c] = a.cq[i]; a.perm_c[c] = o; a.Ug_c[c] = a.seedU[i]; a.out[o] = 0x7fffffff;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------ driver
 size_t pcr_feature_nn_scratch_bytes(int64_t n0, int64_t n1, int prune_mode) {
     const size_t p0 = ((size_t)n0 + FN_QPG) / FN_QPG * FN_QPG, p1 = ((size_t)n1 + FN_QPG) / FN_QPG * FN_QPG;
@@ -915,7 +937,7 @@ size_t pcr_feature_nn_scratch_bytes(int64_t n0, int64_t n1, int prune_mode) {
     const bool may_prune = forced || prune_mode > 0 || (double)n0 * (double)n1 >= 5.0e9;
     const size_t wide = may_prune ? std::min<size_t>(FN_WGS_PRUNED + groups, groups * std::min<size_t>(256, steps ? steps : 1)) : 3072 + groups;
     const size_t waves = (wide + (2 + FN_PRE_SPLIT) * groups + 512) * (FN_WG / 64);
-    return (p0 + p1) * (per_row + 12) + (p0 > p1 ? p0 : p1) * per_query + waves * FN_CHUNK * 21 + (1u << 22) + prune_rows
+    return (p0 + p1) * (per_row + 12 + 160) + (p0 > p1 ? p0 : p1) * per_query + waves * FN_CHUNK * 21 + (1u << 22) + prune_rows
            + (lmat <= ((size_t)512 << 20) ? lmat : 0) + (1u << 20);
 }
 
@@ -968,6 +990,7 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         if (!((hmu[FN_D] + mm) * FN_SCALE < 60000.0)) return PCR_ECAPACITY;
     }
     uint32_t *perm[2] = {nullptr, nullptr};
+    float *Pc[2] = {nullptr, nullptr};                  // principal coordinates (original row order)
     float *blo[2] = {nullptr, nullptr}, *bhi[2] = {nullptr, nullptr};
     int tile_stride[2] = {0, 0};
     float eps2 = 0.0f;
@@ -1015,6 +1038,7 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
             PCR_LAUNCH(ctx, k_fn_rotate, dim3((n[c] + 255) / 256), dim3(256), 0, ctx->stream, f[c], n[c], mu, rot, P, k_in, v_in);
             PCR_TRY(pcr_sort_pairs(ctx, temp, tb, k_in, k_out, v_in, perm[c], (size_t)n[c], FN_MD * FN_MB));
             PCR_LAUNCH(ctx, k_fn_boxes, dim3((nt + 3) / 4), dim3(256), 0, ctx->stream, P, perm[c], n[c], nt, nt, blo[c], bhi[c]);
+            Pc[c] = P;
         }
     }
     for (int c = 0; c < 2; c++) {
@@ -1042,7 +1066,46 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         const int qc = dir == 0 ? 1 : 0, dc = 1 - qc;                          // dir 0: queries = cloud 1, database = cloud 0
         int32_t *out = dir == 0 ? out_1to0 : out_0to1;
         ArenaMark m2(ctx);
-        const int nq = n[qc], nqp = np[qc], steps = np[dc] / FN_STEP;
+        int nq = n[qc], nqp = np[qc];
+        const int steps = np[dc] / FN_STEP;
+        // ---- seeded direction: the live rows (some row of the other cloud points at them) become a query set of their own
+        const _Float16 *qB = B[qc]; const float *q_nrm = rows[qc].nrm, *q_cq = rows[qc].cq; const uint32_t *q_perm = perm[qc];
+        const float *q_blo = blo[qc], *q_bhi = bhi[qc]; int q_tile_stride = tile_stride[qc];
+        int *Ug_seeded = nullptr;
+        if (seeded) {
+            int *seedU = arena<int>(ctx, np[0]); uint8_t *live = arena<uint8_t>(ctx, n[0]); int *cpos = arena<int>(ctx, n[0]), *n_live_dev = arena<int>(ctx, 1);
+            if (!seedU || !live || !cpos || !n_live_dev) return PCR_ENOMEM;
+            PCR_LAUNCH(ctx, k_fn_init, dim3((np[0] + 255) / 256), dim3(256), 0, ctx->stream, n_live_dev, (int *)nullptr, 0, seedU, np[0], (unsigned long long *)nullptr, (int32_t *)nullptr, 0,
+                       (int *)nullptr, (int *)nullptr);
+            FnSeedArgs sa;
+            sa.out_prev = out_1to0; sa.best_prev = best_first; sa.perm_prev = perm[1]; sa.n_prev = n[1]; sa.inv_cur = inv0; sa.q_nrm_cur = rows[0].nrm; sa.Ug = seedU;
+            PCR_LAUNCH(ctx, k_fn_seed, dim3((n[1] + 255) / 256), dim3(256), 0, ctx->stream, sa);
+            PCR_LAUNCH(ctx, k_fn_live, dim3((n[0] + 255) / 256), dim3(256), 0, ctx->stream, (const int *)seedU, n[0], live);
+            PCR_TRY(pcr_dev_flag_scan(ctx, live, nullptr, n[0], cpos, n_live_dev));
+            PCR_HIP_CHECK(ctx, hipMemsetAsync(out, 0xff, sizeof(int32_t) * (size_t)n[0], ctx->stream));          // -1: no mutual match possible
+            int64_t n_live = 0;
+            PCR_TRY(pcr_read_count(ctx, n_live_dev, &n_live));
+            if (n_live == 0) continue;
+            nq = (int)n_live; nqp = (nq + FN_QPG - 1) / FN_QPG * FN_QPG;
+            _Float16 *Bc = arena<_Float16>(ctx, (size_t)nqp * FN_K); float *r2c = arena<float>(ctx, (size_t)2 * nqp); uint32_t *perm_c = arena<uint32_t>(ctx, nqp);
+            Ug_seeded = arena<int>(ctx, nqp);
+            if (!Bc || !r2c || !perm_c || !Ug_seeded) return PCR_ENOMEM;
+            PCR_HIP_CHECK(ctx, hipMemsetAsync(Bc + (size_t)nq * FN_K, 0, sizeof(_Float16) * (size_t)(nqp - nq) * FN_K, ctx->stream));
+            PCR_HIP_CHECK(ctx, hipMemsetAsync(r2c, 0, sizeof(float) * 2 * (size_t)nqp, ctx->stream));
+            if (nqp > nq) PCR_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)(Ug_seeded + nq), 0x7f800000, (size_t)(nqp - nq), ctx->stream));
+            FnCompactArgs ca;
+            ca.seedU = seedU; ca.live = live; ca.cpos = cpos; ca.n = n[0]; ca.B = B[0]; ca.nrm = rows[0].nrm; ca.cq = rows[0].cq; ca.perm = perm[0];
+            ca.Bc = Bc; ca.nrm_c = r2c; ca.cq_c = r2c + nqp; ca.perm_c = perm_c; ca.Ug_c = Ug_seeded; ca.out = out;
+            PCR_LAUNCH(ctx, k_fn_compact, dim3((n[0] + 31) / 32), dim3(256), 0, ctx->stream, ca);
+            qB = Bc; q_nrm = r2c; q_cq = r2c + nqp; q_perm = perm_c;
+            if (prune) {
+                const int ntc = nqp / 64;
+                float *lo = arena<float>(ctx, (size_t)FN_D * ntc), *hi = arena<float>(ctx, (size_t)FN_D * ntc);
+                if (!lo || !hi) return PCR_ENOMEM;
+                PCR_LAUNCH(ctx, k_fn_boxes, dim3((ntc + 3) / 4), dim3(256), 0, ctx->stream, (const float *)Pc[0], (const uint32_t *)perm_c, nq, ntc, ntc, lo, hi);
+                q_blo = lo; q_bhi = hi; q_tile_stride = ntc;
+            }
+        }
         const int groups = nqp / FN_QPG;
         // a pre-pass seeds the bound of every query (first 4096 rows; with tile pruning the 48 tiles nearest to the workgroup's queries);
         // the main pass splits the steps so that the grid has ~8 workgroups per CU (one workgroup = 512 queries x one split)
@@ -1070,34 +1133,30 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         const int pool_cap = (int)(((size_t)nqp * FN_POOL_PER_QUERY + waves * FN_CHUNK + FN_CHUNK - 1) / FN_CHUNK * FN_CHUNK);
         int *pool_used = arena<int>(ctx, 1), *chunk_fill = arena<int>(ctx, pool_cap / FN_CHUNK);
         int *rec_q = arena<int>(ctx, pool_cap), *rec_row = arena<int>(ctx, pool_cap); float *rec_w = arena<float>(ctx, pool_cap);
-        int *Ug = arena<int>(ctx, nqp);
+        int *Ug = seeded ? Ug_seeded : arena<int>(ctx, nqp);
         unsigned long long *best_d = (mutual_only && dir == 0) ? best_first : arena<unsigned long long>(ctx, nq);
         double *rec_d = arena<double>(ctx, pool_cap);
         if (!pool_used || !chunk_fill || !rec_q || !rec_row || !rec_w || !Ug || !best_d || !rec_d) return PCR_ENOMEM;
         {
             const int n_chunks = pool_cap / FN_CHUNK, n_init = std::max(std::max(n_chunks, nqp), nq);
-            PCR_LAUNCH(ctx, k_fn_init, dim3((n_init + 255) / 256), dim3(256), 0, ctx->stream, pool_used, chunk_fill, n_chunks, Ug, nqp, best_d, out, nq,
+            // (seeded: the bounds and the live rows' INT_MAX in `out` come from k_fn_compact; rows beyond the live ones are dead by their index)
+            PCR_LAUNCH(ctx, k_fn_init, dim3((n_init + 255) / 256), dim3(256), 0, ctx->stream, pool_used, chunk_fill, n_chunks, Ug, seeded ? 0 : nqp, best_d, seeded ? (int32_t *)nullptr : out, nq,
                        (int *)nullptr, (int *)nullptr);
         }
         if (dbg) PCR_HIP_CHECK(ctx, hipMemsetAsync(dbg, 0, 8, ctx->stream));
         FnnArgs a;
-        a.dbA = A[dc]; a.db_nlo = rows[dc].nlo; a.db_nup = rows[dc].nup; a.n_db_pad = np[dc]; a.qB = B[qc]; a.q_nrm = rows[qc].nrm; a.q_cq = rows[qc].cq; a.n_q = nq; a.n_q_pad = nqp;
+        a.dbA = A[dc]; a.db_nlo = rows[dc].nlo; a.db_nup = rows[dc].nup; a.n_db_pad = np[dc]; a.qB = qB; a.q_nrm = q_nrm; a.q_cq = q_cq; a.n_q = nq; a.n_q_pad = nqp;
         a.db_first_zero = first_zero + dc; a.Ug = Ug;
         a.pool_used = pool_used; a.pool_cap = pool_cap; a.chunk_fill = chunk_fill; a.rec_q = rec_q; a.rec_row = rec_row; a.rec_w = rec_w; a.flags = flags;
         a.L = nullptr; a.L_stride = 0; a.n_qt = 0; a.prelist = nullptr; a.pre_mode = 0; a.n_bound = 0; a.xcd_chunk = 0; a.stats = nullptr;
         a.seeded = seeded ? 1 : 0;
-        if (seeded) {
-            FnSeedArgs sa;
-            sa.out_prev = out_1to0; sa.best_prev = best_first; sa.perm_prev = perm[1]; sa.n_prev = n[1]; sa.inv_cur = inv0; sa.q_nrm_cur = rows[0].nrm; sa.Ug = Ug;
-            PCR_LAUNCH(ctx, k_fn_seed, dim3((n[1] + 255) / 256), dim3(256), 0, ctx->stream, sa);
-        }
         unsigned long long *stats = nullptr;
         if (check || ctx->profiling) { stats = arena<unsigned long long>(ctx, 16); if (!stats) return PCR_ENOMEM; PCR_HIP_CHECK(ctx, hipMemsetAsync(stats, 0, 128, ctx->stream)); a.stats = stats; }
         if (prune && seeded) {      // the bounds are final already: one pass over the tiles within them
             const int nqt = (nq + 63) / 64, nbt = steps;
             float *L = arena<float>(ctx, (size_t)nqt * nbt);
             if (!L) return PCR_ENOMEM;
-            PCR_LAUNCH(ctx, k_fn_boxlb, dim3((nbt + 255) / 256, nqt), dim3(256), 0, ctx->stream, (const float *)blo[qc], (const float *)bhi[qc], tile_stride[qc],
+            PCR_LAUNCH(ctx, k_fn_boxlb, dim3((nbt + 255) / 256, nqt), dim3(256), 0, ctx->stream, q_blo, q_bhi, q_tile_stride,
                        (const float *)blo[dc], (const float *)bhi[dc], tile_stride[dc], nbt, eps2, L, nbt);
             a.L = L; a.L_stride = nbt; a.n_qt = nqt; a.prelist = nullptr;
             a.pre_mode = 0; a.step0 = 0; a.steps_per_split = sps; a.step_end = steps;
@@ -1145,10 +1204,10 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
             }
         }
         FnxArgs x;
-        x.q = f[qc]; x.q_nrm = rows[qc].nrm; x.q_cq = rows[qc].cq; x.n_q = nq; x.db = f[dc]; x.n_db = n[dc]; x.db_nlo = rows[dc].nlo; x.db_nup = rows[dc].nup; x.db_nrm = rows[dc].nrm;
+        x.q = f[qc]; x.q_nrm = q_nrm; x.q_cq = q_cq; x.n_q = nq; x.db = f[dc]; x.n_db = n[dc]; x.db_nlo = rows[dc].nlo; x.db_nup = rows[dc].nup; x.db_nrm = rows[dc].nrm;
         x.db_first_zero = first_zero + dc; x.Ug = Ug;
         x.pool_used = pool_used; x.chunk_fill = chunk_fill; x.rec_q = rec_q; x.rec_row = rec_row; x.rec_w = rec_w; x.best_d = best_d; x.out = out; x.dbg = dbg;
-        x.perm_q = perm[qc]; x.perm_db = perm[dc]; x.rec_d = rec_d;
+        x.perm_q = q_perm; x.perm_db = perm[dc]; x.rec_d = rec_d;
         const int xgrid = std::min((pool_cap + 255) / 256, 4096);
         PCR_LAUNCH(ctx, k_fn_exact_min, dim3(xgrid), dim3(256), 0, ctx->stream, x, pool_cap);
         PCR_LAUNCH(ctx, k_fn_exact_arg, dim3(xgrid), dim3(256), 0, ctx->stream, x, pool_cap);
