@@ -1573,8 +1573,8 @@ struct RadListArgs {
 // row -- smallest by (float64 d^2, caller index), the order of the reference's k-d tree (oracle/kdtree.c cmp_item), so that a tie at the k-th
 // place falls as it does there (the k-best kernel keeps the first one its walk meets).  Both walks test the same float32 expressions, so they see the same points.  A boundary bin of more than RL_EDGE points
 // (many equal distances) sends the piece to the k-best kernel as before.
-#define RL_BINS 64
-#define RL_EDGE 40
+#define RL_BINS 128            // (two 16-bit counters per LDS word: a ball holds far fewer than 65 536 points)
+#define RL_EDGE 24
 // squared distance as the reference's k-d tree forms it (float64 differences of the float32 coordinates, products and sums rounded one by one)
 __device__ static inline double pcr_d2_f64_unfused(const float4 q, const float4 p) {
 #pragma clang fp contract(off)
@@ -1588,12 +1588,12 @@ __device__ static inline void d_radius_list(const RadListArgs &a) {
     constexpr int OPB = KNN_BS / OCT;
     __shared__ OctMeta m;
     __shared__ OctGroupStack gstk[KNN_BS / 64];
-    __shared__ int hist[OPB][RL_BINS];
+    __shared__ unsigned hist[OPB][RL_BINS / 2];
     __shared__ double edge_d2[OPB][RL_EDGE];     // the boundary bin's points: float64 distance (as the reference's k-d tree orders them),
     __shared__ int2 edge_id[OPB][RL_EDGE];       //   (caller index, index in Morton order)
     __shared__ int nedge[OPB];
     if (threadIdx.x == 0) m = *a.t.meta;
-    for (int b = threadIdx.x; b < OPB * RL_BINS; b += KNN_BS) (&hist[0][0])[b] = 0;
+    for (int b = threadIdx.x; b < OPB * RL_BINS / 2; b += KNN_BS) (&hist[0][0])[b] = 0u;
     if (threadIdx.x < OPB) nedge[threadIdx.x] = 0;
     __syncthreads();
     const int n = m.n;
@@ -1618,7 +1618,7 @@ __device__ static inline void d_radius_list(const RadListArgs &a) {
             const unsigned mask = (unsigned)(__ballot(hit) >> (oct * 8)) & 0xffu;
             const int pos = cnt + __builtin_popcount(mask & ((1u << ol) - 1u));
             if (hit && pos < a.k) row[pos] = idx;
-            if (hit && select) { const int b = (int)(d2 * bin_scale); atomicAdd(&hist[ob][b < RL_BINS ? b : RL_BINS - 1], 1); }
+            if (hit && select) { int b = (int)(d2 * bin_scale); b = b < RL_BINS ? b : RL_BINS - 1; atomicAdd(&hist[ob][b >> 1], 1u << (16 * (b & 1))); }
             cnt += __builtin_popcount(mask);
         }
     };
@@ -1633,7 +1633,7 @@ __device__ static inline void d_radius_list(const RadListArgs &a) {
         // the bin in which the count passes k (octet-uniform: every lane reads the octet's 64 counters)
         int B = 0, below = 0;
         if (mine) {
-            for (int b = 0; b < RL_BINS; b++) { const int h = hist[ob][b]; if (below + h >= a.k) { B = b; break; } below += h; }
+            for (int b = 0; b < RL_BINS; b++) { const int h = (int)((hist[ob][b >> 1] >> (16 * (b & 1))) & 0xffffu); if (below + h >= a.k) { B = b; break; } below += h; }
         }
         const float bound2 = mine ? fminf(a.r2f, (float)(B + 1) / bin_scale * 1.0001f) : -1.0f;
         int cnt2 = 0;
