@@ -922,6 +922,38 @@ __global__ void __launch_bounds__(256) k_fn_compact(FnCompactArgs a) {      // 8
     }
 }
 
+// batch forms (lockstep FGR groups): blockIdx.y = pair
+struct FnLiveDesc { const int *seedU; int n; uint8_t *live; int32_t *out; };
+__global__ void __launch_bounds__(256) k_fn_seed_g(const FnSeedArgs *d) {
+    const FnSeedArgs a = d[blockIdx.y];
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.n_prev) return;
+    const int oi = a.out_prev[a.perm_prev ? a.perm_prev[s] : (uint32_t)s];
+    if (oi < 0) return;
+    const unsigned long long bits = a.best_prev[s];
+    const double d2 = bits == ~0ull ? 0.0 : __longlong_as_double((long long)bits);
+    const int pos = a.inv_cur ? (int)a.inv_cur[oi] : oi;
+    const double nq = fabs((double)a.q_nrm_cur[pos]), ds = d2 * (FN_SCALE * FN_SCALE);
+    const float u = (float)(ds - nq + 2.0e-6 * (ds + nq) + 1.0e-6);
+    atomicMin(&a.Ug[pos], fn_ord(fn_add_up(u, 0.0f)));
+}
+__global__ void __launch_bounds__(256) k_fn_live_g(const FnLiveDesc *d) {     // live flags; the second direction's answers start at -1 (no mutual match possible)
+    const FnLiveDesc a = d[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < a.n) { a.live[i] = a.seedU[i] != 0x7f800000 ? 1 : 0; a.out[i] = -1; }
+}
+__global__ void __launch_bounds__(256) k_fn_compact_g(const FnCompactArgs *d) {
+    const FnCompactArgs a = d[blockIdx.y];
+    const int i = blockIdx.x * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
+    if (i >= a.n || !a.live[i]) return;
+    const int c = a.cpos[i];
+    reinterpret_cast<uint4 *>(a.Bc + (size_t)c * FN_K)[part] = reinterpret_cast<const uint4 *>(a.B + (size_t)i * FN_K)[part];
+    if (part == 0) {
+        const uint32_t o = a.perm ? a.perm[i] : (uint32_t)i;
+        a.nrm_c[c] = a.nrm[i]; a.cq_c[c] = a.cq[i]; a.perm_c[c] = o; a.Ug_c[c] = a.seedU[i]; a.out[o] = 0x7fffffff;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------ driver
 size_t pcr_feature_nn_scratch_bytes(int64_t n0, int64_t n1, int prune_mode) {
     const size_t p0 = ((size_t)n0 + FN_QPG) / FN_QPG * FN_QPG, p1 = ((size_t)n1 + FN_QPG) / FN_QPG * FN_QPG;
@@ -1251,7 +1283,7 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
 // pair wants the pruned form or its features leave the f16 range (the caller then runs the pairs one by one); `overflow_dev[g]` = a device
 // int (the words of all pairs lie in ONE array, two per pair, so overflow_dev[0] + 2 g is pair g's) the caller reads with its next read-back: != 0 means the record pool of pair g overflowed (that pair alone is redone on the float64 path).
 int pcr_feature_nn_mutual_batch(pcr_context *ctx, int G, const float *const *f0, const int *n0, const float *const *f1, const int *n1, int32_t *const *out_1to0,
-                                int32_t *const *out_0to1, const int **overflow_dev) {
+                                int32_t *const *out_0to1, const int **overflow_dev, int mutual_only) {
     if (G < 1) return PCR_OK;
     for (int g = 0; g < G; g++) {
         if (n0[g] < 64 || n1[g] < 64) return PCR_ECAPACITY;
@@ -1309,17 +1341,21 @@ int pcr_feature_nn_mutual_batch(pcr_context *ctx, int G, const float *const *f0,
         if (!ds) return PCR_ENOMEM;
         PCR_LAUNCH(ctx, k_fn_split_g, dim3((max_np + 255) / 256, 2 * G), dim3(256), 0, ctx->stream, ds);
     }
-    // problems = (pair, direction): direction 0 = queries of cloud 1 against the rows of cloud 0
-    const int NP = 2 * G;
-    std::vector<FnInitDesc> is((size_t)NP); std::vector<FnnArgs> bound((size_t)NP), rec((size_t)NP); std::vector<FnxDesc> xs((size_t)NP);
-    int max_init = 0, max_groups = 0, max_pb = 0, max_splits = 0, max_pool = 0, max_nq = 0;
-    for (int g = 0; g < G; g++)
-        for (int dir = 0; dir < 2; dir++) {
-            Pair &p = P[g];
-            const int qc = dir == 0 ? 1 : 0, dc = 1 - qc, k = 2 * g + dir;
-            int32_t *out = dir == 0 ? out_1to0[g] : out_0to1[g];
-            const int nq = p.n[qc], nqp = p.np[qc], steps = p.np[dc] / FN_STEP, groups = nqp / FN_QPG;
-            // the grid is shared by 2 G problems: ~3072 workgroups in all, and no workgroup under FN_MIN_SPS steps (it loads 128 KB of query
+    // problems = (pair, direction): direction 0 = queries of cloud 1 against the rows of cloud 0.  A problem's queries may be a subset of its cloud
+    // (the live rows of a seeded second direction): qB / q_nrm / q_cq / perm_q describe them, Ug_seeded holds their bounds.
+    struct Prob { int g, dir; const _Float16 *qB; const float *q_nrm, *q_cq; const uint32_t *perm_q; int nq, nqp; int *Ug_seeded; unsigned long long *best_d; };
+    auto run = [&](const std::vector<Prob> &probs, const bool seeded) -> int {
+        const int NP = (int)probs.size();
+        if (NP == 0) return PCR_OK;
+        std::vector<FnInitDesc> is((size_t)NP); std::vector<FnnArgs> bound((size_t)NP), rec((size_t)NP); std::vector<FnxDesc> xs((size_t)NP);
+        int max_init = 0, max_groups = 0, max_pb = 0, max_splits = 0, max_pool = 0, max_nq = 0;
+        for (int k = 0; k < NP; k++) {
+            const Prob &pb = probs[k];
+            Pair &p = P[pb.g];
+            const int dir = pb.dir, qc = dir == 0 ? 1 : 0, dc = 1 - qc;
+            int32_t *out = dir == 0 ? out_1to0[pb.g] : out_0to1[pb.g];
+            const int nq = pb.nq, nqp = pb.nqp, steps = p.np[dc] / FN_STEP, groups = nqp / FN_QPG;
+            // the grid is shared by the problems of the launch: ~3072 workgroups in all, and no workgroup under FN_MIN_SPS steps (it loads 128 KB of query
             // operands first; a group of 16 NCLT-size pairs cut as the one-pair call cuts them spent 26 ms per launch on 66 000 workgroups of 6 steps)
             int splits_all = (3072 + groups * NP - 1) / (groups * NP);
             if (splits_all > 256) splits_all = 256;
@@ -1339,17 +1375,19 @@ int pcr_feature_nn_mutual_batch(pcr_context *ctx, int G, const float *const *f0,
             const int pool_cap = (int)(((size_t)nqp * FN_POOL_PER_QUERY + waves * FN_CHUNK + FN_CHUNK - 1) / FN_CHUNK * FN_CHUNK);
             int *pool_used = arena<int>(ctx, 1), *chunk_fill = arena<int>(ctx, pool_cap / FN_CHUNK);
             int *rec_q = arena<int>(ctx, pool_cap), *rec_row = arena<int>(ctx, pool_cap); float *rec_w = arena<float>(ctx, pool_cap);
-            int *Ug = arena<int>(ctx, nqp);
-            unsigned long long *best_d = arena<unsigned long long>(ctx, nq);
+            int *Ug = pb.Ug_seeded ? pb.Ug_seeded : arena<int>(ctx, nqp);
+            unsigned long long *best_d = pb.best_d ? pb.best_d : arena<unsigned long long>(ctx, nq);
             double *rec_d = arena<double>(ctx, pool_cap);
             if (!pool_used || !chunk_fill || !rec_q || !rec_row || !rec_w || !Ug || !best_d || !rec_d) return PCR_ENOMEM;
             const int n_chunks = pool_cap / FN_CHUNK, n_init = std::max(std::max(n_chunks, nqp), nq);
-            is[k] = FnInitDesc{pool_used, chunk_fill, n_chunks, Ug, nqp, best_d, out, nq};
+            // (seeded: the bounds and the live rows' INT_MAX in `out` come from k_fn_compact_g)
+            is[k] = FnInitDesc{pool_used, chunk_fill, n_chunks, Ug, pb.Ug_seeded ? 0 : nqp, best_d, pb.Ug_seeded ? (int32_t *)nullptr : out, nq};
             FnnArgs a;
-            a.dbA = p.A[dc]; a.db_nlo = p.rows[dc].nlo; a.db_nup = p.rows[dc].nup; a.n_db_pad = p.np[dc]; a.qB = p.B[qc]; a.q_nrm = p.rows[qc].nrm; a.q_cq = p.rows[qc].cq; a.n_q = nq; a.n_q_pad = nqp;
+            a.dbA = p.A[dc]; a.db_nlo = p.rows[dc].nlo; a.db_nup = p.rows[dc].nup; a.n_db_pad = p.np[dc]; a.qB = pb.qB; a.q_nrm = pb.q_nrm; a.q_cq = pb.q_cq; a.n_q = nq; a.n_q_pad = nqp;
             a.db_first_zero = p.first_zero + dc; a.Ug = Ug;
             a.pool_used = pool_used; a.pool_cap = pool_cap; a.chunk_fill = chunk_fill; a.rec_q = rec_q; a.rec_row = rec_row; a.rec_w = rec_w; a.flags = p.flags;
             a.L = nullptr; a.L_stride = 0; a.n_qt = 0; a.prelist = nullptr; a.pre_mode = 0; a.n_bound = 0; a.xcd_chunk = 0; a.stats = nullptr;
+            a.seeded = seeded ? 1 : 0;
             int pb_want = (2048 + groups * NP - 1) / (groups * NP);                // the bound-only sweep over the first 64 steps: as many cuts as fill the chip once
             if (pb_want > 8) pb_want = 8;
             const int pre_b = steps < 64 ? steps : 64, pb_splits = pre_b < pb_want ? pre_b : pb_want, pb_sps = (pre_b + pb_splits - 1) / pb_splits;
@@ -1358,25 +1396,91 @@ int pcr_feature_nn_mutual_batch(pcr_context *ctx, int G, const float *const *f0,
             a.step0 = 0; a.steps_per_split = sps_all; a.step_end = steps;
             rec[k] = a;
             FnxArgs x;
-            x.q = p.f[qc]; x.q_nrm = p.rows[qc].nrm; x.q_cq = p.rows[qc].cq; x.n_q = nq; x.db = p.f[dc]; x.n_db = p.n[dc]; x.db_nlo = p.rows[dc].nlo; x.db_nup = p.rows[dc].nup; x.db_nrm = p.rows[dc].nrm;
+            x.q = p.f[qc]; x.q_nrm = pb.q_nrm; x.q_cq = pb.q_cq; x.n_q = nq; x.db = p.f[dc]; x.n_db = p.n[dc]; x.db_nlo = p.rows[dc].nlo; x.db_nup = p.rows[dc].nup; x.db_nrm = p.rows[dc].nrm;
             x.db_first_zero = p.first_zero + dc; x.Ug = Ug;
             x.pool_used = pool_used; x.chunk_fill = chunk_fill; x.rec_q = rec_q; x.rec_row = rec_row; x.rec_w = rec_w; x.best_d = best_d; x.out = out; x.dbg = nullptr;
-            x.perm_q = nullptr; x.perm_db = nullptr; x.rec_d = rec_d;
+            x.perm_q = pb.perm_q; x.perm_db = nullptr; x.rec_d = rec_d;
             xs[k] = FnxDesc{x, pool_cap};
             max_init = n_init > max_init ? n_init : max_init; max_groups = groups > max_groups ? groups : max_groups; max_pb = pb_splits > max_pb ? pb_splits : max_pb;
             max_splits = splits_all > max_splits ? splits_all : max_splits; max_pool = pool_cap > max_pool ? pool_cap : max_pool; max_nq = nq > max_nq ? nq : max_nq;
         }
-    const FnInitDesc *di = pcr_desc_upload(ctx, is.data(), NP);
-    const FnnArgs *db = pcr_desc_upload(ctx, bound.data(), NP), *dr = pcr_desc_upload(ctx, rec.data(), NP);
-    const FnxDesc *dx = pcr_desc_upload(ctx, xs.data(), NP);
-    if (!di || !db || !dr || !dx) return PCR_ENOMEM;
-    PCR_LAUNCH(ctx, k_fn_init_g, dim3((max_init + 255) / 256, NP), dim3(256), 0, ctx->stream, di);
-    PCR_LAUNCH(ctx, k_feature_nn_screen_g<true>, dim3(max_groups, max_pb, NP), dim3(FN_WG), 0, ctx->stream, db);
-    PCR_LAUNCH(ctx, k_feature_nn_screen_g<false>, dim3(max_groups, max_splits, NP), dim3(FN_WG), 0, ctx->stream, dr);
-    const int xgrid = std::min((max_pool + 255) / 256, std::max(64, 4096 / NP));
-    PCR_LAUNCH(ctx, k_fn_exact_min_g, dim3(xgrid, NP), dim3(256), 0, ctx->stream, dx);
-    PCR_LAUNCH(ctx, k_fn_exact_arg_g, dim3(xgrid, NP), dim3(256), 0, ctx->stream, dx);
-    PCR_LAUNCH(ctx, k_fn_finish_g, dim3((max_nq + 255) / 256, NP), dim3(256), 0, ctx->stream, dx);
+        const FnInitDesc *di = pcr_desc_upload(ctx, is.data(), NP);
+        const FnnArgs *db = pcr_desc_upload(ctx, bound.data(), NP), *dr = pcr_desc_upload(ctx, rec.data(), NP);
+        const FnxDesc *dx = pcr_desc_upload(ctx, xs.data(), NP);
+        if (!di || !db || !dr || !dx) return PCR_ENOMEM;
+        PCR_LAUNCH(ctx, k_fn_init_g, dim3((max_init + 255) / 256, NP), dim3(256), 0, ctx->stream, di);
+        if (!seeded) PCR_LAUNCH(ctx, k_feature_nn_screen_g<true>, dim3(max_groups, max_pb, NP), dim3(FN_WG), 0, ctx->stream, db);
+        PCR_LAUNCH(ctx, k_feature_nn_screen_g<false>, dim3(max_groups, max_splits, NP), dim3(FN_WG), 0, ctx->stream, dr);
+        const int xgrid = std::min((max_pool + 255) / 256, std::max(64, 4096 / NP));
+        PCR_LAUNCH(ctx, k_fn_exact_min_g, dim3(xgrid, NP), dim3(256), 0, ctx->stream, dx);
+        PCR_LAUNCH(ctx, k_fn_exact_arg_g, dim3(xgrid, NP), dim3(256), 0, ctx->stream, dx);
+        PCR_LAUNCH(ctx, k_fn_finish_g, dim3((max_nq + 255) / 256, NP), dim3(256), 0, ctx->stream, dx);
+        return PCR_OK;
+    };
+    const bool mutual = mutual_only && pcr_options().featnn_mutual.load(std::memory_order_relaxed) != 0;
+    std::vector<Prob> first, second;
+    std::vector<unsigned long long *> best_first((size_t)G, nullptr);
+    for (int g = 0; g < G; g++) {
+        Pair &p = P[g];
+        if (mutual) { best_first[g] = arena<unsigned long long>(ctx, p.n[1]); if (!best_first[g]) return PCR_ENOMEM; }
+        first.push_back(Prob{g, 0, p.B[1], p.rows[1].nrm, p.rows[1].cq, nullptr, p.n[1], p.np[1], nullptr, best_first[g]});
+        if (!mutual) first.push_back(Prob{g, 1, p.B[0], p.rows[0].nrm, p.rows[0].cq, nullptr, p.n[0], p.np[0], nullptr, nullptr});
+    }
+    PCR_TRY(run(first, false));
+    if (mutual) {
+        // ---- the second direction, seeded by the first (k_fn_seed): only the rows some row of the other cloud points at, under the bound that row gives
+        std::vector<int *> seedU((size_t)G), cpos((size_t)G), n_live_ptr((size_t)G); std::vector<uint8_t *> live((size_t)G); std::vector<int> caps((size_t)G);
+        int *n_live_all = arena<int>(ctx, G);
+        if (!n_live_all) return PCR_ENOMEM;
+        std::vector<FnInitDesc> si((size_t)G); std::vector<FnSeedArgs> sa((size_t)G); std::vector<FnLiveDesc> sl((size_t)G);
+        int max_np0 = 0, max_n1 = 0, max_n0 = 0;
+        for (int g = 0; g < G; g++) {
+            Pair &p = P[g];
+            seedU[g] = arena<int>(ctx, p.np[0]); live[g] = arena<uint8_t>(ctx, p.n[0]); cpos[g] = arena<int>(ctx, p.n[0]);
+            if (!seedU[g] || !live[g] || !cpos[g]) return PCR_ENOMEM;
+            n_live_ptr[g] = n_live_all + g; caps[g] = p.n[0];
+            si[g] = FnInitDesc{n_live_all + g, nullptr, 0, seedU[g], p.np[0], nullptr, nullptr, 0};
+            FnSeedArgs a;
+            a.out_prev = out_1to0[g]; a.best_prev = best_first[g]; a.perm_prev = nullptr; a.n_prev = p.n[1]; a.inv_cur = nullptr; a.q_nrm_cur = p.rows[0].nrm; a.Ug = seedU[g];
+            sa[g] = a;
+            sl[g] = FnLiveDesc{seedU[g], p.n[0], live[g], out_0to1[g]};
+            max_np0 = std::max(max_np0, p.np[0]); max_n1 = std::max(max_n1, p.n[1]); max_n0 = std::max(max_n0, p.n[0]);
+        }
+        const FnInitDesc *dsi = pcr_desc_upload(ctx, si.data(), G);
+        const FnSeedArgs *dsa = pcr_desc_upload(ctx, sa.data(), G);
+        const FnLiveDesc *dsl = pcr_desc_upload(ctx, sl.data(), G);
+        if (!dsi || !dsa || !dsl) return PCR_ENOMEM;
+        PCR_LAUNCH(ctx, k_fn_init_g, dim3((max_np0 + 255) / 256, G), dim3(256), 0, ctx->stream, dsi);
+        PCR_LAUNCH(ctx, k_fn_seed_g, dim3((max_n1 + 255) / 256, G), dim3(256), 0, ctx->stream, dsa);
+        PCR_LAUNCH(ctx, k_fn_live_g, dim3((max_n0 + 255) / 256, G), dim3(256), 0, ctx->stream, dsl);
+        PCR_TRY(pcr_dev_flag_scan_batch(ctx, G, live.data(), nullptr, caps.data(), cpos.data(), n_live_ptr.data()));
+        std::vector<int> n_live((size_t)G);
+        PCR_HIP_CHECK(ctx, hipMemcpyAsync(n_live.data(), n_live_all, sizeof(int) * (size_t)G, hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<FnCompactArgs> ca;
+        for (int g = 0; g < G; g++) {
+            Pair &p = P[g];
+            if (n_live[g] <= 0) continue;
+            const int nq = n_live[g], nqp = (nq + FN_QPG - 1) / FN_QPG * FN_QPG;
+            _Float16 *Bc = arena<_Float16>(ctx, (size_t)nqp * FN_K); float *r2c = arena<float>(ctx, (size_t)2 * nqp); uint32_t *perm_c = arena<uint32_t>(ctx, nqp);
+            int *Ug_c = arena<int>(ctx, nqp);
+            if (!Bc || !r2c || !perm_c || !Ug_c) return PCR_ENOMEM;
+            PCR_HIP_CHECK(ctx, hipMemsetAsync(Bc + (size_t)nq * FN_K, 0, sizeof(_Float16) * (size_t)(nqp - nq) * FN_K, ctx->stream));
+            PCR_HIP_CHECK(ctx, hipMemsetAsync(r2c, 0, sizeof(float) * 2 * (size_t)nqp, ctx->stream));
+            if (nqp > nq) PCR_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)(Ug_c + nq), 0x7f800000, (size_t)(nqp - nq), ctx->stream));
+            FnCompactArgs c;
+            c.seedU = seedU[g]; c.live = live[g]; c.cpos = cpos[g]; c.n = p.n[0]; c.B = p.B[0]; c.nrm = p.rows[0].nrm; c.cq = p.rows[0].cq; c.perm = nullptr;
+            c.Bc = Bc; c.nrm_c = r2c; c.cq_c = r2c + nqp; c.perm_c = perm_c; c.Ug_c = Ug_c; c.out = out_0to1[g];
+            ca.push_back(c);
+            second.push_back(Prob{g, 1, Bc, r2c, r2c + nqp, perm_c, nq, nqp, Ug_c, nullptr});
+        }
+        if (!ca.empty()) {
+            const FnCompactArgs *dca = pcr_desc_upload(ctx, ca.data(), (int)ca.size());
+            if (!dca) return PCR_ENOMEM;
+            PCR_LAUNCH(ctx, k_fn_compact_g, dim3((max_n0 + 31) / 32, (unsigned)ca.size()), dim3(256), 0, ctx->stream, dca);
+            PCR_TRY(run(second, true));
+        }
+    }
     for (int g = 0; g < G; g++) overflow_dev[g] = P[g].flags;         // pool overflow of a pair (either direction): its results are incomplete
     return PCR_OK;
 }

@@ -185,17 +185,14 @@ __global__ void __launch_bounds__(FB) k_spfh_slow(FpfhArgs a) { d_spfh_slow(a); 
 __global__ void __launch_bounds__(FB) k_spfh_fast_g(const FpfhArgs *a) { d_spfh_fast(a[blockIdx.y]); }
 __global__ void __launch_bounds__(FB) k_spfh_slow_g(const FpfhArgs *a) { d_spfh_slow(a[blockIdx.y]); }
 
-#define SPFH_QUEUE 256
+// Every pair in float64 (option "spfh_float64" = 1, the overflow path of the float pass, and -- with a.verify -- the comparison of the two).
 __device__ static inline void d_spfh(const FpfhArgs &a) {
     if (a.only_if_over && *a.only_if_over <= a.over_cap) return;         // (the float pass and its queue did the work)
     __shared__ int hist[FB / OCT][33];
-    __shared__ unsigned queue[SPFH_QUEUE];       // pairs float could not decide: (octet << 16 | slot), evaluated in float64 by the whole workgroup
-    __shared__ int nqueue;
     const int n = *a.n_ptr;
     const int ol = threadIdx.x & 7, ob = threadIdx.x >> 3;
     const int qi = blockIdx.x * (FB / OCT) + ob;
     for (int b = ol; b < 33; b += OCT) hist[ob][b] = 0;
-    if (threadIdx.x == 0) nqueue = 0;
     __syncthreads();
     int cnt = 0;
     if (qi < n) {
@@ -205,14 +202,14 @@ __device__ static inline void d_spfh(const FpfhArgs &a) {
             const int id = a.nbr[(size_t)qi * a.k + slot];
             if (id < 0 || id == qi) continue;
             const float4 qf = a.pts[id], mf = a.nrm[id];
-            const double dx = (double)qf.x - (double)pf.x, dy = (double)qf.y - (double)pf.y, dz = (double)qf.z - (double)pf.z;
+            const double p1[3] = {pf.x, pf.y, pf.z}, n1[3] = {nf.x, nf.y, nf.z}, p2[3] = {qf.x, qf.y, qf.z}, n2[3] = {mf.x, mf.y, mf.z};
+            const double dx = p2[0] - p1[0], dy = p2[1] - p1[1], dz = p2[2] - p1[2];
             if (!(dx * dx + dy * dy + dz * dz < a.r2)) continue;
             cnt++;
             int b0, b1, b2;
-            if (a.verify) {                       // option "spfh_float64" = 2: both ways, disagreements counted, the float64 bins kept
-                const double p1[3] = {pf.x, pf.y, pf.z}, n1[3] = {nf.x, nf.y, nf.z}, p2[3] = {qf.x, qf.y, qf.z}, n2[3] = {mf.x, mf.y, mf.z};
-                pair_bins(p1, n1, p2, n2, &b0, &b1, &b2);
-                int c0, c1, c2;
+            pair_bins(p1, n1, p2, n2, &b0, &b1, &b2);
+            if (a.verify) {                       // option "spfh_float64" = 2: where the float form answers, it must give the same bins; disagreements are counted
+                int c0, c1, c2;                   //   and the first 32 recorded, with a second evaluation (a transient differs from it: DESIGN.md section 4.3)
                 if (pair_bins_fast(pf, nf, qf, mf, &c0, &c1, &c2) && (c0 != b0 || c1 != b1 || c2 != b2)) {
                     const int at = atomicAdd(a.verify, 1);
                     if (at < 32) {
@@ -223,33 +220,11 @@ __device__ static inline void d_spfh(const FpfhArgs &a) {
                         r[18] = again ? (float)d0 : -1.0f; r[19] = (float)d1; r[20] = (float)d2; r[21] = (float)qi; r[22] = (float)id; r[23] = (float)slot;
                     }
                 }
-            } else
-            if (a.float64_only || !pair_bins_fast(pf, nf, qf, mf, &b0, &b1, &b2)) {
-#ifdef SPFH_NO_QUEUE
-                const int at = SPFH_QUEUE;
-#else
-                const int at = a.float64_only ? SPFH_QUEUE : atomicAdd(&nqueue, 1);
-#endif
-                if (at < SPFH_QUEUE) { queue[at] = (unsigned)ob << 16 | (unsigned)slot; continue; }
-                const double p1[3] = {pf.x, pf.y, pf.z}, n1[3] = {nf.x, nf.y, nf.z}, p2[3] = {qf.x, qf.y, qf.z}, n2[3] = {mf.x, mf.y, mf.z};
-                pair_bins(p1, n1, p2, n2, &b0, &b1, &b2);
             }
             atomicAdd(&hist[ob][b0], 1); atomicAdd(&hist[ob][b1], 1); atomicAdd(&hist[ob][b2], 1);
         }
     }
     cnt = pcr_octet_sum_i(cnt);
-    __syncthreads();
-    const int nq = nqueue < SPFH_QUEUE ? nqueue : SPFH_QUEUE;
-    for (int e = threadIdx.x; e < nq; e += FB) {
-        const int eo = (int)(queue[e] >> 16), slot = (int)(queue[e] & 0xffffu);
-        const int q2 = blockIdx.x * (FB / OCT) + eo;
-        const int id = a.nbr[(size_t)q2 * a.k + slot];
-        const float4 pf = a.pts[q2], nf = a.nrm[q2], qf = a.pts[id], mf = a.nrm[id];
-        const double p1[3] = {pf.x, pf.y, pf.z}, n1[3] = {nf.x, nf.y, nf.z}, p2[3] = {qf.x, qf.y, qf.z}, n2[3] = {mf.x, mf.y, mf.z};
-        int b0, b1, b2;
-        pair_bins(p1, n1, p2, n2, &b0, &b1, &b2);
-        atomicAdd(&hist[eo][b0], 1); atomicAdd(&hist[eo][b1], 1); atomicAdd(&hist[eo][b2], 1);
-    }
     __syncthreads();
     if (qi < n) {
         SpfhRow *row = a.spfh + qi;
@@ -1538,7 +1513,7 @@ int pcr_registro_fgr_group(pcr_context *ctx, pcr_fgr_group_pair *q, int G) {
     }
     std::vector<const int *> overflow_dev((size_t)G, nullptr);
     {
-        const int rc = pcr_feature_nn_mutual_batch(ctx, G, fi.data(), nPti.data(), fj.data(), nPtj.data(), j_to_i.data(), i_to_j.data(), overflow_dev.data());
+        const int rc = pcr_feature_nn_mutual_batch(ctx, G, fi.data(), nPti.data(), fj.data(), nPtj.data(), j_to_i.data(), i_to_j.data(), overflow_dev.data(), 1);
         if (rc == PCR_ECAPACITY) { PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); return 1; }
         if (rc != PCR_OK) return rc;
     }

@@ -255,7 +255,7 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
                           int mutual_only = 0 /* 1: out_0to1 is only needed where the cross check can keep it (-1 elsewhere): second direction seeded by the first */);
 
 int pcr_feature_nn_mutual_batch(pcr_context *ctx, int G, const float *const *f0, const int *n0, const float *const *f1, const int *n1, int32_t *const *out_1to0,
-                                int32_t *const *out_0to1, const int **overflow_dev);
+                                int32_t *const *out_0to1, const int **overflow_dev, int mutual_only = 0);
 
 // ---- gicp (pcr_gicp.hip) --------------------------------------------------------------------------
 struct IcpOutputs { pcr_result res; };
