@@ -191,7 +191,10 @@ __device__ static inline void d_spfh(const FpfhArgs &a) {
     __shared__ int hist[FB / OCT][33];
     const int n = *a.n_ptr;
     const int ol = threadIdx.x & 7, ob = threadIdx.x >> 3;
-    const int qi = blockIdx.x * (FB / OCT) + ob;
+    // (a fixed grid strides over the blocks of 32 points: the gated launch behind the float pass is a few hundred workgroups that read one word)
+    for (int blk = blockIdx.x; blk * (FB / OCT) < n; blk += gridDim.x) {
+    const int qi = blk * (FB / OCT) + ob;
+    __syncthreads();
     for (int b = ol; b < 33; b += OCT) hist[ob][b] = 0;
     __syncthreads();
     int cnt = 0;
@@ -230,6 +233,7 @@ __device__ static inline void d_spfh(const FpfhArgs &a) {
         SpfhRow *row = a.spfh + qi;
         for (int b = ol; b < 40; b += OCT) row->bins[b] = b < 33 ? (uint8_t)hist[ob][b] : (uint8_t)0;
         if (ol == 0) row->inc = cnt > 0 ? 100.0 / (double)cnt : 0.0;       // 100 / (m - 1), m counts the point itself
+    }
     }
 }
 
@@ -336,7 +340,7 @@ static int fpfh_of_cloud(pcr_context *ctx, const DevCloud &c, const uint32_t *pe
         PCR_LAUNCH(ctx, k_spfh_slow, dim3(std::min<unsigned>(grid.x, 1024u)), dim3(FB), 0, ctx->stream, a);
         a.only_if_over = a.slow_count; a.over_cap = a.slow_cap; a.float64_only = 1;
     }
-    PCR_LAUNCH(ctx, k_spfh, grid, dim3(FB), 0, ctx->stream, a);
+    PCR_LAUNCH(ctx, k_spfh, a.only_if_over ? dim3(std::min<unsigned>(grid.x, 512u)) : grid, dim3(FB), 0, ctx->stream, a);
     PCR_LAUNCH(ctx, k_fpfh, grid, dim3(FB), 0, ctx->stream, a);
     if (a.verify) {
         std::vector<int> rec(16 + 32 * 32);
@@ -1473,7 +1477,7 @@ int pcr_registro_fgr_group(pcr_context *ctx, pcr_fgr_group_pair *q, int G) {
             dfa = pcr_desc_upload(ctx, fa.data(), C);
             if (!dfa) return PCR_ENOMEM;
         }
-        PCR_LAUNCH(ctx, k_spfh_g, grid, dim3(FB), 0, ctx->stream, dfa);
+        PCR_LAUNCH(ctx, k_spfh_g, fa[0].only_if_over ? dim3(std::min<unsigned>(grid.x, 64u), C) : grid, dim3(FB), 0, ctx->stream, dfa);
         PCR_LAUNCH(ctx, k_fpfh_g, grid, dim3(FB), 0, ctx->stream, dfa);
     }
     // ---- NormalizePointCloud of the 2 G clouds: means and largest norms come back with the feature search's own wait (wait 2)

@@ -20,10 +20,15 @@ python3 "$ROOT/tools/trace_bins.py" "$OUT/stats" > "$ROOT/profiles/${TAG}_timeli
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/fgr" -o run -- python3 "$ROOT/bench.py" --variant fgr --no-cpu-baseline --steps 1 --warmup 1 --pairs-per-step 16 > "$OUT/bench_fgr.log" 2> "$OUT/bench_fgr.err" || exit 1
 cp "$(find "$OUT/fgr" -name '*kernel_stats.csv' | head -1)" "$ROOT/profiles/${TAG}_fgr_kernel_stats.csv"
 grep '^{"metric' "$OUT/bench_fgr.log" | tail -1 > "$ROOT/profiles/${TAG}_bench_line_fgr_under_rocprof.json"
-# the script-1 FGR stage on the shipped-size golden NCLT clouds in lockstep FGR groups (16 pairs per group, 4 groups in flight)
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/fgrn" -o run -- python3 "$ROOT/tools/fgr_group_sweep.py" 16x4 > "$OUT/fgr_nclt.log" 2> "$OUT/fgr_nclt.err" || exit 1
+# the script-1 FGR stage on the shipped-size golden NCLT clouds in lockstep FGR groups (24 pairs per group, 4 groups in flight: the default rule)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/fgrn" -o run -- python3 "$ROOT/tools/fgr_group_sweep.py" 24x4 > "$OUT/fgr_nclt.log" 2> "$OUT/fgr_nclt.err" || exit 1
 cp "$(find "$OUT/fgrn" -name '*kernel_stats.csv' | head -1)" "$ROOT/profiles/${TAG}_fgr_nclt_groups_kernel_stats.csv"
 grep '^fgr_group' "$OUT/fgr_nclt.log" | tail -1 > "$ROOT/profiles/${TAG}_fgr_nclt_groups_line.txt"
+# the script-2 five-scale GICP stage on the same scans (24 x 4)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/gicpn" -o run -- python3 "$ROOT/tools/gicp_nclt_sweep.py" 24x4 > "$OUT/gicp_nclt.log" 2> "$OUT/gicp_nclt.err" || exit 1
+cp "$(find "$OUT/gicpn" -name '*kernel_stats.csv' | head -1)" "$ROOT/profiles/${TAG}_gicp_nclt_groups_kernel_stats.csv"
+grep '^gicp group' "$OUT/gicp_nclt.log" | tail -1 > "$ROOT/profiles/${TAG}_gicp_nclt_groups_line.txt"
+python3 "$ROOT/tools/trace_bins.py" "$OUT/gicpn" > "$ROOT/profiles/${TAG}_gicp_nclt_timeline_bins.txt"
 # one pair at a time: gaps of the iteration chain without other pairs
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/solo" -o run -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 1 --warmup 1 --pairs-per-step 8 --inflight 1 --group 1 > "$OUT/bench_solo.log" 2> "$OUT/bench_solo.err" || exit 1
 python3 "$ROOT/tools/icp_gap_hist.py" "$OUT/solo" "$ROOT/profiles/${TAG}_icp_gaps_solo.txt" > /dev/null
