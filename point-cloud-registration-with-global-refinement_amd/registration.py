@@ -323,7 +323,11 @@ def register_pairs_plan(pairs, stage: str = "gicp", voxel_sizes=None, max_corres
     if group is None:
         mean_pts = float(np.mean([len(s_) + len(t_) for s_, t_, _ in pairs])) / 2
         group = balanced_group(default_group(mean_pts), n, int(inflight))
-    if stage == "fgr+gicp" and group > 1 and n > 1:
+    # FGR groups and GICP groups of the same size (NCLT-size clouds: 24 and 24): ONE library call, every worker runs registro_FGR and the GICP of
+    # its group back to back -- the same poses, 1170 -> 1220 pairs/s on the shipped scans (PCR_PLAN_ONE_CALL=0: two passes as below)
+    import os as _os
+    one_call = (fgr_group == group and _os.environ.get("PCR_PLAN_ONE_CALL", "1") != "0") or _os.environ.get("PCR_PLAN_ONE_CALL") == "2"
+    if stage == "fgr+gicp" and group > 1 and n > 1 and not one_call:
         # Two passes over the batch instead of FGR -> GICP pair by pair: registro_FGR is a chain of ~150 small launches with a few host
         # waits and wants MANY pairs in flight (20k-point pairs: 230 / 590 / 700 pairs/s with 1 / 4 / 8), the GICP wants lockstep groups.
         # Same arithmetic as the single call (same seeds per pair, the FGR normals as the orientation prior, the same radius rule).
