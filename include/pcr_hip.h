@@ -284,8 +284,8 @@ int pcr_debug_feature_nn(pcr_context *ctx, const float *f0, int64_t n0, const fl
  * per launch are the iteration kernels' own; "icp_phase", "icp_verify", "debug_stamps", "debug_visits": diagnostics of the GICP loop and the searches
  * (phase stamps of the fused iteration kernel, re-search of certified queries, per-call stamp print-outs, visit counts instead of results).
  * Switches between two forms of the FGR half that give the same bits (tests compare them): "spfh_float64" (0: pair features of FPFH decided in
- * float where float can and in float64 otherwise; 1: all in float64; 2: both, a disagreement is an error; 3: as 0 with a 16-entry queue, the
- * overflow path), "radius_list_select" (1: overfull Hybrid(r, max_nn) balls finished by threshold selection; 0: by the k-best kernel),
+ * float where float can and in float64 otherwise, for clouds from 60 000 points; 1: all in float64; 2: both, a disagreement is an error; 4: the
+ * float pass whatever the size; 3: as 4 with a 16-entry queue, the overflow path), "radius_list_select" (1: overfull Hybrid(r, max_nn) balls finished by threshold selection; 0: by the k-best kernel),
  * "featnn_mutual" (1: the second direction of the feature search inside FGR runs only for the rows the first direction points at, under the
  * bound it found; 0: both directions in full).  "arena_poison": the scratch arena is filled with this byte before every call (a read of
  * scratch nobody wrote then follows the pattern).  Returns PCR_EINVAL for an unknown name. */

@@ -118,6 +118,10 @@ struct FpfhArgs {
 
 // The float pass: light enough in registers for eight wavefronts per SIMD (the gathers of a lane's neighbours are a chain of dependent
 // loads: the pass is bound by how many of them are in flight; with the float64 evaluation inline the kernel held 178 VGPRs, two wavefronts).
+// Below this many points the float pass does not pay: NCLT-size clouds (20-30k points, 46 neighbours on average) spend their SPFH time on launches and
+// gather latency, not on float64 arithmetic, and three launches (float pass, queue, gate) are slower than one (script-1 stage in lockstep groups: 2290
+// pairs/s all float64 against 2120-2200 with the float pass); at 175k points of 100 neighbours it is 0.7 -> 0.3 ms per cloud.
+#define SPFH_SPLIT_MIN_POINTS 60000
 #define SPFH_WGQ 192
 __device__ static inline void d_spfh_fast(const FpfhArgs &a) {
     __shared__ int hist[FB / OCT][33];
@@ -321,8 +325,10 @@ static int fpfh_of_cloud(pcr_context *ctx, const DevCloud &c, const uint32_t *pe
     FpfhArgs a;
     a.pts = c.pts; a.nrm = c.nrm; a.n_ptr = c.n; a.nbr = nbr; a.k = knn; a.cnt = ncnt;
     a.r2 = search_kind == PCR_SEARCH_HYBRID ? radius * radius : 1e300;
-    const int spfh_mode = pcr_options().spfh_float64.load(std::memory_order_relaxed);       // 0 product, 1 all float64, 2 both + compare, 3 product with a 16-entry queue (the overflow path)
-    a.spfh = spfh; a.perm = perm; a.feat = feat33; a.float64_only = spfh_mode == 3 ? 0 : spfh_mode;
+    // 0 product (float pass + float64 queue from SPFH_SPLIT_MIN_POINTS points, else all float64), 1 all float64, 2 float64 + comparison with the float form,
+    // 3 float pass with a 16-entry queue (the overflow path), 4 float pass whatever the size
+    const int spfh_mode = pcr_options().spfh_float64.load(std::memory_order_relaxed);
+    a.spfh = spfh; a.perm = perm; a.feat = feat33; a.float64_only = (spfh_mode == 3 || spfh_mode == 4) ? 0 : (spfh_mode == 0 ? (n >= SPFH_SPLIT_MIN_POINTS ? 0 : 1) : spfh_mode);
     a.verify = nullptr;
     if (a.float64_only == 2) {
         a.verify = arena<int>(ctx, 16 + 32 * 32);
@@ -339,6 +345,13 @@ static int fpfh_of_cloud(pcr_context *ctx, const DevCloud &c, const uint32_t *pe
         PCR_LAUNCH(ctx, k_spfh_fast, grid, dim3(FB), 0, ctx->stream, a);
         PCR_LAUNCH(ctx, k_spfh_slow, dim3(std::min<unsigned>(grid.x, 1024u)), dim3(FB), 0, ctx->stream, a);
         a.only_if_over = a.slow_count; a.over_cap = a.slow_cap; a.float64_only = 1;
+        static const bool dbg_fgr = getenv("PCR_DEBUG_FGR") != nullptr;
+        if (dbg_fgr) {
+            int h = 0;
+            PCR_HIP_CHECK(ctx, hipMemcpyAsync(&h, a.slow_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            fprintf(stderr, "spfh: %lld points, %d pairs queued for the float64 pass (%.2f per point; queue capacity %d)\n", (long long)n, h, (double)h / (double)n, a.slow_cap);
+        }
     }
     PCR_LAUNCH(ctx, k_spfh, a.only_if_over ? dim3(std::min<unsigned>(grid.x, 512u)) : grid, dim3(FB), 0, ctx->stream, a);
     PCR_LAUNCH(ctx, k_fpfh, grid, dim3(FB), 0, ctx->stream, a);
@@ -1456,7 +1469,9 @@ int pcr_registro_fgr_group(pcr_context *ctx, pcr_fgr_group_pair *q, int G) {
             if (!nbr[k] || !ncnt[k] || !spfh) return PCR_ENOMEM;
             FpfhArgs &a = fa[k];
             a.pts = c[k].pts; a.nrm = c[k].nrm; a.n_ptr = c[k].n; a.nbr = nbr[k]; a.k = p0.feature_max_nn; a.r2 = p0.feature_radius * p0.feature_radius; a.cnt = ncnt[k];
-            a.spfh = spfh; a.perm = perm[k]; a.feat = feat[k]; a.float64_only = pcr_options().spfh_float64.load(std::memory_order_relaxed) == 1; a.verify = nullptr;
+            const int spfh_mode = pcr_options().spfh_float64.load(std::memory_order_relaxed);        // (as fpfh_of_cloud; one form for the launch: by the largest cloud)
+            int64_t n_all_max = 0; for (int kk = 0; kk < C; kk++) n_all_max = n[kk] > n_all_max ? n[kk] : n_all_max;
+            a.spfh = spfh; a.perm = perm[k]; a.feat = feat[k]; a.float64_only = (spfh_mode == 3 || spfh_mode == 4) ? 0 : (spfh_mode == 0 ? (n_all_max >= SPFH_SPLIT_MIN_POINTS ? 0 : 1) : 1); a.verify = nullptr;
             a.slowq = nullptr; a.slow_count = nullptr; a.slow_cap = 0; a.only_if_over = nullptr; a.over_cap = 0;
             if (!a.float64_only) {
                 a.slow_cap = pcr_options().spfh_float64.load(std::memory_order_relaxed) == 3 ? 16 : (int)std::min<int64_t>(8 * n[k], 1 << 28);

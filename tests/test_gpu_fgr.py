@@ -43,7 +43,13 @@ def test_fpfh_float_filter_gives_the_float64_histograms(P, fgr_inputs):
         finally:
             lib.set_option("spfh_float64", 0)
         assert np.array_equal(np.asarray(feat.data), np.asarray(ref.data))
-        got_knn = P.registration.compute_fpfh_feature(pc, P.KDTreeSearchParamKNN(100))
+        lib.set_option("spfh_float64", 4)            # the float pass whatever the size (the product takes it from 60k points)
+        try:
+            got = P.registration.compute_fpfh_feature(pc, P.KDTreeSearchParamHybrid(radius=1.0, max_nn=200))
+            got_knn = P.registration.compute_fpfh_feature(pc, P.KDTreeSearchParamKNN(100))
+        finally:
+            lib.set_option("spfh_float64", 0)
+        assert np.array_equal(np.asarray(got.data), np.asarray(ref.data))
         assert np.array_equal(np.asarray(got_knn.data), np.asarray(ref_knn.data))
         lib.set_option("spfh_float64", 3)            # a 16-entry queue: it overflows, and every row is done again in float64
         try:
