@@ -28,6 +28,7 @@ PcrOptions &pcr_options() {
         if (const char *e = getenv("PCR_SPFH_FLOAT64")) o.spfh_float64 = atoi(e);
         if (const char *e = getenv("PCR_RADIUS_LIST_SELECT")) o.radius_list_select = atoi(e);
         if (const char *e = getenv("PCR_FEATNN_MUTUAL")) o.featnn_mutual = atoi(e);
+        if (const char *e = getenv("PCR_PLAN_STAGGER_US")) o.plan_stagger_us = atoi(e);
     });
     return o;
 }
@@ -54,6 +55,7 @@ extern "C" int pcr_set_option(const char *name, long long value) {
     if (!strcmp(name, "radius_list_select")) { o.radius_list_select = (int)value; return PCR_OK; }
     if (!strcmp(name, "arena_poison")) { o.arena_poison = (int)value; return PCR_OK; }
     if (!strcmp(name, "featnn_mutual")) { o.featnn_mutual = (int)value; return PCR_OK; }
+    if (!strcmp(name, "plan_stagger_us")) { o.plan_stagger_us = (int)value; return PCR_OK; }
     return PCR_EINVAL;
 }
 
@@ -950,8 +952,11 @@ extern "C" int pcr_register_pairs_plan(int device, pcr_pair_ex *pairs, int n_pai
     if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess) return PCR_EHIP;
     if (hipEventRecord(ready, (hipStream_t)after_stream) != hipSuccess) { (void)hipEventDestroy(ready); return PCR_EHIP; }
     for (int i = 0; i < n_pairs; i++) { pairs[i].base.status = PCR_EHIP; snprintf(pairs[i].base.error, sizeof pairs[i].base.error, "not processed (no worker context)"); }
-    std::atomic<int> next(0), failed(0);
+    std::atomic<int> next(0), failed(0), started(0);
+    const int stagger_us = pcr_options().plan_stagger_us.load(std::memory_order_relaxed);      // measurement only: worker w starts w x this later
     auto work = [&]() {
+        const int wid = started.fetch_add(1);
+        if (stagger_us > 0 && wid > 0) std::this_thread::sleep_for(std::chrono::microseconds((long long)wid * stagger_us));
         (void)hipSetDevice(device);
         pcr_context *ctx = pool_take(device);
         if (!ctx) { failed++; return; }

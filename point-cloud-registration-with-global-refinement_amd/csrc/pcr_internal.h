@@ -9,7 +9,7 @@
 #include "../../include/pcr_hip.h"
 
 // process-wide switches (pcr_set_option, include/pcr_hip.h): latched from the environment once, atomics afterwards
-struct PcrOptions { std::atomic<int> knn_wave{-1}, knnw_budget{80}, fence_prep{0}, icp_phase{0}, icp_verify{0}, debug_stamps{0}, debug_visits{0}, spfh_float64{0}, radius_list_select{1}, arena_poison{0}, featnn_mutual{1}; };
+struct PcrOptions { std::atomic<int> knn_wave{-1}, knnw_budget{80}, fence_prep{0}, icp_phase{0}, icp_verify{0}, debug_stamps{0}, debug_visits{0}, spfh_float64{0}, radius_list_select{1}, arena_poison{0}, featnn_mutual{1}, plan_stagger_us{0}; };
 PcrOptions &pcr_options();
 // process-wide event counters (pcr_counter, include/pcr_hip.h): how often a slow fall-back was taken -- invisible in the results, which are the same bits
 struct PcrCounters { std::atomic<long long> fgr_group_barrier_timeouts{0}, fgr_group_pool_overflows{0}, fgr_group_pairs_redone_alone{0}; };
