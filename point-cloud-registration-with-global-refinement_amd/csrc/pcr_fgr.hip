@@ -1462,6 +1462,8 @@ int pcr_registro_fgr_group(pcr_context *ctx, pcr_fgr_group_pair *q, int G) {
     {
         std::vector<const DevCloud *> cp((size_t)C); std::vector<int32_t *> nbr((size_t)C), ncnt((size_t)C);
         int64_t nmax = 0;
+        const int spfh_mode = pcr_options().spfh_float64.load(std::memory_order_relaxed);        // (as fpfh_of_cloud; read ONCE: one form for the launch, by the largest cloud)
+        int64_t n_all_max = 0; for (int kk = 0; kk < C; kk++) n_all_max = n[kk] > n_all_max ? n[kk] : n_all_max;
         for (int k = 0; k < C; k++) {
             cp[k] = &c[k];
             nbr[k] = arena<int32_t>(ctx, (size_t)n[k] * p0.feature_max_nn); ncnt[k] = arena<int32_t>(ctx, n[k]);
@@ -1469,12 +1471,10 @@ int pcr_registro_fgr_group(pcr_context *ctx, pcr_fgr_group_pair *q, int G) {
             if (!nbr[k] || !ncnt[k] || !spfh) return PCR_ENOMEM;
             FpfhArgs &a = fa[k];
             a.pts = c[k].pts; a.nrm = c[k].nrm; a.n_ptr = c[k].n; a.nbr = nbr[k]; a.k = p0.feature_max_nn; a.r2 = p0.feature_radius * p0.feature_radius; a.cnt = ncnt[k];
-            const int spfh_mode = pcr_options().spfh_float64.load(std::memory_order_relaxed);        // (as fpfh_of_cloud; one form for the launch: by the largest cloud)
-            int64_t n_all_max = 0; for (int kk = 0; kk < C; kk++) n_all_max = n[kk] > n_all_max ? n[kk] : n_all_max;
             a.spfh = spfh; a.perm = perm[k]; a.feat = feat[k]; a.float64_only = (spfh_mode == 3 || spfh_mode == 4) ? 0 : (spfh_mode == 0 ? (n_all_max >= SPFH_SPLIT_MIN_POINTS ? 0 : 1) : 1); a.verify = nullptr;
             a.slowq = nullptr; a.slow_count = nullptr; a.slow_cap = 0; a.only_if_over = nullptr; a.over_cap = 0;
             if (!a.float64_only) {
-                a.slow_cap = pcr_options().spfh_float64.load(std::memory_order_relaxed) == 3 ? 16 : (int)std::min<int64_t>(8 * n[k], 1 << 28);
+                a.slow_cap = spfh_mode == 3 ? 16 : (int)std::min<int64_t>(8 * n[k], 1 << 28);
                 a.slowq = arena<uint2>(ctx, (size_t)a.slow_cap); a.slow_count = arena<int>(ctx, 1);
                 if (!a.slowq || !a.slow_count) return PCR_ENOMEM;
                 PCR_HIP_CHECK(ctx, hipMemsetAsync(a.slow_count, 0, sizeof(int), ctx->stream));
