@@ -29,6 +29,7 @@ PcrOptions &pcr_options() {
         if (const char *e = getenv("PCR_RADIUS_LIST_SELECT")) o.radius_list_select = atoi(e);
         if (const char *e = getenv("PCR_FEATNN_MUTUAL")) o.featnn_mutual = atoi(e);
         if (const char *e = getenv("PCR_PLAN_STAGGER_US")) o.plan_stagger_us = atoi(e);
+        if (const char *e = getenv("PCR_PLAN_PREFETCH")) o.plan_prefetch = atoi(e);
     });
     return o;
 }
@@ -56,6 +57,7 @@ extern "C" int pcr_set_option(const char *name, long long value) {
     if (!strcmp(name, "arena_poison")) { o.arena_poison = (int)value; return PCR_OK; }
     if (!strcmp(name, "featnn_mutual")) { o.featnn_mutual = (int)value; return PCR_OK; }
     if (!strcmp(name, "plan_stagger_us")) { o.plan_stagger_us = (int)value; return PCR_OK; }
+    if (!strcmp(name, "plan_prefetch")) { o.plan_prefetch = (int)value; return PCR_OK; }
     return PCR_EINVAL;
 }
 
@@ -655,6 +657,7 @@ static int multiscale_group(pcr_context *ctx, pcr_pair_ex *const *px, int G, con
         for (size_t k = 0; k < vp.size(); k++) vp[k] = &vox[k];
         PCR_TRY(pcr_dev_build_bvh_batch(ctx, vp.data(), (int)vp.size()));
     }
+    PcrGateToken heavy_token(ctx->heavy_gate);         // (held to the end of the group: the function returns after its last read-back)
     {   // the filter chains of ALL clouds and scales of the group as one batch (round 5: sources and targets were two batches -- twice the launches, and
         // twice the tails of the list-driven searches); incomplete normal lists are searched over the voxel trees (piece lists of the filter pass)
         std::vector<const DevCloud *> ins; std::vector<DevCloud *> outs; std::vector<const float4 *> pr; std::vector<uint8_t *> td; std::vector<int *> tc, ci, ck;
@@ -945,7 +948,11 @@ extern "C" int pcr_register_pairs_plan(int device, pcr_pair_ex *pairs, int n_pai
     const int group = plan->stage == PCR_STAGE_FGR ? fgr_group
                     : (((plan->stage == PCR_STAGE_GICP || plan->stage == PCR_STAGE_FGR_GICP) && plan->group > 1) ? (plan->group > 24 ? 24 : plan->group)      /* (32 in lockstep were measured at 310 pairs/s against 1150 with 24 on NCLT-size pairs: capped) */ : 1);
     const int units = (n_pairs + group - 1) / group;
-    const int workers = inflight < 1 ? 1 : (inflight > units ? units : (inflight > 16 ? 16 : inflight));
+    int workers = inflight < 1 ? 1 : (inflight > units ? units : (inflight > 16 ? 16 : inflight));
+    // (option "plan_prefetch": twice the workers, of which `workers` at a time are past the gate of multiscale_group)
+    PcrGate gate;
+    const bool prefetch = pcr_options().plan_prefetch.load(std::memory_order_relaxed) != 0 && plan->stage == PCR_STAGE_GICP && group > 1 && units > workers;
+    if (prefetch) { gate.free_slots = workers; workers = 2 * workers > units ? units : 2 * workers; if (workers > 16) workers = 16; }
     // the workers wait for everything already enqueued on `after_stream` (NULL = the legacy default stream, which is what torch's
     // default stream is): the producers of the clouds, normals and initial poses
     hipEvent_t ready = nullptr;
@@ -961,6 +968,7 @@ extern "C" int pcr_register_pairs_plan(int device, pcr_pair_ex *pairs, int n_pai
         pcr_context *ctx = pool_take(device);
         if (!ctx) { failed++; return; }
         use_private_stream(ctx);
+        ctx->heavy_gate = prefetch ? &gate : nullptr;
         if (ensure_stream(ctx) == PCR_OK) (void)hipStreamWaitEvent(ctx->stream, ready, 0);
         const bool gicp_stage = plan->stage == PCR_STAGE_GICP || plan->stage == PCR_STAGE_FGR_GICP;
         auto group_unit = [&](int i, int cnt) -> int {
@@ -1122,6 +1130,7 @@ extern "C" int pcr_register_pairs_plan(int device, pcr_pair_ex *pairs, int n_pai
         }
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
         ctx->group_forms = false;
+        ctx->heavy_gate = nullptr;
         pool_give(device, ctx);
     };
     std::vector<std::thread> threads;

@@ -3,19 +3,37 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <mutex>
+#include <condition_variable>
 #include <cstring>
 #include <vector>
 #include <atomic>
 #include "../../include/pcr_hip.h"
 
 // process-wide switches (pcr_set_option, include/pcr_hip.h): latched from the environment once, atomics afterwards
-struct PcrOptions { std::atomic<int> knn_wave{-1}, knnw_budget{80}, fence_prep{0}, icp_phase{0}, icp_verify{0}, debug_stamps{0}, debug_visits{0}, spfh_float64{0}, radius_list_select{1}, arena_poison{0}, featnn_mutual{1}, plan_stagger_us{0}; };
+struct PcrOptions { std::atomic<int> knn_wave{-1}, knnw_budget{80}, fence_prep{0}, icp_phase{0}, icp_verify{0}, debug_stamps{0}, debug_visits{0}, spfh_float64{0}, radius_list_select{1}, arena_poison{0}, featnn_mutual{1}, plan_stagger_us{0}, plan_prefetch{0}; };
 PcrOptions &pcr_options();
 // process-wide event counters (pcr_counter, include/pcr_hip.h): how often a slow fall-back was taken -- invisible in the results, which are the same bits
 struct PcrCounters { std::atomic<long long> fgr_group_barrier_timeouts{0}, fgr_group_pool_overflows{0}, fgr_group_pairs_redone_alone{0}; };
 PcrCounters &pcr_counters();
 #define PCR_GROUP_FORMS_MAX_POINTS 400000      // pcr_pairs_plan.pair_forms: pairs with both clouds under this take the group forms of the kernels
 
+
+// A counting gate of a plan call.  A lockstep group starts with ~5 ms of small dependent launches (bounds, voxel keys, sort, means, trees) during
+// which the chip is nearly idle when all groups in flight are in that part together.  With twice the workers, the groups beyond `inflight`
+// run that part early -- next to the other groups' searches and iteration loops -- and wait here before their own chip-filling part, so
+// that at most `inflight` groups are in the searches and loops at a time (more of THOSE in flight is slower: DESIGN.md section 4.2).
+struct PcrGate {
+    std::mutex m; std::condition_variable cv; int free_slots = 0;
+    void acquire() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return free_slots > 0; }); free_slots--; }
+    void release() { { std::lock_guard<std::mutex> l(m); free_slots++; } cv.notify_one(); }
+};
+struct PcrGateToken {
+    PcrGate *g;
+    explicit PcrGateToken(PcrGate *gate) : g(gate) { if (g) g->acquire(); }
+    ~PcrGateToken() { if (g) g->release(); }
+    PcrGateToken(const PcrGateToken &) = delete; PcrGateToken &operator=(const PcrGateToken &) = delete;
+};
 
 // One captured chunk of GICP launches.  Solo calls key it by everything the launches bake in; lockstep groups key it by the launch
 // form only and patch grid widths / by-value arguments into `exec` through `nodes` (kept in launch order, owned by `graph`).
@@ -61,6 +79,7 @@ struct pcr_context {
     // Inside a lockstep-group plan every unit takes the GROUP forms of the kernels (wavefront k-NN, 1024-point iteration tiles) whatever
     // its size: a ragged last group of one pair, or a one-pair shard of another world size, is then the same arithmetic as the pair
     // inside a full group (gathered poses are the single-GPU bits)
+    struct PcrGate *heavy_gate = nullptr;   // pcr_register_pairs_plan with more workers than groups in flight: taken before the chip-filling part of a group (see PcrGate)
     bool group_forms = false;
     bool octet_only = false;     // lockstep FGR groups: every batched search runs the octet kernel, as registro_FGR's one-cloud searches do
 };
