@@ -287,7 +287,8 @@ int pcr_debug_feature_nn(pcr_context *ctx, const float *f0, int64_t n0, const fl
  * float where float can and in float64 otherwise, for clouds from 60 000 points; 1: all in float64; 2: both, a disagreement is an error; 4: the
  * float pass whatever the size; 3: as 4 with a 16-entry queue, the overflow path), "radius_list_select" (1: overfull Hybrid(r, max_nn) balls finished by threshold selection; 0: by the k-best kernel),
  * "featnn_mutual" (1: the second direction of the feature search inside FGR runs only for the rows the first direction points at, under the
- * bound it found; 0: both directions in full).  "plan_stagger_us", "plan_prefetch": measurement only (delayed worker starts; twice the workers
+ * bound it found; 0: both directions in full), "icp_scales" (1: in lockstep groups of small clouds every pair goes through its scales by itself;
+ * 0: one lockstep loop per scale).  "plan_stagger_us", "plan_prefetch": measurement only (delayed worker starts; twice the workers
  * behind a gate in front of a group's chip-filling part) -- both cost throughput, README.md quotes the numbers.  "arena_poison": the scratch arena is filled with this byte before every call (a read of
  * scratch nobody wrote then follows the pattern).  Returns PCR_EINVAL for an unknown name. */
 int pcr_set_option(const char *name, long long value);

@@ -30,6 +30,7 @@ PcrOptions &pcr_options() {
         if (const char *e = getenv("PCR_FEATNN_MUTUAL")) o.featnn_mutual = atoi(e);
         if (const char *e = getenv("PCR_PLAN_STAGGER_US")) o.plan_stagger_us = atoi(e);
         if (const char *e = getenv("PCR_PLAN_PREFETCH")) o.plan_prefetch = atoi(e);
+        if (const char *e = getenv("PCR_ICP_SCALES")) o.icp_scales = atoi(e);
     });
     return o;
 }
@@ -58,6 +59,7 @@ extern "C" int pcr_set_option(const char *name, long long value) {
     if (!strcmp(name, "featnn_mutual")) { o.featnn_mutual = (int)value; return PCR_OK; }
     if (!strcmp(name, "plan_stagger_us")) { o.plan_stagger_us = (int)value; return PCR_OK; }
     if (!strcmp(name, "plan_prefetch")) { o.plan_prefetch = (int)value; return PCR_OK; }
+    if (!strcmp(name, "icp_scales")) { o.icp_scales = (int)value; return PCR_OK; }
     return PCR_EINVAL;
 }
 
@@ -685,7 +687,21 @@ static int multiscale_group(pcr_context *ctx, pcr_pair_ex *const *px, int G, con
         match[g] = arena<int32_t>(ctx, n[2 * g]);
         if (!match[g]) return PCR_ENOMEM;
     }
-    for (int s = 0; s < n_scales; s++) {
+    int rc_all = 1;
+    if (n_scales > 1 && pcr_options().icp_scales.load(std::memory_order_relaxed)) {      // every pair goes on to its next scale by itself (pcr_dev_gicp_group_scales)
+        std::vector<const DevCloud *> ss((size_t)G * n_scales), tt((size_t)G * n_scales);
+        std::vector<double> mds((size_t)G * n_scales); std::vector<pcr_result> rall((size_t)G * n_scales);
+        for (int g = 0; g < G; g++)
+            for (int s = 0; s < n_scales; s++) {
+                ss[(size_t)g * n_scales + s] = &clean[(size_t)(2 * g) * n_scales + s]; tt[(size_t)g * n_scales + s] = &clean[(size_t)(2 * g + 1) * n_scales + s];
+                mds[(size_t)g * n_scales + s] = dists[(size_t)g * n_scales + s];
+            }
+        rc_all = pcr_dev_gicp_group_scales(ctx, G, n_scales, ss.data(), tt.data(), mds.data(), T.data(), params, rall.data(), match.data());
+        if (rc_all != PCR_OK && rc_all != 1) return rc_all;
+        if (rc_all == PCR_OK)
+            for (int g = 0; g < G; g++) for (int s = 0; s < n_scales; s++) px[g]->base.records[s].icp = rall[(size_t)g * n_scales + s];
+    }
+    for (int s = 0; s < n_scales && rc_all == 1; s++) {
         std::vector<const DevCloud *> ss((size_t)G), tt((size_t)G);
         for (int g = 0; g < G; g++) { ss[g] = &clean[(size_t)(2 * g) * n_scales + s]; tt[g] = &clean[(size_t)(2 * g + 1) * n_scales + s]; md[g] = dists[(size_t)g * n_scales + s]; }
         PCR_TRY(pcr_dev_gicp_group(ctx, G, ss.data(), tt.data(), md.data(), T.data(), params, res.data(), match.data()));

@@ -66,6 +66,11 @@ struct IcpArgs {
     int dbg_visits;                              // diagnostics: store node/leaf visit counts instead of matches
     int dbg_phase;                               // diagnostics (PCR_ICP_PHASE = 1 / 2): t_dbg[1] <- slowest workgroup's end of phase A / B of the fused kernel
     unsigned long long *stamps_nn, *stamps_it;   // diagnostics (PCR_ICP_STAMPS): per-wavefront clocks of the first 16 launches
+    // all scales of a pair behind ONE argument slot (pcr_dev_gicp_group_scales; ms_scales == 0: a single scale): when the criteria of scale ms_index
+    // hold, the last workgroup stores the state in ms_hist[ms_index] and -- unless it was the last scale -- starts the next one itself: launches,
+    // iterations and flags back to their start values, the pose kept, and ms_args[ms_index + 1] copied over *ms_self, the slot the next launch reads.
+    // A launch that finds launches == 0 is the scale's first: no certificate is valid, every query is searched (what k_icp_nn + k_icp_lin do).
+    const IcpArgs *ms_args; IcpArgs *ms_self; IcpState *ms_hist; int ms_scales, ms_index;
 };
 #define ICP_STAMP_LAUNCHES 16
 
@@ -717,6 +722,23 @@ __device__ static inline void icp_finish(const IcpArgs &a, IcpState *st, const d
                 a.stamps_it[12 * ((size_t)launches * gridDim.x * (BS / 64) + (size_t)blockIdx.x * (BS / 64)) + 3] = wall_clock64();
             st->done = stop ? 1 : 0;          // visible to the next launch through the kernel boundary
         }
+        if (a.ms_scales > 0 && stop) {        // (wave-uniform) the scale is over: keep its result; not the last one: the pair goes on by itself
+            __builtin_amdgcn_wave_barrier();
+            const bool more = a.ms_index + 1 < a.ms_scales;
+            const IcpArgs *next = a.ms_args + (a.ms_index + 1); IcpArgs *self = a.ms_self; IcpState *hist = a.ms_hist + a.ms_index;
+            if (lead) {
+                __threadfence();
+                *hist = *st;
+                if (more) {
+                    st->launches = 0; st->iter = 0; st->converged = 0; st->done = 0; st->fitness = 0; st->rmse = 0; st->count = 0;
+                    st->dfit = 1e300; st->drmse = 1e300;
+                }
+            }
+            if (more) {                        // the argument slot, a dword per lane and round (nobody reads it any more in this launch: the other workgroups have left)
+                const unsigned *srcw = reinterpret_cast<const unsigned *>(next); unsigned *dstw = reinterpret_cast<unsigned *>(self);
+                for (int w = threadIdx.x; w < (int)(sizeof(IcpArgs) / 4); w += 64) dstw[w] = srcw[w];
+            }
+        }
     }
 }
 
@@ -838,6 +860,10 @@ __device__ static inline void d_icp_fused(const IcpArgs &a) {
     const unsigned gmask = GRID ? *a.grid.dmask : 0u;
     if (done) return;
     if (bid >= nb) return;
+    if (a.ms_scales > 0 && launches == 0) {       // first launch of a scale in the all-scales loop: what match / ref / clist hold belongs to the scale before
+#pragma unroll
+        for (int p = 0; p < PPL; p++) { mraw[p] = -1; refv[p].w = 0.0f; lst[p] = make_int4(-1, -1, -1, -1); }
+    }
 #pragma unroll
     for (int k = 0; k < 12; k++) T[k] = icp_uniform(T[k]);
     const unsigned long long t_entry = wall_clock64();
@@ -1481,6 +1507,193 @@ int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, cons
     for (int g = 0; g < G; g++) {
         state_to_result(fin[g], &out[g]);
         for (int k = 0; k < 16; k++) if (!std::isfinite(fin[g].T[k])) { ctx->err = "non-finite pose"; return PCR_ENUMERIC; }
+    }
+    return PCR_OK;
+}
+
+// ---- ALL scales of a group in one loop (round 5).  pcr_dev_gicp_group per scale makes the whole group wait for the slowest pair of every scale:
+// on the shipped NCLT scans a pair needs 222 launches over its five scales, a lockstep group of 24 pairs 384 (the sum over the scales of the group's
+// maximum), and if every pair went on to its next scale by itself the group would need 242 (the largest sum of a pair).  Here it does, on the
+// DEVICE: the kernels read a pair's arguments from a fixed slot of a device table, the arguments of all its scales wait next to it, and the last
+// workgroup of the launch in which the criteria of a scale hold stores the result and copies the next scale's arguments into the slot
+// (icp_finish, IcpArgs.ms_*).  The first launch of a scale is then k_icp_fused itself with no certificate valid: every query searched, the
+// linearisation in the same 512-point rows as k_icp_lin -- which is why only groups whose tiles are 512 points take this path (NCLT-size clouds):
+// the sums, hence the bits, are those of the scale-by-scale loop.  (A host-driven form -- read-back, argument update and cold-start kernels per
+// pair that moved on -- was built first: its 40-60 extra stream operations per group ate the gain.)
+// src / tgt / max_dists are indexed [g * S + s]; out likewise; match_dev[g] (optional) receives the matches of g's last scale.  Returns 1
+// (nothing done) for groups it does not serve: the caller then runs the scales one after the other.
+int pcr_dev_gicp_group_scales(pcr_context *ctx, int G, int S, const DevCloud *const *src, const DevCloud *const *tgt, const double *max_dists, const double *T0,
+                              const pcr_gicp_params *p, pcr_result *out, int32_t *const *match_dev) {
+    if (G < 1 || G > 32 || S < 1 || S > 8) return 1;
+    static const bool use_fused_g = !(getenv("PCR_ICP_FUSED") && atoi(getenv("PCR_ICP_FUSED")) == 0);
+    if (!use_fused_g || !icp_use_grid()) return 1;
+    if (pcr_options().icp_verify.load(std::memory_order_relaxed) || pcr_options().debug_visits.load(std::memory_order_relaxed)) return 1;
+    for (int k = 0; k < G * S; k++) {
+        if (!(max_dists[k] > 0.0)) { ctx->err = "max_correspondence_distance <= 0"; return PCR_EINVAL; }
+        if (!src[k]->nrm || !tgt[k]->nrm) { ctx->err = "GICP needs normals on both clouds"; return PCR_EINVAL; }
+        if (tgt[k]->cap <= 0) return 1;
+    }
+    int max_cap = 1;
+    for (int k = 0; k < G * S; k++) max_cap = src[k]->cap > max_cap ? src[k]->cap : max_cap;
+    const int tile_pts = fused_tile_points(ctx, max_cap, G);
+    for (int k = 0; k < G * S; k++) {          // rows of 512 points, as k_icp_lin's
+        const int cap = src[k]->cap > 0 ? src[k]->cap : 1;
+        const int tile_k = icp_group_tile(cap, tile_pts) ? icp_group_tile(cap, tile_pts) : tile_pts;
+        if (tile_k != LIN_BS) return 1;
+    }
+    ArenaMark mark(ctx);
+    static const double gfrac = getenv("PCR_ICP_GAP") ? atof(getenv("PCR_ICP_GAP")) : 0.25;
+    // cell hashes of all G x S targets in one batch
+    std::vector<int> levels((size_t)G * S); std::vector<GridView> views((size_t)G * S);
+    for (int k = 0; k < G * S; k++) {
+        double gg = gfrac * max_dists[k]; gg = gg < 0.01 ? 0.01 : (gg > 0.05 ? 0.05 : gg);
+        const double rs = max_dists[k] + gg;
+        levels[k] = pcr_grid_level_for(tgt[k], std::sqrt((double)(float)(rs * rs * (1.0 + 1e-6))));
+        if (levels[k] < 0) return 1;
+    }
+    PCR_TRY(pcr_dev_build_grid_batch(ctx, tgt, levels.data(), G * S, views.data()));
+    for (int k = 0; k < G * S; k++) if (!views[k].tab) return 1;
+    // per pair: one state and one set of certificate / partial-sum / match buffers (a pair is at one scale at a time), sized by its largest scale
+    const size_t args_bytes = sizeof(IcpArgs) * 32 + sizeof(IcpInit) * 32;
+    if (!ctx->icp_group_dev) {
+        if (hipMalloc((void **)&ctx->icp_group_dev, args_bytes) != hipSuccess || hipHostMalloc((void **)&ctx->icp_group_host, args_bytes, hipHostMallocDefault) != hipSuccess) {
+            ctx->err = "GICP group: argument buffers"; return PCR_ENOMEM;
+        }
+    }
+    IcpArgs *dargs = (IcpArgs *)ctx->icp_group_dev;
+    IcpInit *dinit = (IcpInit *)(ctx->icp_group_dev + sizeof(IcpArgs) * 32);
+    const void *dargs_v = dargs;
+    IcpState *st = arena<IcpState>(ctx, G), *hist = arena<IcpState>(ctx, (size_t)G * S);
+    IcpArgs *all_dev = arena<IcpArgs>(ctx, (size_t)G * S);
+    if (!st || !hist || !all_dev) return PCR_ENOMEM;
+    std::vector<IcpArgs> all((size_t)G * S);
+    int nbf = 1;
+    for (int g = 0; g < G; g++) {
+        int cap_g = 1, rows_g = 1;
+        for (int s_ = 0; s_ < S; s_++) {
+            const int cap = src[g * S + s_]->cap > 0 ? src[g * S + s_]->cap : 1;
+            const int f_ = ((cap + LIN_BS - 1) / LIN_BS + 7) & ~7;
+            nbf = f_ > nbf ? f_ : nbf; cap_g = cap > cap_g ? cap : cap_g; rows_g = f_ > rows_g ? f_ : rows_g;
+        }
+        double *partials = arena<double>(ctx, (size_t)rows_g * NVP);
+        int32_t *match = (match_dev && match_dev[g]) ? match_dev[g] : arena<int32_t>(ctx, cap_g);
+        float4 *ref = arena<float4>(ctx, cap_g); int32_t *rbest = arena<int32_t>(ctx, cap_g); int4 *clist = arena<int4>(ctx, cap_g);
+        if (!partials || !match || !ref || !rbest || !clist) return PCR_ENOMEM;
+        for (int s_ = 0; s_ < S; s_++) {
+            const int k = g * S + s_;
+            IcpArgs &a = all[k]; memset(&a, 0, sizeof a);
+            fill_args(a, src[k], tgt[k], max_dists[k], p, match, st + g, partials, 0);
+            a.tile_rt = icp_group_tile(src[k]->cap > 0 ? src[k]->cap : 1, tile_pts);
+            a.ref = ref; a.rbest = rbest; a.clist = clist;
+            double gg = gfrac * max_dists[k]; gg = gg < 0.01 ? 0.01 : (gg > 0.05 ? 0.05 : gg);
+            const double rs = max_dists[k] + icp_gap_for_level(tgt[k], levels[k], max_dists[k], gg);      // (as pcr_dev_gicp_group: the cap grows to what the level's cells cover)
+            a.r2s = (float)(rs * rs * (1.0 + 1e-6)); a.rs_minus_r = (float)(rs - max_dists[k]);
+            a.grid = views[k];
+            a.ms_args = all_dev + (size_t)g * S; a.ms_self = dargs + g; a.ms_hist = hist + (size_t)g * S; a.ms_scales = S; a.ms_index = s_;
+        }
+    }
+    if (nbf > 4096) return 1;
+    std::vector<IcpArgs> first((size_t)G); std::vector<IcpInit> inits((size_t)G);
+    for (int g = 0; g < G; g++) { first[g] = all[(size_t)g * S]; memcpy(inits[g].T, T0 + 16 * g, sizeof inits[g].T); }
+    // (pageable sources: staged before the calls return)
+    PCR_HIP_CHECK(ctx, hipMemcpyAsync(all_dev, all.data(), sizeof(IcpArgs) * all.size(), hipMemcpyHostToDevice, ctx->stream));
+    PCR_HIP_CHECK(ctx, hipMemcpyAsync(dargs, first.data(), sizeof(IcpArgs) * (size_t)G, hipMemcpyHostToDevice, ctx->stream));
+    PCR_HIP_CHECK(ctx, hipMemcpyAsync(dinit, inits.data(), sizeof(IcpInit) * (size_t)G, hipMemcpyHostToDevice, ctx->stream));
+    PCR_LAUNCH(ctx, k_icp_init_g, dim3(G), dim3(64), 0, ctx->stream, st, (const IcpInit *)dinit);
+    static const int chunk_env = getenv("PCR_ICP_CHUNK") ? atoi(getenv("PCR_ICP_CHUNK")) : 8;
+    const int CHUNK = chunk_env < 1 ? 1 : (chunk_env > 32 ? 32 : chunk_env);
+    static const bool use_graph = !(getenv("PCR_ICP_GRAPH") && atoi(getenv("PCR_ICP_GRAPH")) == 0);
+    auto enqueue_fused = [&]() { PCR_FUSED_LAUNCH(ctx, k_icp_fused_g, true, tile_pts, dim3(nbf, G), (const IcpArgs *)dargs); };
+    auto graph_for = [&](int len, hipGraphExec_t *outg) -> int {     // a chunk of `len` fused launches, captured once per (G, tile, grid width, length)
+        *outg = nullptr;
+        if (!use_graph) return PCR_OK;
+        const long long kv[6] = {0x47525053ll /* "GRPS" */, G, tile_pts, len, nbf, (long long)(uintptr_t)dargs_v};
+        std::string key((const char *)kv, sizeof kv);
+        for (auto &gr : ctx->icp_graphs) if (gr.key == key) { *outg = gr.exec; return PCR_OK; }
+        IcpGraph e; e.key = key;
+        struct Owner { IcpGraph *g; ~Owner() { if (g) { if (g->exec) (void)hipGraphExecDestroy(g->exec); if (g->graph) (void)hipGraphDestroy(g->graph); } } } owner{&e};
+        PCR_HIP_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        for (int k = 0; k < len; k++) enqueue_fused();
+        PCR_HIP_CHECK(ctx, hipStreamEndCapture(ctx->stream, &e.graph));
+        PCR_HIP_CHECK(ctx, hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
+        if (ctx->icp_graphs.size() >= 48) {
+            PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipGraphExecDestroy(ctx->icp_graphs[0].exec);
+            if (ctx->icp_graphs[0].graph) (void)hipGraphDestroy(ctx->icp_graphs[0].graph);
+            ctx->icp_graphs.erase(ctx->icp_graphs.begin());
+        }
+        owner.g = nullptr;
+        ctx->icp_graphs.push_back(std::move(e));
+        *outg = ctx->icp_graphs.back().exec;
+        return PCR_OK;
+    };
+    const size_t slot_bytes = sizeof(IcpState) * (size_t)G;
+    if (2 * slot_bytes > ctx->pinned_cap) { ctx->err = "GICP group: pinned window too small"; return PCR_ENOMEM; }
+    IcpState *slots[2] = {(IcpState *)ctx->pinned, (IcpState *)(ctx->pinned + slot_bytes)};
+    int cur = 0, prev = -1, next_len = CHUNK, launched = 0, live_launches = 0, n_chunks = 0;
+    std::vector<int> chunk_first, chunk_last;
+    const int max_it = p ? p->max_iteration : 30;
+    const long long launch_limit = (long long)S * ((long long)max_it + 2) + 4 * CHUNK + 64;
+    bool finished = false;
+    for (;;) {
+        const int c = next_len;
+        if (ctx->profiling) {
+            while ((int)ctx->prof_events.size() < 2 * (n_chunks + 1)) { hipEvent_t e; PCR_HIP_CHECK(ctx, hipEventCreate(&e)); ctx->prof_events.push_back(e); }
+            PCR_HIP_CHECK(ctx, hipEventRecord(ctx->prof_events[2 * n_chunks], ctx->stream));
+        }
+        hipGraphExec_t ge = nullptr;
+        PCR_TRY(graph_for(c, &ge));
+        if (ge) PCR_HIP_CHECK(ctx, hipGraphLaunch(ge, ctx->stream));
+        else for (int k = 0; k < c; k++) enqueue_fused();
+        if (ctx->profiling) PCR_HIP_CHECK(ctx, hipEventRecord(ctx->prof_events[2 * n_chunks + 1], ctx->stream));
+        chunk_first.push_back(launched); chunk_last.push_back(launched + c); n_chunks++;
+        launched += c;
+        PCR_HIP_CHECK(ctx, hipMemcpyAsync(slots[cur], st, slot_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        PCR_HIP_CHECK(ctx, hipEventRecord(ctx->ev[cur], ctx->stream));
+        if (prev >= 0) {
+            PCR_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev[prev]));
+            bool all_done = true;
+            next_len = 1;
+            for (int g = 0; g < G; g++) {
+                const IcpState &sg = slots[prev][g];
+                if (sg.done) continue;                    // (done is set by the LAST scale only)
+                all_done = false;
+                const int l = icp_next_chunk(sg, all[(size_t)g * S].rel_fit, all[(size_t)g * S].rel_rmse, CHUNK, true);
+                next_len = l > next_len ? l : next_len;
+            }
+            if (all_done) { finished = true; break; }
+            live_launches = launched - c;                 // (the chunk just queued may still turn out to be needed: counted when the next read-back says so)
+        }
+        if (launched > launch_limit) { ctx->err = "GICP group loop (all scales) did not end"; return PCR_EHIP; }
+        prev = cur; cur ^= 1;
+    }
+    if (!finished) { ctx->err = "GICP group loop ended without a final state"; return PCR_EHIP; }
+    std::vector<IcpState> hh((size_t)G * S);
+    PCR_HIP_CHECK(ctx, hipMemcpyAsync(hh.data(), hist, sizeof(IcpState) * hh.size(), hipMemcpyDeviceToHost, ctx->stream));
+    PCR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));      // (also drains the no-op tail: pinned slots, argument table and arena are reused)
+    for (int k = 0; k < G * S; k++) {
+        const IcpState &sg = hh[k];
+        state_to_result(sg, &out[k]);
+        for (int q = 0; q < 16; q++) if (!std::isfinite(sg.T[q])) { ctx->err = "non-finite pose"; return PCR_ENUMERIC; }
+        if (ctx->profiling) {
+            ctx->prof[2] += (double)sg.t_live * 0.01; ctx->prof[3] += sg.launches; ctx->prof[4] += 48.0 * (double)sg.ns * (double)sg.launches; ctx->prof[11] += (double)sg.searched;
+            ctx->prof[6] += (double)sg.t_dbg[0] * 0.01; ctx->prof[7] += (double)sg.t_dbg[3] * 0.01; ctx->prof[14] += (double)sg.t_dbg[1] * 0.01;
+        }
+    }
+    if (ctx->profiling) {
+        for (int c = 0; c < n_chunks; c++)
+            if (chunk_last[c] <= live_launches) {          // chunks during which some pair was still iterating: HIP-event time / launches = launch period of the group
+                float ms = 0;
+                PCR_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->prof_events[2 * c], ctx->prof_events[2 * c + 1]));
+                ctx->prof[0] += ms; ctx->prof[1] += chunk_last[c] - chunk_first[c];
+            }
+        ctx->prof[5] += launched; ctx->prof[13] += live_launches;
+    }
+    if (pcr_options().debug_stamps.load(std::memory_order_relaxed)) {
+        long long sum = 0, mx = 0;
+        for (int g = 0; g < G; g++) { long long t = 0; for (int s_ = 0; s_ < S; s_++) t += hh[(size_t)g * S + s_].launches; sum += t; mx = t > mx ? t : mx; }
+        fprintf(stderr, "icp group, all scales in one loop: %d pairs x %d scales, %d launches queued in %d chunks (%d before the last pair stopped); launches of a pair: mean %.1f, largest %lld\n",
+                G, S, launched, n_chunks, live_launches, (double)sum / G, mx);
     }
     return PCR_OK;
 }

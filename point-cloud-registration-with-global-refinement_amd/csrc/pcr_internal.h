@@ -11,7 +11,7 @@
 #include "../../include/pcr_hip.h"
 
 // process-wide switches (pcr_set_option, include/pcr_hip.h): latched from the environment once, atomics afterwards
-struct PcrOptions { std::atomic<int> knn_wave{-1}, knnw_budget{80}, fence_prep{0}, icp_phase{0}, icp_verify{0}, debug_stamps{0}, debug_visits{0}, spfh_float64{0}, radius_list_select{1}, arena_poison{0}, featnn_mutual{1}, plan_stagger_us{0}, plan_prefetch{0}; };
+struct PcrOptions { std::atomic<int> knn_wave{-1}, knnw_budget{80}, fence_prep{0}, icp_phase{0}, icp_verify{0}, debug_stamps{0}, debug_visits{0}, spfh_float64{0}, radius_list_select{1}, arena_poison{0}, featnn_mutual{1}, plan_stagger_us{0}, plan_prefetch{0}, icp_scales{1}; };
 PcrOptions &pcr_options();
 // process-wide event counters (pcr_counter, include/pcr_hip.h): how often a slow fall-back was taken -- invisible in the results, which are the same bits
 struct PcrCounters { std::atomic<long long> fgr_group_barrier_timeouts{0}, fgr_group_pool_overflows{0}, fgr_group_pairs_redone_alone{0}; };
@@ -280,6 +280,8 @@ int pcr_feature_nn_mutual_batch(pcr_context *ctx, int G, const float *const *f0,
 struct IcpOutputs { pcr_result res; };
 int pcr_dev_gicp(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, double max_dist, const double *T0,
                  const pcr_gicp_params *p, pcr_result *out, int32_t *match_dev /*optional src.cap*/);
+int pcr_dev_gicp_group_scales(pcr_context *ctx, int G, int S, const DevCloud *const *src /* G x S */, const DevCloud *const *tgt, const double *max_dists /* G x S */, const double *T0 /* G x 16 */,
+                              const pcr_gicp_params *p, pcr_result *out /* G x S */, int32_t *const *match_dev /* G, optional */);       // all scales of a lockstep group in one loop; 1: declined
 int pcr_dev_gicp_group(pcr_context *ctx, int G, const DevCloud *const *src, const DevCloud *const *tgt, const double *max_dists /* G */, const double *T0 /* G x 16 */,
                        const pcr_gicp_params *p, pcr_result *out /* G */, int32_t *const *match_dev /* optional, G */);
 int pcr_dev_linearize_once(pcr_context *ctx, const DevCloud *src, const DevCloud *tgt, double max_dist, const double *T,

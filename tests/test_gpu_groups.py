@@ -45,6 +45,17 @@ def test_groups_are_bit_identical_by_default_however_the_batch_is_cut():
     assert all(g == groups[0] for g in forms), (groups[0], forms)
 
 
+def test_all_scales_in_one_loop_gives_the_scale_by_scale_bits():
+    """NCLT-size groups run all scales of a pair behind one argument slot: the last workgroup of the launch in which a scale's criteria hold moves
+    the pair on to its next scale on the device (pcr_dev_gicp_group_scales), so a pair does not wait for the slowest pair of every scale.
+    PCR_ICP_SCALES=0 runs the scales one after the other (pcr_dev_gicp_group per scale): poses, iteration counts, cloud counts, radii and
+    correspondence sets are the same bits, for every cut of the batch."""
+    a, _ = _helper({"GROUP_POSE_SIZES": "2,3,8", "PCR_ICP_SCALES": "1"})
+    b, _ = _helper({"GROUP_POSE_SIZES": "2,3,8", "PCR_ICP_SCALES": "0"})
+    assert len(a) == len(b) == 3
+    assert all(g == a[0] for g in a) and all(g == a[0] for g in b), (a, b)
+
+
 def test_fgr_plus_gicp_groups_are_bit_identical():
     """Stage FGR + GICP (Coarse_to_fine / full_registration, ALL_FUNCTIONS.py:317-332, 349-392) with lockstep groups: registro_FGR runs
     pair by pair, the GICP of the group in lockstep from the FGR poses with the FGR normals as orientation prior and the AF radius rule,
