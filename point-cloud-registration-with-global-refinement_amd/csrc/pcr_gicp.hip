@@ -1603,11 +1603,14 @@ int pcr_dev_gicp_group_scales(pcr_context *ctx, int G, int S, const DevCloud *co
     static const int chunk_env = getenv("PCR_ICP_CHUNK") ? atoi(getenv("PCR_ICP_CHUNK")) : 8;
     const int CHUNK = chunk_env < 1 ? 1 : (chunk_env > 32 ? 32 : chunk_env);
     static const bool use_graph = !(getenv("PCR_ICP_GRAPH") && atoi(getenv("PCR_ICP_GRAPH")) == 0);
-    auto enqueue_fused = [&]() { PCR_FUSED_LAUNCH(ctx, k_icp_fused_g, true, tile_pts, dim3(nbf, G), (const IcpArgs *)dargs); };
+    // (every tile of the group is 512 points: the <512> form of the kernel, one point per lane, instead of the <1024> form with its second point masked off)
+    static const bool form512 = !(getenv("PCR_ICP_FORM512") && atoi(getenv("PCR_ICP_FORM512")) == 0);
+    const int launch_tile = form512 ? LIN_BS : tile_pts;
+    auto enqueue_fused = [&]() { PCR_FUSED_LAUNCH(ctx, k_icp_fused_g, true, launch_tile, dim3(nbf, G), (const IcpArgs *)dargs); };
     auto graph_for = [&](int len, hipGraphExec_t *outg) -> int {     // a chunk of `len` fused launches, captured once per (G, tile, grid width, length)
         *outg = nullptr;
         if (!use_graph) return PCR_OK;
-        const long long kv[6] = {0x47525053ll /* "GRPS" */, G, tile_pts, len, nbf, (long long)(uintptr_t)dargs_v};
+        const long long kv[6] = {0x47525053ll /* "GRPS" */, G, launch_tile, len, nbf, (long long)(uintptr_t)dargs_v};
         std::string key((const char *)kv, sizeof kv);
         for (auto &gr : ctx->icp_graphs) if (gr.key == key) { *outg = gr.exec; return PCR_OK; }
         IcpGraph e; e.key = key;
