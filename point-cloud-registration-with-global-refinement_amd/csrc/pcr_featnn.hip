@@ -224,14 +224,70 @@ __device__ static inline void d_fn_split(const float *__restrict__ f_, int n, in
         if (zero) atomicMin(first_zero, src);
     } else { nlo[i] = 1.0e30f; nup[i] = 0.0f; nrm[i] = 0.0f; cq[i] = 0.0f; }
 }
+// The same split with 8 lanes per row (K = 64; round 5).  A row per lane held the whole row in registers (272 VGPRs: one wavefront per SIMD) and
+// stored its two 128-byte rows in 16-byte pieces 128 bytes apart; here lane p of an octet makes the p-th 16-byte piece of both rows -- the
+// halves of the (up to) 8 dimensions its slots hold, computed by the same expressions as above, so the SAME halves -- and an octet's
+// stores are one contiguous 128-byte line per row.  The squared norms are octet sums of per-lane partial sums (another summation order
+// than the sequential one above: |x|^2 differs in its last bits, which the bounds' margins cover; the matches are exact either way).
+#if FN_K == 64
+__device__ static inline void d_fn_split8(const float *__restrict__ f_, int n, int n_pad, const double *__restrict__ mu,
+                                          _Float16 *__restrict__ A, _Float16 *__restrict__ B, float *__restrict__ nlo, float *__restrict__ nup, float *__restrict__ nrm,
+                                          float *__restrict__ cq, int *__restrict__ first_zero, const uint32_t *__restrict__ perm) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int i = t >> 3, part = t & 7;
+    if (i >= n_pad) return;                               // (octet-uniform; n_pad is a multiple of 32)
+    const bool real = i < n;
+    const int src = (real && perm) ? (int)perm[i] : i;
+    const float *__restrict__ row = f_ + (size_t)(real ? src : 0) * FN_D;
+    fn_h8 ra, rb;
+    double sp = 0.0, scp = 0.0; int nz = 0;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int k = 8 * part + u;                        // slot of the 64-entry rows: [hi 0..32 | hc / lc 0..14 | lc / hc 0..14 | 0]
+        const bool plain = k < FN_D, first = k < FN_D + FN_NCOV, pad = k >= FN_D + 2 * FN_NCOV;
+        int dim = 0;
+        if (plain) dim = k;
+        else if (!pad) dim = (int)mu[FN_D + 1 + (first ? k - FN_D : k - FN_D - FN_NCOV)];
+        const float fv = (real && !pad) ? row[dim] : 0.0f;
+        const double x = (real && !pad) ? ((double)fv - mu[dim]) * FN_SCALE : 0.0;
+        const _Float16 h = (_Float16)(float)x;
+        const _Float16 l = (_Float16)(float)(x - (double)(float)h);
+        const _Float16 z = (_Float16)0.0f;
+        ra[u] = pad ? z : (first ? h : l);                 // A: hi | hc | lc
+        rb[u] = pad ? z : (plain ? h : (first ? l : h));   // B: hi | lc | hc
+        if (plain) { sp += x * x; nz += (real && fv != 0.0f) ? 1 : 0; }
+        else if (first) scp += x * x;
+    }
+    reinterpret_cast<fn_h8 *>(A + (size_t)i * FN_K)[part] = ra;
+    reinterpret_cast<fn_h8 *>(B + (size_t)i * FN_K)[part] = rb;
+    const double s = pcr_octet_sum(sp), sc = pcr_octet_sum(scp);
+    nz = pcr_octet_sum_i(nz);
+    if (part != 0) return;
+    if (real) {
+        const bool zero = nz == 0;
+        const double su = fmax(s - sc, 0.0) * (1.0 + 1e-12) + 1e-9 * s;
+        const double E = FN_C * s + FN_CU * su + FN_EABS;
+        const float lo_f = __double2float_rd(s - E);
+        nlo[i] = lo_f;
+        nup[i] = __double2float_ru(2.0 * E * 1.002 + ((s - E) - (double)lo_f));
+        nrm[i] = zero ? -__double2float_ru(s) : __double2float_ru(s);
+        cq[i] = __double2float_ru(2.0 * E * 1.001);
+        if (zero) atomicMin(first_zero, src);
+    } else { nlo[i] = 1.0e30f; nup[i] = 0.0f; nrm[i] = 0.0f; cq[i] = 0.0f; }
+}
+#define FN_SPLIT_LANES 8
+#else
+#define d_fn_split8 d_fn_split
+#define FN_SPLIT_LANES 1
+#endif
 // the four per-row floats of a cloud: nlo = |x|^2 - E rounded down (database role, lower bounds), nup = 2 E with margins (database role, upper
 // bounds), nrm = |x|^2 rounded up with the sign bit marking an all-zero feature row, cq = 2 E with margins (query role, candidate threshold)
 struct FnRows { float *nlo, *nup, *nrm, *cq; };
 __global__ void __launch_bounds__(256) k_fn_split(const float *__restrict__ f_, int n, int n_pad, const double *__restrict__ mu,
                                                   _Float16 *__restrict__ A, _Float16 *__restrict__ B, FnRows r,
-                                                  int *__restrict__ first_zero, const uint32_t *__restrict__ perm) { d_fn_split(f_, n, n_pad, mu, A, B, r.nlo, r.nup, r.nrm, r.cq, first_zero, perm); }
+                                                  int *__restrict__ first_zero, const uint32_t *__restrict__ perm) { d_fn_split8(f_, n, n_pad, mu, A, B, r.nlo, r.nup, r.nrm, r.cq, first_zero, perm); }
 struct FnSplitDesc { const float *f; int n, n_pad; const double *mu; _Float16 *A, *B; FnRows r; int *first_zero; };
-__global__ void __launch_bounds__(256) k_fn_split_g(const FnSplitDesc *d) { const FnSplitDesc a = d[blockIdx.y]; d_fn_split(a.f, a.n, a.n_pad, a.mu, a.A, a.B, a.r.nlo, a.r.nup, a.r.nrm, a.r.cq, a.first_zero, nullptr); }
+__global__ void __launch_bounds__(256) k_fn_split_g(const FnSplitDesc *d) { const FnSplitDesc a = d[blockIdx.y]; d_fn_split8(a.f, a.n, a.n_pad, a.mu, a.A, a.B, a.r.nlo, a.r.nup, a.r.nrm, a.r.cq, a.first_zero, nullptr); }
 
 // ================================================================================================ tile pruning (round 2)
 // The all-pairs screen costs 4 MFMAs per 16 x 16 block whatever the data.  FPFH rows are far from uniform in their 33-D space (four
@@ -1078,7 +1134,7 @@ int pcr_feature_nn_mutual(pcr_context *ctx, const float *f0, int n0, const float
         float *r4 = arena<float>(ctx, (size_t)4 * np[c]);
         if (!A[c] || !B[c] || !r4) return PCR_ENOMEM;
         rows[c] = FnRows{r4, r4 + np[c], r4 + (size_t)2 * np[c], r4 + (size_t)3 * np[c]};
-        PCR_LAUNCH(ctx, k_fn_split, dim3((np[c] + 255) / 256), dim3(256), 0, ctx->stream, f[c], n[c], np[c], mu, A[c], B[c], rows[c], first_zero + c, (const uint32_t *)perm[c]);
+        PCR_LAUNCH(ctx, k_fn_split, dim3((unsigned)(((size_t)np[c] * FN_SPLIT_LANES + 255) / 256)), dim3(256), 0, ctx->stream, f[c], n[c], np[c], mu, A[c], B[c], rows[c], first_zero + c, (const uint32_t *)perm[c]);
     }
     float *dbg = nullptr;
     if (check) { dbg = arena<float>(ctx, 2); if (!dbg) return PCR_ENOMEM; }
@@ -1339,7 +1395,7 @@ int pcr_feature_nn_mutual_batch(pcr_context *ctx, int G, const float *const *f0,
     {
         const FnSplitDesc *ds = pcr_desc_upload(ctx, ss.data(), 2 * G);
         if (!ds) return PCR_ENOMEM;
-        PCR_LAUNCH(ctx, k_fn_split_g, dim3((max_np + 255) / 256, 2 * G), dim3(256), 0, ctx->stream, ds);
+        PCR_LAUNCH(ctx, k_fn_split_g, dim3((unsigned)(((size_t)max_np * FN_SPLIT_LANES + 255) / 256), 2 * G), dim3(256), 0, ctx->stream, ds);
     }
     // problems = (pair, direction): direction 0 = queries of cloud 1 against the rows of cloud 0.  A problem's queries may be a subset of its cloud
     // (the live rows of a seeded second direction): qB / q_nrm / q_cq / perm_q describe them, Ug_seeded holds their bounds.
