@@ -92,21 +92,24 @@ typedef float fn_f4 __attribute__((ext_vector_type(4)));
 // part: gridDim.x rows of 34 = 33 column sums + the largest |value| (the f16 split needs |f - mu| * 128 < 65504)
 #define FN_PC (2 * FN_D + 1)      // [0, 33) column sums, [33] largest |value|, [34, 67) column sums of squares; the mu vector has the same length: [0, 33) means, [33] largest
                                   // |value|, [34, 34 + FN_NCOV) the covered dimensions (ascending, as doubles)
+// (round 5: a lane per COLUMN, a wavefront per row -- coalesced 132-byte reads and two accumulators per lane; a row per lane kept 66 float64
+// accumulators in 254 VGPRs and read 64 rows 132 bytes apart per instruction)
 __device__ static inline void d_fn_colsum(const float *__restrict__ f, int n, double *__restrict__ part) {
     __shared__ double sh[256 / 64][FN_PC];
-    double s[FN_D], sq[FN_D], mx = 0.0;
-#pragma unroll
-    for (int k = 0; k < FN_D; k++) { s[k] = 0.0; sq[k] = 0.0; }
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
-#pragma unroll
-        for (int k = 0; k < FN_D; k++) { const double v = (double)f[(size_t)i * FN_D + k]; s[k] += v; sq[k] += v * v; mx = fmax(mx, fabs(v)); }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const bool col = lane < FN_D;
+    double s = 0.0, sq = 0.0, mx = 0.0;
+    const int stride = gridDim.x * (256 / 64);
+    for (int r0 = blockIdx.x * (256 / 64) + w; r0 < n; r0 += 8 * stride) {
+        float v[8];
 #pragma unroll
-    for (int k = 0; k < FN_D; k++) { const double v = pcr_wave_sum(s[k]); if (lane == 0) sh[w][k] = v; }
+        for (int u = 0; u < 8; u++) { const int r = r0 + u * stride; v[u] = (col && r < n) ? f[(size_t)r * FN_D + lane] : 0.0f; }
 #pragma unroll
-    for (int k = 0; k < FN_D; k++) { const double v = pcr_wave_sum(sq[k]); if (lane == 0) sh[w][FN_D + 1 + k] = v; }
+        for (int u = 0; u < 8; u++) { const double x = (double)v[u]; s += x; sq += x * x; mx = fmax(mx, fabs(x)); }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
+    if (col) { sh[w][lane] = s; sh[w][FN_D + 1 + lane] = sq; }
     if (lane == 0) sh[w][FN_D] = mx;
     __syncthreads();
     if (threadIdx.x < FN_PC) {
