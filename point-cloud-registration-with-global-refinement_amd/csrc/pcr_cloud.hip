@@ -1574,7 +1574,7 @@ struct RadListArgs {
 // place falls as it does there (the k-best kernel keeps the first one its walk meets).  Both walks test the same float32 expressions, so they see the same points.  A boundary bin of more than RL_EDGE points
 // (many equal distances) sends the piece to the k-best kernel as before.
 #define RL_BINS 128            // (two 16-bit counters per LDS word: a ball holds far fewer than 65 536 points)
-#define RL_EDGE 24
+#define RL_EDGE 20
 // squared distance as the reference's k-d tree forms it (float64 differences of the float32 coordinates, products and sums rounded one by one)
 __device__ static inline double pcr_d2_f64_unfused(const float4 q, const float4 p) {
 #pragma clang fp contract(off)
