@@ -305,7 +305,9 @@ __global__ void __launch_bounds__(256) k_fn_split_g(const FnSplitDesc *d) { cons
 #define FN_NG (FN_D * (FN_D + 1) / 2)      // 561 second moments
 #define FN_MD 4                            // principal coordinates in the Morton key
 #define FN_MB 8                            //   bits of each
-#define FN_NPRE 48                         // pre-pass: tiles per workgroup
+#ifndef FN_NPRE
+#define FN_NPRE 48                         // pre-pass: tiles per workgroup (round 5, registro_FGR at 200k points: 24 / 32 / 48 / 64 -> 12.45 / 12.56 / 12.27 / 12.20 ms)
+#endif
 #ifndef FN_WGS_PRUNED
 #define FN_WGS_PRUNED 18432                // workgroups of the pruned main pass (query groups x splits of the database)
 #endif
